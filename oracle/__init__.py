@@ -1,0 +1,205 @@
+"""
+TEST INFRASTRUCTURE ONLY -- CPU oracle for the RIME predict hot path.
+
+ctypes front-end of ``oracle/rime_oracle.c``, a plain-C restatement of the
+reference's numba kernels (file:line citations live in the C sources).  The
+functions keep the reference's numpy signatures so parity tests read like the
+reference's own tests.
+
+Parity pinned: ``tests/test_oracle_golden.py`` checks every function against
+golden vectors generated from the real reference in the build container
+(``tests/golden/make_golden.py``) and against the reference tests' own
+known-answer values.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package; ``codex_africanus_amd`` never does.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_LIBS = {}
+
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    targets = [os.path.join(_BUILD, n) for n in ("liboracle.so", "liboracle_omp.so")]
+    srcs = [os.path.join(_HERE, n) for n in ("rime_oracle.c", "rime_oracle_impl.h")]
+    stale = force or not all(os.path.exists(t) for t in targets) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(t) for t in targets) for s in srcs
+    )
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return targets
+
+
+def _lib(omp=False):
+    key = bool(omp)
+    if key not in _LIBS:
+        name = "liboracle_omp.so" if omp else "liboracle.so"
+        path = os.path.join(_BUILD, name)
+        if not os.path.exists(path):
+            build()
+        _LIBS[key] = ctypes.CDLL(path)
+    return _LIBS[key]
+
+
+def num_threads(omp=True):
+    return int(_lib(omp).orc_num_threads())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _sign(convention):
+    # africanus/rime/phase.py:29-34, africanus/dft/kernels.py:34-39
+    if convention == "fourier":
+        return -1
+    elif convention == "casa":
+        return 1
+    raise ValueError("convention not in ('fourier', 'casa')")
+
+
+def phase_delay(lm, uvw, frequency, convention="fourier"):
+    """africanus/rime/phase.py:11-63."""
+    sign = _sign(convention)
+    out_dtype = np.result_type(np.complex64, lm.dtype, uvw.dtype, frequency.dtype)
+    # all-float32 inputs compute in float32 (constants are cast to lm.dtype, phase.py:23-25);
+    # anything mixed is promoted to float64 first (numba's per-operation promotion
+    # of mixed inputs is not restated).
+    if out_dtype == np.complex64:
+        rt, fn = np.float32, "orc_phase_delay_f32"
+    else:
+        rt, fn = np.float64, "orc_phase_delay_f64"
+    lm_, uvw_, fr_ = _c(lm, rt), _c(uvw, rt), _c(frequency, rt)
+    nsrc, nrow, nchan = lm_.shape[0], uvw_.shape[0], fr_.shape[0]
+    out = np.empty((nsrc, nrow, nchan), dtype=out_dtype)
+    rc = getattr(_lib(), fn)(_p(lm_), _i64(nsrc), _p(uvw_), _i64(nrow), _p(fr_), _i64(nchan),
+                             _int(sign), _p(out))
+    assert rc == 0
+    return out
+
+
+def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None, omp=False):
+    """africanus/dft/kernels.py:14-69."""
+    sign = _sign(convention)
+    if dtype is None:
+        out_dtype = np.result_type(np.complex64, image.dtype, uvw.dtype, lm.dtype, frequency.dtype)
+    else:
+        out_dtype = np.dtype(dtype)
+    is_cplx = np.iscomplexobj(image)
+    img = _c(image, np.complex128 if is_cplx else np.float64)
+    uvw_, lm_, fr_ = _c(uvw, np.float64), _c(lm, np.float64), _c(frequency, np.float64)
+    nsrc, nchan, ncorr = img.shape
+    nrow = uvw_.shape[0]
+    out = np.empty((nrow, nchan, ncorr), dtype=np.complex128)
+    rc = _lib(omp).orc_im_to_vis_f64(_p(img), _int(int(is_cplx)), _p(uvw_), _p(lm_), _p(fr_),
+                                     _i64(nsrc), _i64(nrow), _i64(nchan), _i64(ncorr),
+                                     _int(sign), _int(int(out_dtype == np.complex64)), _p(out))
+    assert rc == 0
+    return out.astype(out_dtype, copy=False)
+
+
+def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None,
+                dde2_jones=None, die1_jones=None, base_vis=None, die2_jones=None):
+    """africanus/rime/predict.py:466-619 (checks are NOT restated here: the
+    product's host wrapper ports them and is tested against the reference's
+    error behaviour separately)."""
+    arrays = [dde1_jones, source_coh, dde2_jones, die1_jones, base_vis, die2_jones]
+    present = [a for a in arrays if a is not None]
+    if not present:
+        raise ValueError("No Jones Matrices were supplied")
+    out_dtype = np.result_type(*[a.dtype for a in present])
+    rt = np.float32 if out_dtype == np.complex64 else np.float64
+    ct = np.complex64 if rt == np.float32 else np.complex128
+    fn = "orc_predict_vis_f32" if rt == np.float32 else "orc_predict_vis_f64"
+
+    have_ddes = dde1_jones is not None
+    have_coh = source_coh is not None
+    have_dies = die1_jones is not None
+    nrow = time_index.shape[0]
+    if have_ddes:
+        nsrc, ntime, nant, nchan = dde1_jones.shape[:4]
+        corrs = dde1_jones.shape[4:]
+    elif have_coh:
+        nsrc, _, nchan = source_coh.shape[:3]
+        corrs = source_coh.shape[3:]
+        ntime = nant = 0
+    elif have_dies:
+        ntime, nant, nchan = die1_jones.shape[:3]
+        corrs = die1_jones.shape[3:]
+        nsrc = 0
+    else:
+        nchan = base_vis.shape[1]
+        corrs = base_vis.shape[2:]
+        nsrc = ntime = nant = 0
+    if have_dies:
+        ntime, nant = die1_jones.shape[:2]
+    ncorr = int(np.prod(corrs))
+    jones_2x2 = int(len(corrs) == 2)
+
+    cs = [None if a is None else _c(a, ct) for a in arrays]
+    ti, a1, a2 = (_c(x, np.int64) for x in (time_index, antenna1, antenna2))
+    out = np.empty((nrow, nchan) + tuple(corrs), dtype=ct)
+    rc = getattr(_lib(), fn)(_p(ti), _p(a1), _p(a2), _i64(nrow), *[_p(c) for c in cs],
+                             _i64(nsrc), _i64(ntime), _i64(nant), _i64(nchan),
+                             _int(ncorr), _int(jones_2x2), _p(out))
+    assert rc == 0
+    return out
+
+
+def apply_gains(time_index, antenna1, antenna2, die1_jones, corrupted_vis, die2_jones):
+    """africanus/rime/predict.py:622-649."""
+    return predict_vis(time_index, antenna1, antenna2, die1_jones=die1_jones,
+                       base_vis=corrupted_vis, die2_jones=die2_jones)
+
+
+def freq_grid_interp(frequency, beam_freq_map):
+    """africanus/rime/fast_beam_cubes.py:10-54."""
+    rt = np.float32 if frequency.dtype == np.float32 else np.float64
+    fn = "orc_freq_grid_interp_f32" if rt == np.float32 else "orc_freq_grid_interp_f64"
+    fr_, fm_ = _c(frequency, rt), _c(beam_freq_map, rt)
+    out = np.empty((fr_.shape[0], 3), dtype=rt)
+    rc = getattr(_lib(), fn)(_p(fr_), _i64(fr_.shape[0]), _p(fm_), _i64(fm_.shape[0]), _p(out))
+    assert rc == 0
+    return out
+
+
+def beam_cube_dde(beam, beam_lm_extents, beam_freq_map, lm, parallactic_angles,
+                  point_errors, antenna_scaling, frequency):
+    """africanus/rime/fast_beam_cubes.py:57-240."""
+    if beam.dtype == np.complex64:
+        rt, ct, fn = np.float32, np.complex64, "orc_beam_cube_dde_f32"
+    else:
+        rt, ct, fn = np.float64, np.complex128, "orc_beam_cube_dde_f64"
+    beam_lw, beam_mh, beam_nud = beam.shape[:3]
+    corrs = beam.shape[3:]
+    ncorr = int(np.prod(corrs, dtype=np.int64)) if corrs else 1
+    if beam_lw < 2 or beam_mh < 2 or beam_nud < 2:
+        raise ValueError("beam_lw, beam_mh and beam_nud must be >= 2")
+    b_, ex_, fm_ = _c(beam, ct), _c(beam_lm_extents, rt), _c(beam_freq_map, rt)
+    lm_, pa_ = _c(lm, rt), _c(parallactic_angles, rt)
+    pe_, as_, fr_ = _c(point_errors, rt), _c(antenna_scaling, rt), _c(frequency, rt)
+    nsrc = lm_.shape[0]
+    ntime, nant = pa_.shape
+    nchan = fr_.shape[0]
+    out = np.empty((nsrc, ntime, nant, nchan) + tuple(corrs), dtype=ct)
+    rc = getattr(_lib(), fn)(_p(b_), _i64(beam_lw), _i64(beam_mh), _i64(beam_nud), _int(ncorr),
+                             _p(ex_), _p(fm_), _p(lm_), _i64(nsrc), _p(pa_), _i64(ntime),
+                             _i64(nant), _p(pe_), _p(as_), _p(fr_), _i64(nchan), _p(out))
+    assert rc == 0
+    return out

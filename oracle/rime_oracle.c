@@ -1,0 +1,138 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the RIME predict hot path.
+ *
+ * Plain-C restatement of the reference's numba kernels (codex-africanus v0.4.4):
+ *   africanus/rime/phase.py:28-61          -> orc_phase_delay_{f64,f32}
+ *   africanus/rime/predict.py:56-373,574-617 -> orc_predict_vis_{f64,f32}
+ *   africanus/dft/kernels.py:33-67         -> orc_im_to_vis_f64
+ *   africanus/rime/fast_beam_cubes.py:10-54  -> orc_freq_grid_interp_{f64,f32}
+ *   africanus/rime/fast_beam_cubes.py:57-240 -> orc_beam_cube_dde_{f64,f32}
+ *   africanus/constants/consts.py:6-9      -> ORC_*_TWO_PI_OVER_C
+ *
+ * Parity pinned: tests/test_oracle_golden.py checks every function here against
+ * golden vectors captured from the real reference (tests/golden/make_golden.py)
+ * and against the reference tests' own known-answer values.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product package must never import it.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_EINVAL 1
+#define ORC_ENOMEM 2
+#define ORC_MAX_CORR 16
+
+/* africanus/constants/consts.py:6-9: c = 2.99792458e8; 2*math.pi/c */
+#define ORC_LIGHTSPEED 2.99792458e8
+#define ORC_TWO_PI_OVER_C (2 * 3.141592653589793 / ORC_LIGHTSPEED)
+#define ORC_MINUS_TWO_PI_OVER_C (-ORC_TWO_PI_OVER_C)
+
+#define REAL double
+#define SUF f64
+#define SQRT sqrt
+#define COS cos
+#define SIN sin
+#define FLOOR floor
+#define HYPOT hypot
+#include "rime_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef SQRT
+#undef COS
+#undef SIN
+#undef FLOOR
+#undef HYPOT
+
+#define REAL float
+#define SUF f32
+#define SQRT sqrtf
+#define COS cosf
+#define SIN sinf
+#define FLOOR floorf
+#define HYPOT hypotf
+#include "rime_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef SQRT
+#undef COS
+#undef SIN
+#undef FLOOR
+#undef HYPOT
+
+/* ------------------------------------------------------------------------
+ * im_to_vis: africanus/dft/kernels.py:33-67.
+ *   constants are Python floats (float64) whatever the input dtype (:35-37);
+ *   n = sqrt(1 - l^2 - m^2) - 1, NOT clamped -> NaN outside the unit disc (:54)
+ *   real_phase = C*(l*u + m*v + n*w) (:57);  p = real_phase*nu*1j (:61)
+ *   if image[s,nu,c]: vis[r,nu,c] += exp(p)*image[s,nu,c]   (:63-65)
+ * numba's complex exp gives exp(0)*(cos y + i sin y) = (cos y, sin y) here.
+ * image: (nsrc, nchan, ncorr) real (image_is_complex=0) or complex interleaved.
+ * out: (nrow, nchan, ncorr) complex128 interleaved.  out_c64 != 0 restates the
+ * reference's behaviour when the output array is complex64: every += rounds
+ * the running sum to float (the array element is c64, the right-hand side c128).
+ * sign: -1 'fourier' (minus_two_pi_over_c), +1 'casa' (:34-39).
+ * Rows are independent, so an OpenMP build may split them; per-row arithmetic
+ * and order are unchanged.
+ * ---------------------------------------------------------------------- */
+int orc_im_to_vis_f64(const double *image, int image_is_complex,
+                      const double *uvw, const double *lm, const double *frequency,
+                      int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                      int sign, int out_c64, double *out)
+{
+    if (sign != 1 && sign != -1) return ORC_EINVAL;
+    const double constant = sign < 0 ? ORC_MINUS_TWO_PI_OVER_C : ORC_TWO_PI_OVER_C;
+    const int64_t istride = image_is_complex ? 2 : 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t r = 0; r < nrow; ++r) {
+        double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+        double *vr = out + 2 * r * nchan * ncorr;
+        for (int64_t k = 0; k < 2 * nchan * ncorr; ++k) vr[k] = 0.0;
+        for (int64_t s = 0; s < nsrc; ++s) {
+            double l = lm[2 * s], m = lm[2 * s + 1];
+            double n = sqrt(1.0 - l * l - m * m) - 1.0;
+            double real_phase = constant * (l * u + m * v + n * w);
+            for (int64_t nu = 0; nu < nchan; ++nu) {
+                double p = real_phase * frequency[nu];
+                double cp = 0.0, sp = 0.0;
+                int have_exp = 0;
+                for (int64_t c = 0; c < ncorr; ++c) {
+                    const double *px = image + ((s * nchan + nu) * ncorr + c) * istride;
+                    double ire = px[0], iim = image_is_complex ? px[1] : 0.0;
+                    /* Python truthiness: nonzero (NaN is truthy) */
+                    if (ire == 0.0 && iim == 0.0) continue;
+                    if (!have_exp) { cp = cos(p); sp = sin(p); have_exp = 1; }
+                    /* exp(p) * image: full complex multiply, real image widened to (x + 0j) */
+                    double tre = cp * ire - sp * iim;
+                    double tim = cp * iim + sp * ire;
+                    double *o = vr + 2 * (nu * ncorr + c);
+                    if (out_c64) {
+                        o[0] = (double)(float)(o[0] + tre);
+                        o[1] = (double)(float)(o[1] + tim);
+                    } else {
+                        o[0] += tre;
+                        o[1] += tim;
+                    }
+                }
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,261 @@
+#!/opt/conda/bin/python3.9
+"""
+Generate golden input/output vectors for the RIME predict hot path by running
+the REAL reference (codex-africanus v0.4.4, numba CPU path) in the build
+container.  The vectors (data only) are committed under tests/golden/*.npz and
+are what pins oracle/ and the HIP kernels; the reference itself never travels.
+
+Run (build container only; /root/reference does not exist on the GPU box):
+
+    NUMBA_CACHE_DIR=/tmp/numba_cache PYTHONPATH=/root/reference:tests/golden \
+        /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+Each .npz holds the inputs and the reference's outputs for one group:
+  g1_phase_delay.npz   phase_delay      (africanus/rime/phase.py:11)
+  g2_predict_vis.npz   predict_vis      (africanus/rime/predict.py:466), 27 presence/corr combos
+  g3_im_to_vis.npz     im_to_vis        (africanus/dft/kernels.py:14)
+  g4_beam.npz          freq_grid_interp / beam_cube_dde (africanus/rime/fast_beam_cubes.py:10,57)
+  g5_chain_c1.npz      BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr): sampled rows + checksums
+"""
+import os
+import sys
+
+import ref_shim  # noqa: F401  (must come first)
+import numpy as np
+
+from africanus.rime.phase import phase_delay
+from africanus.rime.predict import predict_vis
+from africanus.dft.kernels import im_to_vis
+from africanus.rime.fast_beam_cubes import beam_cube_dde, freq_grid_interp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rc(rng, shape):
+    return rng.random(shape) + 1j * rng.random(shape)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+# ----------------------------------------------------------------------------
+def g1_phase_delay():
+    rng = np.random.default_rng(101)
+    lm = (rng.random((7, 2)) - 0.5) * 0.2
+    lm[3] = [0.8, 0.9]            # l^2 + m^2 > 1 -> clamp branch (phase.py:43)
+    lm[5] = [0.0, 0.0]            # phase centre
+    uvw = (rng.random((33, 3)) - 0.5) * 2e4
+    freq = np.linspace(0.856e9, 1.712e9, 5)
+    out = dict(lm=lm, uvw=uvw, frequency=freq)
+    for conv in ("fourier", "casa"):
+        out["f64_" + conv] = phase_delay(lm, uvw, freq, convention=conv)
+    # float32: small baselines so the float32 phase is meaningful
+    lm32 = lm.astype(np.float32)
+    uvw32 = ((rng.random((33, 3)) - 0.5) * 20).astype(np.float32)
+    freq32 = freq.astype(np.float32)
+    out.update(lm32=lm32, uvw32=uvw32, frequency32=freq32)
+    for conv in ("fourier", "casa"):
+        out["f32_" + conv] = phase_delay(lm32, uvw32, freq32, convention=conv)
+    # the reference's own known-answer case (africanus/rime/tests/test_rime.py:19-47)
+    rng2 = np.random.default_rng(7)
+    uvw_k = rng2.random((100, 3))
+    lm_k = rng2.random((10, 2))
+    freq_k = np.linspace(0.856e9, 0.856e9 * 2, 64, endpoint=True)
+    uvw_k[2] = [1, 2, 3]
+    lm_k[3] = [0.1, 0.2]
+    freq_k[5] = 0.856e9
+    out.update(kat_lm=lm_k, kat_uvw=uvw_k, kat_frequency=freq_k,
+               kat_fourier=phase_delay(lm_k, uvw_k, freq_k, convention="fourier")[3, 2],
+               kat_casa=phase_delay(lm_k, uvw_k, freq_k, convention="casa")[3, 2])
+    save("g1_phase_delay.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+CORR_SHAPES = {"c1": (1,), "c2": (2,), "c22": (2, 2)}
+DDE_PRESENCE = {"ddecoh": (True, True, True), "dde": (True, False, True), "coh": (False, True, False)}
+DIE_PRESENCE = {"diebv": (True, True, True), "die": (True, False, True), "bv": (False, True, False)}
+
+
+def g2_predict_vis():
+    # shapes of africanus/rime/tests/test_predict.py:23-30,85-87
+    s, t, a, c, r = 21, 4, 4, 5, 10
+    time_idx = np.asarray([0, 0, 1, 1, 2, 2, 2, 2, 3, 3])
+    ant1 = np.asarray([0, 0, 0, 0, 1, 1, 1, 2, 2, 3])
+    ant2 = np.asarray([0, 1, 2, 3, 1, 2, 3, 2, 3, 3])
+    out = dict(time_idx=time_idx, ant1=ant1, ant2=ant2)
+    rng = np.random.default_rng(202)
+    for ck, corr_shape in CORR_SHAPES.items():
+        arrs = dict(
+            a1=rc(rng, (s, t, a, c) + corr_shape), bl=rc(rng, (s, r, c) + corr_shape),
+            a2=rc(rng, (s, t, a, c) + corr_shape), g1=rc(rng, (t, a, c) + corr_shape),
+            bv=rc(rng, (r, c) + corr_shape), g2=rc(rng, (t, a, c) + corr_shape))
+        for k, v in arrs.items():
+            out["%s_%s" % (ck, k)] = v
+        for dk, (a1j, blj, a2j) in DDE_PRESENCE.items():
+            for gk, (g1j, bvis, g2j) in DIE_PRESENCE.items():
+                vis = predict_vis(
+                    time_idx, ant1, ant2,
+                    arrs["a1"] if a1j else None, arrs["bl"] if blj else None,
+                    arrs["a2"] if a2j else None, arrs["g1"] if g1j else None,
+                    arrs["bv"] if bvis else None, arrs["g2"] if g2j else None)
+                out["%s_%s_%s_vis" % (ck, dk, gk)] = vis
+        # time index offset + int32 indices (africanus/rime/cuda/tests/test_cuda_predict.py:43-45)
+        vis = predict_vis((time_idx + 10).astype(np.int32), ant1.astype(np.int32),
+                          ant2.astype(np.int32), arrs["a1"], arrs["bl"], arrs["a2"],
+                          arrs["g1"], arrs["bv"], arrs["g2"])
+        out["%s_offset_vis" % ck] = vis
+        # complex64 inputs -> complex64 output
+        a64 = {k: v.astype(np.complex64) for k, v in arrs.items()}
+        out["%s_c64_vis" % ck] = predict_vis(time_idx, ant1, ant2, a64["a1"], a64["bl"], a64["a2"],
+                                             a64["g1"], a64["bv"], a64["g2"])
+    save("g2_predict_vis.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def g3_im_to_vis():
+    rng = np.random.default_rng(303)
+    nsrc, nrow, nchan = 13, 50, 6
+    lm = (rng.random((nsrc, 2)) - 0.5) * 0.1
+    uvw = (rng.random((nrow, 3)) - 0.5) * 8e3
+    uvw[:, 2] *= 0.1
+    freq = np.linspace(0.856e9, 1.712e9, nchan)
+    freq_nonuniform = freq * (1.0 + 0.01 * rng.random(nchan))
+    out = dict(lm=lm, uvw=uvw, frequency=freq, frequency_nonuniform=freq_nonuniform)
+    for ncorr in (1, 2, 4):
+        img_r = rng.standard_normal((nsrc, nchan, ncorr))
+        img_r[rng.random(img_r.shape) < 0.2] = 0.0          # zero pixels are skipped (kernels.py:64)
+        img_c = img_r + 1j * rng.standard_normal(img_r.shape)
+        img_c[rng.random(img_c.shape) < 0.2] = 0.0
+        out["img_r%d" % ncorr] = img_r
+        out["img_c%d" % ncorr] = img_c
+        for conv in ("fourier", "casa"):
+            out["vis_r%d_%s" % (ncorr, conv)] = im_to_vis(img_r, uvw, lm, freq, convention=conv)
+            out["vis_c%d_%s" % (ncorr, conv)] = im_to_vis(img_c, uvw, lm, freq, convention=conv)
+        out["vis_r%d_nonuniform" % ncorr] = im_to_vis(img_r, uvw, lm, freq_nonuniform)
+        out["vis_c%d_nonuniform" % ncorr] = im_to_vis(img_c, uvw, lm, freq_nonuniform)
+        out["vis_r%d_c64" % ncorr] = im_to_vis(img_r, uvw, lm, freq, dtype=np.complex64)
+    # 5 correlations (generic ncorr path) and 70 channels (several channel tiles + remainder)
+    img5 = rng.standard_normal((nsrc, nchan, 5))
+    out["img_r5"] = img5
+    out["vis_r5_fourier"] = im_to_vis(img5, uvw, lm, freq)
+    freq70 = np.linspace(0.9e9, 1.6e9, 70)
+    img70 = rng.standard_normal((nsrc, 70, 4))
+    out.update(frequency70=freq70, img_r70=img70, vis_r70_fourier=im_to_vis(img70, uvw, lm, freq70))
+    # a source outside the unit disc -> NaN phase; only its non-zero pixels poison (kernels.py:54,64)
+    lm_nan = lm.copy()
+    lm_nan[4] = [0.9, 0.8]
+    img_nan = out["img_r4"].copy()
+    img_nan[4, :, :] = 0.0
+    img_nan[4, 2, 1] = 1.5
+    out.update(lm_nan=lm_nan, img_nan=img_nan, vis_nan=im_to_vis(img_nan, uvw, lm_nan, freq))
+    # float32 inputs -> complex64 output (small baselines)
+    uvw32 = (uvw * 1e-3).astype(np.float32)
+    out.update(uvw32=uvw32,
+               vis_f32=im_to_vis(out["img_r4"].astype(np.float32), uvw32,
+                                 lm.astype(np.float32), freq.astype(np.float32)))
+    save("g3_im_to_vis.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def g4_beam():
+    rng = np.random.default_rng(404)
+    # fixtures of africanus/rime/tests/test_fast_beams.py:18-40
+    beam_freq_map = np.array([0.5, 0.56, 0.7, 0.91, 1.0])
+    freqs = np.array([0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1])
+    out = dict(beam_freq_map=beam_freq_map, freqs=freqs,
+               freq_data=freq_grid_interp(freqs, beam_freq_map))
+    src, time, ants, chans = 10, 5, 4, freqs.shape[0]
+    lm = (rng.random((src, 2)) - 0.5) * 1.6          # spans most of the cube, some clamp at edges
+    lm[0] = [1.3, -1.2]                               # outside the extents -> clamped (:150-151)
+    parangles = rng.random((time, ants)) * np.pi / 12
+    point_errors = (rng.random((time, ants, chans, 2)) - 0.5) * 0.05
+    antenna_scaling = 1.0 + (rng.random((ants, chans, 2)) - 0.5) * 0.1
+    extents = np.asarray([[-1.0, 1.0], [-1.0, 1.0]])
+    beam = rc(rng, (10, 10, beam_freq_map.shape[0], 2, 2))
+    beam[3, 4, 2] = 0.0                               # exercise the div == 0 branch neighbourhood
+    out.update(lm=lm, parangles=parangles, point_errors=point_errors,
+               antenna_scaling=antenna_scaling, extents=extents, beam=beam)
+    out["ddes"] = beam_cube_dde(beam, extents, beam_freq_map, lm, parangles, point_errors,
+                                antenna_scaling, freqs)
+    # an all-zero cube: the `div == 0` branch (:229-231)
+    out["ddes_zero"] = beam_cube_dde(np.zeros_like(beam), extents, beam_freq_map, lm[:2], parangles,
+                                     point_errors, antenna_scaling, freqs)
+    # float32 / complex64 and 1 correlation
+    f32 = np.float32
+    out["ddes_f32"] = beam_cube_dde(beam.astype(np.complex64), extents.astype(f32),
+                                    beam_freq_map.astype(f32), lm.astype(f32), parangles.astype(f32),
+                                    point_errors.astype(f32), antenna_scaling.astype(f32),
+                                    freqs.astype(f32))
+    beam1 = np.ascontiguousarray(beam[..., 0, :1])
+    out["ddes_1corr"] = beam_cube_dde(beam1, extents, beam_freq_map, lm, parangles, point_errors,
+                                      antenna_scaling, freqs)
+    # the reference's small known-answer test (test_fast_beams.py:43-127): seed 42 -> 0.470255+0.4786j
+    np.random.seed(42)
+    kb = np.random.random((2, 2, 2, 1)) + 1j * np.random.random((2, 2, 2, 1))
+    out["kat_beam"] = kb
+    out["kat_ddes"] = beam_cube_dde(kb, np.asarray([[-1.0, 1.0], [-1.0, 1.0]]), np.asarray([0.0, 1.0]),
+                                    np.asarray([[0.1, 0.1]]), np.zeros((1, 1)), np.zeros((1, 1, 1, 2)),
+                                    np.ones((1, 1, 2)), np.asarray([0.3]))
+    save("g4_beam.npz", **out)
+
+
+# ----------------------------------------------------------------------------
+def c1_inputs(seed=0, nrow=10000, nchan=16, nsrc=100, nant=7):
+    """Synthetic inputs of SURVEY.md 8(d), shape C1.  Re-implemented identically
+    (same rng call order) in tests/_synth.py so only seeds + samples are stored."""
+    rng = np.random.default_rng(seed)
+    rad = 0.05 * np.sqrt(rng.random(nsrc))
+    ang = 2 * np.pi * rng.random(nsrc)
+    lm = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1)
+    uvw = np.empty((nrow, 3))
+    uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 2] = rng.uniform(-400, 400, nrow)
+    freq = np.linspace(0.856e9, 1.712e9, nchan)
+    stokes_i = rng.lognormal(0.0, 1.0, nsrc)
+    q, u, v = (0.1 * rng.standard_normal(nsrc) for _ in range(3))
+    # linear feeds: [I+Q, U+iV, U-iV, I-Q]
+    bright = np.stack([stokes_i + q, u + 1j * v, u - 1j * v, stokes_i - q], axis=1)  # (src, 4) complex
+    nbl = nant * (nant - 1) // 2
+    a1, a2 = np.triu_indices(nant, 1)
+    ntime = -(-nrow // nbl)
+    ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
+    ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
+    time_index = np.repeat(np.arange(ntime, dtype=np.int32), nbl)[:nrow]
+    return dict(lm=lm, uvw=uvw, frequency=freq, brightness=bright, ant1=ant1, ant2=ant2,
+                time_index=time_index, ntime=ntime, nant=nant, rng=rng)
+
+
+def g5_chain_c1():
+    d = c1_inputs()
+    lm, uvw, freq, bright = d["lm"], d["uvw"], d["frequency"], d["brightness"]
+    nsrc, nchan = lm.shape[0], freq.shape[0]
+    rows = np.linspace(0, uvw.shape[0] - 1, 64).astype(np.int64)
+    out = dict(seed=np.int64(0), sample_rows=rows)
+    # (a) im_to_vis with the real image pattern [I+Q, U, U, I-Q]
+    image_r = np.broadcast_to(bright.real[:, None, :], (nsrc, nchan, 4)).copy()
+    vis = im_to_vis(image_r, uvw, lm, freq)
+    out.update(dft_rows=vis[rows], dft_sum=vis.sum(), dft_abssum=np.abs(vis).sum())
+    # (b) chain phase_delay -> einsum -> predict_vis (africanus/rime/examples/predict.py:107-134,525)
+    phase = phase_delay(lm, uvw, freq)
+    coh = np.einsum("srf,si->srfi", phase, bright).reshape(nsrc, uvw.shape[0], nchan, 2, 2)
+    vis2 = predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, None, None, None)
+    out.update(chain_rows=vis2[rows], chain_sum=vis2.sum(), chain_abssum=np.abs(vis2).sum())
+    # (c) the same with per-antenna DIE gains and a base_vis
+    rng = d["rng"]
+    die = (1.0 + 0.1 * rng.standard_normal((d["ntime"], d["nant"], nchan, 2, 2))
+           + 0.1j * rng.standard_normal((d["ntime"], d["nant"], nchan, 2, 2)))
+    bvis = 0.01 * (rng.standard_normal(vis2.shape) + 1j * rng.standard_normal(vis2.shape))
+    vis3 = predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, die, bvis, die)
+    out.update(die_rows=vis3[rows], die_sum=vis3.sum(), die_abssum=np.abs(vis3).sum())
+    save("g5_chain_c1.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1)
+    for w in which:
+        fns[w]()

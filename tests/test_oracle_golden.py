@@ -1,0 +1,260 @@
+"""
+Pins the CPU oracle (oracle/rime_oracle.c) to the real reference: every oracle
+function is compared with golden vectors captured from codex-africanus' numba
+path (tests/golden/make_golden.py) and with the reference tests' own
+known-answer values.  CPU only.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_array_almost_equal, assert_array_equal
+
+import oracle
+from codex_africanus_amd.testing import synthetic_inputs
+
+CORR = {"c1": (1,), "c2": (2,), "c22": (2, 2)}
+DDE = {"ddecoh": (True, True, True), "dde": (True, False, True), "coh": (False, True, False)}
+DIE = {"diebv": (True, True, True), "die": (True, False, True), "bv": (False, True, False)}
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0
+
+
+# --------------------------------------------------------------------------- phase_delay
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_phase_delay_f64_bit_exact(g1, conv):
+    out = oracle.phase_delay(g1["lm"], g1["uvw"], g1["frequency"], convention=conv)
+    ref = g1["f64_" + conv]
+    assert out.dtype == ref.dtype == np.complex128 and out.shape == ref.shape
+    # same operation order + same libm: identical bits
+    assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_phase_delay_f32(g1, conv):
+    out = oracle.phase_delay(g1["lm32"], g1["uvw32"], g1["frequency32"], convention=conv)
+    ref = g1["f32_" + conv]
+    assert out.dtype == ref.dtype == np.complex64
+    assert maxabs(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("conv, sign", [("fourier", 1), ("casa", -1)])
+def test_phase_delay_reference_kat(g1, conv, sign):
+    """africanus/rime/tests/test_rime.py:19-47 (exact equality there)."""
+    out = oracle.phase_delay(g1["kat_lm"], g1["kat_uvw"], g1["kat_frequency"], convention=conv)
+    minus_two_pi_over_c = -2 * np.pi / 2.99792458e8
+    u, v, w, l, m, freq = 1, 2, 3, 0.1, 0.2, 0.856e9
+    n = np.sqrt(1.0 - l**2 - m**2) - 1.0
+    phase = sign * minus_two_pi_over_c * (u * l + v * m + w * n) * freq
+    assert np.exp(1j * phase) == out[3, 2, 5]
+    assert out[3, 2, 5] == g1["kat_" + conv][5]
+
+
+def test_phase_delay_bad_convention(g1):
+    with pytest.raises(ValueError):
+        oracle.phase_delay(g1["lm"], g1["uvw"], g1["frequency"], convention="bob")
+
+
+# --------------------------------------------------------------------------- predict_vis
+@pytest.mark.parametrize("ck", list(CORR))
+@pytest.mark.parametrize("dk", list(DDE))
+@pytest.mark.parametrize("gk", list(DIE))
+def test_predict_vis_27_combos_bit_exact(g2, ck, dk, gk):
+    a1j, blj, a2j = DDE[dk]
+    g1j, bvis, g2j = DIE[gk]
+    get = lambda k: g2["%s_%s" % (ck, k)]
+    out = oracle.predict_vis(
+        g2["time_idx"], g2["ant1"], g2["ant2"],
+        get("a1") if a1j else None, get("bl") if blj else None, get("a2") if a2j else None,
+        get("g1") if g1j else None, get("bv") if bvis else None, get("g2") if g2j else None)
+    ref = g2["%s_%s_%s_vis" % (ck, dk, gk)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("ck", list(CORR))
+def test_predict_vis_einsum_identity(g2, ck):
+    """africanus/rime/tests/test_predict.py:110-126 (6 decimals there)."""
+    sig1, sig2 = (("srcij,srcjk,srclk->rcil", "rcij,rcjk,rclk->rcil") if ck == "c22"
+                  else ("srci,srci,srci->rci", "rci,rci,rci->rci"))
+    get = lambda k: g2["%s_%s" % (ck, k)]
+    ti, a1, a2 = g2["time_idx"], g2["ant1"], g2["ant2"]
+    out = oracle.predict_vis(ti, a1, a2, get("a1"), get("bl"), get("a2"), get("g1"), get("bv"), get("g2"))
+    v = np.einsum(sig1, get("a1")[:, ti, a1], get("bl"), get("a2")[:, ti, a2].conj()) + get("bv")
+    v = np.einsum(sig2, get("g1")[ti, a1], v, get("g2")[ti, a2].conj())
+    assert_array_almost_equal(v, out)
+
+
+@pytest.mark.parametrize("ck", list(CORR))
+def test_predict_vis_time_offset_and_int32(g2, ck):
+    get = lambda k: g2["%s_%s" % (ck, k)]
+    out = oracle.predict_vis((g2["time_idx"] + 10).astype(np.int32), g2["ant1"].astype(np.int32),
+                             g2["ant2"].astype(np.int32), get("a1"), get("bl"), get("a2"),
+                             get("g1"), get("bv"), get("g2"))
+    assert_array_equal(out, g2["%s_offset_vis" % ck])
+
+
+@pytest.mark.parametrize("ck", list(CORR))
+def test_predict_vis_c64(g2, ck):
+    get = lambda k: g2["%s_%s" % (ck, k)].astype(np.complex64)
+    out = oracle.predict_vis(g2["time_idx"], g2["ant1"], g2["ant2"], get("a1"), get("bl"), get("a2"),
+                             get("g1"), get("bv"), get("g2"))
+    ref = g2["%s_c64_vis" % ck]
+    assert out.dtype == ref.dtype == np.complex64
+    assert_array_equal(out, ref)
+
+
+# --------------------------------------------------------------------------- im_to_vis
+@pytest.mark.parametrize("ncorr", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["r", "c"])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_im_to_vis_bit_exact(g3, ncorr, kind, conv):
+    img = g3["img_%s%d" % (kind, ncorr)]
+    out = oracle.im_to_vis(img, g3["uvw"], g3["lm"], g3["frequency"], convention=conv)
+    ref = g3["vis_%s%d_%s" % (kind, ncorr, conv)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("key, img, freq", [
+    ("vis_r4_nonuniform", "img_r4", "frequency_nonuniform"),
+    ("vis_c2_nonuniform", "img_c2", "frequency_nonuniform"),
+    ("vis_r5_fourier", "img_r5", "frequency"),
+    ("vis_r70_fourier", "img_r70", "frequency70"),
+])
+def test_im_to_vis_other_shapes(g3, key, img, freq):
+    out = oracle.im_to_vis(g3[img], g3["uvw"], g3["lm"], g3[freq])
+    assert_array_equal(out, g3[key])
+
+
+def test_im_to_vis_nan_source(g3):
+    out = oracle.im_to_vis(g3["img_nan"], g3["uvw"], g3["lm_nan"], g3["frequency"])
+    ref = g3["vis_nan"]
+    assert np.isnan(ref[:, 2, 1]).all() and np.isnan(ref).sum() == ref.shape[0]
+    assert_array_equal(np.isnan(out), np.isnan(ref))
+    assert_array_equal(out[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+def test_im_to_vis_c64_output(g3):
+    out = oracle.im_to_vis(g3["img_r4"], g3["uvw"], g3["lm"], g3["frequency"], dtype=np.complex64)
+    ref = g3["vis_r4_c64"]
+    assert out.dtype == ref.dtype == np.complex64
+    assert_array_equal(out, ref)
+
+
+def test_im_to_vis_f32_inputs(g3):
+    out = oracle.im_to_vis(g3["img_r4"].astype(np.float32), g3["uvw32"],
+                           g3["lm"].astype(np.float32), g3["frequency"].astype(np.float32))
+    ref = g3["vis_f32"]
+    assert out.dtype == ref.dtype == np.complex64
+    # inputs are promoted to float64 in the oracle; numba mixes float32 products in
+    assert maxabs(out, ref) < 5e-4 * np.abs(ref).max()
+
+
+def test_im_to_vis_omp_matches_serial(g3):
+    a = oracle.im_to_vis(g3["img_c4"], g3["uvw"], g3["lm"], g3["frequency"], omp=False)
+    b = oracle.im_to_vis(g3["img_c4"], g3["uvw"], g3["lm"], g3["frequency"], omp=True)
+    assert_array_equal(a, b)
+
+
+def test_im_to_vis_fft_kat():
+    """africanus/dft/tests/test_dft.py:86-133: DFT on a regular grid == FFT."""
+    rng = np.random.default_rng(123)
+    Fs, iFs = np.fft.fftshift, np.fft.ifftshift
+    npix, nsource = 29, 25
+    image = np.zeros((npix, npix, 1))
+    image[rng.integers(5, npix - 5, nsource), rng.integers(5, npix - 5, nsource), 0] = \
+        rng.standard_normal(nsource)
+    fft_image = Fs(np.fft.fft2(iFs(image[:, :, 0])))[:, :, None]
+    deltal = 0.001
+    l_coord = np.arange(-(npix // 2), npix // 2 + 1) * deltal
+    ll, mm = np.meshgrid(l_coord, l_coord)
+    lm = np.vstack((ll.flatten(), mm.flatten())).T
+    u = Fs(np.fft.fftfreq(npix, d=deltal))
+    uu, vv = np.meshgrid(u, u)
+    uvw = np.zeros((npix**2, 3))
+    uvw[:, 0], uvw[:, 1] = uu.flatten(), vv.flatten()
+    frequency = np.ones(1) * 2.99792458e8
+    for conv in ("fourier", "casa"):
+        vis = oracle.im_to_vis(image.reshape(npix**2, 1, 1), uvw, lm, frequency, convention=conv)
+        ref = fft_image.reshape(npix**2, 1, 1)
+        ref = np.conj(ref) if conv == "casa" else ref
+        assert_array_almost_equal(vis, ref, decimal=13)
+
+
+# --------------------------------------------------------------------------- beams
+def test_freq_grid_interp_kat(g4):
+    """africanus/rime/tests/test_fast_beams.py:130-150."""
+    fd = oracle.freq_grid_interp(g4["freqs"], g4["beam_freq_map"])
+    assert_array_equal(fd, g4["freq_data"])
+    assert_array_almost_equal(fd[:, 0], [0.8, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.1])
+    assert_array_equal(np.int32(fd[:, 2]), [0, 0, 1, 2, 2, 2, 3, 3])
+    assert_array_almost_equal(fd[:, 1], [1.0, 1.0, 0.71428571, 1.0, 0.52380952, 0.04761905, 0.0, 0.0])
+
+
+def _beam_args(g4, lm=None, beam=None, dtype=None):
+    args = [g4["beam"] if beam is None else beam, g4["extents"], g4["beam_freq_map"],
+            g4["lm"] if lm is None else lm, g4["parangles"], g4["point_errors"],
+            g4["antenna_scaling"], g4["freqs"]]
+    if dtype is not None:
+        args = [a.astype(np.complex64 if np.iscomplexobj(a) else dtype) for a in args]
+    return args
+
+
+def test_beam_cube_dde_golden(g4):
+    out = oracle.beam_cube_dde(*_beam_args(g4))
+    ref = g4["ddes"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert maxabs(out, ref) < 1e-15
+    out0 = oracle.beam_cube_dde(*_beam_args(g4, lm=g4["lm"][:2], beam=np.zeros_like(g4["beam"])))
+    assert_array_equal(out0, g4["ddes_zero"])
+    beam1 = np.ascontiguousarray(g4["beam"][..., 0, :1])
+    out1 = oracle.beam_cube_dde(*_beam_args(g4, beam=beam1))
+    assert maxabs(out1, g4["ddes_1corr"]) < 1e-15
+
+
+def test_beam_cube_dde_f32(g4):
+    out = oracle.beam_cube_dde(*_beam_args(g4, dtype=np.float32))
+    ref = g4["ddes_f32"]
+    assert out.dtype == ref.dtype == np.complex64
+    assert maxabs(out, ref) < 1e-5
+
+
+def test_beam_cube_dde_reference_kat(g4):
+    """africanus/rime/tests/test_fast_beams.py:43-127: seed 42 -> 0.470255+0.4786j."""
+    ddes = oracle.beam_cube_dde(g4["kat_beam"], np.asarray([[-1.0, 1.0], [-1.0, 1.0]]),
+                                np.asarray([0.0, 1.0]), np.asarray([[0.1, 0.1]]), np.zeros((1, 1)),
+                                np.zeros((1, 1, 1, 2)), np.ones((1, 1, 2)), np.asarray([0.3]))
+    assert_array_almost_equal([[[[[0.470255 + 0.4786j]]]]], ddes)
+    assert maxabs(ddes, g4["kat_ddes"]) < 1e-16
+    with pytest.raises(ValueError):
+        oracle.beam_cube_dde(g4["kat_beam"][:1], np.asarray([[-1.0, 1.0], [-1.0, 1.0]]),
+                             np.asarray([0.0, 1.0]), np.asarray([[0.1, 0.1]]), np.zeros((1, 1)),
+                             np.zeros((1, 1, 1, 2)), np.ones((1, 1, 2)), np.asarray([0.3]))
+
+
+# --------------------------------------------------------------------------- C1 chain
+def test_chain_c1_samples_and_checksums(g5):
+    """BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr): oracle vs the
+    reference's sampled rows and whole-array checksums."""
+    d = synthetic_inputs(seed=int(g5["seed"]), nrow=10000, nchan=16, nsrc=100, nant=7)
+    rows = g5["sample_rows"]
+    image_r = np.broadcast_to(d["brightness"].real[:, None, :], (100, 16, 4)).copy()
+    vis = oracle.im_to_vis(image_r, d["uvw"], d["lm"], d["frequency"], omp=True)
+    assert_array_equal(vis[rows], g5["dft_rows"])
+    assert abs(vis.sum() - g5["dft_sum"]) <= 1e-9 * abs(g5["dft_sum"])
+    assert abs(np.abs(vis).sum() - g5["dft_abssum"]) <= 1e-12 * g5["dft_abssum"]
+
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"])
+    coh = np.einsum("srf,si->srfi", phase, d["brightness"]).reshape(100, 10000, 16, 2, 2)
+    vis2 = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, None, None, None)
+    assert_array_equal(vis2[rows], g5["chain_rows"])
+    assert abs(np.abs(vis2).sum() - g5["chain_abssum"]) <= 1e-12 * g5["chain_abssum"]
+
+    rng = d["rng"]
+    shp = (d["ntime"], d["nant"], 16, 2, 2)
+    die = 1.0 + 0.1 * rng.standard_normal(shp) + 0.1j * rng.standard_normal(shp)
+    bvis = 0.01 * (rng.standard_normal(vis2.shape) + 1j * rng.standard_normal(vis2.shape))
+    vis3 = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, die, bvis, die)
+    assert_array_equal(vis3[rows], g5["die_rows"])
+    assert abs(np.abs(vis3).sum() - g5["die_abssum"]) <= 1e-12 * g5["die_abssum"]
