@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the RIME visibility-predict hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+    vis = im_to_vis(image, uvw, lm, frequency)       # direct-transform predict, BASELINE configs[1]
+    chi2[nu] = sum |data - vis|^2                    # per-channel chi^2 of the shard
+    (N > 1) RCCL all-reduce of chi2 over xGMI         # the only cross-GPU exchange of the path
+at the shape BASELINE.json's metric is quoted on: 1e6 rows x 64 chan x 1000 point sources x
+4 corr, fp64, PER GPU (rows shard across GPUs, weak scaling: BASELINE configs[3] is 8e6 rows
+on 8 GPUs).  Metric: Mvis/s = rows x chans / second / 1e6 (whole job).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R --chans C --sources S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  "roofline"     for the dominant kernel (dft_recurrence_kernel): algorithmic HBM bytes per
+                 launch / its average duration measured with HIP events on its own stream,
+                 against the 8 TB/s HBM peak -- plus the fp64-VALU fraction that actually
+                 bounds it ("Rooflines");
+  "cpu_baseline" the CPU oracle (C restatement of the numba loop, OpenMP over rows) timed on
+                 this box's host cores on a bounded row sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--rows", type=int, default=1000000, help="rows PER GPU")
+    p.add_argument("--chans", type=int, default=64)
+    p.add_argument("--sources", type=int, default=1000)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
+    p.add_argument("--check-rows", type=int, default=256, help="rows checked against the oracle")
+    return p.parse_args()
+
+
+def cpu_baseline(image, uvw, lm, freq, target_core_seconds):
+    """Time the CPU oracle (kind 'port') on a bounded row sample; OpenMP over rows."""
+    import oracle
+    nchan, nsrc = freq.shape[0], lm.shape[0]
+    threads = oracle.num_threads(omp=True)
+    # calibrate on a few rows, single thread
+    t0 = time.perf_counter()
+    oracle.im_to_vis(image, uvw[:16], lm, freq, omp=False)
+    per_row = (time.perf_counter() - t0) / 16
+    rows = int(max(threads * 8, min(uvw.shape[0], target_core_seconds / per_row)))
+    rows -= rows % threads
+    t0 = time.perf_counter()
+    oracle.im_to_vis(image, uvw[:rows], lm, freq, omp=True)
+    dt = time.perf_counter() - t0
+    return {
+        "value": rows * nchan / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+        "sample": "oracle im_to_vis (C restatement of africanus/dft/kernels.py:33-67, OpenMP over rows), "
+                  "%d rows x %d chan x %d src x 4 corr fp64 in %.2f s; linear in rows; "
+                  "single-thread rate %.4f Mvis/s" % (rows, nchan, nsrc, dt, nchan / per_row / 1e6),
+        "single_thread_value": nchan / per_row / 1e6,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from codex_africanus_amd import _lib
+    from codex_africanus_amd.testing import synthetic_inputs, real_image
+    lib = _lib.load()
+
+    nrow, nchan, nsrc, ncorr = args.rows, args.chans, args.sources, 4
+    # every rank draws the same sky and its own uvw shard (seed + rank): rows are independent
+    d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
+    rng = np.random.default_rng(1000 + args.seed + rank)
+    uvw = np.empty((nrow, 3))
+    uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 2] = rng.uniform(-400, 400, nrow)
+    image = real_image(d)
+    lm, freq = d["lm"], d["frequency"]
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_image, d_uvw, d_lm, d_freq = t(image), t(uvw), t(lm), t(freq)
+    d_vis = torch.empty((nrow, nchan, ncorr), dtype=torch.complex128, device=dev)
+    d_chi2 = torch.zeros(nchan, dtype=torch.float64, device=dev)
+    ws_bytes = int(lib.af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, 0))
+    d_ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    mode = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE}[args.mode]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+
+    def predict():
+        _lib.call("af_im_to_vis_f64", P(d_image), 0, P(d_uvw), P(d_lm), P(d_freq), nsrc, nrow, nchan, ncorr,
+                  _lib.CONVENTION["fourier"], mode, P(d_vis), P(d_ws), ws_bytes, stream)
+
+    # "observed" data for the chi^2: the model itself plus a fixed perturbation (one extra predict)
+    predict()
+    d_data = d_vis.clone()
+    d_data += 0.01
+
+    def step():
+        predict()
+        _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
+        if world > 1:
+            dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+
+    # HIP events around the dominant kernel of every timed step, on its own stream
+    evs = []
+    for _ in range(args.steps):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("af_event_create", ctypes.byref(a))
+        _lib.call("af_event_create", ctypes.byref(b))
+        evs.append((a, b))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        _lib.call("af_profile_events", evs[k][0], evs[k][1])
+        step()
+    _lib.call("af_profile_events", None, None)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel_ms = []
+    for a, b in evs:
+        ms = ctypes.c_float(0)
+        _lib.call("af_event_elapsed_ms", a, b, ctypes.byref(ms))
+        kernel_ms.append(ms.value)
+        _lib.call("af_event_destroy", a)
+        _lib.call("af_event_destroy", b)
+    kernel_s = float(np.mean(kernel_ms)) / 1e3 if kernel_ms else float("nan")
+
+    # parity of the benchmarked output against the CPU oracle on a row sample (checker only)
+    max_err = None
+    if rank == 0 and args.check_rows > 0:
+        import oracle
+        rows = np.linspace(0, nrow - 1, min(args.check_rows, nrow)).astype(np.int64)
+        ref = oracle.im_to_vis(image, uvw[rows], lm, freq, omp=True)
+        got = d_vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        max_err = float(np.abs(got - ref).max())
+
+    if rank == 0:
+        total_vis = world * nrow * nchan
+        ms_per_step = elapsed / args.steps * 1e3
+        # algorithmic HBM bytes of one dft kernel launch: 64 B written per vis +
+        # uvw 24 B/row + packed real image + lmn; the kernel reads nothing else from HBM
+        alg_bytes = nrow * nchan * ncorr * 16 + nrow * 24 + nsrc * nchan * ncorr * 8 + nsrc * 32
+        # algorithmic flops: per (row, chan, src) one complex phasor step (recurrence, 2 FMA) +
+        # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop
+        alg_flops = float(nrow) * nchan * nsrc * (2 + 2 * ncorr) * 2
+        achieved = alg_bytes / kernel_s / 1e9
+        out = {
+            "metric": "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err",
+            "value": total_vis / (elapsed / args.steps) / 1e6,
+            "unit": "Mvis/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "im_to_vis DFT predict (BASELINE configs[1]) + per-channel chi^2"
+                            + (" + RCCL all-reduce" if world > 1 else ""),
+                "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": ncorr,
+                "rows_total": world * nrow, "phasor_mode": args.mode,
+                "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce" % world,
+            },
+            "fp64_max_abs_err": max_err,
+            "roofline": {
+                "kernel": "dft_recurrence_kernel<13,4,false,6>" if args.mode != "exact" else "dft_exact_kernel",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
+                "note": "fp64-VALU-bound, not HBM-bound: nsrc=1000 phasors per 64-byte visibility",
+                "fp64_valu": {"achieved": alg_flops / kernel_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": alg_flops / kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                              "algorithmic_flops": alg_flops},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(image, uvw, lm, freq, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""
+Device-buffer plumbing between the reference's array-in / array-out signatures
+and the device-pointer C ABI.
+
+Two modes, chosen per call:
+  * host mode   -- every array argument is a numpy array (or array-like): inputs are
+                   uploaded with af_malloc / af_memcpy_h2d, the result comes back as a
+                   fresh numpy array (the reference's contract);
+  * device mode -- at least one argument is a torch tensor on a ROCm device: tensors are
+                   used in place (zero copy), numpy arguments are uploaded, and the result
+                   is a torch tensor on that device, enqueued on torch's current stream.
+PyTorch is only plumbing here (device memory and streams); no torch op does arithmetic
+of the path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+_TORCH_DTYPES = None
+
+
+def _torch_dtype(np_dtype):
+    global _TORCH_DTYPES
+    import torch
+    if _TORCH_DTYPES is None:
+        _TORCH_DTYPES = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                         np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128,
+                         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+    return _TORCH_DTYPES[np.dtype(np_dtype)]
+
+
+def np_dtype_of(x):
+    """numpy dtype of a numpy array / torch tensor / array-like."""
+    if _is_torch(x):
+        import torch
+        return np.dtype({torch.float32: np.float32, torch.float64: np.float64,
+                         torch.complex64: np.complex64, torch.complex128: np.complex128,
+                         torch.int32: np.int32, torch.int64: np.int64, torch.int16: np.int16,
+                         torch.int8: np.int8, torch.uint8: np.uint8, torch.bool: np.bool_}[x.dtype])
+    return np.asarray(x).dtype if not hasattr(x, "dtype") else np.dtype(x.dtype)
+
+
+class _OwnedBuffer(object):
+    """Device memory owned by libafhip (host mode)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        _lib.call("af_malloc", ctypes.byref(p), max(self.nbytes, 1))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            _lib.call("af_free", self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Call(object):
+    """Marshals the arrays of ONE API call; use as a context manager."""
+
+    def __init__(self, *arrays):
+        self.torch_device = None
+        for a in arrays:
+            if a is not None and _is_torch(a):
+                if not a.is_cuda:
+                    raise ValueError("torch tensors passed to codex_africanus_amd must live on a ROCm device")
+                if self.torch_device is None:
+                    self.torch_device = a.device
+                elif a.device != self.torch_device:
+                    raise ValueError("all torch tensors of one call must be on the same device")
+        self.device_mode = self.torch_device is not None
+        self._keep = []
+        self._owned = []
+        self._dev_ctx = None
+        self.stream = None
+
+    def __enter__(self):
+        if self.device_mode:
+            import torch
+            self._dev_ctx = torch.cuda.device(self.torch_device)
+            self._dev_ctx.__enter__()
+            self.stream = ctypes.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
+        else:
+            _lib.load()
+            self.stream = None  # default stream of the thread's current device
+        return self
+
+    def __exit__(self, *exc):
+        for b in self._owned:
+            b.free()
+        self._owned = []
+        self._keep = []
+        if self._dev_ctx is not None:
+            self._dev_ctx.__exit__(*exc)
+        return False
+
+    # ---- inputs -------------------------------------------------------------------
+    def inp(self, a, dtype):
+        """Device pointer of `a` converted to `dtype`, C-contiguous (None -> NULL)."""
+        if a is None:
+            return None
+        dtype = np.dtype(dtype)
+        if self.device_mode:
+            import torch
+            if _is_torch(a):
+                t = a
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(self.torch_device)
+            td = _torch_dtype(dtype)
+            if t.dtype != td:
+                t = t.to(td)
+            t = t.contiguous()
+            self._keep.append(t)
+            return ctypes.c_void_p(t.data_ptr())
+        arr = np.ascontiguousarray(a, dtype=dtype)
+        buf = _OwnedBuffer(arr.nbytes)
+        self._owned.append(buf)
+        self._keep.append(arr)
+        if arr.nbytes:
+            _lib.call("af_memcpy_h2d", buf.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, self.stream)
+        return ctypes.c_void_p(buf.ptr)
+
+    def scratch(self, nbytes):
+        nbytes = int(max(nbytes, 256))
+        if self.device_mode:
+            import torch
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.torch_device)
+            self._keep.append(t)
+            return ctypes.c_void_p(t.data_ptr())
+        buf = _OwnedBuffer(nbytes)
+        self._owned.append(buf)
+        return ctypes.c_void_p(buf.ptr)
+
+    # ---- outputs --------------------------------------------------------------------
+    def out(self, shape, dtype):
+        """Allocate the result; returns (device pointer, handle for `result`)."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in shape)
+        if self.device_mode:
+            import torch
+            t = torch.empty(shape, dtype=_torch_dtype(dtype), device=self.torch_device)
+            return ctypes.c_void_p(t.data_ptr()), t
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        buf = _OwnedBuffer(nbytes)
+        self._owned.append(buf)
+        return ctypes.c_void_p(buf.ptr), (buf, shape, dtype)
+
+    def result(self, handle, cast=None):
+        """Materialise the result: torch tensor (device mode) or numpy array (host mode)."""
+        if self.device_mode:
+            return handle if cast is None else handle.to(_torch_dtype(cast))
+        buf, shape, dtype = handle
+        arr = np.empty(shape, dtype=dtype)
+        if arr.nbytes:
+            _lib.call("af_memcpy_d2h", arr.ctypes.data_as(ctypes.c_void_p), buf.ptr, arr.nbytes, self.stream)
+        _lib.call("af_stream_synchronize", self.stream)
+        return arr if cast is None else arr.astype(cast, copy=False)

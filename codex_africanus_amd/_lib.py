@@ -1,0 +1,158 @@
+"""
+ctypes binding of libafhip.so (C ABI declared in include/afhip.h).
+
+The shared library is built in-tree (codex_africanus_amd/lib/libafhip.so) by
+``build()`` / ``make -C codex_africanus_amd/csrc``; there is no CPU fallback: if
+the library is missing, loading raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libafhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+AF_OK, AF_EINVAL, AF_ENOMEM, AF_ENOTSUP, AF_EHIP_BASE = 0, 1, 2, 3, 1000
+CONVENTION = {"fourier": -1, "casa": 1}
+AF_DFT_AUTO, AF_DFT_EXACT, AF_DFT_RECURRENCE = 0, 1, 2
+AF_JONES_DIAG, AF_JONES_2X2 = 1, 2
+
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/afhip.h one to one
+_SIGNATURES = {
+    "af_version": (_int, []),
+    "af_last_error": (ctypes.c_char_p, []),
+    "af_device_count": (_int, [ctypes.POINTER(_int)]),
+    "af_set_device": (_int, [_int]),
+    "af_get_device": (_int, [ctypes.POINTER(_int)]),
+    "af_device_info": (_int, [_int, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz, ctypes.POINTER(_int),
+                              ctypes.POINTER(_sz)]),
+    "af_malloc": (_int, [ctypes.POINTER(_vp), _sz]),
+    "af_free": (_int, [_vp]),
+    "af_malloc_host": (_int, [ctypes.POINTER(_vp), _sz]),
+    "af_free_host": (_int, [_vp]),
+    "af_memcpy_h2d": (_int, [_vp, _vp, _sz, _vp]),
+    "af_memcpy_d2h": (_int, [_vp, _vp, _sz, _vp]),
+    "af_memcpy_d2d": (_int, [_vp, _vp, _sz, _vp]),
+    "af_memset": (_int, [_vp, _int, _sz, _vp]),
+    "af_stream_create": (_int, [ctypes.POINTER(_vp)]),
+    "af_stream_destroy": (_int, [_vp]),
+    "af_stream_synchronize": (_int, [_vp]),
+    "af_device_synchronize": (_int, []),
+    "af_event_create": (_int, [ctypes.POINTER(_vp)]),
+    "af_event_destroy": (_int, [_vp]),
+    "af_event_record": (_int, [_vp, _vp]),
+    "af_event_synchronize": (_int, [_vp]),
+    "af_event_elapsed_ms": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "af_profile_events": (_int, [_vp, _vp]),
+    "af_convert_f32_to_f64": (_int, [_vp, _vp, _i64, _vp]),
+    "af_convert_f64_to_f32": (_int, [_vp, _vp, _i64, _vp]),
+    "af_phase_delay_f64": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp]),
+    "af_phase_delay_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp]),
+    "af_im_to_vis_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "af_im_to_vis_f64": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz,
+                                _vp]),
+    "af_predict_vis_workspace_bytes": (_sz, []),
+    "af_predict_vis_c128": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                   _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "af_predict_vis_c64": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                  _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "af_freq_grid_interp_f64": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "af_freq_grid_interp_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "af_beam_cube_dde_c128": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp,
+                                     _vp, _vp, _i64, _vp, _vp, _vp]),
+    "af_beam_cube_dde_c64": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp,
+                                    _vp, _vp, _i64, _vp, _vp, _vp]),
+    "af_chi2_c128": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class AfHipError(RuntimeError):
+    """A HIP runtime failure reported by libafhip (status >= AF_EHIP_BASE)."""
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into codex_africanus_amd/lib/libafhip.so."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "afhip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", CSRC, "-j", "4", "all"]
+        if force:
+            cmd.insert(1, "-B")
+        subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load libafhip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        "libafhip.so not found at %s: build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                        "`make -C codex_africanus_amd/csrc`" % LIB_PATH)
+                lib = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(lib, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = lib
+    return _lib
+
+
+def check(status, lib=None):
+    """Map a libafhip status to the exception the reference raises for it."""
+    if status == AF_OK:
+        return
+    lib = lib or load()
+    msg = lib.af_last_error().decode("utf-8", "replace")
+    if status == AF_EINVAL:
+        raise ValueError(msg)
+    if status == AF_ENOMEM:
+        raise MemoryError(msg)
+    if status == AF_ENOTSUP:
+        raise NotImplementedError(msg)
+    raise AfHipError("libafhip status %d: %s" % (status, msg))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), lib)
+
+
+def device_count():
+    n = _int(0)
+    call("af_device_count", ctypes.byref(n))
+    return n.value
+
+
+def set_device(device):
+    call("af_set_device", int(device))
+
+
+def get_device():
+    d = _int(0)
+    call("af_get_device", ctypes.byref(d))
+    return d.value
+
+
+def device_info(device=None):
+    device = get_device() if device is None else device
+    name, arch = ctypes.create_string_buffer(256), ctypes.create_string_buffer(256)
+    cus, mem = _int(0), _sz(0)
+    call("af_device_info", device, name, 256, arch, 256, ctypes.byref(cus), ctypes.byref(mem))
+    return dict(name=name.value.decode(), arch=arch.value.decode(), compute_units=cus.value,
+                total_mem=mem.value)

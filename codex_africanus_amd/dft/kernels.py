@@ -1,0 +1,67 @@
+"""im_to_vis with the signature of africanus/dft/kernels.py:14-16."""
+import os
+
+import numpy as np
+
+from .. import _lib
+from .._device import Call, np_dtype_of
+
+_MODES = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE}
+_mode = os.environ.get("AFHIP_DFT_MODE", "auto")
+if _mode not in _MODES:
+    raise ValueError("AFHIP_DFT_MODE must be one of %s" % sorted(_MODES))
+
+
+def set_mode(mode):
+    """Phasor evaluation: 'auto' (channel recurrence when ``frequency`` is uniformly
+    spaced, decided on the device; otherwise the exact path), 'exact' (reference operation
+    order + full-accuracy sincos per (row, source, chan)), 'recurrence' (force)."""
+    global _mode
+    if mode not in _MODES:
+        raise ValueError("mode must be one of %s" % sorted(_MODES))
+    _mode = mode
+
+
+def get_mode():
+    return _mode
+
+
+def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
+    """
+    Direct Fourier transform image -> visibilities,
+    ``vis[r,nu,c] = sum_s exp(-+2 pi i (u l + v m + w (n-1)) nu / c) * image[s,nu,c]``.
+
+    Same contract as ``africanus.dft.im_to_vis`` (africanus/dft/kernels.py:14-69):
+    ``image`` (source, chan, corr) real or complex, ``uvw`` (row, 3), ``lm`` (source, 2),
+    ``frequency`` (chan,) -> complex (row, chan, corr); output dtype ``dtype`` or
+    ``result_type(complex64, image, uvw, lm, frequency)``; ``n`` is NOT clamped (NaN outside
+    the unit disc, kernels.py:54) and zero pixels are skipped (kernels.py:64).
+    Arithmetic is always float64 on the device; a complex64 result is rounded once at the end.
+    """
+    if convention not in _lib.CONVENTION:
+        raise ValueError("convention not in ('fourier', 'casa')")
+    img_dt = np_dtype_of(image)
+    if dtype is None:
+        out_dtype = np.result_type(np.complex64, img_dt, *[np_dtype_of(a) for a in (uvw, lm, frequency)])
+    else:
+        out_dtype = np.dtype(dtype)
+    if len(image.shape) != 3:
+        raise ValueError("image must have shape (source, chan, corr)")
+    if len(uvw.shape) != 2 or uvw.shape[1] != 3:
+        raise ValueError("uvw must have shape (row, 3)")
+    if len(lm.shape) != 2 or lm.shape[1] != 2:
+        raise ValueError("lm must have shape (source, 2)")
+    nsrc, nchan, ncorr = (int(s) for s in image.shape)
+    nrow = int(uvw.shape[0])
+    if int(lm.shape[0]) != nsrc or tuple(frequency.shape) != (nchan,):
+        raise ValueError("image (source, chan, corr), lm (source, 2) and frequency (chan,) disagree")
+    is_cplx = img_dt.kind == "c"
+    with Call(image, uvw, lm, frequency) as c:
+        p_img = c.inp(image, np.complex128 if is_cplx else np.float64)
+        p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)
+        p_out, h = c.out((nrow, nchan, ncorr), np.complex128)
+        ws_bytes = _lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, int(is_cplx))
+        p_ws = c.scratch(ws_bytes)
+        _lib.call("af_im_to_vis_f64", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
+                  _lib.CONVENTION[convention], _MODES[_mode], p_out, p_ws, max(int(ws_bytes), 256), c.stream)
+        return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)

@@ -1,0 +1,188 @@
+/*
+ * afhip.h -- C ABI of libafhip.so: the MI355X (gfx950) implementation of
+ * codex-africanus' RIME visibility-predict hot path.
+ *
+ * Every entry point replaces one function of the reference (file:line given
+ * per declaration, paths relative to the reference tree).  The ABI is plain C:
+ * raw pointers, explicit extents, an int status.  Unless a declaration says
+ * otherwise, data pointers are DEVICE pointers (HBM) and `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream); calls are
+ * asynchronous with respect to the host and never synchronise the device.
+ * Complex arrays are interleaved (re, im) pairs of the stated real type;
+ * all arrays are C-contiguous with the reference's axis order.
+ *
+ * Status: 0 = AF_OK, AF_EINVAL = bad argument, AF_ENOMEM, AF_ENOTSUP,
+ * >= AF_EHIP_BASE = AF_EHIP_BASE + hipError_t.  af_last_error() returns a
+ * thread-local message for the last failing call on this thread.
+ *
+ * Thread safety: all entry points are re-entrant; there is no global mutable
+ * state besides per-thread error text (reference kernels are nogil and called
+ * concurrently from dask worker threads, africanus/util/numba.py:9-12).
+ */
+#ifndef AFHIP_H
+#define AFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AF_OK 0
+#define AF_EINVAL 1
+#define AF_ENOMEM 2
+#define AF_ENOTSUP 3
+#define AF_EHIP_BASE 1000
+
+/* sign conventions: africanus/rime/phase.py:29-34, africanus/dft/kernels.py:34-39 */
+#define AF_CONVENTION_FOURIER (-1) /* exp(-2 pi i ...) : minus_two_pi_over_c */
+#define AF_CONVENTION_CASA (+1)    /* exp(+2 pi i ...) : two_pi_over_c       */
+
+/* im_to_vis / fused-predict phasor evaluation modes */
+#define AF_DFT_AUTO 0       /* channel recurrence when `frequency` is uniformly spaced
+                               (decided on the device, no host sync), else AF_DFT_EXACT */
+#define AF_DFT_EXACT 1      /* reference operation order + full-accuracy sincos per (row,src,chan) */
+#define AF_DFT_RECURRENCE 2 /* force the recurrence (caller asserts uniform spacing) */
+
+/* Jones layouts: africanus/rime/predict.py:10-12 */
+#define AF_JONES_DIAG 1 /* JONES_1_OR_2: corr shape (1,) or (2,), element-wise products */
+#define AF_JONES_2X2 2  /* JONES_2X2:    corr shape (2,2), 2x2 matrix products */
+
+/* ---- runtime -------------------------------------------------------------- */
+int af_version(void);
+/* thread-local text of the last error on the calling thread ("" if none) */
+const char *af_last_error(void);
+int af_device_count(int *count);
+int af_set_device(int device);
+int af_get_device(int *device);
+/* device name / arch (e.g. "gfx950") / CU count of `device` */
+int af_device_info(int device, char *name, size_t name_len, char *arch, size_t arch_len,
+                   int *compute_units, size_t *total_mem);
+int af_malloc(void **dptr, size_t bytes);
+int af_free(void *dptr);
+int af_malloc_host(void **hptr, size_t bytes); /* pinned host memory */
+int af_free_host(void *hptr);
+int af_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int af_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int af_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+int af_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int af_stream_create(void **stream);
+int af_stream_destroy(void *stream);
+int af_stream_synchronize(void *stream);
+int af_device_synchronize(void);
+/* hipEvent pair timing on `stream` (measurement support) */
+int af_event_create(void **event);
+int af_event_destroy(void *event);
+int af_event_record(void *event, void *stream);
+int af_event_synchronize(void *event);
+int af_event_elapsed_ms(void *start, void *stop, float *ms);
+/* Measurement hook (bench.py): while set (non-NULL) on the calling thread, entry
+ * points record `start` right before and `stop` right after their dominant kernel launch(es),
+ * on the stream those are launched on.  Pass NULLs to clear. */
+int af_profile_events(void *start, void *stop);
+/* element-wise precision conversion of n reals (dtype promotion on the device) */
+int af_convert_f32_to_f64(const float *src, double *dst, int64_t n, void *stream);
+int af_convert_f64_to_f32(const double *src, float *dst, int64_t n, void *stream);
+
+/* ---- phase_delay ------------------------------------------------------------
+ * Replaces africanus.rime.phase_delay (africanus/rime/phase.py:11-63).
+ *   lm (nsrc,2), uvw (nrow,3), frequency (nchan) -> out (nsrc,nrow,nchan) complex
+ *   n = sqrt(max(0, 1-l^2-m^2)) - 1 (clamped); p = C*(l*u+m*v+n*w)*nu in the
+ *   reference's operation order; out = (cos p, sin p).
+ * _f64: float64 in, complex128 out.  _f32: float32 in, complex64 out (all
+ * arithmetic in float32, as the reference does when every input is float32). */
+int af_phase_delay_f64(const double *lm, int64_t nsrc, const double *uvw, int64_t nrow,
+                       const double *frequency, int64_t nchan, int convention,
+                       double *out, void *stream);
+int af_phase_delay_f32(const float *lm, int64_t nsrc, const float *uvw, int64_t nrow,
+                       const float *frequency, int64_t nchan, int convention,
+                       float *out, void *stream);
+
+/* ---- im_to_vis --------------------------------------------------------------
+ * Replaces africanus.dft.im_to_vis (africanus/dft/kernels.py:14-69).
+ *   image (nsrc,nchan,ncorr) real (image_is_complex=0) or complex (=1);
+ *   uvw (nrow,3); lm (nsrc,2); frequency (nchan) -> out (nrow,nchan,ncorr) complex128
+ *   vis[r,nu,c] = sum_s exp(i*C*(l u+m v+n w)*nu) * image[s,nu,c], n unclamped
+ *   (NaN outside the unit disc), zero pixels skipped (kernels.py:54,64).
+ * `workspace`: device scratch of at least af_im_to_vis_workspace_bytes(...) bytes,
+ * 256-byte aligned; it must stay untouched until the call's work on `stream` is done.
+ * `mode`: AF_DFT_AUTO / AF_DFT_EXACT / AF_DFT_RECURRENCE. */
+size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t ncorr,
+                                    int image_is_complex);
+int af_im_to_vis_f64(const double *image, int image_is_complex, const double *uvw,
+                     const double *lm, const double *frequency, int64_t nsrc, int64_t nrow,
+                     int64_t nchan, int64_t ncorr, int convention, int mode, double *out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- predict_vis ------------------------------------------------------------
+ * Replaces africanus.rime.predict_vis (africanus/rime/predict.py:466-619) and
+ * apply_gains (:622-649: dies + base_vis only).
+ *   V = G_p ( B + sum_s E_ps X_pqs E_qs^H ) G_q^H
+ *   time_index/antenna1/antenna2 (nrow) integer, index_bytes = 4 (int32) or 8 (int64);
+ *   time_index is normalised by its own minimum inside the call (predict.py:597)
+ *   dde1/dde2 (nsrc,ntime,nant,nchan,ncorr)  -- both or neither (predict.py:403-404)
+ *   source_coh (nsrc,nrow,nchan,ncorr)
+ *   die1/die2 (ntime,nant,nchan,ncorr)       -- both or neither (predict.py:406-407)
+ *   base_vis (nrow,nchan,ncorr)
+ *   out (nrow,nchan,ncorr)
+ * Absent terms are NULL.  ncorr in {1,2,4}; jones_kind AF_JONES_2X2 requires
+ * ncorr == 4.  Sums run over sources in ascending order with the reference's
+ * operation order and no fp contraction, so results are bit-identical to the
+ * numba path.  `workspace`: >= af_predict_vis_workspace_bytes() device bytes. */
+size_t af_predict_vis_workspace_bytes(void);
+int af_predict_vis_c128(const void *time_index, const void *antenna1, const void *antenna2,
+                        int index_bytes, int64_t nrow, const double *dde1_jones,
+                        const double *source_coh, const double *dde2_jones,
+                        const double *die1_jones, const double *base_vis,
+                        const double *die2_jones, int64_t nsrc, int64_t ntime, int64_t nant,
+                        int64_t nchan, int ncorr, int jones_kind, double *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int af_predict_vis_c64(const void *time_index, const void *antenna1, const void *antenna2,
+                       int index_bytes, int64_t nrow, const float *dde1_jones,
+                       const float *source_coh, const float *dde2_jones,
+                       const float *die1_jones, const float *base_vis,
+                       const float *die2_jones, int64_t nsrc, int64_t ntime, int64_t nant,
+                       int64_t nchan, int ncorr, int jones_kind, float *out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- beam cubes -------------------------------------------------------------
+ * Replaces africanus.rime.fast_beam_cubes.freq_grid_interp
+ * (africanus/rime/fast_beam_cubes.py:10-54): frequency (nchan), beam_freq_map
+ * (beam_nud) -> freq_data (nchan,3) = (scale, lower weight, lower grid index). */
+int af_freq_grid_interp_f64(const double *frequency, int64_t nchan, const double *beam_freq_map,
+                            int64_t beam_nud, double *freq_data, void *stream);
+int af_freq_grid_interp_f32(const float *frequency, int64_t nchan, const float *beam_freq_map,
+                            int64_t beam_nud, float *freq_data, void *stream);
+/* Replaces africanus.rime.beam_cube_dde (africanus/rime/fast_beam_cubes.py:57-240).
+ *   beam (beam_lw,beam_mh,beam_nud,ncorr) complex; beam_lm_extents (2,2);
+ *   beam_freq_map (beam_nud); lm (nsrc,2); parallactic_angles (ntime,nant);
+ *   point_errors (ntime,nant,nchan,2); antenna_scaling (nant,nchan,2);
+ *   frequency (nchan) -> out (nsrc,ntime,nant,nchan,ncorr) complex.
+ * `freq_data_ws`: device scratch for nchan*3 reals. */
+int af_beam_cube_dde_c128(const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                          int ncorr, const double *beam_lm_extents, const double *beam_freq_map,
+                          const double *lm, int64_t nsrc, const double *parallactic_angles,
+                          int64_t ntime, int64_t nant, const double *point_errors,
+                          const double *antenna_scaling, const double *frequency, int64_t nchan,
+                          double *out, double *freq_data_ws, void *stream);
+int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                         int ncorr, const float *beam_lm_extents, const float *beam_freq_map,
+                         const float *lm, int64_t nsrc, const float *parallactic_angles,
+                         int64_t ntime, int64_t nant, const float *point_errors,
+                         const float *antenna_scaling, const float *frequency, int64_t nchan,
+                         float *out, float *freq_data_ws, void *stream);
+
+/* ---- chi-squared ---------------------------------------------------------------
+ * chi2_per_chan[nu] = sum_{r,c} weight[r,nu,c] * |data[r,nu,c] - model[r,nu,c]|^2
+ * (weight NULL = 1).  model/data (nrow,nchan,ncorr) complex128, weight real float64,
+ * chi2_per_chan (nchan) float64, zeroed by the call.  No reference counterpart (the
+ * reference has no chi^2; africanus/calibration/utils/residual_vis.py:63 forms the
+ * residual): this is the quantity the row-sharded multi-GPU predict all-reduces. */
+int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
+                 int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFHIP_H */

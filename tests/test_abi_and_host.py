@@ -1,0 +1,128 @@
+"""
+CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/afhip.h declares, and the host wrappers reproduce the reference's
+argument checking / dtype rules (africanus/rime/predict.py:380-463,542-563).
+No compute entry point is called here.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from codex_africanus_amd import _lib
+from codex_africanus_amd.rime import predict as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "afhip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(af_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.af_version() >= 100
+    assert lib.af_last_error() == b""
+
+
+def test_workspace_queries_are_pure():
+    lib = _lib.load()
+    assert lib.af_predict_vis_workspace_bytes() >= 8
+    small = lib.af_im_to_vis_workspace_bytes(10, 16, 4, 0)
+    big = lib.af_im_to_vis_workspace_bytes(1000, 64, 4, 0)
+    assert 0 < small < big
+    # packed image dominates: nsrc * padded chans * ncorr * 8 bytes
+    assert big >= 1000 * 64 * 4 * 8
+    assert lib.af_im_to_vis_workspace_bytes(1000, 64, 4, 1) > big
+
+
+def test_no_oracle_import_in_product():
+    """The product must never route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "codex_africanus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src, f
+
+
+# ---- predict_checks: same conditions / messages as the reference ---------------------
+def z(*shape):
+    return np.zeros(shape, dtype=np.complex128)
+
+
+IDX = (np.zeros(10, np.int32),) * 3
+
+
+def test_predict_checks_presence_tuple():
+    tup = P.predict_checks(*IDX, z(3, 2, 4, 5, 2, 2), z(3, 10, 5, 2, 2), z(3, 2, 4, 5, 2, 2), None, None, None)
+    assert tup == (True, True, True, False, False, False)
+
+
+@pytest.mark.parametrize("kwargs, msg", [
+    (dict(dde1_jones=z(3, 2, 4, 5, 2)), "Both dde1_jones and dde2_jones must be present or absent"),
+    (dict(die2_jones=z(2, 4, 5, 2)), "Both die1_jones and die2_jones must be present or absent"),
+    (dict(dde1_jones=z(3, 2, 4, 5), dde2_jones=z(3, 2, 4, 5)), r"dde1_jones.ndim 4 not in \(5, 6\)"),
+    (dict(dde1_jones=z(3, 2, 4, 5, 2), dde2_jones=z(3, 2, 4, 5, 2, 2)), "dde1_jones.ndim != dde2_jones.ndim"),
+    (dict(source_coh=z(3, 10, 5)), r"source_coh.ndim 3 not in \(4, 5\)"),
+    (dict(base_vis=z(10, 5)), r"base_vis.ndim 2 not in \(3, 4\)"),
+    (dict(die1_jones=z(2, 4, 5), die2_jones=z(2, 4, 5)), r"die1_jones.ndim 3 not in \(4, 5\)"),
+    (dict(die1_jones=z(2, 4, 5, 2), die2_jones=z(2, 4, 5, 2, 2)), "die1_jones.ndim != die2_jones.ndim"),
+    (dict(source_coh=z(3, 10, 5, 2), base_vis=z(10, 5, 2, 2)), "One of the following pre-conditions is broken"),
+    (dict(dde1_jones=z(3, 2, 4, 5, 2, 2), dde2_jones=z(3, 2, 4, 5, 2, 2), source_coh=z(3, 10, 5, 2)),
+     "One of the following pre-conditions is broken"),
+])
+def test_predict_vis_value_errors(kwargs, msg):
+    with pytest.raises(ValueError, match=msg):
+        P.predict_vis(*IDX, **kwargs)
+
+
+def test_predict_vis_no_inputs():
+    with pytest.raises(ValueError, match="No Jones Matrices were supplied"):
+        P.predict_vis(*IDX)
+
+
+def test_predict_vis_shape_mismatch_is_refused():
+    with pytest.raises(ValueError, match="source_coh has shape"):
+        P.predict_vis(*IDX, source_coh=z(3, 9, 5, 2, 2))
+    with pytest.raises(ValueError, match="correlation shape"):
+        P.predict_vis(*IDX, source_coh=z(3, 10, 5, 3))
+
+
+def test_convention_errors_raise_before_any_device_work():
+    from codex_africanus_amd.rime import phase_delay
+    from codex_africanus_amd.dft import im_to_vis
+    lm, uvw, fr = np.zeros((3, 2)), np.zeros((5, 3)), np.ones(4)
+    with pytest.raises(ValueError, match=r"convention not in \('fourier', 'casa'\)"):
+        phase_delay(lm, uvw, fr, convention="bob")
+    with pytest.raises(ValueError, match=r"convention not in \('fourier', 'casa'\)"):
+        im_to_vis(np.zeros((3, 4, 2)), uvw, lm, fr, convention="bob")
+    from codex_africanus_amd.rime import beam_cube_dde
+    with pytest.raises(ValueError, match="beam_lw, beam_mh and beam_nud must be >= 2"):
+        beam_cube_dde(z(1, 2, 2, 1), np.zeros((2, 2)), np.zeros(2), lm, np.zeros((1, 1)),
+                      np.zeros((1, 1, 4, 2)), np.ones((1, 4, 2)), fr)
+
+
+def test_dft_mode_switch():
+    from codex_africanus_amd.dft import kernels
+    assert kernels.get_mode() in ("auto", "exact", "recurrence")
+    old = kernels.get_mode()
+    kernels.set_mode("exact")
+    assert kernels.get_mode() == "exact"
+    with pytest.raises(ValueError):
+        kernels.set_mode("fast")
+    kernels.set_mode(old)
+
+
+def test_constants_match_reference_bits():
+    from codex_africanus_amd import constants
+    import math
+    assert constants.c == 2.99792458e8
+    assert constants.two_pi_over_c == 2 * math.pi / 2.99792458e8
+    assert constants.minus_two_pi_over_c == -constants.two_pi_over_c

@@ -1,0 +1,339 @@
+"""
+GPU parity tests: the HIP path (through the C ABI) against the golden vectors captured
+from the real reference and against the CPU oracle on seeded inputs.  Tolerances:
+  predict_vis   bit-exact (integer-style equality of every float)
+  phase_delay   |err| <= 4e-16 * max(1, |phase|)-free bound: 1e-15 absolute (f64 sincos, <=1 ulp each side)
+  im_to_vis     exact mode 1e-12 relative to sum_s |image|; recurrence mode 1e-8 absolute (north star)
+  beam_cube_dde 1e-14 absolute (f64), 1e-5 (f32)
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+import oracle
+from codex_africanus_amd import rime, dft
+from codex_africanus_amd.dft import kernels as dft_kernels
+from codex_africanus_amd.testing import synthetic_inputs, real_image
+
+pytestmark = pytest.mark.gpu
+
+CORR = {"c1": (1,), "c2": (2,), "c22": (2, 2)}
+DDE = {"ddecoh": (True, True, True), "dde": (True, False, True), "coh": (False, True, False)}
+DIE = {"diebv": (True, True, True), "die": (True, False, True), "bv": (False, True, False)}
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0
+
+
+@pytest.fixture
+def dft_mode():
+    old = dft_kernels.get_mode()
+    yield dft_kernels.set_mode
+    dft_kernels.set_mode(old)
+
+
+# ---------------------------------------------------------------------------- phase_delay
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_phase_delay_f64_golden(g1, conv):
+    out = rime.phase_delay(g1["lm"], g1["uvw"], g1["frequency"], convention=conv)
+    ref = g1["f64_" + conv]
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    assert maxabs(out, ref) < 1e-15
+
+
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_phase_delay_f32_golden(g1, conv):
+    out = rime.phase_delay(g1["lm32"], g1["uvw32"], g1["frequency32"], convention=conv)
+    ref = g1["f32_" + conv]
+    assert out.dtype == ref.dtype == np.complex64
+    assert maxabs(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("conv, sign", [("fourier", 1), ("casa", -1)])
+def test_phase_delay_reference_kat(g1, conv, sign):
+    """africanus/rime/tests/test_rime.py:19-47."""
+    out = rime.phase_delay(g1["kat_lm"], g1["kat_uvw"], g1["kat_frequency"], convention=conv)
+    minus_two_pi_over_c = -2 * np.pi / 2.99792458e8
+    n = np.sqrt(1.0 - 0.1**2 - 0.2**2) - 1.0
+    phase = sign * minus_two_pi_over_c * (1 * 0.1 + 2 * 0.2 + 3 * n) * 0.856e9
+    assert abs(np.exp(1j * phase) - out[3, 2, 5]) < 5e-16
+    assert maxabs(out[3, 2], g1["kat_" + conv]) < 1e-15
+
+
+def test_phase_delay_vs_oracle_seeded():
+    d = synthetic_inputs(seed=11, nrow=3000, nchan=16, nsrc=37)
+    out = rime.phase_delay(d["lm"], d["uvw"], d["frequency"])
+    ref = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"])
+    assert maxabs(out, ref) < 1e-15
+    assert np.abs(np.abs(out) - 1.0).max() < 1e-15       # unit modulus
+
+
+def test_phase_delay_torch_device_resident():
+    import torch
+    d = synthetic_inputs(seed=12, nrow=500, nchan=8, nsrc=5)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = rime.phase_delay(t(d["lm"]), t(d["uvw"]), t(d["frequency"]))
+    assert isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.complex128
+    assert_array_equal(out.cpu().numpy(), rime.phase_delay(d["lm"], d["uvw"], d["frequency"]))
+
+
+def test_phase_delay_empty():
+    out = rime.phase_delay(np.zeros((0, 2)), np.zeros((4, 3)), np.ones(3))
+    assert out.shape == (0, 4, 3)
+
+
+# ---------------------------------------------------------------------------- predict_vis
+@pytest.mark.parametrize("ck", list(CORR))
+@pytest.mark.parametrize("dk", list(DDE))
+@pytest.mark.parametrize("gk", list(DIE))
+def test_predict_vis_27_combos_bit_exact(g2, ck, dk, gk):
+    a1j, blj, a2j = DDE[dk]
+    g1j, bvis, g2j = DIE[gk]
+    get = lambda k: g2["%s_%s" % (ck, k)]
+    out = rime.predict_vis(
+        g2["time_idx"], g2["ant1"], g2["ant2"],
+        get("a1") if a1j else None, get("bl") if blj else None, get("a2") if a2j else None,
+        get("g1") if g1j else None, get("bv") if bvis else None, get("g2") if g2j else None)
+    ref = g2["%s_%s_%s_vis" % (ck, dk, gk)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("ck", list(CORR))
+def test_predict_vis_offset_int32_and_c64(g2, ck):
+    get = lambda k: g2["%s_%s" % (ck, k)]
+    out = rime.predict_vis((g2["time_idx"] + 10).astype(np.int32), g2["ant1"].astype(np.int32),
+                           g2["ant2"].astype(np.int32), get("a1"), get("bl"), get("a2"),
+                           get("g1"), get("bv"), get("g2"))
+    assert_array_equal(out, g2["%s_offset_vis" % ck])
+    g64 = lambda k: get(k).astype(np.complex64)
+    out64 = rime.predict_vis(g2["time_idx"], g2["ant1"], g2["ant2"], g64("a1"), g64("bl"), g64("a2"),
+                             g64("g1"), g64("bv"), g64("g2"))
+    assert out64.dtype == np.complex64
+    assert_array_equal(out64, g2["%s_c64_vis" % ck])
+
+
+def test_apply_gains(g2):
+    get = lambda k: g2["c22_%s" % k]
+    out = rime.apply_gains(g2["time_idx"], g2["ant1"], g2["ant2"], get("g1"), get("bv"), get("g2"))
+    ref = oracle.apply_gains(g2["time_idx"], g2["ant1"], g2["ant2"], get("g1"), get("bv"), get("g2"))
+    assert_array_equal(out, ref)
+
+
+def test_predict_vis_chain_c1_golden(g5):
+    """BASELINE config C1 chain: phase_delay -> einsum -> predict_vis (+ DIEs, base_vis)."""
+    d = synthetic_inputs(seed=int(g5["seed"]), nrow=10000, nchan=16, nsrc=100, nant=7)
+    rows = g5["sample_rows"]
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"])   # caller-side input
+    coh = np.einsum("srf,si->srfi", phase, d["brightness"]).reshape(100, 10000, 16, 2, 2)
+    vis = rime.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, None, None, None)
+    assert_array_equal(vis[rows], g5["chain_rows"])
+    assert abs(np.abs(vis).sum() - g5["chain_abssum"]) <= 1e-12 * g5["chain_abssum"]
+    rng = d["rng"]
+    shp = (d["ntime"], d["nant"], 16, 2, 2)
+    die = 1.0 + 0.1 * rng.standard_normal(shp) + 0.1j * rng.standard_normal(shp)
+    bvis = 0.01 * (rng.standard_normal(vis.shape) + 1j * rng.standard_normal(vis.shape))
+    vis3 = rime.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, die, bvis, die)
+    assert_array_equal(vis3[rows], g5["die_rows"])
+
+
+def test_predict_vis_dde_vs_oracle_seeded():
+    rng = np.random.default_rng(5)
+    s, t, a, c, r = 9, 6, 5, 7, 333
+    rc = lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)
+    ti = np.sort(rng.integers(0, t, r)) + 3
+    a1, a2 = rng.integers(0, a, r), rng.integers(0, a, r)
+    dde, coh, die, bv = rc(s, t, a, c, 2, 2), rc(s, r, c, 2, 2), rc(t, a, c, 2, 2), rc(r, c, 2, 2)
+    out = rime.predict_vis(ti, a1, a2, dde, coh, dde, die, bv, die)
+    ref = oracle.predict_vis(ti, a1, a2, dde, coh, dde, die, bv, die)
+    assert_array_equal(out, ref)
+
+
+def test_predict_vis_empty_rows():
+    out = rime.predict_vis(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                           source_coh=np.zeros((3, 0, 4, 2, 2), np.complex128))
+    assert out.shape == (0, 4, 2, 2)
+
+
+# ---------------------------------------------------------------------------- im_to_vis
+def _scale(img):
+    return float(np.abs(img).sum(axis=0).max())
+
+
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+@pytest.mark.parametrize("ncorr", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["r", "c"])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_im_to_vis_golden(g3, dft_mode, mode, rtol, ncorr, kind, conv):
+    dft_mode(mode)
+    img = g3["img_%s%d" % (kind, ncorr)]
+    out = dft.im_to_vis(img, g3["uvw"], g3["lm"], g3["frequency"], convention=conv)
+    ref = g3["vis_%s%d_%s" % (kind, ncorr, conv)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert maxabs(out, ref) <= rtol * _scale(img)
+
+
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+@pytest.mark.parametrize("key, img, freq", [
+    ("vis_r4_nonuniform", "img_r4", "frequency_nonuniform"),
+    ("vis_c2_nonuniform", "img_c2", "frequency_nonuniform"),
+    ("vis_r5_fourier", "img_r5", "frequency"),
+    ("vis_r70_fourier", "img_r70", "frequency70"),
+])
+def test_im_to_vis_other_shapes(g3, dft_mode, mode, rtol, key, img, freq):
+    dft_mode(mode)
+    out = dft.im_to_vis(g3[img], g3["uvw"], g3["lm"], g3[freq])
+    assert maxabs(out, g3[key]) <= rtol * _scale(g3[img])
+
+
+def test_im_to_vis_nonuniform_auto_takes_exact_path(g3, dft_mode):
+    dft_mode("auto")
+    a = dft.im_to_vis(g3["img_r4"], g3["uvw"], g3["lm"], g3["frequency_nonuniform"])
+    dft_mode("exact")
+    b = dft.im_to_vis(g3["img_r4"], g3["uvw"], g3["lm"], g3["frequency_nonuniform"])
+    assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["exact", "auto"])
+def test_im_to_vis_nan_source_semantics(g3, dft_mode, mode):
+    """A source outside the unit disc poisons only its non-zero pixels' columns (kernels.py:54,64)."""
+    dft_mode(mode)
+    out = dft.im_to_vis(g3["img_nan"], g3["uvw"], g3["lm_nan"], g3["frequency"])
+    ref = g3["vis_nan"]
+    assert_array_equal(np.isnan(out), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert maxabs(out[ok], ref[ok]) <= 1e-11 * _scale(g3["img_nan"])
+
+
+def test_im_to_vis_all_zero_column_stays_zero(g3, dft_mode):
+    dft_mode("auto")
+    img = g3["img_r4"].copy()
+    img[:, 3, 2] = 0.0
+    uvw = g3["uvw"].copy()
+    uvw[7] = np.nan                      # NaN row: only non-zero columns become NaN
+    out = dft.im_to_vis(img, uvw, g3["lm"], g3["frequency"])
+    ref = oracle.im_to_vis(img, uvw, g3["lm"], g3["frequency"])
+    assert_array_equal(np.isnan(out), np.isnan(ref))
+    assert (out[:, 3, 2] == 0).all()
+
+
+def test_im_to_vis_dtype_rules(g3, dft_mode):
+    dft_mode("exact")
+    out = dft.im_to_vis(g3["img_r4"], g3["uvw"], g3["lm"], g3["frequency"], dtype=np.complex64)
+    assert out.dtype == np.complex64
+    assert maxabs(out, g3["vis_r4_c64"]) < 2e-6 * _scale(g3["img_r4"])
+    out32 = dft.im_to_vis(g3["img_r4"].astype(np.float32), g3["uvw32"], g3["lm"].astype(np.float32),
+                          g3["frequency"].astype(np.float32))
+    assert out32.dtype == np.complex64
+    assert maxabs(out32, g3["vis_f32"]) < 5e-4 * np.abs(g3["vis_f32"]).max()
+
+
+def test_im_to_vis_fft_kat(dft_mode):
+    """africanus/dft/tests/test_dft.py:86-133: DFT on a regular grid == FFT (decimal 13)."""
+    rng = np.random.default_rng(123)
+    Fs, iFs = np.fft.fftshift, np.fft.ifftshift
+    npix, nsource = 29, 25
+    image = np.zeros((npix, npix, 1))
+    image[rng.integers(5, npix - 5, nsource), rng.integers(5, npix - 5, nsource), 0] = \
+        rng.standard_normal(nsource)
+    fft_image = Fs(np.fft.fft2(iFs(image[:, :, 0])))[:, :, None]
+    deltal = 0.001
+    l_coord = np.arange(-(npix // 2), npix // 2 + 1) * deltal
+    ll, mm = np.meshgrid(l_coord, l_coord)
+    lm = np.vstack((ll.flatten(), mm.flatten())).T
+    u = Fs(np.fft.fftfreq(npix, d=deltal))
+    uu, vv = np.meshgrid(u, u)
+    uvw = np.zeros((npix**2, 3))
+    uvw[:, 0], uvw[:, 1] = uu.flatten(), vv.flatten()
+    frequency = np.ones(1) * 2.99792458e8
+    for mode in ("exact", "auto"):
+        dft_mode(mode)
+        for conv in ("fourier", "casa"):
+            vis = dft.im_to_vis(image.reshape(npix**2, 1, 1), uvw, lm, frequency, convention=conv)
+            ref = fft_image.reshape(npix**2, 1, 1)
+            ref = np.conj(ref) if conv == "casa" else ref
+            np.testing.assert_array_almost_equal(vis, ref, decimal=13)
+
+
+def test_im_to_vis_phase_centre(dft_mode):
+    """africanus/dft/tests/test_dft.py:12-42: a single source at the phase centre."""
+    dft_mode("auto")
+    rng = np.random.default_rng(0)
+    nrow, npix, nchan, ncorr = 100, 35, 11, 2
+    uvw = rng.random((nrow, 3))
+    x = np.linspace(-0.1, 0.1, npix)
+    ll, mm = np.meshgrid(x, x)
+    lm = np.vstack((ll.flatten(), mm.flatten())).T
+    frequency = np.linspace(1.0, 2.0, nchan)
+    image = np.zeros((npix, npix, nchan, ncorr))
+    Inu = (frequency / frequency[nchan // 2]) ** (-0.7)
+    image[npix // 2, npix // 2] = Inu[:, None]
+    vis = dft.im_to_vis(image.reshape(npix**2, nchan, ncorr), uvw, lm, frequency)
+    assert np.abs(vis - Inu[None, :, None]).max() < 1e-13
+
+
+@pytest.mark.parametrize("mode, tol", [("exact", 2e-12), ("auto", 1e-8)])
+def test_im_to_vis_c1_golden(g5, dft_mode, mode, tol):
+    """BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr) against the reference's rows."""
+    dft_mode(mode)
+    d = synthetic_inputs(seed=int(g5["seed"]), nrow=10000, nchan=16, nsrc=100, nant=7)
+    vis = dft.im_to_vis(real_image(d), d["uvw"], d["lm"], d["frequency"])
+    assert maxabs(vis[g5["sample_rows"]], g5["dft_rows"]) < tol
+    assert abs(np.abs(vis).sum() - g5["dft_abssum"]) <= 1e-9 * g5["dft_abssum"]
+
+
+def test_im_to_vis_linearity_and_row_independence(dft_mode):
+    """Size-independent properties: linear in the image; a row's result does not depend on
+    which other rows are in the call (row sharding is exact)."""
+    dft_mode("auto")
+    d = synthetic_inputs(seed=21, nrow=5000, nchan=64, nsrc=50)
+    img = real_image(d)
+    a = dft.im_to_vis(img, d["uvw"], d["lm"], d["frequency"])
+    b = dft.im_to_vis(2.0 * img, d["uvw"], d["lm"], d["frequency"])
+    assert_array_equal(b, 2.0 * a)       # power-of-two scaling commutes with rounding
+    part = dft.im_to_vis(img, d["uvw"][1234:2345], d["lm"], d["frequency"])
+    assert_array_equal(part, a[1234:2345])
+    ref = oracle.im_to_vis(img, d["uvw"][:300], d["lm"], d["frequency"])
+    assert maxabs(a[:300], ref) < 1e-8
+
+
+# ---------------------------------------------------------------------------- beams
+def _beam_args(g4, lm=None, beam=None, dtype=None):
+    args = [g4["beam"] if beam is None else beam, g4["extents"], g4["beam_freq_map"],
+            g4["lm"] if lm is None else lm, g4["parangles"], g4["point_errors"],
+            g4["antenna_scaling"], g4["freqs"]]
+    if dtype is not None:
+        args = [a.astype(np.complex64 if np.iscomplexobj(a) else dtype) for a in args]
+    return args
+
+
+def test_freq_grid_interp(g4):
+    fd = rime.freq_grid_interp(g4["freqs"], g4["beam_freq_map"])
+    assert_array_equal(fd, g4["freq_data"])
+
+
+def test_beam_cube_dde_golden(g4):
+    out = rime.beam_cube_dde(*_beam_args(g4))
+    ref = g4["ddes"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert maxabs(out, ref) < 1e-14
+    out0 = rime.beam_cube_dde(*_beam_args(g4, lm=g4["lm"][:2], beam=np.zeros_like(g4["beam"])))
+    assert_array_equal(out0, g4["ddes_zero"])
+    beam1 = np.ascontiguousarray(g4["beam"][..., 0, :1])
+    assert maxabs(rime.beam_cube_dde(*_beam_args(g4, beam=beam1)), g4["ddes_1corr"]) < 1e-14
+
+
+def test_beam_cube_dde_f32(g4):
+    out = rime.beam_cube_dde(*_beam_args(g4, dtype=np.float32))
+    assert out.dtype == np.complex64
+    assert maxabs(out, g4["ddes_f32"]) < 1e-5
+
+
+def test_beam_cube_dde_reference_kat(g4):
+    """africanus/rime/tests/test_fast_beams.py:43-127: 0.470255+0.4786j."""
+    ddes = rime.beam_cube_dde(g4["kat_beam"], np.asarray([[-1.0, 1.0], [-1.0, 1.0]]),
+                              np.asarray([0.0, 1.0]), np.asarray([[0.1, 0.1]]), np.zeros((1, 1)),
+                              np.zeros((1, 1, 1, 2)), np.ones((1, 1, 2)), np.asarray([0.3]))
+    np.testing.assert_array_almost_equal([[[[[0.470255 + 0.4786j]]]]], ddes)
+    assert maxabs(ddes, g4["kat_ddes"]) < 1e-15
