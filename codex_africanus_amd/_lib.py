@@ -93,6 +93,24 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: when PyTorch-ROCm is installed it bundles its own
+    libamdhip64.so.7 (+ HSA runtime); loading ROCm's copy first and torch's afterwards leaves
+    torch without devices.  Bind libafhip to torch's copy (same SONAME) by loading that one
+    first -- without importing torch.  Without torch, /opt/rocm's runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    return None
+
+
 def load():
     """Load libafhip.so (once).  Raises if it has not been built: there is no fallback."""
     global _lib
@@ -104,6 +122,7 @@ def load():
                         "libafhip.so not found at %s: build it with "
                         "`python -c 'import __graft_entry__ as g; g.build()'` or "
                         "`make -C codex_africanus_amd/csrc`" % LIB_PATH)
+                _preload_hip_runtime()
                 lib = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(lib, name)

@@ -166,7 +166,9 @@ __global__ void dft_colstate(const double *__restrict__ image, int W, int64_t ns
 // (cos, sin)(2*pi*t) for t given in QUARTER turns t4 = 4*t.  Reduction: r = rint(t4) by the
 // 1.5*2^52 magic-number add (also yields the quadrant in the low dword), f = t4 - r exact in
 // [-0.5, 0.5]; sin(pi/2 f) = f*S(f^2), cos(pi/2 f) = C(f^2), Chebyshev-node fits on
-// f^2 in [0, 0.25]: |err| <= 7e-15 (S), 6e-14 (C) with 6 terms; ~1e-16 with 7 terms.
+// f^2 in [0, 0.25]: |err| <= 7e-15 (S), 6e-14 (C) with 6 terms; ~1e-16 with 7 terms (and exactly
+// (1, 0) at f = 0, so a source at the phase centre gets a unit phasor).  The kernels use 7: an
+// error e in cos of the channel-step angle is amplified by the recurrence to ~j^2*e at channel j.
 template <int NTERM>
 __device__ __forceinline__ void sincos_quarter_turns(double t4, double &c_out, double &s_out)
 {
@@ -256,8 +258,21 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
         for (int c = 0; c < NC; ++c) acc[j][c][0] = acc[j][c][1] = 0.0;
 
     const double *__restrict__ img = packed + (int64_t)tile * nsrc * (CT * NC * W);
+    // (l, m, n) of the NEXT source is fetched one iteration ahead, so the scalar loads of this
+    // source's image pixels can be issued at the top of the iteration and land while the
+    // sincos setup (which only needs l, m, n) runs.
+    // hipcc sinks a plain prefetch load back to its use, so the three scalar loads are issued
+    // from an asm statement (not counted by hipcc) and retired by the explicit lgkmcnt(0) at the
+    // bottom of the iteration, by which time every scalar load of the iteration has landed.
+    double l = lmn[0], m = lmn[1], n = lmn[2];
+#pragma unroll 1
     for (int s = 0; s < nsrc; ++s) {
-        const double l = lmn[4 * s], m = lmn[4 * s + 1], n = lmn[4 * s + 2];
+        const int sn = (s + 1 < nsrc) ? s + 1 : s;
+        const double *lmn_next = lmn + 4 * sn;
+        double ln, mn, nn;
+        asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dwordx2 %2, %3, 0x10"
+                     : "=&s"(ln), "=&s"(mn), "=&s"(nn)
+                     : "s"(lmn_next));
         // path difference in metres; FMA-contracted (one rounding less than the reference)
         const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
         double c0r, c0i, dr, di;
@@ -293,6 +308,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ln), "+s"(mn), "+s"(nn));
+        l = ln; m = mn; n = nn;
     }
     store_tile<CT, NC>(acc, out, row, valid, nchan, ncorr, c0, corr0, colstate,
                    tilestate[tile * nchunk + chunk]);
@@ -411,7 +428,7 @@ int launch_chunk(const Args &a)
     const int64_t corr0 = (int64_t)a.chunk * MAXNC;
     if (a.mode == AF_DFT_AUTO || a.mode == AF_DFT_RECURRENCE) {
         // runs iff flags[0] == 1 (set by dft_prep_freq, or forced for AF_DFT_RECURRENCE)
-        hipLaunchKernelGGL((dft_recurrence_kernel<CT, NC, CPLX, 6>), grid, block, 0, a.st, a.uvw, lmn, packed,
+        hipLaunchKernelGGL((dft_recurrence_kernel<CT, NC, CPLX, 7>), grid, block, 0, a.st, a.uvw, lmn, packed,
                            tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, a.nchan, a.ncorr,
                            corr0, a.chunk, (int)L.nchunk, 1);
         AF_LAUNCH_CHECK();

@@ -27,8 +27,16 @@ template <> struct Ops<float> {
     static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
     static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
     static __device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
-    static __device__ __forceinline__ float sqrt_(float a) { return __fsqrt_rn(a); }
-    static __device__ __forceinline__ void sincos_(float p, float *s, float *c) { sincosf(p, s, c); }
+    // correctly rounded float sqrt via double (53 >= 2*24+2 bits: double rounding is innocuous)
+    static __device__ __forceinline__ float sqrt_(float a) { return (float)__dsqrt_rn((double)a); }
+    // float sin/cos evaluated in double and rounded once (within 0.5 ulp + of libm's cosf/sinf)
+    static __device__ __forceinline__ void sincos_(float p, float *s, float *c)
+    {
+        double sd, cd;
+        sincos((double)p, &sd, &cd);
+        *s = (float)sd;
+        *c = (float)cd;
+    }
     typedef float2 vec2;
     static __device__ __forceinline__ vec2 make2(float a, float b) { return make_float2(a, b); }
 };
