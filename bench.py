@@ -212,7 +212,7 @@ def main():
             },
             "fp64_max_abs_err": max_err,
             "roofline": {
-                "kernel": "dft_recurrence_kernel<13,4,false,7>" if args.mode != "exact" else "dft_exact_kernel",
+                "kernel": "dft_exact_kernel<13,4,false>" if args.mode == "exact" else "dft_recurrence_dpp_kernel<13,4,false,7>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,

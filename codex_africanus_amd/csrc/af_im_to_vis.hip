@@ -7,48 +7,61 @@
 // Design ("im_to_vis"):
 //   * one lane owns one row and a tile of CT channels x NC correlations of complex
 //     accumulators in VGPRs (CT=13, NC=4 -> 104 doubles = 208 VGPRs); the wave walks all sources.
-//   * everything that is uniform across the wave (l,m,n of the source, the image
-//     pixels of the (source, channel tile), tile frequency constants) is read through
-//     the scalar data cache into SGPRs and used directly as v_fma_f64 operands, so the
-//     inner loop has no LDS or vector-memory traffic at all: it is pure fp64 VALU.
-//   * recurrence kernel (uniformly spaced channels): per (row, source, tile) two
-//     quarter-turn-reduced polynomial sincos give the phasor at the tile's first
-//     channel and the channel-to-channel rotation; the remaining channels follow from
-//     the three-term recurrence y[j+1] = 2cos(d)*y[j] - y[j-1] (1 FMA per component).
-//   * exact kernel: the reference's operation order (no contraction) and a full
-//     accuracy sincos per (row, source, channel); used for non-uniform frequencies and
-//     on request (AF_DFT_EXACT).
-//   * a prep pass (tiny kernels, no host sync) computes n per source, repacks the image
-//     into zero-padded channel tiles, decides uniformity on the device and records the
-//     reference's zero-pixel / NaN-source semantics per (channel, corr) column.
+//     The kernel is fp64-VALU bound (nsrc phasors per 64-byte visibility), so everything is
+//     organised to keep the inner loop pure v_fma_f64 / v_fmac_f64.
+//   * per (channel tile, source) the prep pass builds one RECORD of 16-double groups:
+//     [l, m, n, 0, image pixels of the tile...].  A wave reads a record with one
+//     global_load_dwordx2 per group (lane i fetches double i%16, so every row of 16 lanes
+//     holds the group) and feeds the values to the FMAs through the 64-bit DPP operand
+//     `row_newbcast:k` of v_fmac_f64 -- a wave-uniform scalar operand at zero instruction
+//     cost, without scalar loads (whose only wait is lgkmcnt(0)) and without LDS.  Each
+//     group register is refreshed for the NEXT source right after its last use, so the
+//     vector loads have most of an iteration (~600 cycles) to land.
+//   * recurrence (uniformly spaced channels): per (row, source, tile) two quarter-turn
+//     reduced polynomial sincos give the phasor at the tile's first channel and the
+//     channel-to-channel rotation; the other channels follow from the three-term
+//     recurrence y[j+1] = 2cos(d)*y[j] - y[j-1] (1 FMA per component).
+//   * exact kernel: the reference's operation order (no contraction) and a full-accuracy
+//     sincos per (row, source, channel); for non-uniform frequencies and AF_DFT_EXACT.
+//   * the prep pass (tiny kernels, no host sync) computes n per source, builds the records,
+//     decides uniformity on the device and records the reference's zero-pixel / NaN-source
+//     semantics per (channel, corr) column.
+#include <type_traits>
+
 #include "af_common.h"
 
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 256;
-constexpr int MAXNC = 4;         // correlations per launch (ncorr is processed in chunks)
+constexpr int MAXNC = 4;  // correlations per launch (ncorr is processed in chunks)
+constexpr int GROUP = 16; // doubles per record group = one DPP row
+
+__host__ __device__ constexpr int record_groups(int ct, int nc, int w) { return (4 + ct * nc * w + GROUP - 1) / GROUP; }
 
 // ---- workspace layout ------------------------------------------------------------
 struct WsLayout {
-    size_t flags;     // int[64]        [0] uniform
-    size_t lmn;       // double[nsrc*4] (l, m, n, 0), non-finite sources zeroed
-    size_t srcbad;    // int[nsrc]      1 if (l,m,n) is not finite
-    size_t tilef;     // double[ntile*4] (F0_4, FD_4, 0, 0): quarter-turns per metre
-    size_t freq;      // double[ntile*CT] sign*nu/c scaled (exact kernel: nu itself)
-    size_t colstate;  // int[nchan_pad*ncorr] 0 normal, 1 force zero, 2 force NaN
+    size_t flags;     // int[64]          [0] uniform
+    size_t lmn;       // double[nsrc*4]   (l, m, n, 0), non-finite sources zeroed
+    size_t srcbad;    // int[nsrc]        1 if (l,m,n) is not finite
+    size_t tilef;     // double[ntile*4]  (F0_4, FD_4, 0, 0): quarter-turns per metre
+    size_t freq;      // double[ntile*CT] channel frequencies, padded per tile
+    size_t colstate;  // int[ntile*CT*ncorr] 0 normal, 1 force zero, 2 force NaN
     size_t tilestate; // int[ntile*nchunk] OR of colstate in the tile/chunk
-    size_t image;     // packed image, chunk-major: [chunk][tile][src][CT][nc][W]
+    size_t records;   // double: chunk-major [chunk][tile][src][groups(chunk)*16]
     size_t total;
     int64_t ntile, nchunk;
-    int ct;
+    int ct, w;
+    int64_t chunk_off[64];  // offset (in doubles) of each chunk's records
+    int chunk_nc[64], chunk_groups[64];
 };
 
-WsLayout ws_layout(int64_t nsrc, int64_t nchan, int64_t ncorr, int is_complex, int CT)
+bool ws_layout(WsLayout &L, int64_t nsrc, int64_t nchan, int64_t ncorr, int is_complex, int CT)
 {
-    WsLayout L;
     L.ct = CT;
+    L.w = is_complex ? 2 : 1;
     L.ntile = af_cdiv(nchan > 0 ? nchan : 1, CT);
     L.nchunk = af_cdiv(ncorr > 0 ? ncorr : 1, MAXNC);
+    if (L.nchunk > 64) return false;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
     L.flags = take(64 * sizeof(int));
@@ -58,9 +71,17 @@ WsLayout ws_layout(int64_t nsrc, int64_t nchan, int64_t ncorr, int is_complex, i
     L.freq = take((size_t)L.ntile * CT * sizeof(double));
     L.colstate = take((size_t)L.ntile * CT * ncorr * sizeof(int));
     L.tilestate = take((size_t)L.ntile * L.nchunk * sizeof(int));
-    L.image = take((size_t)nsrc * L.ntile * CT * ncorr * (is_complex ? 2 : 1) * sizeof(double));
+    int64_t rec = 0;
+    for (int k = 0; k < (int)L.nchunk; ++k) {
+        int nc = (int)((ncorr - (int64_t)k * MAXNC < MAXNC) ? (ncorr - (int64_t)k * MAXNC) : MAXNC);
+        L.chunk_nc[k] = nc;
+        L.chunk_groups[k] = record_groups(CT, nc, L.w);
+        L.chunk_off[k] = rec;
+        rec += L.ntile * nsrc * (int64_t)L.chunk_groups[k] * GROUP;
+    }
+    L.records = take((size_t)rec * sizeof(double));
     L.total = o;
-    return L;
+    return true;
 }
 
 // ---- prep kernels ------------------------------------------------------------------
@@ -110,56 +131,63 @@ __global__ void dft_prep_freq(const double *__restrict__ freq, int64_t nchan, in
     if (!uniform) atomicAnd(&flags[0], 0);
 }
 
-// Repack image (nsrc, nchan, ncorr[, 2]) into [chunk][tile][src][CT][nc][W], zero padded;
-// sources whose (l,m,n) is not finite are zeroed (their effect is applied via colstate).
-__global__ void dft_pack_image(const double *__restrict__ image, int W, int64_t nsrc, int64_t nchan,
-                               int64_t ncorr, int64_t ntile, int CT, const int *__restrict__ srcbad,
-                               double *__restrict__ packed)
+// Build the records of one correlation chunk: for every (tile, source) a block of
+// groups*16 doubles = [l, m, n, 0, pixel(j=0,c=0)[.re,.im], pixel(0,1), ..., zero padding].
+// Pixels beyond nchan and pixels of sources whose (l,m,n) is not finite are zero (the
+// effect of such sources is applied through colstate).
+__global__ void dft_pack_records(const double *__restrict__ image, int W, int64_t nsrc, int64_t nchan,
+                                 int64_t ncorr, int64_t ntile, int CT, int corr0, int nc, int groups,
+                                 const double *__restrict__ lmn, const int *__restrict__ srcbad,
+                                 double *__restrict__ rec)
 {
-    const int64_t total = nsrc * ntile * CT * ncorr;
+    const int64_t per = (int64_t)groups * GROUP;
+    const int64_t total = ntile * nsrc * per;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
-        // source order of the scan: (s, chan_padded, corr)
-        int64_t c = i % ncorr;
-        int64_t ch = (i / ncorr) % (ntile * CT);
-        int64_t s = i / (ncorr * ntile * CT);
-        int64_t chunk = c / MAXNC, cc = c % MAXNC;
-        int64_t nc = (ncorr - chunk * MAXNC < MAXNC) ? (ncorr - chunk * MAXNC) : MAXNC;
-        int64_t tile = ch / CT, j = ch % CT;
-        // elements before this chunk: chunk*MAXNC correlations over all (tile, src, CT)
-        int64_t base = chunk * MAXNC * (ntile * nsrc * CT);
-        int64_t dst = base + ((tile * nsrc + s) * CT + j) * nc + cc;
-        bool live = (ch < nchan) && !srcbad[s];
-        for (int k = 0; k < W; ++k)
-            packed[dst * W + k] = live ? image[((s * nchan + ch) * ncorr + c) * W + k] : 0.0;
+        const int64_t slot = i % per;
+        const int64_t s = (i / per) % nsrc;
+        const int64_t tile = i / (per * nsrc);
+        double v = 0.0;
+        if (slot < 3) {
+            v = lmn[4 * s + slot];
+        } else if (slot >= 4 && slot < 4 + (int64_t)CT * nc * W) {
+            const int64_t e = slot - 4;
+            const int64_t k = e % W, c = (e / W) % nc, j = e / (W * nc);
+            const int64_t ch = tile * CT + j;
+            if (ch < nchan && !srcbad[s]) v = image[((s * nchan + ch) * ncorr + corr0 + c) * W + k];
+        }
+        rec[i] = v;
     }
 }
 
 // Column state per (chan, corr): reference semantics of `if image[s,nu,c]:` (kernels.py:64)
-//   all pixels zero                       -> the output stays exactly 0 (state 1)
+//   all pixels zero                         -> the output stays exactly 0 (state 1)
 //   a non-finite source has a nonzero pixel -> every row gets NaN there (state 2)
-__global__ void dft_colstate(const double *__restrict__ image, int W, int64_t nsrc, int64_t nchan,
-                             int64_t ncorr, int64_t ntile, int CT, const int *__restrict__ srcbad,
-                             int *__restrict__ colstate, int *__restrict__ tilestate, int nchunk)
+// One wave per column: lanes stride the sources, then a wave-wide OR.
+__global__ __launch_bounds__(64) void dft_colstate(const double *__restrict__ image, int W, int64_t nsrc,
+                                                   int64_t nchan, int64_t ncorr, int64_t ntile, int CT,
+                                                   const int *__restrict__ srcbad, int *__restrict__ colstate,
+                                                   int *__restrict__ tilestate, int nchunk)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ncol = ntile * CT * ncorr;
-    if (i >= ncol) return;
-    int64_t c = i % ncorr, ch = i / ncorr;
+    const int64_t i = blockIdx.x;  // column (padded chan, corr)
+    const int64_t c = i % ncorr, ch = i / ncorr;
     int state = 0;
     if (ch < nchan) {
         bool any_nz = false, poison = false;
-        for (int64_t s = 0; s < nsrc; ++s) {
+        for (int64_t s = threadIdx.x; s < nsrc; s += 64) {
             const double *px = image + ((s * nchan + ch) * ncorr + c) * W;
             bool nz = (px[0] != 0.0) || (W == 2 && px[1] != 0.0);
             any_nz |= nz;
             poison |= (nz && srcbad[s]);
         }
-        state = poison ? 2 : (any_nz ? 0 : 1);
+        const bool w_nz = __ballot(any_nz) != 0ULL, w_poison = __ballot(poison) != 0ULL;
+        state = w_poison ? 2 : (w_nz ? 0 : 1);
     }
-    colstate[i] = state;
-    if (state) atomicOr(&tilestate[(ch / CT) * nchunk + c / MAXNC], state);
+    if (threadIdx.x == 0) {
+        colstate[i] = state;
+        if (state) atomicOr(&tilestate[(ch / CT) * nchunk + c / MAXNC], state);
+    }
 }
 
 // ---- quarter-turn sincos ---------------------------------------------------------
@@ -206,7 +234,76 @@ __device__ __forceinline__ void sincos_quarter_turns(double t4, double &c_out, d
     s_out = __hiloint2double(shi, __double2loint(ss));
 }
 
-// ---- epilogue shared by both kernels ------------------------------------------------
+// ---- compile-time loop and the DPP-operand FMA -------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// acc += (double held by lane LANE of this lane's row of 16 in `g`) * y      [NEG: -= ]
+// 64-bit DPP row_newbcast on the VOP2 form of v_fmac_f64 (full fp64 rate, measured).
+// volatile: every statement that touches a record-group register stays in program order
+// with the asm loads / waits below (hipcc only orders asm statements among themselves).
+template <int LANE, bool NEG = false>
+__device__ __forceinline__ void fmac_bcast(double &acc, double g, double y)
+{
+    if constexpr (NEG)
+        asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(g), "v"(y), "i"(LANE));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(g), "v"(y), "i"(LANE));
+}
+
+// In-place refresh of one record-group register: r <- base[lane_off + OFF bytes].  Issued from
+// asm because hipcc sinks a plain load down to its first use (load + vmcnt(0) back to back);
+// "+v" ties the destination to the live register so no copy of a not-yet-landed value is made.
+// hipcc does not count this load: group_wait<N> retires it.
+template <int OFF>
+__device__ __forceinline__ void group_refresh(double &r, unsigned lane_off, const double *base)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(r) : "v"(lane_off), "s"(base), "i"(OFF));
+}
+
+// Wait until at most N younger vector-memory operations are outstanding; names the register it
+// makes valid so that its consumers are ordered behind the wait.
+template <int N>
+__device__ __forceinline__ void group_wait(double &r)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N));
+}
+
+// Record-group schedule of one source iteration (all compile time).  Slots are consumed in
+// increasing order: (l,m,n) at the top ("channel -1"), then channel by channel.  Group g is
+// first used in channel group_first_chan(g) and refreshed for the next source right after
+// channel group_last_chan(g).  At g's first use the loads issued after g's own refresh are:
+// the later refreshes of the previous iteration plus the refreshes this iteration has already
+// issued -- that many may stay in flight (vmcnt is in order).
+__host__ __device__ constexpr int group_last_chan(int g, int nslot, int per_chan)
+{
+    int last = g * GROUP + GROUP - 1 < nslot - 1 ? g * GROUP + GROUP - 1 : nslot - 1;
+    return last < 4 ? -1 : (last - 4) / per_chan;
+}
+__host__ __device__ constexpr int group_first_chan(int g, int per_chan)
+{
+    return g == 0 ? -1 : (g * GROUP - 4) / per_chan;
+}
+__host__ __device__ constexpr int group_wait_count(int g, int ng, int nslot, int per_chan)
+{
+    int n = 0;
+    for (int h = 0; h < ng; ++h) {
+        int ph = group_last_chan(h, nslot, per_chan), pg = group_last_chan(g, nslot, per_chan);
+        if (ph > pg || (ph == pg && h > g)) ++n;               // previous iteration, issued after g's refresh
+        if (ph < group_first_chan(g, per_chan)) ++n;            // this iteration, issued before g's first use
+    }
+    return n;
+}
+
+// ---- epilogue of the recurrence kernel --------------------------------------------
 template <int CT, int NC>
 __device__ __forceinline__ void store_tile(const double (&acc)[CT][NC][2], double *__restrict__ out,
                                            int64_t row, bool valid, int64_t nchan, int64_t ncorr,
@@ -232,17 +329,19 @@ __device__ __forceinline__ void store_tile(const double (&acc)[CT][NC][2], doubl
     }
 }
 
-// ---- recurrence kernel ---------------------------------------------------------------
+// ---- recurrence kernel, DPP operands ---------------------------------------------------------
 // grid: (ceil(nrow/256), ntile); block 256 = 4 waves, each wave 64 consecutive rows.
 template <int CT, int NC, bool CPLX, int NTERM>
-__global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
-    const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ packed,
-    const double *__restrict__ tilef, const int *__restrict__ flags, const int *__restrict__ colstate,
-    const int *__restrict__ tilestate, double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan,
-    int64_t ncorr, int64_t corr0, int chunk, int nchunk, int want_uniform)
+__global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
+    const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tilef,
+    const int *__restrict__ flags, const int *__restrict__ colstate, const int *__restrict__ tilestate,
+    double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan, int64_t ncorr, int64_t corr0, int chunk,
+    int nchunk, int want_uniform)
 {
     if (flags[0] != want_uniform) return;  // decided on the device by dft_prep_freq
     constexpr int W = CPLX ? 2 : 1;
+    constexpr int NG = record_groups(CT, NC, W);
+    constexpr int NSLOT = 4 + CT * NC * W;
     const int tile = blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
     int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
@@ -257,24 +356,31 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[j][c][0] = acc[j][c][1] = 0.0;
 
-    const double *__restrict__ img = packed + (int64_t)tile * nsrc * (CT * NC * W);
-    // (l, m, n) of the NEXT source is fetched one iteration ahead, so the scalar loads of this
-    // source's image pixels can be issued at the top of the iteration and land while the
-    // sincos setup (which only needs l, m, n) runs.
-    // hipcc sinks a plain prefetch load back to its use, so the three scalar loads are issued
-    // from an asm statement (not counted by hipcc) and retired by the explicit lgkmcnt(0) at the
-    // bottom of the iteration, by which time every scalar load of the iteration has landed.
-    double l = lmn[0], m = lmn[1], n = lmn[2];
+    // this lane's double of every group of the (tile, source) record
+    constexpr int PER_CHAN = NC * W;
+    const unsigned lane_off = (threadIdx.x & (GROUP - 1)) * (unsigned)sizeof(double);
+    const double *__restrict__ rec = records + (int64_t)tile * nsrc * (NG * GROUP);
+    double R[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) R[g] = rec[g * GROUP + (threadIdx.x & (GROUP - 1))];
+    // Touch everything loaded so far, so that hipcc's own s_waitcnt for these (counted) loads
+    // lands here and not at their first use inside the loop, where a vmcnt(0) would drain the
+    // asm-issued refreshes every iteration.
+    asm volatile("" :: "v"(u), "v"(v), "v"(w), "s"(F0), "s"(FD));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(R[g]));
+
 #pragma unroll 1
     for (int s = 0; s < nsrc; ++s) {
         const int sn = (s + 1 < nsrc) ? s + 1 : s;
-        const double *lmn_next = lmn + 4 * sn;
-        double ln, mn, nn;
-        asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dwordx2 %2, %3, 0x10"
-                     : "=&s"(ln), "=&s"(mn), "=&s"(nn)
-                     : "s"(lmn_next));
-        // path difference in metres; FMA-contracted (one rounding less than the reference)
-        const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
+        const double *rec_next = rec + (int64_t)sn * (NG * GROUP);
+        // path difference in metres, q = l*u + m*v + n*w  (slots 0, 1, 2 of group 0)
+        group_wait<group_wait_count(0, NG, NSLOT, PER_CHAN)>(R[0]);
+        double q = 0.0;
+        fmac_bcast<0>(q, R[0], u);
+        fmac_bcast<1>(q, R[0], v);
+        fmac_bcast<2>(q, R[0], w);
+        if constexpr (group_last_chan(0, NSLOT, PER_CHAN) < 0) group_refresh<0>(R[0], lane_off, rec_next);
         double c0r, c0i, dr, di;
         sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
         sincos_quarter_turns<NTERM>(__dmul_rn(q, FD), dr, di);
@@ -282,37 +388,48 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
         double y0r = c0r, y0i = c0i;
         double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
         double y1i = fma(c0r, di, __dmul_rn(c0i, dr));
-        const double *__restrict__ g = img + (int64_t)s * (CT * NC * W);
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
+        static_for<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             double yr, yi;
-            if (j == 0) { yr = y0r; yi = y0i; }
-            else if (j == 1) { yr = y1r; yi = y1i; }
+            if constexpr (j == 0) { yr = y0r; yi = y0i; }
+            else if constexpr (j == 1) { yr = y1r; yi = y1i; }
             else {
                 yr = fma(k, y1r, -y0r);
                 yi = fma(k, y1i, -y0i);
                 y0r = y1r; y0i = y1i; y1r = yr; y1i = yi;
             }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (CPLX) {
-                    const double gr = g[(j * NC + c) * 2], gi = g[(j * NC + c) * 2 + 1];
-                    acc[j][c][0] = fma(gr, yr, acc[j][c][0]);
-                    acc[j][c][0] = fma(-gi, yi, acc[j][c][0]);
-                    acc[j][c][1] = fma(gi, yr, acc[j][c][1]);
-                    acc[j][c][1] = fma(gr, yi, acc[j][c][1]);
+            // groups first touched by this channel: retire their refresh of the previous iteration
+            static_for<1, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (group_first_chan(g, PER_CHAN) == j)
+                    group_wait<group_wait_count(g, NG, NSLOT, PER_CHAN)>(R[g]);
+            });
+            static_for<0, NC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (CPLX) {
+                    constexpr int sr = 4 + (j * NC + c) * 2, si = sr + 1;
+                    fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
+                    fmac_bcast<si % GROUP, true>(acc[j][c][0], R[si / GROUP], yi);
+                    fmac_bcast<si % GROUP>(acc[j][c][1], R[si / GROUP], yr);
+                    fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
                 } else {
-                    const double gr = g[j * NC + c];
-                    acc[j][c][0] = fma(gr, yr, acc[j][c][0]);
-                    acc[j][c][1] = fma(gr, yi, acc[j][c][1]);
+                    constexpr int sr = 4 + j * NC + c;
+                    fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
+                    fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
                 }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ln), "+s"(mn), "+s"(nn));
-        l = ln; m = mn; n = nn;
+            });
+            // refresh, for the next source, every group whose last slot this channel consumed
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (group_last_chan(g, NSLOT, PER_CHAN) == j)
+                    group_refresh<g * GROUP * (int)sizeof(double)>(R[g], lane_off, rec_next);
+            });
+        });
     }
+    // retire the (redundant) refreshes of the last iteration before the registers die
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_tile<CT, NC>(acc, out, row, valid, nchan, ncorr, c0, corr0, colstate,
-                   tilestate[tile * nchunk + chunk]);
+                       tilestate[tile * nchunk + chunk]);
 }
 
 // ---- exact kernel -----------------------------------------------------------------------
@@ -321,20 +438,21 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_kernel(
 // are live; real_phase is recomputed per channel (6 ops against a ~100-op sincos).
 template <int CT, int NC, bool CPLX>
 __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
-    const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ packed,
-    const double *__restrict__ freq_pad, const int *__restrict__ flags, const int *__restrict__ colstate,
-    const int *__restrict__ tilestate, double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan,
-    int64_t ncorr, int64_t corr0, int chunk, int nchunk, int want_uniform, double constant)
+    const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ freq_pad,
+    const int *__restrict__ flags, const int *__restrict__ colstate, const int *__restrict__ tilestate,
+    double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan, int64_t ncorr, int64_t corr0, int chunk,
+    int nchunk, int want_uniform, double constant)
 {
     if (want_uniform >= 0 && flags[0] != want_uniform) return;
     constexpr int W = CPLX ? 2 : 1;
+    constexpr int NG = record_groups(CT, NC, W);
     const int tile = blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
     int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
     const bool valid = row < nrow;
     if (!valid) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
-    const double *__restrict__ img = packed + (int64_t)tile * nsrc * (CT * NC * W);
+    const double *__restrict__ rec = records + (int64_t)tile * nsrc * (NG * GROUP);
     const int tstate = tilestate[tile * nchunk + chunk];
 
     for (int j = 0; j < CT; ++j) {
@@ -344,12 +462,13 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = 0.0;
         for (int s = 0; s < nsrc; ++s) {
-            const double l = lmn[4 * s], m = lmn[4 * s + 1], n = lmn[4 * s + 2];
+            const double *__restrict__ rs = rec + (int64_t)s * (NG * GROUP);
+            const double l = rs[0], m = rs[1], n = rs[2];
             const double real_phase = __dmul_rn(
                 constant, __dadd_rn(__dadd_rn(__dmul_rn(l, u), __dmul_rn(m, v)), __dmul_rn(n, w)));
             double yr, yi;
             sincos(__dmul_rn(real_phase, nu), &yi, &yr);
-            const double *__restrict__ g = img + ((int64_t)s * CT + j) * (NC * W);
+            const double *__restrict__ g = rs + 4 + j * (NC * W);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (CPLX) {
@@ -381,19 +500,21 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------
-// Tile width: the lane's accumulators (CT*NC*2 doubles) plus ~45 working VGPRs must fit the
-// 256 architectural VGPRs a VALU instruction can address; per (row, source, tile) the
-// recurrence kernel spends ~51 fp64 ops of setup plus CT*(2 + 2*NC*(CPLX?2:1)) in the
-// channel loop, so the widest tile that fits wins unless padding the last tile costs more.
+// Tile width: the lane's accumulators (CT*NC*2 doubles) plus the record groups plus ~40
+// working VGPRs must fit the 256 architectural VGPRs a VALU instruction can address; per
+// (row, source, tile) the recurrence kernel spends ~50 fp64 ops of setup plus
+// CT*(2 + 2*NC*(CPLX?2:1)) in the channel loop, so the widest tile that fits wins unless
+// padding the last tile costs more.  Real images: CT in {13, 8}; complex: CT in {11, 8}.
 int choose_ct(int64_t nchan, int nc_max, bool cplx)
 {
-    const int cands[3] = {13, 12, 8};
+    const int cands_r[2] = {13, 8}, cands_c[2] = {11, 8};
+    const int *cands = cplx ? cands_c : cands_r;
     const int per_chan = 2 + 2 * nc_max * (cplx ? 2 : 1);
     int best = cands[0];
     int64_t best_cost = -1;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 2; ++k) {
         int ct = cands[k];
-        int64_t cost = af_cdiv(nchan, ct) * (51 + (int64_t)ct * per_chan);
+        int64_t cost = af_cdiv(nchan, ct) * (50 + (int64_t)ct * per_chan);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ct; }
     }
     return best;
@@ -413,29 +534,26 @@ struct Args {
 template <int CT, int NC, bool CPLX>
 int launch_chunk(const Args &a)
 {
-    constexpr int W = CPLX ? 2 : 1;
     const WsLayout &L = *a.L;
     char *ws = a.ws;
-    const double *lmn = reinterpret_cast<const double *>(ws + L.lmn);
     const double *tilef = reinterpret_cast<const double *>(ws + L.tilef);
     const double *freq_pad = reinterpret_cast<const double *>(ws + L.freq);
     const int *flags = reinterpret_cast<const int *>(ws + L.flags);
     const int *colstate = reinterpret_cast<const int *>(ws + L.colstate);
     const int *tilestate = reinterpret_cast<const int *>(ws + L.tilestate);
-    const double *packed = reinterpret_cast<const double *>(ws + L.image) +
-                           (int64_t)a.chunk * MAXNC * (L.ntile * a.nsrc * CT) * W;
+    const double *records = reinterpret_cast<const double *>(ws + L.records) + L.chunk_off[a.chunk];
     dim3 grid((unsigned)af_cdiv(a.nrow, ROWS_PER_BLOCK), (unsigned)L.ntile), block(ROWS_PER_BLOCK);
     const int64_t corr0 = (int64_t)a.chunk * MAXNC;
     if (a.mode == AF_DFT_AUTO || a.mode == AF_DFT_RECURRENCE) {
         // runs iff flags[0] == 1 (set by dft_prep_freq, or forced for AF_DFT_RECURRENCE)
-        hipLaunchKernelGGL((dft_recurrence_kernel<CT, NC, CPLX, 7>), grid, block, 0, a.st, a.uvw, lmn, packed,
+        hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), grid, block, 0, a.st, a.uvw, records,
                            tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, a.nchan, a.ncorr,
                            corr0, a.chunk, (int)L.nchunk, 1);
         AF_LAUNCH_CHECK();
     }
     if (a.mode == AF_DFT_AUTO || a.mode == AF_DFT_EXACT) {
         // AUTO: runs iff flags[0] == 0 (non-uniform frequencies); EXACT: always (-1)
-        hipLaunchKernelGGL((dft_exact_kernel<CT, NC, CPLX>), grid, block, 0, a.st, a.uvw, lmn, packed, freq_pad,
+        hipLaunchKernelGGL((dft_exact_kernel<CT, NC, CPLX>), grid, block, 0, a.st, a.uvw, records, freq_pad,
                            flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, a.nchan, a.ncorr, corr0,
                            a.chunk, (int)L.nchunk, a.mode == AF_DFT_EXACT ? -1 : 0, a.constant);
         AF_LAUNCH_CHECK();
@@ -454,14 +572,10 @@ int launch_chunk_nc(int nc, const Args &a)
     }
 }
 
-template <bool CPLX>
-int launch_chunk_ct(int ct, int nc, const Args &a)
+int launch_chunk_ct(bool cplx, int ct, int nc, const Args &a)
 {
-    switch (ct) {
-    case 8: return launch_chunk_nc<8, CPLX>(nc, a);
-    case 12: return launch_chunk_nc<12, CPLX>(nc, a);
-    default: return launch_chunk_nc<13, CPLX>(nc, a);
-    }
+    if (cplx) return ct == 8 ? launch_chunk_nc<8, true>(nc, a) : launch_chunk_nc<11, true>(nc, a);
+    return ct == 8 ? launch_chunk_nc<8, false>(nc, a) : launch_chunk_nc<13, false>(nc, a);
 }
 
 }  // namespace
@@ -471,10 +585,11 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
     if (nsrc < 0 || nchan < 0 || ncorr < 0) return 0;
     // sized for the widest padding any tile width can produce
     size_t m = 0;
-    const int cands[3] = {8, 12, 13};
+    const int cands[3] = {8, 11, 13};
     for (int k = 0; k < 3; ++k) {
-        size_t t = ws_layout(nsrc, nchan, ncorr, image_is_complex, cands[k]).total;
-        if (t > m) m = t;
+        WsLayout L;
+        if (!ws_layout(L, nsrc, nchan, ncorr, image_is_complex, cands[k])) return 0;
+        if (L.total > m) m = L.total;
     }
     return m;
 }
@@ -490,6 +605,7 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
                "af_im_to_vis_f64: unknown mode %d", mode);
     AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_im_to_vis_f64: negative extent");
     AF_REQUIRE(nsrc < (1LL << 31), "af_im_to_vis_f64: nsrc too large");
+    AF_REQUIRE(ncorr <= 64 * MAXNC, "af_im_to_vis_f64: more than %d correlations", 64 * MAXNC);
     hipStream_t st = af_stream(stream);
     if (nrow == 0 || nchan == 0 || ncorr == 0) return AF_OK;
     AF_REQUIRE(out != nullptr && uvw != nullptr && frequency != nullptr, "af_im_to_vis_f64: NULL array");
@@ -500,7 +616,8 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     AF_REQUIRE(image != nullptr && lm != nullptr, "af_im_to_vis_f64: NULL array");
     const bool cplx = image_is_complex != 0;
     const int ct = choose_ct(nchan, (int)(ncorr < MAXNC ? ncorr : MAXNC), cplx);
-    const WsLayout L = ws_layout(nsrc, nchan, ncorr, image_is_complex, ct);
+    WsLayout L;
+    ws_layout(L, nsrc, nchan, ncorr, image_is_complex, ct);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total,
                "af_im_to_vis_f64: workspace too small (%zu < %zu)", workspace_bytes, L.total);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_im_to_vis_f64: workspace must be 256-byte aligned");
@@ -521,17 +638,21 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     AF_LAUNCH_CHECK();
     if (mode == AF_DFT_RECURRENCE)  // caller asserts uniform spacing
         AF_HIP(hipMemsetAsync(ws + L.flags, 1, 1, st));
-    {
-        int64_t total = nsrc * L.ntile * ct * ncorr;
+    for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
+        const int64_t total = L.ntile * nsrc * (int64_t)L.chunk_groups[chunk] * GROUP;
         int64_t blocks = af_cdiv(total, 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(dft_pack_image, dim3((unsigned)blocks), dim3(256), 0, st, image, W, nsrc, nchan, ncorr,
-                           L.ntile, ct, reinterpret_cast<const int *>(ws + L.srcbad),
-                           reinterpret_cast<double *>(ws + L.image));
+        hipLaunchKernelGGL(dft_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, W, nsrc, nchan, ncorr,
+                           L.ntile, ct, chunk * MAXNC, L.chunk_nc[chunk], L.chunk_groups[chunk],
+                           reinterpret_cast<const double *>(ws + L.lmn),
+                           reinterpret_cast<const int *>(ws + L.srcbad),
+                           reinterpret_cast<double *>(ws + L.records) + L.chunk_off[chunk]);
         AF_LAUNCH_CHECK();
+    }
+    {
         int64_t ncol = L.ntile * ct * ncorr;
-        hipLaunchKernelGGL(dft_colstate, dim3((unsigned)af_cdiv(ncol, 64)), dim3(64), 0, st, image, W, nsrc, nchan,
-                           ncorr, L.ntile, ct, reinterpret_cast<const int *>(ws + L.srcbad),
+        hipLaunchKernelGGL(dft_colstate, dim3((unsigned)ncol), dim3(64), 0, st, image, W, nsrc, nchan, ncorr,
+                           L.ntile, ct, reinterpret_cast<const int *>(ws + L.srcbad),
                            reinterpret_cast<int *>(ws + L.colstate), reinterpret_cast<int *>(ws + L.tilestate),
                            (int)L.nchunk);
         AF_LAUNCH_CHECK();
@@ -543,9 +664,8 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     a.constant = convention == AF_CONVENTION_FOURIER ? AF_MINUS_TWO_PI_OVER_C : AF_TWO_PI_OVER_C;
     af_prof_begin(st);
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
-        int nc = (int)((ncorr - (int64_t)chunk * MAXNC < MAXNC) ? (ncorr - (int64_t)chunk * MAXNC) : MAXNC);
         a.chunk = chunk;
-        int rc = cplx ? launch_chunk_ct<true>(ct, nc, a) : launch_chunk_ct<false>(ct, nc, a);
+        int rc = launch_chunk_ct(cplx, ct, L.chunk_nc[chunk], a);
         if (rc != AF_OK) return rc;
     }
     af_prof_end(st);
