@@ -195,6 +195,15 @@ def main():
         # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop
         alg_flops = float(nrow) * nchan * nsrc * (2 + 2 * ncorr) * 2
         achieved = alg_bytes / kernel_s / 1e9
+        # HBM bytes per launch from the PMC passes of THIS command committed under profiles/
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; KB units; FETCH_SIZE doubled
+        # as MI355X_MICROARCH.md prescribes for gfx950 streaming reads -- an upper bound here).
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and (nrow, nchan, nsrc, args.mode) == (1000000, 64, 1000, "auto"):
+            c = json.load(open(pmc))
+            traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/r01_pmc_summary.json"
         out = {
             "metric": "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err",
             "value": total_vis / (elapsed / args.steps) / 1e6,
@@ -214,7 +223,7 @@ def main():
             "roofline": {
                 "kernel": "dft_exact_kernel<13,4,false>" if args.mode == "exact" else "dft_recurrence_dpp_kernel<13,4,false,7>",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
                 "note": "fp64-VALU-bound, not HBM-bound: nsrc=1000 phasors per 64-byte visibility",
                 "fp64_valu": {"achieved": alg_flops / kernel_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,

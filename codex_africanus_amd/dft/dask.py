@@ -1,0 +1,42 @@
+"""
+dask.array front-end of ``im_to_vis`` with the signature of ``africanus.dft.dask.im_to_vis``
+(africanus/dft/dask.py:26-51): blocks over (row, chan); the source axis must be a single chunk
+and image / frequency channel chunks must agree (same ``ValueError``s, :29-36).
+"""
+import numpy as np
+
+try:
+    import dask.array as da
+    _dask_error = None
+except ImportError as e:  # pragma: no cover - depends on the environment
+    da = None
+    _dask_error = e
+
+from .kernels import im_to_vis as _np_im_to_vis
+
+
+def _first(x):
+    while isinstance(x, list):
+        x = x[0]
+    return x
+
+
+def _im_to_vis_block(image, uvw, lm, frequency, convention, dtype_):
+    return _np_im_to_vis(_first(image), _first(uvw), _first(lm), frequency,
+                         convention=convention, dtype=dtype_)
+
+
+def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=np.complex128):
+    if da is None:
+        raise ImportError("dask.array is required for codex_africanus_amd.dft.dask: %s" % (_dask_error,))
+    if lm.chunks[0][0] != lm.shape[0]:
+        raise ValueError("lm chunks must match lm shape on first axis")
+    if image.chunks[0][0] != image.shape[0]:
+        raise ValueError("Image chunks must match image shape on first axis")
+    if image.chunks[0][0] != lm.chunks[0][0]:
+        raise ValueError("Image chunks and lm chunks must match on first axis")
+    if image.chunks[1] != frequency.chunks[0]:
+        raise ValueError("Image chunks must match frequency chunks on second axis")
+    return da.blockwise(_im_to_vis_block, ("row", "chan", "corr"), image, ("src", "chan", "corr"),
+                        uvw, ("row", "uvwc"), lm, ("src", "lmc"), frequency, ("chan",),
+                        convention=convention, dtype_=dtype, dtype=dtype)
