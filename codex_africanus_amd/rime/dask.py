@@ -68,7 +68,10 @@ def beam_cube_dde(beam, beam_lm_extents, beam_freq_map, lm, parallactic_angles, 
 
 # ---------------------------------------------------------------------------- predict_vis
 def _coh_block(time_index, antenna1, antenna2, dde1, coh, dde2, base_vis):
-    # dde blocks lose the single-chunk 'ant' axis into a list
+    # dde blocks lose the single-chunk 'ant' axis into a list; a chained running sum arrives
+    # with the length-1 source axis the previous link added
+    if base_vis is not None:
+        base_vis = base_vis[0]
     vis = _np_predict_vis(time_index, antenna1, antenna2,
                           None if dde1 is None else _first(dde1), coh,
                           None if dde2 is None else _first(dde2), None, base_vis, None)
