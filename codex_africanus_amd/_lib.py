@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 AF_OK, AF_EINVAL, AF_ENOMEM, AF_ENOTSUP, AF_EHIP_BASE = 0, 1, 2, 3, 1000
 CONVENTION = {"fourier": -1, "casa": 1}
 AF_DFT_AUTO, AF_DFT_EXACT, AF_DFT_RECURRENCE = 0, 1, 2
+AF_DFT_CLAMP_N = 0x100
 AF_JONES_DIAG, AF_JONES_2X2 = 1, 2
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -66,6 +67,10 @@ _SIGNATURES = {
                                      _vp, _vp, _i64, _vp, _vp, _vp]),
     "af_beam_cube_dde_c64": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp,
                                     _vp, _vp, _i64, _vp, _vp, _vp]),
+    "af_fused_plan_rows": (_int, [_vp, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
+    "af_fused_predict_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "af_fused_predict_c128": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                                     _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_chi2_c128": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
 }
 

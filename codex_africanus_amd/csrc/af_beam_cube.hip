@@ -9,30 +9,11 @@
 // is read-only and resident).  Arithmetic keeps the reference's operation order with
 // explicitly rounded operations (no contraction).
 #include "af_common.h"
+#include "af_beam_device.h"
 
 namespace {
 
-template <typename T> struct B;
-template <> struct B<double> {
-    static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
-    static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
-    static __device__ __forceinline__ double sub(double a, double b) { return __dsub_rn(a, b); }
-    static __device__ __forceinline__ double div(double a, double b) { return __ddiv_rn(a, b); }
-    static __device__ __forceinline__ double floor_(double a) { return floor(a); }
-    static __device__ __forceinline__ double hypot_(double a, double b) { return hypot(a, b); }
-    static __device__ __forceinline__ void sincos_(double p, double *s, double *c) { sincos(p, s, c); }
-    typedef double2 vec2;
-};
-template <> struct B<float> {
-    static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
-    static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
-    static __device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
-    static __device__ __forceinline__ float div(float a, float b) { return __fdiv_rn(a, b); }
-    static __device__ __forceinline__ float floor_(float a) { return floorf(a); }
-    static __device__ __forceinline__ float hypot_(float a, float b) { return hypotf(a, b); }
-    static __device__ __forceinline__ void sincos_(float p, float *s, float *c) { sincosf(p, s, c); }
-    typedef float2 vec2;
-};
+template <typename T> using B = BeamOps<T>;
 
 // fast_beam_cubes.py:10-54
 template <typename T>
@@ -88,77 +69,17 @@ __global__ __launch_bounds__(256) void beam_cube_dde_kernel(
     const int64_t t = (idx / (nchan * nant)) % ntime;
     const int64_t s = idx / (nchan * nant * ntime);
 
-    const T one = (T)1.0, zero = (T)0.0;
-    const T lower_l = lm_ext[0], upper_l = lm_ext[1], lower_m = lm_ext[2], upper_m = lm_ext[3];
-    const T lmaxf = (T)(beam_lw - 1), mmaxf = (T)(beam_mh - 1);
-    const int64_t lmaxi = beam_lw - 1, mmaxi = beam_mh - 1;
-    const T lscale = O::div(lmaxf, O::sub(upper_l, lower_l));
-    const T mscale = O::div(mmaxf, O::sub(upper_m, lower_m));
-
+    const BeamGrid<T> grid = beam_grid<T>(lm_ext, beam_lw, beam_mh, beam_nud);
     T sin_pa, cos_pa;
     O::sincos_(parangles[t * nant + a], &sin_pa, &cos_pa);
-    const T l = lm[2 * s], m = lm[2 * s + 1];
-    const T freq_scale = freq_data[3 * f + 0];
-    const T nud = freq_data[3 * f + 1];
-    const T inv_nud = O::sub(one, nud);
-    const int gc0 = (int)freq_data[3 * f + 2];
-    const int gc1 = gc0 + 1;
-
-    const T sl = O::mul(l, freq_scale), sm = O::mul(m, freq_scale);
     const T *pe = point_errors + ((t * nant + a) * nchan + f) * 2;
-    const T tl = O::add(sl, pe[0]), tm = O::add(sm, pe[1]);
-    T vl = O::sub(O::mul(tl, cos_pa), O::mul(tm, sin_pa));
-    T vm = O::add(O::mul(tl, sin_pa), O::mul(tm, cos_pa));
     const T *as = antenna_scaling + (a * nchan + f) * 2;
-    vl = O::mul(vl, as[0]);
-    vm = O::mul(vm, as[1]);
-    vl = O::mul(lscale, O::sub(vl, lower_l));
-    vm = O::mul(mscale, O::sub(vm, lower_m));
-    {   // max(zero, min(v, maxf)) with Python's comparison semantics (:150-151)
-        T t1 = vl < lmaxf ? vl : lmaxf; vl = zero > t1 ? zero : t1;
-        T t2 = vm < mmaxf ? vm : mmaxf; vm = zero > t2 ? zero : t2;
-    }
-    const int gl0 = (int)O::floor_(vl), gm0 = (int)O::floor_(vm);
-    const int64_t gl1 = (gl0 + 1 < lmaxi) ? gl0 + 1 : lmaxi;
-    const int64_t gm1 = (gm0 + 1 < mmaxi) ? gm0 + 1 : mmaxi;
-    const T ld = O::sub(vl, (T)gl0), md = O::sub(vm, (T)gm0);
-    const T omld = O::sub(one, ld), ommd = O::sub(one, md);
-
-    // voxel order and weights of :170-225
-    const int64_t GL[8] = {gl0, gl1, gl0, gl1, gl0, gl1, gl0, gl1};
-    const int64_t GM[8] = {gm0, gm0, gm1, gm1, gm0, gm0, gm1, gm1};
-    const int64_t GC[8] = {gc0, gc0, gc0, gc0, gc1, gc1, gc1, gc1};
-    const T WT[8] = {O::mul(O::mul(omld, ommd), nud),     O::mul(O::mul(ld, ommd), nud),
-                     O::mul(O::mul(omld, md), nud),       O::mul(O::mul(ld, md), nud),
-                     O::mul(O::mul(omld, ommd), inv_nud), O::mul(O::mul(ld, ommd), inv_nud),
-                     O::mul(O::mul(omld, md), inv_nud),   O::mul(O::mul(ld, md), inv_nud)};
-    int64_t voff[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) voff[k] = ((GL[k] * beam_mh + GM[k]) * beam_nud + GC[k]) * ncorr;
-
+    BeamVoxels<T> vx;
+    beam_voxels<T, int64_t>(grid, lm[2 * s], lm[2 * s + 1], sin_pa, cos_pa, pe[0], pe[1], as[0], as[1], freq_data[3 * f + 0],
+                   freq_data[3 * f + 1], (int)freq_data[3 * f + 2], ncorr, vx);
     const V2 *fbeam = reinterpret_cast<const V2 *>(beam);
     V2 *o = reinterpret_cast<V2 *>(out) + idx * ncorr;
-    for (int c = 0; c < ncorr; ++c) {
-        T cre = zero, cim = zero, absc = zero;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const V2 b = fbeam[voff[k] + c];
-            const T wgt = WT[k];
-            absc = O::add(absc, O::mul(wgt, O::hypot_(b.x, b.y)));
-            // (wgt + 0j) * b as a full complex multiply (numba widens the real weight)
-            const T pre = O::sub(O::mul(wgt, b.x), O::mul(zero, b.y));
-            const T pim = O::add(O::mul(wgt, b.y), O::mul(zero, b.x));
-            cre = O::add(cre, pre);
-            cim = O::add(cim, pim);
-        }
-        const T div = O::hypot_(cre, cim);
-        const T sc = (div == zero) ? absc : O::div(absc, div);
-        // corr_sum * (sc + 0j)
-        V2 r;
-        r.x = O::sub(O::mul(cre, sc), O::mul(cim, zero));
-        r.y = O::add(O::mul(cre, zero), O::mul(cim, sc));
-        o[c] = r;
-    }
+    for (int c = 0; c < ncorr; ++c) o[c] = beam_sample_corr<T, int64_t>(fbeam, nullptr, vx, c);
 }
 
 template <typename T>

@@ -1,0 +1,350 @@
+// Fused RIME predict with per-antenna beam-cube DDEs (BASELINE config 3):
+//
+//     V[r,nu] = sum_s  E_p(s,t,nu) . ( K(r,s,nu) B(s,nu) ) . E_q(s,t,nu)^H
+//
+// i.e. the reference's chain  phase_delay -> einsum("srf,sfij->srfij") -> beam_cube_dde ->
+// predict_vis  (africanus/rime/examples/predict.py:107-134,404-472,525 with
+// africanus/rime/phase.py:28-61, africanus/rime/fast_beam_cubes.py:57-240 and
+// africanus/rime/predict.py:199-212) evaluated without materialising the (src,row,chan)
+// coherencies (4.1 TB at C2) or the (src,time,ant,chan) Jones terms (130 GB at C3).
+//
+// One workgroup (512 lanes, one per CU: 237 VGPRs, up to 128 KB of LDS) owns one run of rows with
+// equal time_index (<= 2048 rows: a whole 64-antenna timestep) and one channel, and walks the
+// sources in batches:
+//   stage 1  lane = (source of the batch, antenna): sample the beam cube (|beam| precomputed once per
+//            call) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
+//            stage 2's reads are conflict-free (consecutive rows = consecutive antenna2) or
+//            broadcasts (antenna1);
+//   stage 2  lane = four rows: per source q = l u + m v + n w, the phasor by the quarter-turn
+//            polynomial sincos, M = G_p . E_q^H (one 2x2 complex product instead of two because B
+//            was folded into G per antenna), acc += K M.
+// Every per-antenna Jones is computed once per (timestep, channel, source) and reused by all
+// baselines of the timestep from LDS; the output is written once.  fp64-VALU bound
+// (~70 fp64 ops per (row,chan,src) + ~15 % for the beam stage).
+#include "af_common.h"
+#include "af_beam_device.h"
+#include "af_sincos.h"
+
+namespace {
+
+constexpr int THREADS = 512;
+constexpr int RPT = 4;  // rows per lane
+
+struct FusedWs {
+    size_t lmn, f4, freq_data, babs, total;
+};
+
+FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud)
+{
+    FusedWs w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    w.lmn = take((size_t)nsrc * 4 * sizeof(double));
+    w.f4 = take((size_t)nchan * sizeof(double));
+    w.freq_data = take((size_t)nchan * 3 * sizeof(double));
+    w.babs = take((size_t)beam_lw * beam_mh * beam_nud * 4 * sizeof(double));
+    w.total = o;
+    return w;
+}
+
+// n = sqrt(max(0, 1 - l^2 - m^2)) - 1: phase_delay's clamped form (africanus/rime/phase.py:42-43)
+__global__ void fused_prep_src(const double *__restrict__ lm, int64_t nsrc, double *__restrict__ lmn)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    double l = lm[2 * s], m = lm[2 * s + 1];
+    double n = __dsub_rn(__dsub_rn(1.0, __dmul_rn(l, l)), __dmul_rn(m, m));
+    n = __dsub_rn(__dsqrt_rn(n < 0.0 ? 0.0 : n), 1.0);
+    lmn[4 * s + 0] = l;
+    lmn[4 * s + 1] = m;
+    lmn[4 * s + 2] = n;
+    lmn[4 * s + 3] = 0.0;
+}
+
+// quarter turns per metre of path difference for every channel: 4*sign*nu/c
+__global__ void fused_prep_freq(const double *__restrict__ freq, int64_t nchan, int sign, double *__restrict__ f4)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchan) f4[c] = 4.0 * (double)sign * freq[c] / AF_LIGHTSPEED;
+}
+
+// |beam| of every voxel and correlation, once per call (hypot dominates the beam stage otherwise)
+__global__ void beam_abs_kernel(const double2 *__restrict__ beam, int64_t n, double *__restrict__ babs)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double2 b = beam[i];
+        babs[i] = hypot(b.x, b.y);
+    }
+}
+
+struct C2 {
+    double re, im;
+};
+__device__ __forceinline__ C2 cmul(C2 a, C2 b)
+{
+    C2 z;
+    z.re = fma(a.re, b.re, -__dmul_rn(a.im, b.im));
+    z.im = fma(a.re, b.im, __dmul_rn(a.im, b.re));
+    return z;
+}
+// a * conj(b)
+__device__ __forceinline__ C2 cmulc(C2 a, C2 b)
+{
+    C2 z;
+    z.re = fma(a.re, b.re, __dmul_rn(a.im, b.im));
+    z.im = fma(a.im, b.re, -__dmul_rn(a.re, b.im));
+    return z;
+}
+// acc += a * conj(b)
+__device__ __forceinline__ void cmacc(C2 &acc, C2 a, C2 b)
+{
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(a.im, b.im, acc.re);
+    acc.im = fma(a.im, b.re, acc.im);
+    acc.im = fma(-a.re, b.im, acc.im);
+}
+// acc += a * b
+__device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
+{
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+}
+
+// grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * nant double2 (E then G).
+__global__ __launch_bounds__(THREADS) void fused_predict_kernel(
+    const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
+    const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
+    const double2 *__restrict__ brightness, const double2 *__restrict__ beam, const double *__restrict__ babs,
+    int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
+    const double *__restrict__ freq_data, const double *__restrict__ parangles,
+    const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling, int nsrc, int64_t nchan,
+    int64_t ntime, int nant, int st, double2 *__restrict__ out)
+{
+    extern __shared__ double2 lds[];
+    double2 *ldsE = lds;                            // [st][4][nant]
+    double2 *ldsG = lds + (size_t)st * 4 * nant;    // [st][4][nant]
+    const int tid = threadIdx.x;
+    const int64_t f = blockIdx.y;
+    const int t = items[4 * blockIdx.x + 0];
+    const int64_t r0 = items[4 * blockIdx.x + 1];
+    const int rc = items[4 * blockIdx.x + 2];
+
+    // ---- stage-2 state: this lane's rows -----------------------------------------------------
+    double u[RPT], v[RPT], w[RPT];
+    int a1[RPT], a2[RPT];
+    bool live[RPT];
+    C2 acc[RPT][4];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int rl = tid + k * THREADS;
+        live[k] = rl < rc;
+        const int64_t r = r0 + (live[k] ? rl : 0);
+        u[k] = uvw[3 * r]; v[k] = uvw[3 * r + 1]; w[k] = uvw[3 * r + 2];
+        a1[k] = ant1[r]; a2[k] = ant2[r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
+    }
+    const double F4 = f4[f];
+
+    // ---- stage-1 state: this lane's (batch slot, antenna) ------------------------------------------
+    const bool e_task = tid < st * nant;
+    const int e_sl = e_task ? tid / nant : 0, e_ant = e_task ? tid % nant : 0;
+    const BeamGrid<double> grid = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+    double sin_pa, cos_pa;
+    sincos(parangles[(int64_t)t * nant + e_ant], &sin_pa, &cos_pa);
+    const double *pe = point_errors + (((int64_t)t * nant + e_ant) * nchan + f) * 2;
+    const double *as = antenna_scaling + ((int64_t)e_ant * nchan + f) * 2;
+    const double pe_l = pe[0], pe_m = pe[1], as_l = as[0], as_m = as[1];
+    const double fscale = freq_data[3 * f + 0], fnud = freq_data[3 * f + 1];
+    const int fgc0 = (int)freq_data[3 * f + 2];
+
+    for (int s0 = 0; s0 < nsrc; s0 += st) {
+        // ---- stage 1: E and G = E.B for (source s0 + e_sl, antenna e_ant) -> LDS ------------------
+        // E goes to LDS one correlation at a time (keeps the 8-voxel geometry the only large live
+        // set), then the lane reads its own E back and folds the source's brightness into G.
+        if (e_task) {
+            const int s = s0 + e_sl;
+            const bool have = s < nsrc;
+            {
+                BeamVoxels<double, int> vx;
+                const int sc = have ? s : 0;
+                beam_voxels<double, int>(grid, lmn[4 * sc], lmn[4 * sc + 1], sin_pa, cos_pa, pe_l, pe_m, as_l, as_m,
+                                         fscale, fnud, fgc0, 4, vx);
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    double2 e = beam_sample_corr<double, int>(beam, babs, vx, c);
+                    if (!have) e = make_double2(0.0, 0.0);
+                    ldsE[((size_t)e_sl * 4 + c) * nant + e_ant] = e;
+                }
+            }
+            C2 E[4], B[4];
+            const double2 *bp = brightness + ((int64_t)(have ? s : 0) * nchan + f) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double2 e = ldsE[((size_t)e_sl * 4 + c) * nant + e_ant], b = bp[c];
+                E[c].re = e.x; E[c].im = e.y;
+                B[c].re = b.x; B[c].im = b.y;
+            }
+            // G = E . B  (2x2, row-major components 0..3 = xx, xy, yx, yy); zero when E is zero
+            C2 G;
+            G = cmul(E[0], B[0]); cmac(G, E[1], B[2]);
+            ldsG[((size_t)e_sl * 4 + 0) * nant + e_ant] = make_double2(G.re, G.im);
+            G = cmul(E[0], B[1]); cmac(G, E[1], B[3]);
+            ldsG[((size_t)e_sl * 4 + 1) * nant + e_ant] = make_double2(G.re, G.im);
+            G = cmul(E[2], B[0]); cmac(G, E[3], B[2]);
+            ldsG[((size_t)e_sl * 4 + 2) * nant + e_ant] = make_double2(G.re, G.im);
+            G = cmul(E[2], B[1]); cmac(G, E[3], B[3]);
+            ldsG[((size_t)e_sl * 4 + 3) * nant + e_ant] = make_double2(G.re, G.im);
+        }
+        __syncthreads();
+        // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
+        const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
+        for (int sl = 0; sl < nb; ++sl) {
+            const double l = lmn[4 * (s0 + sl)], m = lmn[4 * (s0 + sl) + 1], n = lmn[4 * (s0 + sl) + 2];
+            const double2 *pE = ldsE + (size_t)sl * 4 * nant, *pG = ldsG + (size_t)sl * 4 * nant;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const double q = fma(n, w[k], fma(m, v[k], __dmul_rn(l, u[k])));
+                C2 y;
+                sincos_quarter_turns<7>(__dmul_rn(q, F4), y.re, y.im);
+                C2 Gp[4], Eq[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double2 g = pG[c * nant + a1[k]], e = pE[c * nant + a2[k]];
+                    Gp[c].re = g.x; Gp[c].im = g.y;
+                    Eq[c].re = e.x; Eq[c].im = e.y;
+                }
+                // M = G_p . E_q^H :  M[i][j] = sum_k G[i][k] conj(E[j][k])
+                C2 M0 = cmulc(Gp[0], Eq[0]); cmacc(M0, Gp[1], Eq[1]);
+                C2 M1 = cmulc(Gp[0], Eq[2]); cmacc(M1, Gp[1], Eq[3]);
+                C2 M2 = cmulc(Gp[2], Eq[0]); cmacc(M2, Gp[3], Eq[1]);
+                C2 M3 = cmulc(Gp[2], Eq[2]); cmacc(M3, Gp[3], Eq[3]);
+                cmac(acc[k][0], y, M0);
+                cmac(acc[k][1], y, M1);
+                cmac(acc[k][2], y, M2);
+                cmac(acc[k][3], y, M3);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (live[k]) {
+            double2 *o = out + ((r0 + tid + k * THREADS) * nchan + f) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = make_double2(acc[k][c].re, acc[k][c].im);
+        }
+    }
+}
+
+}  // namespace
+
+// Host-side helper (host pointers): split rows (time_index non-decreasing... any order of equal
+// runs) into items of consecutive rows with equal time_index, at most max_rows each;
+// item = (time_index - min(time_index), row_start, row_count, 0).
+AF_EXPORT int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *items_host,
+                                 int64_t max_items, int64_t *nitems)
+{
+    AF_REQUIRE(nitems != nullptr, "af_fused_plan_rows: nitems is NULL");
+    *nitems = 0;
+    if (nrow == 0) return AF_OK;
+    AF_REQUIRE(time_index_host != nullptr, "af_fused_plan_rows: time_index is NULL");
+    int64_t tmin = time_index_host[0];
+    for (int64_t r = 1; r < nrow; ++r) tmin = time_index_host[r] < tmin ? time_index_host[r] : tmin;
+    const int64_t max_rows = (int64_t)THREADS * RPT;
+    int64_t n = 0, start = 0;
+    for (int64_t r = 1; r <= nrow; ++r) {
+        if (r == nrow || time_index_host[r] != time_index_host[start] || r - start == max_rows) {
+            if (items_host != nullptr) {
+                AF_REQUIRE(n < max_items, "af_fused_plan_rows: more than %lld items", (long long)max_items);
+                AF_REQUIRE(time_index_host[start] - tmin < (1LL << 31) && start < (1LL << 31),
+                           "af_fused_plan_rows: index does not fit int32");
+                items_host[4 * n + 0] = (int32_t)(time_index_host[start] - tmin);
+                items_host[4 * n + 1] = (int32_t)start;
+                items_host[4 * n + 2] = (int32_t)(r - start);
+                items_host[4 * n + 3] = 0;
+            }
+            ++n;
+            start = r;
+        }
+    }
+    *nitems = n;
+    return AF_OK;
+}
+
+AF_EXPORT size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
+                                                  int64_t beam_nud)
+{
+    if (nsrc < 0 || nchan < 0 || beam_lw < 0 || beam_mh < 0 || beam_nud < 0) return 0;
+    return fused_ws(nsrc, nchan, beam_lw, beam_mh, beam_nud).total;
+}
+
+AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *antenna1,
+                                    const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                                    const double *frequency, const double *brightness, int64_t nsrc, int64_t nchan,
+                                    const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                                    const double *beam_lm_extents, const double *beam_freq_map,
+                                    const double *parallactic_angles, int64_t ntime, int64_t nant,
+                                    const double *point_errors, const double *antenna_scaling, int convention,
+                                    double *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
+               "convention not in ('fourier', 'casa')");
+    AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
+    AF_REQUIRE(nitems >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
+               "af_fused_predict_c128: negative extent");
+    AF_REQUIRE(nant <= THREADS, "af_fused_predict_c128: more than %d antennas", THREADS);
+    AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nitems < (1LL << 31), "af_fused_predict_c128: too large");
+    hipStream_t st_ = af_stream(stream);
+    if (nrow == 0 || nchan == 0) return AF_OK;
+    AF_REQUIRE(out != nullptr, "af_fused_predict_c128: out is NULL");
+    if (nsrc == 0 || nitems == 0) {
+        AF_HIP(hipMemsetAsync(out, 0, sizeof(double) * 2 * 4 * (size_t)(nrow * nchan), st_));
+        return AF_OK;
+    }
+    AF_REQUIRE(items && antenna1 && antenna2 && lm && uvw && frequency && brightness && beam && beam_lm_extents &&
+                   beam_freq_map && parallactic_angles && point_errors && antenna_scaling,
+               "af_fused_predict_c128: NULL array");
+    const FusedWs W = fused_ws(nsrc, nchan, beam_lw, beam_mh, beam_nud);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= W.total, "af_fused_predict_c128: workspace too small (%zu < %zu)",
+               workspace_bytes, W.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_fused_predict_c128: workspace must be 256-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    double *lmn = reinterpret_cast<double *>(ws + W.lmn), *f4 = reinterpret_cast<double *>(ws + W.f4);
+    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *babs = reinterpret_cast<double *>(ws + W.babs);
+
+    hipLaunchKernelGGL(fused_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st_, lm, nsrc, lmn);
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fused_prep_freq, dim3((unsigned)af_cdiv(nchan, 64)), dim3(64), 0, st_, frequency, nchan,
+                       convention, f4);
+    AF_LAUNCH_CHECK();
+    int rc = af_freq_grid_interp_f64(frequency, nchan, beam_freq_map, beam_nud, freq_data, stream);
+    if (rc != AF_OK) return rc;
+    {
+        const int64_t n = beam_lw * beam_mh * beam_nud * 4;
+        int64_t blocks = af_cdiv(n, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(beam_abs_kernel, dim3((unsigned)blocks), dim3(256), 0, st_,
+                           reinterpret_cast<const double2 *>(beam), n, babs);
+        AF_LAUNCH_CHECK();
+    }
+    int st = (int)(THREADS / nant);
+    if (st > nsrc) st = (int)nsrc;
+    if (st < 1) st = 1;
+    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2);
+    AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_predict_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    af_prof_begin(st_);
+    hipLaunchKernelGGL(fused_predict_kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(THREADS), lds_bytes, st_,
+                       items, antenna1, antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness),
+                       reinterpret_cast<const double2 *>(beam), babs, beam_lw, beam_mh, beam_nud, beam_lm_extents,
+                       freq_data, parallactic_angles, point_errors, antenna_scaling, (int)nsrc, nchan, ntime,
+                       (int)nant, st, reinterpret_cast<double2 *>(out));
+    AF_LAUNCH_CHECK();
+    af_prof_end(st_);
+    return AF_OK;
+}

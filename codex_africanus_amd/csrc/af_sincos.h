@@ -1,0 +1,47 @@
+// Quarter-turn polynomial sincos shared by the im_to_vis and fused-predict kernels.
+#pragma once
+#include "af_common.h"
+
+// (cos, sin)(2*pi*t) for t given in QUARTER turns t4 = 4*t.  Reduction: r = rint(t4) by the
+// 1.5*2^52 magic-number add (also yields the quadrant in the low dword), f = t4 - r exact in
+// [-0.5, 0.5]; sin(pi/2 f) = f*S(f^2), cos(pi/2 f) = C(f^2), Chebyshev-node fits on
+// f^2 in [0, 0.25]: |err| <= 7e-15 (S), 6e-14 (C) with 6 terms; ~1e-16 with 7 terms (and exactly
+// (1, 0) at f = 0, so a source at the phase centre gets a unit phasor).  The kernels use 7: an
+// error e in cos of the channel-step angle is amplified by the recurrence to ~j^2*e at channel j.
+template <int NTERM>
+__device__ __forceinline__ void sincos_quarter_turns(double t4, double &c_out, double &s_out)
+{
+    static_assert(NTERM == 6 || NTERM == 7, "6 or 7 polynomial terms");
+    constexpr double S6[7] = {0x1.921fb54442cfap+0, -0x1.4abbce6257a2ap-1, 0x1.466bc67123fa1p-4,
+                              -0x1.32d2c644adc0bp-8, 0x1.5071ce4b47930p-13, -0x1.dd54805f3f706p-19, 0.0};
+    constexpr double C6[7] = {0x1.ffffffffffe0bp-1, -0x1.3bd3cc9bd2c35p+0, 0x1.03c1f074ded21p-2,
+                              -0x1.55d3ba300cd50p-6, 0x1.e1e7ccccb387ap-11, -0x1.a0ee132c60c1fp-16, 0.0};
+    constexpr double S7[7] = {0x1.921fb54442d18p+0, -0x1.4abbce625be41p-1, 0x1.466bc677587f8p-4,
+                              -0x1.32d2cce2e5b19p-8, 0x1.50782fda12d96p-13, -0x1.e30071afc3e59p-19,
+                              0x1.e3f38399551bfp-25};
+    constexpr double C7[7] = {0x1.0000000000000p+0, -0x1.3bd3cc9be458bp+0, 0x1.03c1f081b0780p-2,
+                              -0x1.55d3c7dbfd139p-6, 0x1.e1f4fb60281f6p-11, -0x1.a6c9c1be9eb49p-16,
+                              0x1.f3dbcea61b1a4p-22};
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    double a = __dadd_rn(t4, MAGIC);
+    int q = __double2loint(a);                // low 32 bits = rint(t4) mod 2^32
+    double r = __dsub_rn(a, MAGIC);
+    double f = __dsub_rn(t4, r);
+    double z = __dmul_rn(f, f);
+    double ps = NTERM == 6 ? S6[5] : S7[6], pc = NTERM == 6 ? C6[5] : C7[6];
+#pragma unroll
+    for (int i = NTERM - 2; i >= 0; --i) {
+        ps = fma(ps, z, NTERM == 6 ? S6[i] : S7[i]);
+        pc = fma(pc, z, NTERM == 6 ? C6[i] : C7[i]);
+    }
+    ps = __dmul_rn(ps, f);
+    // quadrant: 0 (c,s)  1 (-s,c)  2 (-c,-s)  3 (s,-c)
+    const bool swap = q & 1;
+    double cc = swap ? ps : pc;
+    double ss = swap ? pc : ps;
+    int chi = __double2hiint(cc) ^ (((q + 1) & 2) << 30);
+    int shi = __double2hiint(ss) ^ ((q & 2) << 30);
+    c_out = __hiloint2double(chi, __double2loint(cc));
+    s_out = __hiloint2double(shi, __double2loint(ss));
+}
+

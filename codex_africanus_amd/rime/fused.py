@@ -1,0 +1,121 @@
+"""
+Fused RIME predict: the reference's chain
+
+    phase  = phase_delay(lm, uvw, frequency)                              africanus/rime/phase.py:11
+    coh    = einsum("srf,sfij->srfij", phase, brightness)                 africanus/rime/examples/predict.py:107-134
+    ddes   = beam_cube_dde(beam, ..., lm, parangles, point_errors, ...)   africanus/rime/fast_beam_cubes.py:57
+    vis    = predict_vis(time_index, a1, a2, ddes, coh, ddes, die1, base_vis, die2)   africanus/rime/predict.py:466
+
+evaluated on the device without materialising ``coh`` (4.1 TB at 1e6 rows x 64 chan x 1000 src)
+or ``ddes`` (130 GB with 64 antennas): the form in which BASELINE configs 2-4 are feasible at all.
+The reference's own counterpart is the experimental fused RIME
+(africanus/experimental/rime/fused/core.py:88-120).
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from .._device import Call, np_dtype_of, _is_torch
+from .predict import predict_vis
+
+
+def _host(a):
+    return a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
+
+
+def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
+                      beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
+                      point_errors=None, antenna_scaling=None,
+                      die1_jones=None, base_vis=None, die2_jones=None, convention="fourier"):
+    """
+    ``V_pq = G_p ( B_pq + sum_s E_ps (K_pqs X_s) E_qs^H ) G_q^H`` from source-level inputs.
+
+    ``time_index``/``antenna1``/``antenna2`` (row,); ``lm`` (source, 2); ``uvw`` (row, 3);
+    ``frequency`` (chan,); ``brightness`` (source, chan, 2, 2) -- or (source, 2, 2), flat in
+    frequency -- the per-source coherency matrix X_s (africanus.model.coherency.convert output);
+    optional beam cube arguments exactly as ``beam_cube_dde`` (all or none); optional
+    ``die{1,2}_jones`` (time, ant, chan, 2, 2) and ``base_vis`` (row, chan, 2, 2) exactly as
+    ``predict_vis``.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
+    per-antenna Jones terms on the device.  float64 / complex128 only.
+    """
+    if convention not in _lib.CONVENTION:
+        raise ValueError("convention not in ('fourier', 'casa')")
+    beam_args = (beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
+    have_beam = beam is not None
+    if any((a is None) != (not have_beam) for a in beam_args):
+        raise ValueError("beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors and "
+                         "antenna_scaling must all be present or all absent")
+    if (die1_jones is None) != (die2_jones is None):
+        raise ValueError("Both die1_jones and die2_jones must be present or absent")
+    nsrc, nrow, nchan = int(lm.shape[0]), int(uvw.shape[0]), int(frequency.shape[0])
+    if tuple(lm.shape) != (nsrc, 2) or tuple(uvw.shape) != (nrow, 3):
+        raise ValueError("lm must be (source, 2) and uvw (row, 3)")
+    bshape = tuple(int(s) for s in brightness.shape)
+    if bshape == (nsrc, 2, 2):
+        flat_spectrum = True
+    elif bshape == (nsrc, nchan, 2, 2):
+        flat_spectrum = False
+    else:
+        raise ValueError("brightness must have shape (source, chan, 2, 2) or (source, 2, 2)")
+    for name, a in (("time_index", time_index), ("antenna1", antenna1), ("antenna2", antenna2)):
+        if tuple(a.shape) != (nrow,):
+            raise ValueError("%s must have shape (row,)" % name)
+
+    with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, *beam_args) as c:
+        if flat_spectrum:
+            if _is_torch(brightness):
+                brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
+            else:
+                brightness = np.broadcast_to(np.asarray(brightness)[:, None], (nsrc, nchan, 2, 2))
+        p_lm, p_uvw, p_fr = c.inp(lm, np.float64), c.inp(uvw, np.float64), c.inp(frequency, np.float64)
+        p_b = c.inp(brightness, np.complex128)
+        p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
+        conv = _lib.CONVENTION[convention]
+        if not have_beam:
+            # sum_s K X_s: the direct transform with a complex image and phase_delay's clamped n
+            ws_bytes = int(_lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, 4, 1))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_im_to_vis_f64", p_b, 1, p_uvw, p_lm, p_fr, nsrc, nrow, nchan, 4, conv,
+                      _lib.AF_DFT_AUTO | _lib.AF_DFT_CLAMP_N, p_out, p_ws, max(ws_bytes, 256), c.stream)
+        else:
+            if len(beam.shape) != 5 or tuple(beam.shape[3:]) != (2, 2):
+                raise ValueError("beam must have shape (beam_lw, beam_mh, beam_nud, 2, 2)")
+            beam_lw, beam_mh, beam_nud = (int(s) for s in beam.shape[:3])
+            if beam_lw < 2 or beam_mh < 2 or beam_nud < 2:
+                raise ValueError("beam_lw, beam_mh and beam_nud must be >= 2")
+            ntime, nant = (int(s) for s in parallactic_angles.shape)
+            if tuple(point_errors.shape) != (ntime, nant, nchan, 2):
+                raise ValueError("point_errors must have shape (time, ant, chan, 2)")
+            if tuple(antenna_scaling.shape) != (nant, nchan, 2):
+                raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
+            # plan: runs of equal time_index (host side, O(nrow))
+            ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
+            if nrow and (int(ti.max()) - int(ti.min()) >= ntime):
+                raise ValueError("time_index spans more timesteps than parallactic_angles has")
+            a1h, a2h = _host(antenna1), _host(antenna2)
+            if nrow and (min(a1h.min(), a2h.min()) < 0 or max(a1h.max(), a2h.max()) >= nant):
+                raise ValueError("antenna index out of range")
+            n_items = ctypes.c_int64(0)
+            tip = ti.ctypes.data_as(ctypes.c_void_p)
+            _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+            items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
+            _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p),
+                      n_items.value, ctypes.byref(n_items))
+            p_items = c.inp(items, np.int32)
+            p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
+            p_beam, p_ext, p_map = c.inp(beam, np.complex128), c.inp(beam_lm_extents, np.float64), \
+                c.inp(beam_freq_map, np.float64)
+            p_pa, p_pe, p_as = c.inp(parallactic_angles, np.float64), c.inp(point_errors, np.float64), \
+                c.inp(antenna_scaling, np.float64)
+            ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, p_b,
+                      nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
+                      p_as, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+        vis = c.result(h)
+    if die1_jones is None and base_vis is None:
+        return vis
+    # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
+    return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)

@@ -44,6 +44,10 @@ extern "C" {
                                (decided on the device, no host sync), else AF_DFT_EXACT */
 #define AF_DFT_EXACT 1      /* reference operation order + full-accuracy sincos per (row,src,chan) */
 #define AF_DFT_RECURRENCE 2 /* force the recurrence (caller asserts uniform spacing) */
+/* OR-able into `mode`: compute n = sqrt(max(0, 1-l^2-m^2)) - 1 as phase_delay does
+ * (africanus/rime/phase.py:42-43) instead of im_to_vis' unclamped form: the
+ * phase_delay -> einsum -> predict_vis chain without materialising the coherencies */
+#define AF_DFT_CLAMP_N 0x100
 
 /* Jones layouts: africanus/rime/predict.py:10-12 */
 #define AF_JONES_DIAG 1 /* JONES_1_OR_2: corr shape (1,) or (2,), element-wise products */
@@ -172,6 +176,33 @@ int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, in
                          int64_t ntime, int64_t nant, const float *point_errors,
                          const float *antenna_scaling, const float *frequency, int64_t nchan,
                          float *out, float *freq_data_ws, void *stream);
+
+/* ---- fused predict with beam-cube DDEs -------------------------------------------
+ * The reference's chain phase_delay -> einsum("srf,sfij->srfij", phase, brightness) ->
+ * beam_cube_dde -> predict_vis(time_index, a1, a2, dde, coh, dde)
+ * (africanus/rime/examples/predict.py:107-134,404-472,525; africanus/rime/phase.py:28-61;
+ * africanus/rime/fast_beam_cubes.py:57-240; africanus/rime/predict.py:199-212) in one kernel:
+ *   out[r,nu] = sum_s E_p(s,t,nu) . (K(r,s,nu) B(s,nu)) . E_q(s,t,nu)^H     (2x2 complex128)
+ * without materialising the (src,row,chan) coherencies or the (src,time,ant,chan) Jones terms.
+ *   items (nitems,4) int32 DEVICE: (time index into parallactic_angles/point_errors, row_start,
+ *       row_count <= 2048, 0): runs of consecutive rows with equal time_index, built by
+ *       af_fused_plan_rows (HOST pointers) from the row time_index array
+ *   antenna1/antenna2 (nrow) int32; lm (nsrc,2); uvw (nrow,3); frequency (nchan);
+ *   brightness (nsrc,nchan,2,2) complex128; beam (lw,mh,nud,2,2) complex128 and the other
+ *   beam_cube_dde arguments as in af_beam_cube_dde_c128; out (nrow,nchan,2,2) complex128.
+ * DIE terms / base_vis are applied afterwards with af_predict_vis_c128 (source_coh = out). */
+int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *items_host,
+                       int64_t max_items, int64_t *nitems);
+size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
+                                        int64_t beam_nud);
+int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *antenna1,
+                          const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                          const double *frequency, const double *brightness, int64_t nsrc,
+                          int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh,
+                          int64_t beam_nud, const double *beam_lm_extents, const double *beam_freq_map,
+                          const double *parallactic_angles, int64_t ntime, int64_t nant,
+                          const double *point_errors, const double *antenna_scaling, int convention,
+                          double *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- chi-squared ---------------------------------------------------------------
  * chi2_per_chan[nu] = sum_{r,c} weight[r,nu,c] * |data[r,nu,c] - model[r,nu,c]|^2
