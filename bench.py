@@ -49,6 +49,13 @@ def parse():
     p.add_argument("--sources", type=int, default=1000)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
+    p.add_argument("--workload", default="dft", choices=["dft", "fused_dde"],
+                   help="dft: im_to_vis (BASELINE configs[1], the headline); fused_dde: fused predict with "
+                        "per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2])")
+    p.add_argument("--pa", default="random", choices=["random", "common"],
+                   help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
+                        "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
+                        "(a real array: coherent beam gathers)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     p.add_argument("--check-rows", type=int, default=256, help="rows checked against the oracle")
@@ -121,9 +128,52 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     P = lambda x: ctypes.c_void_p(x.data_ptr())
 
-    def predict():
-        _lib.call("af_im_to_vis_f64", P(d_image), 0, P(d_uvw), P(d_lm), P(d_freq), nsrc, nrow, nchan, ncorr,
-                  _lib.CONVENTION["fourier"], mode, P(d_vis), P(d_ws), ws_bytes, stream)
+    if args.workload == "dft":
+        def predict():
+            _lib.call("af_im_to_vis_f64", P(d_image), 0, P(d_uvw), P(d_lm), P(d_freq), nsrc, nrow, nchan, ncorr,
+                      _lib.CONVENTION["fourier"], mode, P(d_vis), P(d_ws), ws_bytes, stream)
+    else:
+        # BASELINE configs[2]: 64 antennas, 2016 baselines per timestep, beam cube
+        # 257 x 257 x 33 x 2 x 2 complex128, parallactic angles U(0, pi/6), pointing errors 1e-3 N(0,1),
+        # antenna scaling 1 +- 1e-3; brightness = flat-spectrum coherency matrices of the synthetic sky
+        nant = 64
+        a1, a2 = np.triu_indices(nant, 1)
+        nbl = a1.shape[0]
+        ntime = -(-nrow // nbl)
+        ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
+        ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
+        time_index = np.repeat(np.arange(ntime, dtype=np.int64), nbl)[:nrow]
+        g = np.linspace(-1, 1, 257)
+        ll, mm = np.meshgrid(g, g, indexing="ij")
+        pattern = np.exp(-(ll**2 + mm**2) / 0.5) * np.exp(1j * (0.3 * ll + 0.2 * mm))
+        gains = (1 + 0.02 * np.arange(33))[:, None] * np.array([1.0, 0.05j, -0.04j, 0.95])[None, :]
+        beam = (pattern[:, :, None, None] * gains[None, None]).reshape(257, 257, 33, 2, 2)
+        extents = np.array([[-0.06, 0.06], [-0.06, 0.06]])
+        beam_freq_map = np.linspace(freq[0], freq[-1], 33)
+        pa = rng.uniform(0, np.pi / 6, (ntime, nant))
+        if args.pa == "common":
+            pa = np.linspace(0, np.pi / 6, ntime)[:, None] + 1e-3 * rng.standard_normal((ntime, nant))
+        pe = 1e-3 * rng.standard_normal((ntime, nant, nchan, 2))
+        asc = 1.0 + 1e-3 * rng.standard_normal((nant, nchan, 2))
+        X = np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4)).reshape(nsrc, nchan, 2, 2)
+        n_items = ctypes.c_int64(0)
+        tip = time_index.ctypes.data_as(ctypes.c_void_p)
+        _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+        items = np.zeros((n_items.value, 4), dtype=np.int32)
+        _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
+                  ctypes.byref(n_items))
+        fd = dict(items=t(items), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
+                  fmap=t(beam_freq_map), pa=t(pa), pe=t(pe), asc=t(asc))
+        fws_bytes = int(lib.af_fused_predict_workspace_bytes(nsrc, nchan, 257, 257, 33))
+        d_fws = torch.empty(max(fws_bytes, 256), dtype=torch.uint8, device=dev)
+        fused_host = dict(time_index=time_index, ant1=ant1, ant2=ant2, X=X, beam=beam, extents=extents,
+                          beam_freq_map=beam_freq_map, pa=pa, pe=pe, asc=asc)
+
+        def predict():
+            _lib.call("af_fused_predict_c128", P(fd["items"]), n_items.value, P(fd["a1"]), P(fd["a2"]), nrow,
+                      P(d_lm), P(d_uvw), P(d_freq), P(fd["X"]), nsrc, nchan, P(fd["beam"]), 257, 257, 33,
+                      P(fd["ext"]), P(fd["fmap"]), P(fd["pa"]), ntime, nant, P(fd["pe"]), P(fd["asc"]),
+                      _lib.CONVENTION["fourier"], P(d_vis), P(d_fws), fws_bytes, stream)
 
     # "observed" data for the chi^2: the model itself plus a fixed perturbation (one extra predict)
     predict()
@@ -181,8 +231,20 @@ def main():
     if rank == 0 and args.check_rows > 0:
         import oracle
         rows = np.linspace(0, nrow - 1, min(args.check_rows, nrow)).astype(np.int64)
-        ref = oracle.im_to_vis(image, uvw[rows], lm, freq, omp=True)
         got = d_vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        if args.workload == "dft":
+            ref = oracle.im_to_vis(image, uvw[rows], lm, freq, omp=True)
+        else:
+            # the reference chain on the sampled rows (only their timesteps' Jones terms are built)
+            h = fused_host
+            rows = rows[:32]
+            got = got[:32].reshape(32, nchan, 2, 2)
+            tsel, tinv = np.unique(h["time_index"][rows], return_inverse=True)
+            dde = oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], lm, h["pa"][tsel],
+                                       h["pe"][tsel], h["asc"], freq)
+            phase = oracle.phase_delay(lm, uvw[rows], freq)
+            coh = np.einsum("srf,sfij->srfij", phase, h["X"])
+            ref = oracle.predict_vis(tinv, h["ant1"][rows], h["ant2"][rows], dde, coh, dde, None, None, None)
         max_err = float(np.abs(got - ref).max())
 
     if rank == 0:
@@ -194,13 +256,24 @@ def main():
         # algorithmic flops: per (row, chan, src) one complex phasor step (recurrence, 2 FMA) +
         # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop
         alg_flops = float(nrow) * nchan * nsrc * (2 + 2 * ncorr) * 2
+        kernel_name = "dft_exact_kernel<13,4,false>" if args.mode == "exact" else "dft_recurrence_dpp_kernel<13,4,false,7>"
+        workload = "im_to_vis DFT predict (BASELINE configs[1])"
+        if args.workload == "fused_dde":
+            # + indices 12 B/row, beam cube + |beam| + parangles/pointing/scaling; ~150 flop
+            # per (row, chan, src): phasor 8 + E X E^H 112 + 4 complex MACs 32
+            alg_bytes = (nrow * nchan * 64 + nrow * 36 + 257 * 257 * 33 * 4 * 24 + ntime * nant * (8 + nchan * 16)
+                         + nant * nchan * 16 + nsrc * nchan * 64)
+            alg_flops = float(nrow) * nchan * nsrc * 150.0
+            kernel_name = "fused_predict_kernel"
+            workload = ("fused predict with per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2]), "
+                        "parallactic angles %s" % args.pa)
         achieved = alg_bytes / kernel_s / 1e9
         # HBM bytes per launch from the PMC passes of THIS command committed under profiles/
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; KB units; FETCH_SIZE doubled
         # as MI355X_MICROARCH.md prescribes for gfx950 streaming reads -- an upper bound here).
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and (nrow, nchan, nsrc, args.mode) == (1000000, 64, 1000, "auto"):
+        if os.path.exists(pmc) and (nrow, nchan, nsrc, args.mode, args.workload) == (1000000, 64, 1000, "auto", "dft"):
             c = json.load(open(pmc))
             traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             traffic_src = "profiles/r01_pmc_summary.json"
@@ -213,15 +286,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "im_to_vis DFT predict (BASELINE configs[1]) + per-channel chi^2"
-                            + (" + RCCL all-reduce" if world > 1 else ""),
+                "workload": workload + " + per-channel chi^2" + (" + RCCL all-reduce" if world > 1 else ""),
                 "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": ncorr,
                 "rows_total": world * nrow, "phasor_mode": args.mode,
                 "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce" % world,
             },
             "fp64_max_abs_err": max_err,
             "roofline": {
-                "kernel": "dft_exact_kernel<13,4,false>" if args.mode == "exact" else "dft_recurrence_dpp_kernel<13,4,false,7>",
+                "kernel": kernel_name,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
@@ -231,7 +303,7 @@ def main():
                               "algorithmic_flops": alg_flops},
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "dft":
             out["cpu_baseline"] = cpu_baseline(image, uvw, lm, freq, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void beam_cube_dde_kernel(
                    freq_data[3 * f + 1], (int)freq_data[3 * f + 2], ncorr, vx);
     const V2 *fbeam = reinterpret_cast<const V2 *>(beam);
     V2 *o = reinterpret_cast<V2 *>(out) + idx * ncorr;
-    for (int c = 0; c < ncorr; ++c) o[c] = beam_sample_corr<T, int64_t>(fbeam, nullptr, vx, c);
+    for (int c = 0; c < ncorr; ++c) o[c] = beam_sample_corr<T, int64_t, false>(fbeam, nullptr, vx, c);
 }
 
 template <typename T>

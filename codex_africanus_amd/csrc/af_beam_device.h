@@ -103,9 +103,10 @@ __device__ __forceinline__ void beam_voxels(const BeamGrid<T> &g, T l, T m, T si
 }
 
 // One correlation of the sample: weighted sums of the complex voxels and of their amplitudes,
-// then the amplitude-preserving normalisation (:170-235).  `babs` (optional) is a cube of
+// then the amplitude-preserving normalisation (:170-235).  HAVE_ABS: `babs` is a cube of
 // precomputed |beam| values with the same indexing (hypot is the dominant cost otherwise).
-template <typename T, typename I>
+// All 8 voxel gathers are issued before the first is consumed (one memory latency, not eight).
+template <typename T, typename I, bool HAVE_ABS>
 __device__ __forceinline__ typename BeamOps<T>::vec2 beam_sample_corr(
     const typename BeamOps<T>::vec2 *__restrict__ fbeam, const T *__restrict__ babs, const BeamVoxels<T, I> &vx,
     int c)
@@ -113,16 +114,22 @@ __device__ __forceinline__ typename BeamOps<T>::vec2 beam_sample_corr(
     using O = BeamOps<T>;
     using V2 = typename O::vec2;
     const T zero = (T)0.0;
+    V2 b[8];
+    T ab[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        b[k] = fbeam[vx.off[k] + c];
+        if constexpr (HAVE_ABS) ab[k] = babs[vx.off[k] + c];
+    }
     T cre = zero, cim = zero, absc = zero;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const V2 b = fbeam[vx.off[k] + c];
         const T wgt = vx.wt[k];
-        const T ab = babs ? babs[vx.off[k] + c] : O::hypot_(b.x, b.y);
-        absc = O::add(absc, O::mul(wgt, ab));
+        if constexpr (!HAVE_ABS) ab[k] = O::hypot_(b[k].x, b[k].y);
+        absc = O::add(absc, O::mul(wgt, ab[k]));
         // (wgt + 0j) * b as a full complex multiply (numba widens the real weight)
-        const T pre = O::sub(O::mul(wgt, b.x), O::mul(zero, b.y));
-        const T pim = O::add(O::mul(wgt, b.y), O::mul(zero, b.x));
+        const T pre = O::sub(O::mul(wgt, b[k].x), O::mul(zero, b[k].y));
+        const T pim = O::add(O::mul(wgt, b[k].y), O::mul(zero, b[k].x));
         cre = O::add(cre, pre);
         cim = O::add(cim, pim);
     }

@@ -11,8 +11,8 @@
 // One workgroup (512 lanes, one per CU: 237 VGPRs, up to 128 KB of LDS) owns one run of rows with
 // equal time_index (<= 2048 rows: a whole 64-antenna timestep) and one channel, and walks the
 // sources in batches:
-//   stage 1  lane = (source of the batch, antenna): sample the beam cube (|beam| precomputed once per
-//            call) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
+//   stage 1  lane = (source of the batch, antenna): sample the beam cube (repacked once per call into
+//            128-byte voxel records holding the 4 correlations and their moduli) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
 //            stage 2's reads are conflict-free (consecutive rows = consecutive antenna2) or
 //            broadcasts (antenna1);
 //   stage 2  lane = four rows: per source q = l u + m v + n w, the phasor by the quarter-turn
@@ -42,7 +42,7 @@ FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, 
     w.lmn = take((size_t)nsrc * 4 * sizeof(double));
     w.f4 = take((size_t)nchan * sizeof(double));
     w.freq_data = take((size_t)nchan * 3 * sizeof(double));
-    w.babs = take((size_t)beam_lw * beam_mh * beam_nud * 4 * sizeof(double));
+    w.babs = take((size_t)beam_lw * beam_mh * beam_nud * 16 * sizeof(double));  // 128-B voxel records
     w.total = o;
     return w;
 }
@@ -68,14 +68,52 @@ __global__ void fused_prep_freq(const double *__restrict__ freq, int64_t nchan, 
     if (c < nchan) f4[c] = 4.0 * (double)sign * freq[c] / AF_LIGHTSPEED;
 }
 
-// |beam| of every voxel and correlation, once per call (hypot dominates the beam stage otherwise)
-__global__ void beam_abs_kernel(const double2 *__restrict__ beam, int64_t n, double *__restrict__ babs)
+// One 128-byte record per voxel, once per call: (re, im) of the 4 correlations, then their
+// moduli (hypot dominates the beam stage otherwise), then padding -- so that sampling a voxel
+// touches exactly one cache line instead of one line of `beam` plus one of a |beam| array.
+constexpr int VREC = 16;  // doubles per voxel record
+__global__ void beam_pack_kernel(const double2 *__restrict__ beam, int64_t nvox, double *__restrict__ rec)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (voxel, corr)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+    for (; i < nvox * 4; i += stride) {
+        const int64_t vx = i >> 2;
+        const int c = (int)(i & 3);
         double2 b = beam[i];
-        babs[i] = hypot(b.x, b.y);
+        rec[vx * VREC + 2 * c] = b.x;
+        rec[vx * VREC + 2 * c + 1] = b.y;
+        rec[vx * VREC + 8 + c] = hypot(b.x, b.y);
+        rec[vx * VREC + 12 + c] = 0.0;
+    }
+}
+
+// beam_sample_corr (af_beam_device.h) for all four correlations from the packed records:
+// per voxel 6 x 16-byte loads of one line; sums in the reference's voxel order.
+__device__ __forceinline__ void beam_sample4(const double *__restrict__ rec, const BeamVoxels<double, int> &vx,
+                                             double2 (&E)[4])
+{
+    double cre[4] = {0, 0, 0, 0}, cim[4] = {0, 0, 0, 0}, absc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double2 *r = reinterpret_cast<const double2 *>(rec + (int64_t)vx.off[k] * VREC);
+        const double2 b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], a01 = r[4], a23 = r[5];
+        const double wgt = vx.wt[k];
+        const double br[4] = {b0.x, b1.x, b2.x, b3.x}, bi[4] = {b0.y, b1.y, b2.y, b3.y};
+        const double ab[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            absc[c] = __dadd_rn(absc[c], __dmul_rn(wgt, ab[c]));
+            // (wgt + 0j) * b as a full complex multiply (numba widens the real weight)
+            cre[c] = __dadd_rn(cre[c], __dsub_rn(__dmul_rn(wgt, br[c]), __dmul_rn(0.0, bi[c])));
+            cim[c] = __dadd_rn(cim[c], __dadd_rn(__dmul_rn(wgt, bi[c]), __dmul_rn(0.0, br[c])));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double div = hypot(cre[c], cim[c]);
+        const double sc = (div == 0.0) ? absc[c] : __ddiv_rn(absc[c], div);
+        E[c].x = __dsub_rn(__dmul_rn(cre[c], sc), __dmul_rn(cim[c], 0.0));
+        E[c].y = __dadd_rn(__dmul_rn(cre[c], 0.0), __dmul_rn(cim[c], sc));
     }
 }
 
@@ -118,7 +156,7 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
 __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
-    const double2 *__restrict__ brightness, const double2 *__restrict__ beam, const double *__restrict__ babs,
+    const double2 *__restrict__ brightness, const double *__restrict__ vrec,
     int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
     const double *__restrict__ freq_data, const double *__restrict__ parangles,
     const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling, int nsrc, int64_t nchan,
@@ -172,14 +210,14 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
             {
                 BeamVoxels<double, int> vx;
                 const int sc = have ? s : 0;
+                // voxel offsets in voxels (ncorr = 1): the packed records are indexed per voxel
                 beam_voxels<double, int>(grid, lmn[4 * sc], lmn[4 * sc + 1], sin_pa, cos_pa, pe_l, pe_m, as_l, as_m,
-                                         fscale, fnud, fgc0, 4, vx);
-#pragma unroll 1
-                for (int c = 0; c < 4; ++c) {
-                    double2 e = beam_sample_corr<double, int>(beam, babs, vx, c);
-                    if (!have) e = make_double2(0.0, 0.0);
-                    ldsE[((size_t)e_sl * 4 + c) * nant + e_ant] = e;
-                }
+                                         fscale, fnud, fgc0, 1, vx);
+                double2 e4[4];
+                beam_sample4(vrec, vx, e4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    ldsE[((size_t)e_sl * 4 + c) * nant + e_ant] = have ? e4[c] : make_double2(0.0, 0.0);
             }
             C2 E[4], B[4];
             const double2 *bp = brightness + ((int64_t)(have ? s : 0) * nchan + f) * 4;
@@ -325,11 +363,12 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     int rc = af_freq_grid_interp_f64(frequency, nchan, beam_freq_map, beam_nud, freq_data, stream);
     if (rc != AF_OK) return rc;
     {
-        const int64_t n = beam_lw * beam_mh * beam_nud * 4;
-        int64_t blocks = af_cdiv(n, 256);
+        const int64_t nvox = beam_lw * beam_mh * beam_nud;
+        AF_REQUIRE(nvox < (1LL << 31), "af_fused_predict_c128: beam cube too large");
+        int64_t blocks = af_cdiv(nvox * 4, 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(beam_abs_kernel, dim3((unsigned)blocks), dim3(256), 0, st_,
-                           reinterpret_cast<const double2 *>(beam), n, babs);
+        hipLaunchKernelGGL(beam_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st_,
+                           reinterpret_cast<const double2 *>(beam), nvox, babs);
         AF_LAUNCH_CHECK();
     }
     int st = (int)(THREADS / nant);
@@ -341,7 +380,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     af_prof_begin(st_);
     hipLaunchKernelGGL(fused_predict_kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(THREADS), lds_bytes, st_,
                        items, antenna1, antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness),
-                       reinterpret_cast<const double2 *>(beam), babs, beam_lw, beam_mh, beam_nud, beam_lm_extents,
+                       babs, beam_lw, beam_mh, beam_nud, beam_lm_extents,
                        freq_data, parallactic_angles, point_errors, antenna_scaling, (int)nsrc, nchan, ntime,
                        (int)nant, st, reinterpret_cast<double2 *>(out));
     AF_LAUNCH_CHECK();
