@@ -10,7 +10,9 @@
 
 namespace {
 
-// grid: blocks over row ranges; block: 256 lanes striding the (chan*corr) columns of a row
+// grid: blocks over row ranges; block: 256 lanes striding the (chan*corr) columns of a row.
+// Four rows per step with independent partial sums keep 8 x 16-byte loads in flight per lane.
+template <bool HAS_WEIGHT>
 __global__ __launch_bounds__(256) void chi2_kernel(const double2 *__restrict__ model,
                                                    const double2 *__restrict__ data,
                                                    const double *__restrict__ weight, int64_t nrow,
@@ -21,16 +23,71 @@ __global__ __launch_bounds__(256) void chi2_kernel(const double2 *__restrict__ m
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < nrow) ? r0 + rows_per_block : nrow;
     for (int64_t col = threadIdx.x; col < ncol; col += blockDim.x) {
-        double acc = 0.0;
-        for (int64_t r = r0; r < r1; ++r) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            double2 m[4], d[4];
+            double wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = (r + k) * ncol + col;
+                m[k] = model[i];
+                d[k] = data[i];
+                if (HAS_WEIGHT) wv[k] = weight[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dr = d[k].x - m[k].x, di = d[k].y - m[k].y;
+                const double a = fma(dr, dr, di * di);
+                acc[k] = HAS_WEIGHT ? fma(wv[k], a, acc[k]) : acc[k] + a;
+            }
+        }
+        for (; r < r1; ++r) {
             const int64_t i = r * ncol + col;
             const double2 m = model[i], d = data[i];
             const double dr = d.x - m.x, di = d.y - m.y;
             const double a = fma(dr, dr, di * di);
-            acc = weight ? fma(weight[i], a, acc) : acc + a;
+            acc[0] = HAS_WEIGHT ? fma(weight[i], a, acc[0]) : acc[0] + a;
         }
-        atomicAdd(&chi2[col / ncorr], acc);
+        atomicAdd(&chi2[col / ncorr], (acc[0] + acc[1]) + (acc[2] + acc[3]));
     }
+}
+
+// Flat variant for the common case ncol | (grid * 256): the whole grid sweeps one contiguous
+// window of model/data per step (DRAM-friendly), every lane keeps its column, four steps in flight.
+template <bool HAS_WEIGHT>
+__global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restrict__ model,
+                                                        const double2 *__restrict__ data,
+                                                        const double *__restrict__ weight, int64_t ncell,
+                                                        int64_t ncol, int64_t ncorr, double *__restrict__ chi2)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t col = i % ncol;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; i + 3 * stride < ncell; i += 4 * stride) {
+        double2 m[4], d[4];
+        double wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = model[i + k * stride];
+            d[k] = data[i + k * stride];
+            if (HAS_WEIGHT) wv[k] = weight[i + k * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double dr = d[k].x - m[k].x, di = d[k].y - m[k].y;
+            const double a = fma(dr, dr, di * di);
+            acc[k] = HAS_WEIGHT ? fma(wv[k], a, acc[k]) : acc[k] + a;
+        }
+    }
+    for (; i < ncell; i += stride) {
+        const double2 m = model[i], d = data[i];
+        const double dr = d.x - m.x, di = d.y - m.y;
+        const double a = fma(dr, dr, di * di);
+        acc[0] = HAS_WEIGHT ? fma(weight[i], a, acc[0]) : acc[0] + a;
+    }
+    atomicAdd(&chi2[col / ncorr], (acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
 }  // namespace
@@ -45,13 +102,35 @@ AF_EXPORT int af_chi2_c128(const double *model, const double *data, const double
     AF_HIP(hipMemsetAsync(chi2_per_chan, 0, sizeof(double) * (size_t)nchan, st));
     if (nrow == 0 || ncorr == 0) return AF_OK;
     AF_REQUIRE(model && data, "af_chi2_c128: NULL array");
+    const int64_t ncol = nchan * ncorr, ncell = nrow * ncol;
+    {   // flat sweep when a grid of whole 256-lane blocks can keep one column per lane
+        int64_t grid = 2048;
+        while (grid > 1 && (grid * 256 > ncell || (grid * 256) % ncol != 0)) --grid;
+        if ((grid * 256) % ncol == 0 && grid * 256 <= ncell && grid >= 256) {
+            if (weight)
+                hipLaunchKernelGGL(chi2_flat_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st,
+                                   reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data),
+                                   weight, ncell, ncol, ncorr, chi2_per_chan);
+            else
+                hipLaunchKernelGGL(chi2_flat_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st,
+                                   reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data),
+                                   weight, ncell, ncol, ncorr, chi2_per_chan);
+            AF_LAUNCH_CHECK();
+            return AF_OK;
+        }
+    }
     // ~8 blocks per CU on a 256-CU part, at least 8 rows per block
     int64_t rows_per_block = af_cdiv(nrow, 2048);
     if (rows_per_block < 8) rows_per_block = 8;
     const int64_t blocks = af_cdiv(nrow, rows_per_block);
-    hipLaunchKernelGGL(chi2_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data), weight,
-                       nrow, nchan, ncorr, rows_per_block, chi2_per_chan);
+    if (weight)
+        hipLaunchKernelGGL(chi2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data), weight,
+                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan);
+    else
+        hipLaunchKernelGGL(chi2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data), weight,
+                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan);
     AF_LAUNCH_CHECK();
     return AF_OK;
 }

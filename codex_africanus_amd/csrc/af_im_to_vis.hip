@@ -21,6 +21,10 @@
 //     reduced polynomial sincos give the phasor at the tile's first channel and the
 //     channel-to-channel rotation; the other channels follow from the three-term
 //     recurrence y[j+1] = 2cos(d)*y[j] - y[j-1] (1 FMA per component).
+//   * when the whole band has one channel spacing, tiles are processed four at a time by the four
+//     waves of a workgroup on the SAME 64 rows: q and the channel-step phasor of a (row, source)
+//     are tile-independent, so each wave computes them for one source of a batch of four and
+//     publishes them in LDS (one barrier per four sources).
 //   * exact kernel: the reference's operation order (no contraction) and a full-accuracy
 //     sincos per (row, source, channel); for non-uniform frequencies and AF_DFT_EXACT.
 //   * the prep pass (tiny kernels, no host sync) computes n per source, builds the records,
@@ -48,9 +52,10 @@ struct WsLayout {
     size_t freq;      // double[ntile*CT] channel frequencies, padded per tile
     size_t colstate;  // int[ntile*CT*ncorr] 0 normal, 1 force zero, 2 force NaN
     size_t tilestate; // int[ntile*nchunk] OR of colstate in the tile/chunk
-    size_t records;   // double: chunk-major [chunk][tile][src][groups(chunk)*16]
+    size_t records;   // double: chunk-major [chunk][tile][src_pad][groups(chunk)*16]
+    size_t lgroups;   // double[nsrc_pad/4][16]: [l,m,n,0] of the 4 sources of a batch
     size_t total;
-    int64_t ntile, nchunk;
+    int64_t ntile, nchunk, nsrc_pad;
     int ct, w;
     int64_t chunk_off[64];  // offset (in doubles) of each chunk's records
     int chunk_nc[64], chunk_groups[64];
@@ -61,6 +66,7 @@ bool ws_layout(WsLayout &L, int64_t nsrc, int64_t nchan, int64_t ncorr, int is_c
     L.ct = CT;
     L.w = is_complex ? 2 : 1;
     L.ntile = af_cdiv(nchan > 0 ? nchan : 1, CT);
+    L.nsrc_pad = af_cdiv(nsrc > 0 ? nsrc : 1, 4) * 4;  // whole batches of 4 sources (zero records)
     L.nchunk = af_cdiv(ncorr > 0 ? ncorr : 1, MAXNC);
     if (L.nchunk > 64) return false;
     size_t o = 0;
@@ -78,9 +84,10 @@ bool ws_layout(WsLayout &L, int64_t nsrc, int64_t nchan, int64_t ncorr, int is_c
         L.chunk_nc[k] = nc;
         L.chunk_groups[k] = record_groups(CT, nc, L.w);
         L.chunk_off[k] = rec;
-        rec += L.ntile * nsrc * (int64_t)L.chunk_groups[k] * GROUP;
+        rec += L.ntile * L.nsrc_pad * (int64_t)L.chunk_groups[k] * GROUP;
     }
     L.records = take((size_t)rec * sizeof(double));
+    L.lgroups = take((size_t)L.nsrc_pad * 4 * sizeof(double));
     L.total = o;
     return true;
 }
@@ -131,27 +138,35 @@ __global__ void dft_prep_freq(const double *__restrict__ freq, int64_t nchan, in
     tilef[4 * t + 2] = 0.0;
     tilef[4 * t + 3] = 0.0;
     if (!uniform) atomicAnd(&flags[0], 0);
+    // flags[1]: every tile has tile 0's channel spacing (4 ulp), so the channel-step phasor of a
+    // (row, source) can be shared by all tiles
+    const int64_t n0 = nchan < CT ? nchan : CT;
+    const double df0 = (n0 > 1) ? (freq[n0 - 1] - freq[0]) / (double)(n0 - 1) : 0.0;
+    if (nc > 1 && !(fabs(df - df0) <= 4.0 * 2.220446049250313e-16 * fmax(fabs(df), fabs(df0)) * (double)CT))
+        atomicAnd(&flags[1], 0);
 }
 
 // Build the records of one correlation chunk: for every (tile, source) a block of
 // groups*16 doubles = [l, m, n, 0, pixel(j=0,c=0)[.re,.im], pixel(0,1), ..., zero padding].
 // Pixels beyond nchan and pixels of sources whose (l,m,n) is not finite are zero (the
 // effect of such sources is applied through colstate).
-__global__ void dft_pack_records(const double *__restrict__ image, int W, int64_t nsrc, int64_t nchan,
-                                 int64_t ncorr, int64_t ntile, int CT, int corr0, int nc, int groups,
-                                 const double *__restrict__ lmn, const int *__restrict__ srcbad,
+__global__ void dft_pack_records(const double *__restrict__ image, int W, int64_t nsrc, int64_t nsrc_pad,
+                                 int64_t nchan, int64_t ncorr, int64_t ntile, int CT, int corr0, int nc,
+                                 int groups, const double *__restrict__ lmn, const int *__restrict__ srcbad,
                                  double *__restrict__ rec)
 {
     const int64_t per = (int64_t)groups * GROUP;
-    const int64_t total = ntile * nsrc * per;
+    const int64_t total = ntile * nsrc_pad * per;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
         const int64_t slot = i % per;
-        const int64_t s = (i / per) % nsrc;
-        const int64_t tile = i / (per * nsrc);
+        const int64_t s = (i / per) % nsrc_pad;
+        const int64_t tile = i / (per * nsrc_pad);
         double v = 0.0;
-        if (slot < 3) {
+        if (s >= nsrc) {
+            // padding source: zero (l,m,n) and zero pixels contribute exactly nothing
+        } else if (slot < 3) {
             v = lmn[4 * s + slot];
         } else if (slot >= 4 && slot < 4 + (int64_t)CT * nc * W) {
             const int64_t e = slot - 4;
@@ -161,6 +176,14 @@ __global__ void dft_pack_records(const double *__restrict__ image, int W, int64_
         }
         rec[i] = v;
     }
+}
+
+// (l,m,n,0) of the 4 sources of every batch, contiguous (16 doubles per batch)
+__global__ void dft_pack_lgroups(const double *__restrict__ lmn, int64_t nsrc, int64_t nsrc_pad,
+                                 double *__restrict__ lg)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nsrc_pad * 4) lg[i] = (i < nsrc * 4) ? lmn[i] : 0.0;
 }
 
 // Column state per (chan, corr): reference semantics of `if image[s,nu,c]:` (kernels.py:64)
@@ -287,20 +310,82 @@ __device__ __forceinline__ void store_tile(const double (&acc)[CT][NC][2], doubl
     }
 }
 
-// ---- recurrence kernel, DPP operands ---------------------------------------------------------
-// grid: (ceil(nrow/256), ntile); block 256 = 4 waves, each wave 64 consecutive rows.
+// ---- one source's pass over the lane's channel tile ------------------------------------------
+// Given the source's path difference q (metres) and channel-step phasor (dr, di) for this row:
+// phasor at the tile's first channel, three-term recurrence over the tile, accumulate through the
+// DPP operands, and refresh every record group right after its last use.  EXTRA = vector loads
+// (besides the record refreshes) issued between the previous source's refreshes and this pass;
+// WAIT0 = group 0 has not been retired by the caller yet.
+template <int CT, int NC, bool CPLX, int NTERM, int EXTRA, bool WAIT0, int NG>
+__device__ __forceinline__ void channel_pass(double (&acc)[CT][NC][2], double (&R)[NG], double q, double dr,
+                                             double di, double F0, unsigned lane_off, const double *rec_next)
+{
+    constexpr int W = CPLX ? 2 : 1;
+    constexpr int NSLOT = 4 + CT * NC * W;
+    constexpr int PER_CHAN = NC * W;
+    double c0r, c0i;
+    sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
+    const double k = __dadd_rn(dr, dr);
+    double y0r = c0r, y0i = c0i;
+    double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
+    double y1i = fma(c0r, di, __dmul_rn(c0i, dr));
+    static_for<0, CT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        double yr, yi;
+        if constexpr (j == 0) { yr = y0r; yi = y0i; }
+        else if constexpr (j == 1) { yr = y1r; yi = y1i; }
+        else {
+            yr = fma(k, y1r, -y0r);
+            yi = fma(k, y1i, -y0i);
+            y0r = y1r; y0i = y1i; y1r = yr; y1i = yi;
+        }
+        // groups first touched by this channel: retire their refresh of the previous source
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr bool first_here = (g == 0) ? (WAIT0 && j == 0) : (group_first_chan(g, PER_CHAN) == j);
+            if constexpr (first_here) group_wait<group_wait_count(g, NG, NSLOT, PER_CHAN) + EXTRA>(R[g]);
+        });
+        static_for<0, NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (CPLX) {
+                constexpr int sr = 4 + (j * NC + c) * 2, si = sr + 1;
+                fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
+                fmac_bcast<si % GROUP, true>(acc[j][c][0], R[si / GROUP], yi);
+                fmac_bcast<si % GROUP>(acc[j][c][1], R[si / GROUP], yr);
+                fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
+            } else {
+                constexpr int sr = 4 + j * NC + c;
+                fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
+                fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
+            }
+        });
+        // refresh, for the next source, every group whose last slot this channel consumed
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (group_last_chan(g, NSLOT, PER_CHAN) == j)
+                group_refresh<g * GROUP * (int)sizeof(double)>(R[g], lane_off, rec_next);
+        });
+    });
+}
+
+// ---- recurrence kernel: one channel tile per workgroup ----------------------------------------------
+// grid: (ceil(nrow/256), tiles); block 256 = 4 waves, each wave 64 consecutive rows, all on tile
+// tile0 + blockIdx.y.  Every lane computes q and both sincos itself.  Runs iff flags[0] ==
+// want_uniform and (want_global < 0 or flags[1] == want_global).
 template <int CT, int NC, bool CPLX, int NTERM>
 __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tilef,
     const int *__restrict__ flags, const int *__restrict__ colstate, const int *__restrict__ tilestate,
-    double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan, int64_t ncorr, int64_t corr0, int chunk,
-    int nchunk, int want_uniform)
+    double *__restrict__ out, int64_t nrow, int nsrc, int nsrc_pad, int64_t nchan, int64_t ncorr, int64_t corr0,
+    int chunk, int nchunk, int tile0, int want_uniform, int want_global)
 {
     if (flags[0] != want_uniform) return;  // decided on the device by dft_prep_freq
+    if (want_global >= 0 && flags[1] != want_global) return;
     constexpr int W = CPLX ? 2 : 1;
     constexpr int NG = record_groups(CT, NC, W);
     constexpr int NSLOT = 4 + CT * NC * W;
-    const int tile = blockIdx.y;
+    constexpr int PER_CHAN = NC * W;
+    const int tile = tile0 + blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
     int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
     const bool valid = row < nrow;
@@ -315,9 +400,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
         for (int c = 0; c < NC; ++c) acc[j][c][0] = acc[j][c][1] = 0.0;
 
     // this lane's double of every group of the (tile, source) record
-    constexpr int PER_CHAN = NC * W;
     const unsigned lane_off = (threadIdx.x & (GROUP - 1)) * (unsigned)sizeof(double);
-    const double *__restrict__ rec = records + (int64_t)tile * nsrc * (NG * GROUP);
+    const double *__restrict__ rec = records + (int64_t)tile * nsrc_pad * (NG * GROUP);
     double R[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) R[g] = rec[g * GROUP + (threadIdx.x & (GROUP - 1))];
@@ -339,52 +423,99 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
         fmac_bcast<1>(q, R[0], v);
         fmac_bcast<2>(q, R[0], w);
         if constexpr (group_last_chan(0, NSLOT, PER_CHAN) < 0) group_refresh<0>(R[0], lane_off, rec_next);
-        double c0r, c0i, dr, di;
-        sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
+        double dr, di;
         sincos_quarter_turns<NTERM>(__dmul_rn(q, FD), dr, di);
-        const double k = __dadd_rn(dr, dr);
-        double y0r = c0r, y0i = c0i;
-        double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
-        double y1i = fma(c0r, di, __dmul_rn(c0i, dr));
-        static_for<0, CT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            double yr, yi;
-            if constexpr (j == 0) { yr = y0r; yi = y0i; }
-            else if constexpr (j == 1) { yr = y1r; yi = y1i; }
-            else {
-                yr = fma(k, y1r, -y0r);
-                yi = fma(k, y1i, -y0i);
-                y0r = y1r; y0i = y1i; y1r = yr; y1i = yi;
-            }
-            // groups first touched by this channel: retire their refresh of the previous iteration
-            static_for<1, NG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                if constexpr (group_first_chan(g, PER_CHAN) == j)
-                    group_wait<group_wait_count(g, NG, NSLOT, PER_CHAN)>(R[g]);
-            });
-            static_for<0, NC>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                if constexpr (CPLX) {
-                    constexpr int sr = 4 + (j * NC + c) * 2, si = sr + 1;
-                    fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
-                    fmac_bcast<si % GROUP, true>(acc[j][c][0], R[si / GROUP], yi);
-                    fmac_bcast<si % GROUP>(acc[j][c][1], R[si / GROUP], yr);
-                    fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
-                } else {
-                    constexpr int sr = 4 + j * NC + c;
-                    fmac_bcast<sr % GROUP>(acc[j][c][0], R[sr / GROUP], yr);
-                    fmac_bcast<sr % GROUP>(acc[j][c][1], R[sr / GROUP], yi);
-                }
-            });
-            // refresh, for the next source, every group whose last slot this channel consumed
-            static_for<0, NG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                if constexpr (group_last_chan(g, NSLOT, PER_CHAN) == j)
-                    group_refresh<g * GROUP * (int)sizeof(double)>(R[g], lane_off, rec_next);
-            });
-        });
+        channel_pass<CT, NC, CPLX, NTERM, 0, false, NG>(acc, R, q, dr, di, F0, lane_off, rec_next);
     }
     // retire the (redundant) refreshes of the last iteration before the registers die
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_tile<CT, NC>(acc, out, row, valid, nchan, ncorr, c0, corr0, colstate,
+                       tilestate[tile * nchunk + chunk]);
+}
+
+// ---- recurrence kernel: four channel tiles per workgroup, shared channel-step phasor -------------------
+// grid: (ceil(nrow/64), tiles/4); block 256 = 4 waves on the SAME 64 rows, wave w on tile
+// 4*blockIdx.y + w.  With one channel spacing for the whole band (flags[1]) the path difference q and
+// the channel-step phasor (dr, di) of a (row, source) are the same for every tile, so the four waves
+// split that work: per batch of 4 sources wave w computes them for source 4b+w and publishes them
+// in LDS; every wave then runs the four sources of the batch on its own tile.  One barrier per batch.
+// (l,m,n) of a batch come from `lgroups` (16 doubles per batch: [l,m,n,0] x 4), loaded rotated by
+// 4*w lanes so that row_newbcast:0..2 hands wave w its own source.
+template <int CT, int NC, bool CPLX, int NTERM>
+__global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp4_kernel(
+    const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ lgroups,
+    const double *__restrict__ tilef, const int *__restrict__ flags, const int *__restrict__ colstate,
+    const int *__restrict__ tilestate, double *__restrict__ out, int64_t nrow, int nsrc_pad, int64_t nchan,
+    int64_t ncorr, int64_t corr0, int chunk, int nchunk)
+{
+    if (flags[0] != 1 || flags[1] != 1) return;
+    constexpr int W = CPLX ? 2 : 1;
+    constexpr int NG = record_groups(CT, NC, W);
+    __shared__ double xch[2][4][3][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = 4 * blockIdx.y + wave;
+    const int64_t c0 = (int64_t)tile * CT;
+    int64_t row = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = row < nrow;
+    if (!valid) row = nrow - 1;
+    const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
+    const double F0 = tilef[4 * tile], FD = tilef[1];  // one channel spacing for the whole band
+
+    double acc[CT][NC][2];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[j][c][0] = acc[j][c][1] = 0.0;
+
+    const unsigned lane_off = (lane & (GROUP - 1)) * (unsigned)sizeof(double);
+    const unsigned lg_off = ((lane + 4 * wave) & (GROUP - 1)) * (unsigned)sizeof(double);
+    const double *__restrict__ rec = records + (int64_t)tile * nsrc_pad * (NG * GROUP);
+    const int nb = nsrc_pad >> 2;
+    double R[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) R[g] = rec[g * GROUP + (lane & (GROUP - 1))];
+    double Lg = lgroups[(lane + 4 * wave) & (GROUP - 1)];
+    asm volatile("" :: "v"(u), "v"(v), "v"(w), "s"(F0), "s"(FD));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(R[g]));
+    asm volatile("" : "+v"(Lg));
+
+    // q and the channel-step phasor of this wave's source of a batch -> LDS
+    auto produce = [&](int buf) {
+        double q = 0.0;
+        fmac_bcast<0>(q, Lg, u);
+        fmac_bcast<1>(q, Lg, v);
+        fmac_bcast<2>(q, Lg, w);
+        double dr, di;
+        sincos_quarter_turns<NTERM>(__dmul_rn(q, FD), dr, di);
+        xch[buf][wave][0][lane] = q;
+        xch[buf][wave][1][lane] = dr;
+        xch[buf][wave][2][lane] = di;
+    };
+    produce(0);
+    group_refresh<0>(Lg, lg_off, lgroups + (int64_t)(nb > 1 ? 1 : 0) * GROUP);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(Lg));
+    __syncthreads();
+
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        // ---- produce batch b+1 (Lg was refreshed one batch ago: 4*NG record refreshes since) -------
+        group_wait<4 * NG>(Lg);
+        produce((b + 1) & 1);
+        const int bn = (b + 2 < nb) ? b + 2 : nb - 1;
+        group_refresh<0>(Lg, lg_off, lgroups + (int64_t)bn * GROUP);
+        // ---- consume batch b on this wave's tile --------------------------------------------------
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int s = 4 * b + j;
+            const int sn = (s + 1 < nsrc_pad) ? s + 1 : s;
+            const double q = xch[b & 1][j][0][lane], dr = xch[b & 1][j][1][lane], di = xch[b & 1][j][2][lane];
+            // the Lg refresh above sits between the previous batch's record refreshes and pass j = 0
+            channel_pass<CT, NC, CPLX, NTERM, (j == 0 ? 1 : 0), true, NG>(acc, R, q, dr, di, F0, lane_off,
+                                                                       rec + (int64_t)sn * (NG * GROUP));
+        });
+        __syncthreads();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_tile<CT, NC>(acc, out, row, valid, nchan, ncorr, c0, corr0, colstate,
                        tilestate[tile * nchunk + chunk]);
@@ -398,8 +529,8 @@ template <int CT, int NC, bool CPLX>
 __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ freq_pad,
     const int *__restrict__ flags, const int *__restrict__ colstate, const int *__restrict__ tilestate,
-    double *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan, int64_t ncorr, int64_t corr0, int chunk,
-    int nchunk, int want_uniform, double constant)
+    double *__restrict__ out, int64_t nrow, int nsrc, int nsrc_pad, int64_t nchan, int64_t ncorr, int64_t corr0,
+    int chunk, int nchunk, int want_uniform, double constant)
 {
     if (want_uniform >= 0 && flags[0] != want_uniform) return;
     constexpr int W = CPLX ? 2 : 1;
@@ -410,7 +541,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
     const bool valid = row < nrow;
     if (!valid) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
-    const double *__restrict__ rec = records + (int64_t)tile * nsrc * (NG * GROUP);
+    const double *__restrict__ rec = records + (int64_t)tile * nsrc_pad * (NG * GROUP);
     const int tstate = tilestate[tile * nchunk + chunk];
 
     for (int j = 0; j < CT; ++j) {
@@ -502,18 +633,44 @@ int launch_chunk(const Args &a)
     const double *records = reinterpret_cast<const double *>(ws + L.records) + L.chunk_off[a.chunk];
     dim3 grid((unsigned)af_cdiv(a.nrow, ROWS_PER_BLOCK), (unsigned)L.ntile), block(ROWS_PER_BLOCK);
     const int64_t corr0 = (int64_t)a.chunk * MAXNC;
+    const double *lgroups = reinterpret_cast<const double *>(ws + L.lgroups);
     if (a.mode == AF_DFT_AUTO || a.mode == AF_DFT_RECURRENCE) {
-        // runs iff flags[0] == 1 (set by dft_prep_freq, or forced for AF_DFT_RECURRENCE)
-        hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), grid, block, 0, a.st, a.uvw, records,
-                           tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, a.nchan, a.ncorr,
-                           corr0, a.chunk, (int)L.nchunk, 1);
-        AF_LAUNCH_CHECK();
+        // Uniform channels (flags[0] == 1, set by dft_prep_freq or forced for AF_DFT_RECURRENCE).
+        // Tiles in groups of four run the shared-phasor kernel when the whole band has one channel
+        // spacing (flags[1] == 1) and the per-tile kernel otherwise; leftover tiles always run the
+        // per-tile kernel.  Which of the launches does the work is decided on the device.
+        const int quads = (int)(L.ntile / 4), rest = (int)(L.ntile - 4 * (int64_t)quads);
+        if (quads > 0) {
+            dim3 g4((unsigned)af_cdiv(a.nrow, 64), (unsigned)quads);
+            if (a.chunk == 0) af_prof_begin(a.st);  // measurement hook: the dominant kernel only
+            hipLaunchKernelGGL((dft_recurrence_dpp4_kernel<CT, NC, CPLX, 7>), g4, block, 0, a.st, a.uvw, records,
+                               lgroups, tilef, flags, colstate, tilestate, a.out, a.nrow, (int)L.nsrc_pad, a.nchan,
+                               a.ncorr, corr0, a.chunk, (int)L.nchunk);
+            if (a.chunk == 0) af_prof_end(a.st);
+            AF_LAUNCH_CHECK();
+            dim3 gq((unsigned)af_cdiv(a.nrow, ROWS_PER_BLOCK), (unsigned)(4 * quads));
+            hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), gq, block, 0, a.st, a.uvw, records,
+                               tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, (int)L.nsrc_pad,
+                               a.nchan, a.ncorr, corr0, a.chunk, (int)L.nchunk, 0, 1, 0);
+            AF_LAUNCH_CHECK();
+        }
+        if (rest > 0) {
+            dim3 gr((unsigned)af_cdiv(a.nrow, ROWS_PER_BLOCK), (unsigned)rest);
+            if (a.chunk == 0 && quads == 0) af_prof_begin(a.st);
+            hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), gr, block, 0, a.st, a.uvw, records,
+                               tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, (int)L.nsrc_pad,
+                               a.nchan, a.ncorr, corr0, a.chunk, (int)L.nchunk, 4 * quads, 1, -1);
+            if (a.chunk == 0 && quads == 0) af_prof_end(a.st);
+            AF_LAUNCH_CHECK();
+        }
     }
     if (a.mode == AF_DFT_AUTO || a.mode == AF_DFT_EXACT) {
         // AUTO: runs iff flags[0] == 0 (non-uniform frequencies); EXACT: always (-1)
+        if (a.chunk == 0 && a.mode == AF_DFT_EXACT) af_prof_begin(a.st);
         hipLaunchKernelGGL((dft_exact_kernel<CT, NC, CPLX>), grid, block, 0, a.st, a.uvw, records, freq_pad,
-                           flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, a.nchan, a.ncorr, corr0,
-                           a.chunk, (int)L.nchunk, a.mode == AF_DFT_EXACT ? -1 : 0, a.constant);
+                           flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, (int)L.nsrc_pad, a.nchan, a.ncorr,
+                           corr0, a.chunk, (int)L.nchunk, a.mode == AF_DFT_EXACT ? -1 : 0, a.constant);
+        if (a.chunk == 0 && a.mode == AF_DFT_EXACT) af_prof_end(a.st);
         AF_LAUNCH_CHECK();
     }
     return AF_OK;
@@ -589,6 +746,7 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     AF_HIP(hipMemsetAsync(ws + L.tilestate, 0, (size_t)L.ntile * L.nchunk * sizeof(int), st));
     AF_HIP(hipMemsetAsync(ws + L.flags, 0, 64 * sizeof(int), st));
     AF_HIP(hipMemsetAsync(ws + L.flags, 1, 1, st));
+    AF_HIP(hipMemsetAsync(ws + L.flags + sizeof(int), 1, 1, st));  // flags[1] = 1: one channel spacing
     hipLaunchKernelGGL(dft_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, clamp_n,
                        reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad));
     AF_LAUNCH_CHECK();
@@ -599,16 +757,20 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     if (mode == AF_DFT_RECURRENCE)  // caller asserts uniform spacing
         AF_HIP(hipMemsetAsync(ws + L.flags, 1, 1, st));
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
-        const int64_t total = L.ntile * nsrc * (int64_t)L.chunk_groups[chunk] * GROUP;
+        const int64_t total = L.ntile * L.nsrc_pad * (int64_t)L.chunk_groups[chunk] * GROUP;
         int64_t blocks = af_cdiv(total, 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(dft_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, W, nsrc, nchan, ncorr,
-                           L.ntile, ct, chunk * MAXNC, L.chunk_nc[chunk], L.chunk_groups[chunk],
+        hipLaunchKernelGGL(dft_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, W, nsrc, L.nsrc_pad,
+                           nchan, ncorr, L.ntile, ct, chunk * MAXNC, L.chunk_nc[chunk], L.chunk_groups[chunk],
                            reinterpret_cast<const double *>(ws + L.lmn),
                            reinterpret_cast<const int *>(ws + L.srcbad),
                            reinterpret_cast<double *>(ws + L.records) + L.chunk_off[chunk]);
         AF_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(dft_pack_lgroups, dim3((unsigned)af_cdiv(L.nsrc_pad * 4, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const double *>(ws + L.lmn), nsrc, L.nsrc_pad,
+                       reinterpret_cast<double *>(ws + L.lgroups));
+    AF_LAUNCH_CHECK();
     {
         int64_t ncol = L.ntile * ct * ncorr;
         hipLaunchKernelGGL(dft_colstate, dim3((unsigned)ncol), dim3(64), 0, st, image, W, nsrc, nchan, ncorr,
@@ -622,12 +784,10 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     a.nrow = nrow; a.nsrc = nsrc; a.nchan = nchan; a.ncorr = ncorr;
     a.mode = mode; a.st = st;
     a.constant = convention == AF_CONVENTION_FOURIER ? AF_MINUS_TWO_PI_OVER_C : AF_TWO_PI_OVER_C;
-    af_prof_begin(st);
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
         a.chunk = chunk;
         int rc = launch_chunk_ct(cplx, ct, L.chunk_nc[chunk], a);
         if (rc != AF_OK) return rc;
     }
-    af_prof_end(st);
     return AF_OK;
 }

@@ -337,3 +337,20 @@ def test_beam_cube_dde_reference_kat(g4):
                               np.zeros((1, 1, 1, 2)), np.ones((1, 1, 2)), np.asarray([0.3]))
     np.testing.assert_array_almost_equal([[[[[0.470255 + 0.4786j]]]]], ddes)
     assert maxabs(ddes, g4["kat_ddes"]) < 1e-15
+
+
+# ---------------------------------------------------------------------------- chi^2
+def test_chi2_against_numpy():
+    """af_chi2_c128 has no reference counterpart (parity unpinned): checked against numpy."""
+    import torch
+    from codex_africanus_amd import sharding
+    rng = np.random.default_rng(9)
+    shape = (1237, 13, 4)
+    m = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    d = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    w = rng.random(shape)
+    t = lambda a: torch.from_numpy(a).cuda()
+    c = sharding.chi2(t(m), t(d)).cpu().numpy()
+    np.testing.assert_allclose(c, (np.abs(d - m) ** 2).sum(axis=(0, 2)), rtol=1e-12)
+    cw = sharding.chi2(t(m), t(d), t(w)).cpu().numpy()
+    np.testing.assert_allclose(cw, (w * np.abs(d - m) ** 2).sum(axis=(0, 2)), rtol=1e-12)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Achieved HBM bandwidth of the API-compatible (materialised-input) kernels on one MI355X:
+predict_vis (coh only / dde+coh+die), phase_delay, beam_cube_dde, chi2.  Device-resident torch
+tensors, HIP-event timing on torch's stream, algorithmic bytes = inputs read once + output written once."""
+import ctypes, json, sys, os
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from codex_africanus_amd import rime, sharding
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def rc(*shape):
+    return torch.randn(*shape, dtype=torch.complex128, device=dev)
+
+
+out = {}
+# predict_vis, coh only: (src=16, row=262144, chan=64, 2, 2) c128 = 17.2 GB read, 1.07 GB written
+s, r, c, t, a = 16, 262144, 64, 130, 64
+nbl = a * (a - 1) // 2
+ti = torch.arange(r, device=dev, dtype=torch.int32) // nbl
+a1 = torch.randint(0, a, (r,), device=dev, dtype=torch.int32)
+a2 = torch.randint(0, a, (r,), device=dev, dtype=torch.int32)
+coh = rc(s, r, c, 2, 2)
+dt = timeit(lambda: rime.predict_vis(ti, a1, a2, None, coh, None, None, None, None))
+b = coh.numel() * 16 + r * c * 64
+out["predict_vis coh-only c128 (16 src x 262144 rows x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+ntime = int(ti.max().item()) + 1
+dde = rc(s, ntime, a, c, 2, 2)
+die = rc(ntime, a, c, 2, 2)
+bv = rc(r, c, 2, 2)
+dt = timeit(lambda: rime.predict_vis(ti, a1, a2, dde, coh, dde, die, bv, die))
+b2 = b + dde.numel() * 16 + die.numel() * 16 + bv.numel() * 16
+out["predict_vis dde+coh+die+bvis c128 (same shape, 64 ant)"] = dict(ms=dt * 1e3, GBs=b2 / dt / 1e9, bytes=b2)
+del coh, dde, bv
+coh64 = torch.randn(s, r, c, 2, 2, dtype=torch.complex64, device=dev)
+dt = timeit(lambda: rime.predict_vis(ti, a1, a2, None, coh64, None, None, None, None))
+b = coh64.numel() * 8 + r * c * 32
+out["predict_vis coh-only c64"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+del coh64
+# phase_delay: (100 src, 100k rows, 64 chan) c128 = 10.2 GB written
+lm = (torch.rand(100, 2, dtype=torch.float64, device=dev) - 0.5) * 0.1
+uvw = (torch.rand(100000, 3, dtype=torch.float64, device=dev) - 0.5) * 8000
+fr = torch.linspace(0.856e9, 1.712e9, 64, dtype=torch.float64, device=dev)
+dt = timeit(lambda: rime.phase_delay(lm, uvw, fr))
+b = 100 * 100000 * 64 * 16
+out["phase_delay f64 (100 src x 100k rows x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+# beam_cube_dde: (100 src, 100 time, 64 ant, 64 chan, 2, 2) = 2.6 GB written
+g = torch.linspace(-1, 1, 257, dtype=torch.float64, device=dev)
+beam = (torch.exp(-(g[:, None] ** 2 + g[None, :] ** 2) / 0.5)[:, :, None, None, None]
+        * torch.ones(1, 1, 33, 2, 2, dtype=torch.complex128, device=dev)).contiguous()
+ext = torch.tensor([[-0.06, 0.06], [-0.06, 0.06]], dtype=torch.float64, device=dev)
+fmap = torch.linspace(0.856e9, 1.712e9, 33, dtype=torch.float64, device=dev)
+pa = torch.rand(100, 64, dtype=torch.float64, device=dev) * np.pi / 6
+pe = 1e-3 * torch.randn(100, 64, 64, 2, dtype=torch.float64, device=dev)
+asc = 1 + 1e-3 * torch.randn(64, 64, 2, dtype=torch.float64, device=dev)
+dt = timeit(lambda: rime.beam_cube_dde(beam, ext, fmap, lm, pa, pe, asc, fr), reps=3)
+b = 100 * 100 * 64 * 64 * 64
+out["beam_cube_dde c128 (100 src x 100 t x 64 ant x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b,
+                                                                      MJones_per_s=100 * 100 * 64 * 64 / dt / 1e6)
+# chi2: 2 x (1e6 x 64 x 4) c128 = 8.2 GB read
+m, d = rc(1000000, 64, 4), rc(1000000, 64, 4)
+dt = timeit(lambda: sharding.chi2(m, d))
+b = 2 * m.numel() * 16
+out["chi2 c128 (1e6 rows x 64 chan x 4 corr)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+print(json.dumps(out, indent=1))
