@@ -286,7 +286,6 @@ def main():
         if os.path.exists(pmc) and (nrow, nchan, nsrc, args.mode, args.workload) == (1000000, 64, 1000, "auto", "dft"):
             c = json.load(open(pmc))
             traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            kernel_name = c.get("kernel", kernel_name) if False else kernel_name
             traffic_src = "profiles/r01_pmc_summary.json"
         out = {
             "metric": "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err",
