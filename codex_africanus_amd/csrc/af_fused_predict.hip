@@ -11,8 +11,8 @@
 // One workgroup (512 lanes, one per CU: 237 VGPRs, up to 128 KB of LDS) owns one run of rows with
 // equal time_index (<= 2048 rows: a whole 64-antenna timestep) and one channel, and walks the
 // sources in batches:
-//   stage 1  lane = (source of the batch, antenna): sample the beam cube (repacked once per call into
-//            128-byte voxel records holding the 4 correlations and their moduli) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
+//   stage 1  four lanes per (source of the batch, antenna), one per correlation: sample the beam cube
+//            (repacked once per call into 128-byte voxel records [corr][re, im, |.|, 0]) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
 //            stage 2's reads are conflict-free (consecutive rows = consecutive antenna2) or
 //            broadcasts (antenna1);
 //   stage 2  lane = four rows: per source q = l u + m v + n w, the phasor by the quarter-turn
@@ -68,53 +68,47 @@ __global__ void fused_prep_freq(const double *__restrict__ freq, int64_t nchan, 
     if (c < nchan) f4[c] = 4.0 * (double)sign * freq[c] / AF_LIGHTSPEED;
 }
 
-// One 128-byte record per voxel, once per call: (re, im) of the 4 correlations, then their
-// moduli (hypot dominates the beam stage otherwise), then padding -- so that sampling a voxel
-// touches exactly one cache line instead of one line of `beam` plus one of a |beam| array.
+// One 128-byte record per voxel, once per call: for each of the 4 correlations (re, im, |.|, 0).
+// Sampling a voxel then touches exactly one cache line, and a lane that owns one correlation
+// reads its own 32 bytes (hypot per sample would otherwise dominate the beam stage).
 constexpr int VREC = 16;  // doubles per voxel record
 __global__ void beam_pack_kernel(const double2 *__restrict__ beam, int64_t nvox, double *__restrict__ rec)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (voxel, corr)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < nvox * 4; i += stride) {
-        const int64_t vx = i >> 2;
-        const int c = (int)(i & 3);
         double2 b = beam[i];
-        rec[vx * VREC + 2 * c] = b.x;
-        rec[vx * VREC + 2 * c + 1] = b.y;
-        rec[vx * VREC + 8 + c] = hypot(b.x, b.y);
-        rec[vx * VREC + 12 + c] = 0.0;
+        rec[i * 4 + 0] = b.x;
+        rec[i * 4 + 1] = b.y;
+        rec[i * 4 + 2] = hypot(b.x, b.y);
+        rec[i * 4 + 3] = 0.0;
     }
 }
 
-// beam_sample_corr (af_beam_device.h) for all four correlations from the packed records:
-// per voxel 6 x 16-byte loads of one line; sums in the reference's voxel order.
-__device__ __forceinline__ void beam_sample4(const double *__restrict__ rec, const BeamVoxels<double, int> &vx,
-                                             double2 (&E)[4])
+// One correlation of beam_sample_corr (af_beam_device.h) from the packed records: weighted sums of
+// the 8 voxels in the reference's order (FMA-contracted: the fused path is checked to 1e-9, not bit
+// for bit), then the amplitude-preserving normalisation corr_sum * absc_sum / |corr_sum|.
+__device__ __forceinline__ double2 beam_sample1(const double *__restrict__ rec, const BeamVoxels<double, int> &vx,
+                                                int c)
 {
-    double cre[4] = {0, 0, 0, 0}, cim[4] = {0, 0, 0, 0}, absc[4] = {0, 0, 0, 0};
+    double2 v[8];
+    double ab[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const double2 *r = reinterpret_cast<const double2 *>(rec + (int64_t)vx.off[k] * VREC);
-        const double2 b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], a01 = r[4], a23 = r[5];
-        const double wgt = vx.wt[k];
-        const double br[4] = {b0.x, b1.x, b2.x, b3.x}, bi[4] = {b0.y, b1.y, b2.y, b3.y};
-        const double ab[4] = {a01.x, a01.y, a23.x, a23.y};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            absc[c] = __dadd_rn(absc[c], __dmul_rn(wgt, ab[c]));
-            // (wgt + 0j) * b as a full complex multiply (numba widens the real weight)
-            cre[c] = __dadd_rn(cre[c], __dsub_rn(__dmul_rn(wgt, br[c]), __dmul_rn(0.0, bi[c])));
-            cim[c] = __dadd_rn(cim[c], __dadd_rn(__dmul_rn(wgt, bi[c]), __dmul_rn(0.0, br[c])));
-        }
+        const double *r = rec + (int64_t)vx.off[k] * VREC + c * 4;
+        v[k] = *reinterpret_cast<const double2 *>(r);
+        ab[k] = r[2];
     }
+    double cre = 0.0, cim = 0.0, absc = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double div = hypot(cre[c], cim[c]);
-        const double sc = (div == 0.0) ? absc[c] : __ddiv_rn(absc[c], div);
-        E[c].x = __dsub_rn(__dmul_rn(cre[c], sc), __dmul_rn(cim[c], 0.0));
-        E[c].y = __dadd_rn(__dmul_rn(cre[c], 0.0), __dmul_rn(cim[c], sc));
+    for (int k = 0; k < 8; ++k) {
+        cre = fma(vx.wt[k], v[k].x, cre);
+        cim = fma(vx.wt[k], v[k].y, cim);
+        absc = fma(vx.wt[k], ab[k], absc);
     }
+    const double div = __dsqrt_rn(fma(cre, cre, __dmul_rn(cim, cim)));
+    const double sc = (div == 0.0) ? absc : __ddiv_rn(absc, div);
+    return make_double2(__dmul_rn(cre, sc), __dmul_rn(cim, sc));
 }
 
 struct C2 {
@@ -152,7 +146,7 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
     acc.im = fma(a.im, b.re, acc.im);
 }
 
-// grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * nant double2 (E then G).
+// grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * nant double2 (E then G) + 6 * nant doubles.
 __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
@@ -188,55 +182,62 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     }
     const double F4 = f4[f];
 
-    // ---- stage-1 state: this lane's (batch slot, antenna) ------------------------------------------
-    const bool e_task = tid < st * nant;
-    const int e_sl = e_task ? tid / nant : 0, e_ant = e_task ? tid % nant : 0;
+    // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
+    // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m)
+    double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * nant);
+    for (int a = tid; a < nant; a += THREADS) {
+        double sp, cp;
+        sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
+        const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
+        const double *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
+        ldsA[6 * a + 0] = sp; ldsA[6 * a + 1] = cp;
+        ldsA[6 * a + 2] = pe[0]; ldsA[6 * a + 3] = pe[1];
+        ldsA[6 * a + 4] = as[0]; ldsA[6 * a + 5] = as[1];
+    }
     const BeamGrid<double> grid = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
-    double sin_pa, cos_pa;
-    sincos(parangles[(int64_t)t * nant + e_ant], &sin_pa, &cos_pa);
-    const double *pe = point_errors + (((int64_t)t * nant + e_ant) * nchan + f) * 2;
-    const double *as = antenna_scaling + ((int64_t)e_ant * nchan + f) * 2;
-    const double pe_l = pe[0], pe_m = pe[1], as_l = as[0], as_m = as[1];
     const double fscale = freq_data[3 * f + 0], fnud = freq_data[3 * f + 1];
     const int fgc0 = (int)freq_data[3 * f + 2];
+    const int ntask = st * nant;           // Jones terms per batch
+    const int e_corr = tid & 3;            // this lane's correlation in stage 1
+    __syncthreads();
 
     for (int s0 = 0; s0 < nsrc; s0 += st) {
-        // ---- stage 1: E and G = E.B for (source s0 + e_sl, antenna e_ant) -> LDS ------------------
-        // E goes to LDS one correlation at a time (keeps the 8-voxel geometry the only large live
-        // set), then the lane reads its own E back and folds the source's brightness into G.
-        if (e_task) {
+        // ---- stage 1: E and G = E.B for the batch's (source, antenna) pairs -> LDS ------------------
+        // Four lanes per Jones term, one per correlation: every lane gathers its own 32 bytes
+        // (re, im, |.|) of each of the 8 voxel records, so a record's cache line is fetched once and no
+        // cross-lane reduction is needed.  THREADS/4 terms per round.
+        for (int task0 = 0; task0 < ntask; task0 += THREADS / 4) {
+            const int task = task0 + (tid >> 2);
+            const bool have_task = task < ntask;
+            const int e_sl = have_task ? task / nant : 0, e_ant = have_task ? task % nant : 0;
             const int s = s0 + e_sl;
-            const bool have = s < nsrc;
-            {
-                BeamVoxels<double, int> vx;
-                const int sc = have ? s : 0;
-                // voxel offsets in voxels (ncorr = 1): the packed records are indexed per voxel
-                beam_voxels<double, int>(grid, lmn[4 * sc], lmn[4 * sc + 1], sin_pa, cos_pa, pe_l, pe_m, as_l, as_m,
-                                         fscale, fnud, fgc0, 1, vx);
-                double2 e4[4];
-                beam_sample4(vrec, vx, e4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    ldsE[((size_t)e_sl * 4 + c) * nant + e_ant] = have ? e4[c] : make_double2(0.0, 0.0);
+            const bool have = have_task && s < nsrc;
+            const int sc = have ? s : 0;
+            BeamVoxels<double, int> vx;
+            // voxel offsets in voxels (ncorr = 1): the packed records are indexed per voxel
+            beam_voxels<double, int>(grid, lmn[4 * sc], lmn[4 * sc + 1], ldsA[6 * e_ant + 0], ldsA[6 * e_ant + 1],
+                                     ldsA[6 * e_ant + 2], ldsA[6 * e_ant + 3], ldsA[6 * e_ant + 4],
+                                     ldsA[6 * e_ant + 5], fscale, fnud, fgc0, 1, vx);
+            double2 e = beam_sample1(vrec, vx, e_corr);
+            if (!have) e = make_double2(0.0, 0.0);
+            // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
+            C2 Eme, Emate;
+            Eme.re = e.x; Eme.im = e.y;
+            Emate.re = __shfl_xor(e.x, 1, 64);
+            Emate.im = __shfl_xor(e.y, 1, 64);
+            const C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
+            // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]   (G = E.B, row-major 2x2)
+            const double2 *bp = brightness + ((int64_t)sc * nchan + f) * 4;
+            const double2 b0 = bp[e_corr & 1], b1 = bp[2 + (e_corr & 1)];
+            C2 B0, B1, G;
+            B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+            G = cmul(E0, B0);
+            cmac(G, E1, B1);
+            if (have_task) {
+                ldsE[((size_t)e_sl * 4 + e_corr) * nant + e_ant] = e;
+                ldsG[((size_t)e_sl * 4 + e_corr) * nant + e_ant] = have ? make_double2(G.re, G.im)
+                                                                        : make_double2(0.0, 0.0);
             }
-            C2 E[4], B[4];
-            const double2 *bp = brightness + ((int64_t)(have ? s : 0) * nchan + f) * 4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double2 e = ldsE[((size_t)e_sl * 4 + c) * nant + e_ant], b = bp[c];
-                E[c].re = e.x; E[c].im = e.y;
-                B[c].re = b.x; B[c].im = b.y;
-            }
-            // G = E . B  (2x2, row-major components 0..3 = xx, xy, yx, yy); zero when E is zero
-            C2 G;
-            G = cmul(E[0], B[0]); cmac(G, E[1], B[2]);
-            ldsG[((size_t)e_sl * 4 + 0) * nant + e_ant] = make_double2(G.re, G.im);
-            G = cmul(E[0], B[1]); cmac(G, E[1], B[3]);
-            ldsG[((size_t)e_sl * 4 + 1) * nant + e_ant] = make_double2(G.re, G.im);
-            G = cmul(E[2], B[0]); cmac(G, E[3], B[2]);
-            ldsG[((size_t)e_sl * 4 + 2) * nant + e_ant] = make_double2(G.re, G.im);
-            G = cmul(E[2], B[1]); cmac(G, E[3], B[3]);
-            ldsG[((size_t)e_sl * 4 + 3) * nant + e_ant] = make_double2(G.re, G.im);
         }
         __syncthreads();
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
@@ -374,7 +375,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     int st = (int)(THREADS / nant);
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2);
+    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double);
     AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_predict_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     af_prof_begin(st_);
