@@ -336,7 +336,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
     AF_REQUIRE(nitems >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_c128: negative extent");
-    AF_REQUIRE(nant <= THREADS, "af_fused_predict_c128: more than %d antennas", THREADS);
+    AF_REQUIRE(nant <= 1024, "af_fused_predict_c128: more than 1024 antennas");
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nitems < (1LL << 31), "af_fused_predict_c128: too large");
     hipStream_t st_ = af_stream(stream);
     if (nrow == 0 || nchan == 0) return AF_OK;
@@ -372,7 +372,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
                            reinterpret_cast<const double2 *>(beam), nvox, babs);
         AF_LAUNCH_CHECK();
     }
-    int st = (int)(THREADS / nant);
+    // sources per batch: as many as fit 128 KB of LDS (E and G: 128 bytes per (source, antenna))
+    int st = (int)(1024 / nant);
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
     const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double);
