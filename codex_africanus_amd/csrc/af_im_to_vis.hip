@@ -607,8 +607,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp4_kernel(
 }
 
 // ---- exact kernel -----------------------------------------------------------------------
-// Reference operation order, no contraction (kernels.py:57,61,65), full-accuracy sincos per
-// (row, source, channel).  Channel-outermost inside the lane so only NC complex accumulators
+// Reference operation order, no contraction (kernels.py:57,61,65), full-accuracy sincos
+// (sincos_radians: Cody-Waite + 7-term polynomials, ~1e-16) per (row, source, channel).  Channel-outermost inside the lane so only NC complex accumulators
 // are live; real_phase is recomputed per channel (6 ops against a ~100-op sincos).
 template <int CT, int NC, bool CPLX>
 __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
             const double real_phase = __dmul_rn(
                 constant, __dadd_rn(__dadd_rn(__dmul_rn(l, u), __dmul_rn(m, v)), __dmul_rn(n, w)));
             double yr, yi;
-            sincos(__dmul_rn(real_phase, nu), &yi, &yr);
+            sincos_radians(__dmul_rn(real_phase, nu), yr, yi);
             const double *__restrict__ g = rs + 4 + j * (NC * W);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {

@@ -6,7 +6,10 @@
 // Arithmetic follows the reference's operation order with no fp contraction:
 //   n = sqrt(max(0, 1 - l^2 - m^2)) - 1 (:42-43), real_phase = C*(l*u + m*v + n*w) (:49),
 //   p = real_phase*nu (:53), out = (cos p, sin p) (:58-59); constants in lm's dtype (:23-25).
+// p is the reference's value bit for bit; cos/sin come from sincos_radians (af_sincos.h): Cody-Waite
+// reduction + 7-term polynomials, ~1e-16 absolute, a third of the library routine's instructions.
 #include "af_common.h"
+#include "af_sincos.h"
 
 namespace {
 
@@ -19,7 +22,7 @@ template <> struct Ops<double> {
     static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
     static __device__ __forceinline__ double sub(double a, double b) { return __dsub_rn(a, b); }
     static __device__ __forceinline__ double sqrt_(double a) { return __dsqrt_rn(a); }
-    static __device__ __forceinline__ void sincos_(double p, double *s, double *c) { sincos(p, s, c); }
+    static __device__ __forceinline__ void sincos_(double p, double *s, double *c) { sincos_radians(p, *c, *s); }
     typedef double2 vec2;
     static __device__ __forceinline__ vec2 make2(double a, double b) { return make_double2(a, b); }
 };
@@ -33,7 +36,7 @@ template <> struct Ops<float> {
     static __device__ __forceinline__ void sincos_(float p, float *s, float *c)
     {
         double sd, cd;
-        sincos((double)p, &sd, &cd);
+        sincos_radians((double)p, cd, sd);
         *s = (float)sd;
         *c = (float)cd;
     }

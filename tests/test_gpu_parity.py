@@ -354,3 +354,53 @@ def test_chi2_against_numpy():
     np.testing.assert_allclose(c, (np.abs(d - m) ** 2).sum(axis=(0, 2)), rtol=1e-12)
     cw = sharding.chi2(t(m), t(d), t(w)).cpu().numpy()
     np.testing.assert_allclose(cw, (w * np.abs(d - m) ** 2).sum(axis=(0, 2)), rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------- full size (C2)
+def test_im_to_vis_full_size_c2_properties():
+    """BASELINE configs[1] at full size (1e6 rows x 64 chan x 1000 src x 4 corr), device resident:
+    sampled rows against the CPU oracle (north-star tolerance 1e-8 absolute), exact linearity under a
+    power-of-two scaling, and row-shard invariance (a shard's rows equal the same rows of the full
+    call bit for bit: the multi-GPU sharding changes nothing)."""
+    import torch
+    d = synthetic_inputs(seed=0, nrow=16, nchan=64, nsrc=1000, nant=64)
+    rng = np.random.default_rng(1000)
+    nrow = 1000000
+    uvw = np.empty((nrow, 3))
+    uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+    uvw[:, 2] = rng.uniform(-400, 400, nrow)
+    image = real_image(d)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_img, d_uvw, d_lm, d_fr = t(image), t(uvw), t(d["lm"]), t(d["frequency"])
+    vis = dft.im_to_vis(d_img, d_uvw, d_lm, d_fr)
+    assert tuple(vis.shape) == (nrow, 64, 4) and vis.dtype == torch.complex128
+    rows = np.linspace(0, nrow - 1, 48).astype(np.int64)
+    ref = oracle.im_to_vis(image, uvw[rows], d["lm"], d["frequency"], omp=True)
+    got = vis[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-8
+    # linearity: x4 commutes with every rounding
+    vis4 = dft.im_to_vis(d_img * 4.0, d_uvw, d_lm, d_fr)
+    assert torch.equal(vis4, vis * 4.0)
+    del vis4
+    # row-shard invariance on shard boundaries that are not multiples of the block size
+    a, b = 123457, 654321
+    part = dft.im_to_vis(d_img, d_uvw[a:b], d_lm, d_fr)
+    assert torch.equal(part, vis[a:b])
+    # checksum of checksums: per-channel power is finite and positive
+    power = (vis.real ** 2 + vis.imag ** 2).sum(dim=(0, 2))
+    assert bool(torch.isfinite(power).all()) and bool((power > 0).all())
+
+
+def test_phase_delay_large_phases_and_fallback():
+    """|p| spans the Cody-Waite range (< 2^19 pi/2 ~ 8.2e5 rad) and the library fallback beyond it."""
+    rng = np.random.default_rng(17)
+    lm = (rng.random((9, 2)) - 0.5) * 0.6
+    freq = np.linspace(0.9e9, 1.7e9, 7)
+    for span in (3e4, 3e6, 3e8):         # |p| up to ~1e4, ~1e6 (both branches), ~1e8 (fallback)
+        uvw = (rng.random((257, 3)) - 0.5) * span
+        out = rime.phase_delay(lm, uvw, freq)
+        ref = oracle.phase_delay(lm, uvw, freq)
+        assert maxabs(out, ref) < 1e-15
+    out = rime.phase_delay(lm, np.full((3, 3), np.inf), freq)
+    assert np.isnan(out).all()
