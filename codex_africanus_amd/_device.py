@@ -32,7 +32,8 @@ def _torch_dtype(np_dtype):
     if _TORCH_DTYPES is None:
         _TORCH_DTYPES = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
                          np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128,
-                         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+                         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
+                         np.dtype(np.uint8): torch.uint8, np.dtype(np.bool_): torch.bool}
     return _TORCH_DTYPES[np.dtype(np_dtype)]
 
 

@@ -5,7 +5,7 @@ dask wrappers, without needing dask:
     africanus/rime/dask_predict.py:443-593  predict_vis (chunk checks :478-524,
         parallel_reduction :311-369, linear_reduction :181-254, apply_dies :372-439)
     africanus/rime/dask.py:38-52            phase_delay
-    africanus/dft/dask.py:26-51             im_to_vis
+    africanus/dft/dask.py:26-51,60-90       im_to_vis, vis_to_im
 
 Arrays are plain numpy arrays (or torch ROCm tensors); chunking is described like
 ``dask.array.Array.chunks``: a tuple of block lengths per axis.  Every block is one call of the
@@ -23,7 +23,7 @@ import numpy as np
 
 from .rime.predict import predict_vis as _predict_vis, predict_checks
 from .rime.phase import phase_delay as _phase_delay
-from .dft.kernels import im_to_vis as _im_to_vis
+from .dft.kernels import im_to_vis as _im_to_vis, vis_to_im as _vis_to_im
 
 
 def normalize_chunks(chunks, size, name="axis"):
@@ -78,6 +78,23 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=np.complex1
     return _cat([_cat([_im_to_vis(image[:, c0:c1], uvw[r0:r1], lm, frequency[c0:c1],
                                   convention=convention, dtype=dtype)
                        for (c0, c1) in cb], 1) for (r0, r1) in rb], 0)
+
+
+def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=np.float64, chunks=None):
+    """Blockwise vis_to_im over (row, chan) chunks, summed over the row chunks
+    (africanus/dft/dask.py:60-90: ``ims.sum(axis=0)``).  The source axis stays whole."""
+    chunks = chunks or {}
+    rb = _bounds(normalize_chunks(chunks.get("row"), uvw.shape[0], "row"))
+    cb = _bounds(normalize_chunks(chunks.get("chan"), frequency.shape[0], "chan"))
+    chan_blocks = []
+    for (c0, c1) in cb:
+        acc = None
+        for (r0, r1) in rb:
+            part = _vis_to_im(vis[r0:r1, c0:c1], uvw[r0:r1], lm, frequency[c0:c1], flags[r0:r1, c0:c1],
+                              convention=convention, dtype=dtype)
+            acc = part if acc is None else acc + part
+        chan_blocks.append(acc)
+    return _cat(chan_blocks, 1)
 
 
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None, dde2_jones=None,

@@ -12,7 +12,7 @@ except ImportError as e:  # pragma: no cover - depends on the environment
     da = None
     _dask_error = e
 
-from .kernels import im_to_vis as _np_im_to_vis
+from .kernels import im_to_vis as _np_im_to_vis, vis_to_im as _np_vis_to_im
 
 
 def _first(x):
@@ -40,3 +40,26 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=np.complex1
     return da.blockwise(_im_to_vis_block, ("row", "chan", "corr"), image, ("src", "chan", "corr"),
                         uvw, ("row", "uvwc"), lm, ("src", "lmc"), frequency, ("chan",),
                         convention=convention, dtype_=dtype, dtype=dtype)
+
+
+def _vis_to_im_block(vis, uvw, lm, frequency, flags, convention, dtype_):
+    return _np_vis_to_im(vis, _first(uvw), _first(lm), frequency, flags, convention=convention,
+                         dtype=dtype_)[None, ...]
+
+
+def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=np.float64):
+    """``africanus.dft.dask.vis_to_im`` (africanus/dft/dask.py:60-90): one image per row chunk,
+    summed over the row chunks; same chunk checks."""
+    if da is None:
+        raise ImportError("dask.array is required for codex_africanus_amd.dft.dask: %s" % (_dask_error,))
+    if vis.chunks[0] != uvw.chunks[0]:
+        raise ValueError("Vis chunks and uvw chunks must match on first axis")
+    if vis.chunks[1] != frequency.chunks[0]:
+        raise ValueError("Vis chunks must match frequency chunks on second axis")
+    if vis.chunks != flags.chunks:
+        raise ValueError("Vis chunks must match flags chunks on all axes")
+    ims = da.blockwise(_vis_to_im_block, ("row", "src", "chan", "corr"), vis, ("row", "chan", "corr"),
+                       uvw, ("row", "uvwc"), lm, ("src", "lmc"), frequency, ("chan",),
+                       flags, ("row", "chan", "corr"), adjust_chunks={"row": 1},
+                       convention=convention, dtype_=dtype, dtype=dtype)
+    return ims.sum(axis=0)

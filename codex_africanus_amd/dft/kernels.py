@@ -65,3 +65,46 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
         _lib.call("af_im_to_vis_f64", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
                   _lib.CONVENTION[convention], _MODES[_mode], p_out, p_ws, max(int(ws_bytes), 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
+
+
+def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
+    """
+    Adjoint direct Fourier transform visibilities -> image,
+    ``im[s,nu,c] = sum_r Re(vis[r,nu,c] exp(+-2 pi i (u l + v m + w (n-1)) nu / c))`` over the
+    unflagged (row, chan).
+
+    Same contract as ``africanus.dft.vis_to_im`` (africanus/dft/kernels.py:72-148): ``vis``
+    (row, chan, corr) real or complex, ``uvw`` (row, 3), ``lm`` (source, 2), ``frequency`` (chan,),
+    ``flags`` (row, chan, corr) boolean -- a (row, chan) is dropped when ANY of its correlations is
+    flagged (:139-140) -> float (source, chan, corr); output dtype ``dtype`` or
+    ``result_type(real type of vis, uvw, lm, frequency)``; 'fourier' is exp(+2 pi i ...) here, the
+    opposite of ``im_to_vis`` (:113-118).  Arithmetic is float64 on the device.
+    """
+    if convention not in _lib.CONVENTION:
+        raise ValueError("convention not in ('fourier', 'casa')")
+    vdt = np_dtype_of(vis)
+    if dtype is None:
+        vreal = np.empty(0, vdt).real.dtype
+        out_dtype = np.result_type(vreal, *[np_dtype_of(a) for a in (uvw, lm, frequency)])
+    else:
+        out_dtype = np.dtype(dtype)
+        if out_dtype.kind == "c":
+            raise TypeError("dtype must be real")
+    if len(vis.shape) != 3 or tuple(vis.shape) != tuple(flags.shape):
+        raise ValueError("vis and flags must both have shape (row, chan, corr)")
+    if len(uvw.shape) != 2 or uvw.shape[1] != 3 or len(lm.shape) != 2 or lm.shape[1] != 2:
+        raise ValueError("uvw must be (row, 3) and lm (source, 2)")
+    nrow, nchan, ncorr = (int(s) for s in vis.shape)
+    nsrc = int(lm.shape[0])
+    if int(uvw.shape[0]) != nrow or tuple(frequency.shape) != (nchan,):
+        raise ValueError("vis (row, chan, corr), uvw (row, 3) and frequency (chan,) disagree")
+    with Call(vis, uvw, lm, frequency, flags) as c:
+        p_vis = c.inp(vis, np.complex128)
+        p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)
+        p_fl = c.inp(flags, np.uint8)
+        p_out, h = c.out((nsrc, nchan, ncorr), np.float64)
+        ws_bytes = int(_lib.load().af_vis_to_im_workspace_bytes(nsrc, nrow, nchan, ncorr))
+        p_ws = c.scratch(ws_bytes)
+        _lib.call("af_vis_to_im_f64", p_vis, p_uvw, p_lm, p_fr, p_fl, nsrc, nrow, nchan, ncorr,
+                  _lib.CONVENTION[convention], _MODES[_mode], p_out, p_ws, max(ws_bytes, 256), c.stream)
+        return c.result(h, cast=None if out_dtype == np.float64 else out_dtype)

@@ -53,6 +53,27 @@ def allreduce_chi2(chi2, group=None):
     return chi2
 
 
+def allreduce_image(image, group=None):
+    """Sum a (source, chan, corr) dirty image over all ranks, in place: the cross-GPU step of the
+    row-sharded ``vis_to_im`` (the reference sums row-chunk images, africanus/dft/dask.py:90).
+    No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image
+
+
+def vis_to_im_shard(rank, world_size, vis, uvw, lm, frequency, flags, convention="fourier", group=None):
+    """One rank's part of the row-sharded adjoint transform: ``vis_to_im`` of its row block
+    (torch ROCm tensors), then the all-reduced image.  ``vis``/``uvw``/``flags`` hold the FULL row
+    range on every rank only in tests; in production each rank passes its own rows with
+    ``world_size=1``-style slicing done by the caller."""
+    from .dft.kernels import vis_to_im
+    start, stop = shard_bounds(uvw.shape[0], world_size)[rank]
+    im = vis_to_im(vis[start:stop], uvw[start:stop], lm, frequency, flags[start:stop], convention=convention)
+    return allreduce_image(im, group=group), (start, stop)
+
+
 def chi2(model, data, weight=None):
     """chi2[nu] = sum_{r,c} w |data - model|^2 on the device (af_chi2_c128); torch ROCm tensors
     (row, chan, corr) complex128 in, (chan,) float64 tensor out."""

@@ -119,6 +119,22 @@ int af_im_to_vis_f64(const double *image, int image_is_complex, const double *uv
                      int64_t nchan, int64_t ncorr, int convention, int mode, double *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- vis_to_im --------------------------------------------------------------
+ * Replaces africanus.dft.vis_to_im (africanus/dft/kernels.py:72-148), the adjoint of im_to_vis.
+ *   vis (nrow,nchan,ncorr) complex128; uvw (nrow,3); lm (nsrc,2); frequency (nchan);
+ *   flags (nrow,nchan,ncorr) bytes (nonzero = flagged) -> out (nsrc,nchan,ncorr) float64
+ *   im[s,nu,c] = sum_r cos(p) vis.re - sin(p) vis.im over the (r,nu) none of whose correlations
+ *   is flagged (:139-140); p = C (l u + m v + n w) nu with C = +2pi/c for AF_CONVENTION_FOURIER
+ *   (:113-118, the opposite of im_to_vis); n unclamped (:125).
+ * `mode` as for af_im_to_vis_f64.  The row sum is evaluated in row partitions that are added in
+ * a fixed order (deterministic).  `workspace`: >= af_vis_to_im_workspace_bytes(...) device bytes
+ * (it holds a flag-masked, tile-major repack of `vis`: about 1.1x its size). */
+size_t af_vis_to_im_workspace_bytes(int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr);
+int af_vis_to_im_f64(const double *vis, const double *uvw, const double *lm, const double *frequency,
+                     const unsigned char *flags, int64_t nsrc, int64_t nrow, int64_t nchan,
+                     int64_t ncorr, int convention, int mode, double *out, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* ---- predict_vis ------------------------------------------------------------
  * Replaces africanus.rime.predict_vis (africanus/rime/predict.py:466-619) and
  * apply_gains (:622-649: dies + base_vis only).

@@ -114,6 +114,28 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None, omp=F
     return out.astype(out_dtype, copy=False)
 
 
+def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None, omp=False):
+    """africanus/dft/kernels.py:72-148."""
+    sign = _sign(convention)
+    if dtype is None:
+        vdt = np.dtype(vis.dtype)
+        vreal = np.empty(0, vdt).real.dtype
+        out_dtype = np.result_type(vreal, uvw.dtype, lm.dtype, frequency.dtype)
+    else:
+        out_dtype = np.dtype(dtype)
+    assert vis.shape == flags.shape
+    v_ = _c(vis, np.complex128)
+    uvw_, lm_, fr_ = _c(uvw, np.float64), _c(lm, np.float64), _c(frequency, np.float64)
+    fl_ = _c(flags, np.uint8)
+    nrow, nchan, ncorr = v_.shape
+    nsrc = lm_.shape[0]
+    out = np.empty((nsrc, nchan, ncorr), dtype=np.float64)
+    rc = _lib(omp).orc_vis_to_im_f64(_p(v_), _p(uvw_), _p(lm_), _p(fr_), _p(fl_), _i64(nsrc), _i64(nrow),
+                                     _i64(nchan), _i64(ncorr), _int(sign), _p(out))
+    assert rc == 0
+    return out.astype(out_dtype, copy=False)
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None,
                 dde2_jones=None, die1_jones=None, base_vis=None, die2_jones=None):
     """africanus/rime/predict.py:466-619 (checks are NOT restated here: the

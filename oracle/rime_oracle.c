@@ -5,6 +5,7 @@
  *   africanus/rime/phase.py:28-61          -> orc_phase_delay_{f64,f32}
  *   africanus/rime/predict.py:56-373,574-617 -> orc_predict_vis_{f64,f32}
  *   africanus/dft/kernels.py:33-67         -> orc_im_to_vis_f64
+ *   africanus/dft/kernels.py:104-146       -> orc_vis_to_im_f64
  *   africanus/rime/fast_beam_cubes.py:10-54  -> orc_freq_grid_interp_{f64,f32}
  *   africanus/rime/fast_beam_cubes.py:57-240 -> orc_beam_cube_dde_{f64,f32}
  *   africanus/constants/consts.py:6-9      -> ORC_*_TWO_PI_OVER_C
@@ -121,6 +122,51 @@ int orc_im_to_vis_f64(const double *image, int image_is_complex,
                         o[1] += tim;
                     }
                 }
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * vis_to_im: africanus/dft/kernels.py:104-146 (adjoint of im_to_vis).
+ *   constant: 'fourier' -> +two_pi_over_c, 'casa' -> minus (:113-118: the opposite of im_to_vis)
+ *   n = sqrt(1 - l^2 - m^2) - 1 unclamped (:125)
+ *   for s: for r: real_phase = C*(l*u + m*v + n*w) (:131); for nu: p = real_phase*nu (:135);
+ *     if any(flags[r,nu]): continue (:139-140)
+ *     for c: im[s,nu,c] += cos(p)*vis.re - sin(p)*vis.im   (:142-146)
+ * vis: (nrow, nchan, ncorr) complex128 interleaved (a real vis has zero imaginary parts);
+ * flags: (nrow, nchan, ncorr) bytes; out: (nsrc, nchan, ncorr) float64.
+ * sign: -1 'fourier', +1 'casa' (same labels as the other entry points).
+ * Sources are independent, so an OpenMP build may split them.
+ * ---------------------------------------------------------------------- */
+int orc_vis_to_im_f64(const double *vis, const double *uvw, const double *lm, const double *frequency,
+                      const unsigned char *flags, int64_t nsrc, int64_t nrow, int64_t nchan,
+                      int64_t ncorr, int sign, double *out)
+{
+    if (sign != 1 && sign != -1) return ORC_EINVAL;
+    const double constant = sign < 0 ? ORC_TWO_PI_OVER_C : ORC_MINUS_TWO_PI_OVER_C;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t s = 0; s < nsrc; ++s) {
+        double l = lm[2 * s], m = lm[2 * s + 1];
+        double n = sqrt(1.0 - l * l - m * m) - 1.0;
+        double *im = out + s * nchan * ncorr;
+        for (int64_t k = 0; k < nchan * ncorr; ++k) im[k] = 0.0;
+        for (int64_t r = 0; r < nrow; ++r) {
+            double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+            double real_phase = constant * (l * u + m * v + n * w);
+            for (int64_t nu = 0; nu < nchan; ++nu) {
+                double p = real_phase * frequency[nu];
+                const unsigned char *fl = flags + (r * nchan + nu) * ncorr;
+                int flagged = 0;
+                for (int64_t c = 0; c < ncorr; ++c) flagged |= fl[c];
+                if (flagged) continue;
+                double cp = cos(p), sp = sin(p);
+                const double *vv = vis + 2 * (r * nchan + nu) * ncorr;
+                for (int64_t c = 0; c < ncorr; ++c)
+                    im[nu * ncorr + c] += cp * vv[2 * c] - sp * vv[2 * c + 1];
             }
         }
     }

@@ -15,6 +15,7 @@ Each .npz holds the inputs and the reference's outputs for one group:
   g2_predict_vis.npz   predict_vis      (africanus/rime/predict.py:466), 27 presence/corr combos
   g3_im_to_vis.npz     im_to_vis        (africanus/dft/kernels.py:14)
   g4_beam.npz          freq_grid_interp / beam_cube_dde (africanus/rime/fast_beam_cubes.py:10,57)
+  g6_vis_to_im.npz     vis_to_im        (africanus/dft/kernels.py:72), flags / real vis / shapes
   g5_chain_c1.npz      BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr): sampled rows + checksums
 """
 import os
@@ -25,7 +26,7 @@ import numpy as np
 
 from africanus.rime.phase import phase_delay
 from africanus.rime.predict import predict_vis
-from africanus.dft.kernels import im_to_vis
+from africanus.dft.kernels import im_to_vis, vis_to_im
 from africanus.rime.fast_beam_cubes import beam_cube_dde, freq_grid_interp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -254,8 +255,45 @@ def g5_chain_c1():
     save("g5_chain_c1.npz", **out)
 
 
+# ----------------------------------------------------------------------------
+def g6_vis_to_im():
+    """vis_to_im (africanus/dft/kernels.py:72): flags, real/complex vis, conventions, shapes."""
+    rng = np.random.default_rng(606)
+    nsrc, nrow, nchan = 11, 57, 6
+    lm = (rng.random((nsrc, 2)) - 0.5) * 0.1
+    uvw = (rng.random((nrow, 3)) - 0.5) * 8e3
+    uvw[:, 2] *= 0.1
+    freq = np.linspace(0.856e9, 1.712e9, nchan)
+    freq_nonuniform = freq * (1.0 + 0.01 * rng.random(nchan))
+    out = dict(lm=lm, uvw=uvw, frequency=freq, frequency_nonuniform=freq_nonuniform)
+    for ncorr in (1, 2, 4):
+        vis = rng.standard_normal((nrow, nchan, ncorr)) + 1j * rng.standard_normal((nrow, nchan, ncorr))
+        flags = rng.random((nrow, nchan, ncorr)) < 0.15
+        out["vis%d" % ncorr] = vis
+        out["flags%d" % ncorr] = flags
+        for conv in ("fourier", "casa"):
+            out["im%d_%s" % (ncorr, conv)] = vis_to_im(vis, uvw, lm, freq, flags, convention=conv)
+        out["im%d_nonuniform" % ncorr] = vis_to_im(vis, uvw, lm, freq_nonuniform, flags)
+    out["im4_realvis"] = vis_to_im(out["vis4"].real.copy(), uvw, lm, freq, out["flags4"])
+    out["im4_noflags"] = vis_to_im(out["vis4"], uvw, lm, freq, np.zeros_like(out["flags4"]))
+    out["im4_f32"] = vis_to_im(out["vis4"], uvw, lm, freq, out["flags4"], dtype=np.float32)
+    # 70 channels (several tiles), 300 rows (several row partitions)
+    freq70 = np.linspace(0.9e9, 1.6e9, 70)
+    uvw300 = (rng.random((300, 3)) - 0.5) * 8e3
+    vis70 = rng.standard_normal((300, 70, 4)) + 1j * rng.standard_normal((300, 70, 4))
+    flags70 = rng.random((300, 70, 4)) < 0.1
+    out.update(frequency70=freq70, uvw300=uvw300, vis70=vis70, flags70=flags70,
+               im70=vis_to_im(vis70, uvw300, lm, freq70, flags70))
+    # a source outside the unit disc: NaN image row (kernels.py:125)
+    lm_nan = lm.copy()
+    lm_nan[2] = [0.9, 0.8]
+    out.update(lm_nan=lm_nan, im4_nan=vis_to_im(out["vis4"], uvw, lm_nan, freq, out["flags4"]))
+    save("g6_vis_to_im.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
-    fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1,
+               g6=g6_vis_to_im)
     for w in which:
         fns[w]()

@@ -404,3 +404,90 @@ def test_phase_delay_large_phases_and_fallback():
         assert maxabs(out, ref) < 1e-15
     out = rime.phase_delay(lm, np.full((3, 3), np.inf), freq)
     assert np.isnan(out).all()
+
+
+# ---------------------------------------------------------------------------- vis_to_im
+@pytest.fixture(scope="module")
+def g6():
+    from conftest import load_golden
+    return load_golden("g6_vis_to_im.npz")
+
+
+def _vscale(vis):
+    return float(np.abs(vis).sum(axis=0).max())
+
+
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+@pytest.mark.parametrize("ncorr", [1, 2, 4])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_vis_to_im_golden(g6, dft_mode, mode, rtol, ncorr, conv):
+    dft_mode(mode)
+    vis = g6["vis%d" % ncorr]
+    out = dft.vis_to_im(vis, g6["uvw"], g6["lm"], g6["frequency"], g6["flags%d" % ncorr], convention=conv)
+    ref = g6["im%d_%s" % (ncorr, conv)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype == np.float64
+    assert maxabs(out, ref) <= rtol * _vscale(vis)
+
+
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+def test_vis_to_im_other_cases(g6, dft_mode, mode, rtol):
+    dft_mode(mode)
+    sc = _vscale(g6["vis4"])
+    f = dft.vis_to_im
+    assert maxabs(f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency_nonuniform"], g6["flags4"]),
+                  g6["im4_nonuniform"]) <= rtol * sc
+    assert maxabs(f(g6["vis4"].real.copy(), g6["uvw"], g6["lm"], g6["frequency"], g6["flags4"]),
+                  g6["im4_realvis"]) <= rtol * sc
+    assert maxabs(f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency"], np.zeros_like(g6["flags4"])),
+                  g6["im4_noflags"]) <= rtol * sc
+    # 70 channels x 300 rows: several tiles and row partitions
+    assert maxabs(f(g6["vis70"], g6["uvw300"], g6["lm"], g6["frequency70"], g6["flags70"]),
+                  g6["im70"]) <= rtol * _vscale(g6["vis70"])
+    out32 = f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency"], g6["flags4"], dtype=np.float32)
+    assert out32.dtype == np.float32 and maxabs(out32, g6["im4_f32"]) < 2e-5 * np.abs(g6["im4_f32"]).max()
+    nan = f(g6["vis4"], g6["uvw"], g6["lm_nan"], g6["frequency"], g6["flags4"])
+    assert_array_equal(np.isnan(nan), np.isnan(g6["im4_nan"]))
+
+
+def test_vis_to_im_flagged_kat(dft_mode):
+    """africanus/dft/tests/test_dft.py:180-215: everything flagged but row 0 at the origin."""
+    dft_mode("auto")
+    rng = np.random.default_rng(123)
+    nsource, nrow, nchan, ncorr = 21, 31, 3, 4
+    uvw = 100 * rng.random((nrow, 3))
+    uvw[0] = 0.0
+    lm = 0.01 * rng.standard_normal((nsource, 2))
+    vis = rng.standard_normal((nrow, nchan, ncorr)) + 1j * rng.standard_normal((nrow, nchan, ncorr))
+    vis[0] = 1.0
+    flags = np.ones((nrow, nchan, ncorr), dtype=bool)
+    flags[0] = False
+    frequency = np.ones(nchan) * 2.99792458e8
+    im = dft.vis_to_im(vis, uvw, lm, frequency, flags)
+    np.testing.assert_array_almost_equal(im, np.ones((nsource, nchan, ncorr)), decimal=13)
+    # a fully flagged channel stays exactly zero, even for a NaN source
+    flags[0, 1] = True
+    lm[3] = [0.9, 0.9]
+    im = dft.vis_to_im(vis, uvw, lm, frequency, flags)
+    ref = oracle.vis_to_im(vis, uvw, lm, frequency, flags)
+    assert (im[:, 1] == 0).all() and np.isnan(im[3, 0]).all()
+    assert_array_equal(np.isnan(im), np.isnan(ref))
+
+
+def test_vis_to_im_adjointness_and_shard_sum(dft_mode):
+    """<y, R x> = <R^H y, x> (test_dft.py:136-177) at a larger shape, and the image of all rows is
+    the sum of the images of row shards (what the multi-GPU all-reduce relies on)."""
+    dft_mode("auto")
+    d = synthetic_inputs(seed=31, nrow=6000, nchan=64, nsrc=130)
+    rng = d["rng"]
+    x = rng.standard_normal((130, 64, 4))
+    y = rng.standard_normal((6000, 64, 4)) + 1j * rng.standard_normal((6000, 64, 4))
+    flag = np.zeros(y.shape, dtype=bool)
+    Rx = dft.im_to_vis(x, d["uvw"], d["lm"], d["frequency"])
+    RHy = dft.vis_to_im(y, d["uvw"], d["lm"], d["frequency"], flag, convention="fourier")
+    lhs, rhs = np.vdot(y, Rx).real, np.vdot(RHy, x)
+    assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+    parts = sum(dft.vis_to_im(y[a:b], d["uvw"][a:b], d["lm"], d["frequency"], flag[a:b])
+                for a, b in ((0, 2500), (2500, 6000)))
+    assert maxabs(parts, RHy) < 1e-11 * np.abs(RHy).max()
+    ref = oracle.vis_to_im(y, d["uvw"], d["lm"][:8], d["frequency"], flag, omp=True)
+    assert maxabs(RHy[:8], ref) < 1e-8

@@ -258,3 +258,52 @@ def test_chain_c1_samples_and_checksums(g5):
     vis3 = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, die, bvis, die)
     assert_array_equal(vis3[rows], g5["die_rows"])
     assert abs(np.abs(vis3).sum() - g5["die_abssum"]) <= 1e-12 * g5["die_abssum"]
+
+
+# --------------------------------------------------------------------------- vis_to_im
+@pytest.fixture(scope="module")
+def g6():
+    from conftest import load_golden
+    return load_golden("g6_vis_to_im.npz")
+
+
+@pytest.mark.parametrize("ncorr", [1, 2, 4])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_vis_to_im_bit_exact(g6, ncorr, conv):
+    out = oracle.vis_to_im(g6["vis%d" % ncorr], g6["uvw"], g6["lm"], g6["frequency"], g6["flags%d" % ncorr],
+                           convention=conv)
+    ref = g6["im%d_%s" % (ncorr, conv)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype == np.float64
+    assert_array_equal(out, ref)
+
+
+def test_vis_to_im_other_cases(g6):
+    f = lambda *a, **k: oracle.vis_to_im(*a, **k)
+    assert_array_equal(f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency_nonuniform"], g6["flags4"]),
+                       g6["im4_nonuniform"])
+    assert_array_equal(f(g6["vis4"].real.copy(), g6["uvw"], g6["lm"], g6["frequency"], g6["flags4"]),
+                       g6["im4_realvis"])
+    assert_array_equal(f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency"], np.zeros_like(g6["flags4"])),
+                       g6["im4_noflags"])
+    assert_array_equal(f(g6["vis70"], g6["uvw300"], g6["lm"], g6["frequency70"], g6["flags70"]), g6["im70"])
+    out32 = f(g6["vis4"], g6["uvw"], g6["lm"], g6["frequency"], g6["flags4"], dtype=np.float32)
+    assert out32.dtype == np.float32
+    assert np.abs(out32 - g6["im4_f32"]).max() < 2e-5 * np.abs(g6["im4_f32"]).max()
+    nan = f(g6["vis4"], g6["uvw"], g6["lm_nan"], g6["frequency"], g6["flags4"])
+    assert_array_equal(np.isnan(nan), np.isnan(g6["im4_nan"]))
+    assert np.isnan(nan[2]).all() and not np.isnan(np.delete(nan, 2, axis=0)).any()
+
+
+def test_vis_to_im_adjointness():
+    """africanus/dft/tests/test_dft.py:136-177: <y, R x> == <R^H y, x>."""
+    rng = np.random.default_rng(123)
+    nsource, nrow, nchan, ncorr = 21, 31, 3, 4
+    uvw = 100 * rng.random((nrow, 3))
+    lm = 0.01 * rng.standard_normal((nsource, 2))
+    frequency = np.arange(1, nchan + 1) * 2.99792458e8
+    gamma_im = rng.standard_normal((nsource, nchan, ncorr))
+    gamma_vis = rng.standard_normal((nrow, nchan, ncorr))
+    flag = np.zeros((nrow, nchan, ncorr), dtype=bool)
+    lhs = np.vdot(gamma_vis, oracle.im_to_vis(gamma_im, uvw, lm, frequency)).real
+    rhs = np.vdot(oracle.vis_to_im(gamma_vis, uvw, lm, frequency, flag), gamma_im)
+    assert abs(lhs - rhs) < 1e-13 * max(1.0, abs(lhs))

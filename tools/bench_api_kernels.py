@@ -74,4 +74,13 @@ m, d = rc(1000000, 64, 4), rc(1000000, 64, 4)
 dt = timeit(lambda: sharding.chi2(m, d))
 b = 2 * m.numel() * 16
 out["chi2 c128 (1e6 rows x 64 chan x 4 corr)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+# vis_to_im at the C2 shape: 1e6 rows x 64 chan x 4 corr visibilities -> 1000 sources
+from codex_africanus_amd import dft
+del m
+lm1k = (torch.rand(1000, 2, dtype=torch.float64, device=dev) - 0.5) * 0.07
+uvw1m = (torch.rand(1000000, 3, dtype=torch.float64, device=dev) - 0.5) * 8000
+fl = torch.zeros(1000000, 64, 4, dtype=torch.bool, device=dev)
+dt = timeit(lambda: dft.vis_to_im(d, uvw1m, lm1k, fr, fl), reps=2)
+out["vis_to_im f64 (1e6 rows x 64 chan x 1000 src x 4 corr)"] = dict(
+    ms=dt * 1e3, Mvis_per_s=1e6 * 64 / dt / 1e6, TFLOPs_algorithmic=1e6 * 64 * 1000 * 20 / dt / 1e12)
 print(json.dumps(out, indent=1))
