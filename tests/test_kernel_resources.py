@@ -1,0 +1,45 @@
+"""
+Build-time invariant of the direct-transform kernels: their record-group refreshes are issued from
+inline asm and retired by hand-counted ``s_waitcnt vmcnt(N)``; a compiler spill to scratch inside
+those loops would add vector-memory operations the counts do not know about.  Every instantiation
+must therefore compile with zero scratch and zero spilled registers (CPU-only check: hipcc
+cross-compiles gfx950 without a GPU).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "codex_africanus_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.parametrize("source, kernels", [
+    ("af_im_to_vis.hip", ("dft_recurrence_dpp_kernel", "dft_recurrence_dpp4_kernel")),
+    ("af_vis_to_im.hip", ("v2i_recurrence_kernel",)),
+])
+def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+           "--cuda-device-only", "-c", os.path.join(CSRC, source), "-o", str(tmp_path / "k.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    text = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if not any(k in name for k in kernels):
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        sspill = int(re.search(r"SGPRs Spill: (\d+)", b).group(1))
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        assert scratch == 0 and vspill == 0 and sspill == 0, (name, scratch, vspill, sspill)
+        assert vgprs + agprs <= 256, (name, vgprs, agprs)   # two waves per SIMD
+    assert seen >= 8, "expected the template instantiations, found %d" % seen
