@@ -56,6 +56,9 @@ def parse():
                    help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
                         "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
                         "(a real array: coherent beam gathers)")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend; nccl = RCCL over xGMI (default).  gloo exists to "
+                        "exercise the N>1 code path on a one-GPU box (with AFHIP_BENCH_DEVICE=0)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     p.add_argument("--check-rows", type=int, default=256, help="rows checked against the oracle")
@@ -97,11 +100,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("AFHIP_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from codex_africanus_amd import _lib
     from codex_africanus_amd.testing import synthetic_inputs, real_image
@@ -296,10 +303,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload + " + per-channel chi^2" + (" + RCCL all-reduce" if world > 1 else ""),
+                "workload": workload + " + per-channel chi^2" + (
+                    "" if world == 1 else " + RCCL all-reduce" if args.backend == "nccl" else " + gloo all-reduce"),
                 "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": ncorr,
                 "rows_total": world * nrow, "phasor_mode": args.mode,
-                "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce" % world,
+                "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce (%s)"
+                            % (world, "none" if world == 1 else args.backend),
             },
             "fp64_max_abs_err": max_err,
             "roofline": {

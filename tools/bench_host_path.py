@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""PCIe-inclusive rate of the numpy-in / numpy-out path (the reference's calling convention) at the
+C2 shape: upload of uvw/image/lm/frequency, the kernels, download of the 4.1 GB result."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from codex_africanus_amd import dft
+from codex_africanus_amd.testing import synthetic_inputs, real_image
+
+d = synthetic_inputs(seed=0, nrow=16, nchan=64, nsrc=1000, nant=64)
+rng = np.random.default_rng(1)
+nrow = 1000000
+uvw = np.empty((nrow, 3))
+uvw[:, 0] = rng.uniform(-4000, 4000, nrow); uvw[:, 1] = rng.uniform(-4000, 4000, nrow); uvw[:, 2] = rng.uniform(-400, 400, nrow)
+image = real_image(d)
+dft.im_to_vis(image, uvw[:1000], d["lm"], d["frequency"])          # warm-up (library load, first launch)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    vis = dft.im_to_vis(image, uvw, d["lm"], d["frequency"])
+    ts.append(time.perf_counter() - t0)
+t = min(ts)
+print(json.dumps({"numpy_in_numpy_out_seconds": ts, "Mvis_per_s_pcie_inclusive": nrow * 64 / t / 1e6,
+                  "result_GB": vis.nbytes / 1e9}))
