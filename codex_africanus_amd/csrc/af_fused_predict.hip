@@ -336,7 +336,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
     AF_REQUIRE(nitems >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_c128: negative extent");
-    AF_REQUIRE(nant <= 1024, "af_fused_predict_c128: more than 1024 antennas");
+    // one time step's Jones of a source batch + per-antenna constants live in LDS (160 KiB per workgroup)
+    AF_REQUIRE(nant <= 930, "af_fused_predict_c128: more than 930 antennas");
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nitems < (1LL << 31), "af_fused_predict_c128: too large");
     hipStream_t st_ = af_stream(stream);
     if (nrow == 0 || nchan == 0) return AF_OK;
@@ -377,6 +378,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
     const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double);
+    AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_c128: %zu bytes of LDS needed (nant = %lld)", lds_bytes,
+               (long long)nant);
     AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_predict_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     af_prof_begin(st_);

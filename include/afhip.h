@@ -229,6 +229,28 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
 int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
                  int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream);
 
+/* ---- WSClean component-list predict ------------------------------------------------
+ * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
+ * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):
+ *   spectrum[s,f] = flux[s] * exp(sum_k coeffs[s,k] * log(nu_f/ref_freq[s])^(k+1))   log_poly[s] != 0
+ *                 = flux[s] + sum_k coeffs[s,k] * (nu_f/ref_freq[s] - 1)^(k+1)       otherwise
+ *   vis[r,f]      = sum_s spectrum[s,f] * shape_s(r,f) * exp(+2 pi i (u l + v m + w (n-1)) nu_f / c)
+ * shape = 1 for point components (is_gaussian[s] == 0), the elliptical Gaussian envelope of
+ * gauss_shape[s] = (major, minor, position angle) [rad] otherwise (wsclean_predict.py:49-77).
+ * uvw (nrow,3), lm (nsrc,2), is_gaussian / log_poly (nsrc) bytes, flux / ref_freq (nsrc), coeffs
+ * (nsrc,ncoeffs), gauss_shape (nsrc,3), frequency (nchan), all float64; out (nrow,nchan) complex128
+ * (the reference's trailing correlation axis of length 1).  mode as for af_im_to_vis_f64 (without
+ * AF_DFT_CLAMP_N): the recurrence path also advances the Gaussian envelope by a product recurrence. */
+int af_wsclean_spectra_f64(const double *flux, const double *coeffs, const unsigned char *log_poly,
+                           const double *ref_freq, const double *frequency, int64_t nsrc, int64_t ncoeffs,
+                           int64_t nchan, double *out, void *stream);
+size_t af_wsclean_predict_workspace_bytes(int64_t nsrc, int64_t nchan);
+int af_wsclean_predict_f64(const double *uvw, const double *lm, const unsigned char *is_gaussian,
+                           const double *flux, const double *coeffs, const unsigned char *log_poly,
+                           const double *ref_freq, const double *gauss_shape, const double *frequency,
+                           int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncoeffs, int mode, double *out,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

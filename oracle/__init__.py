@@ -136,6 +136,38 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None, 
     return out.astype(out_dtype, copy=False)
 
 
+def spectra(I, coeffs, log_poly, ref_freq, frequency):  # noqa: E741
+    """africanus/model/wsclean/spec_model.py:70-126."""
+    I_, co, rf, fr = (_c(a, np.float64) for a in (I, coeffs, ref_freq, frequency))
+    if co.ndim != 2 or not (I_.shape[0] == co.shape[0] == rf.shape[0]):
+        raise ValueError("first dimensions of I, coeffs and ref_freq don't match.")
+    lp = np.asarray(log_poly)
+    if lp.ndim == 1 and lp.shape[0] != co.shape[0]:
+        raise ValueError("coeffs.shape[0] != log_poly.shape[0]")
+    lp = _c(np.broadcast_to(lp.astype(bool), (co.shape[0],)), np.uint8)
+    out = np.empty((co.shape[0], fr.shape[0]), dtype=np.float64)
+    rc = _lib().orc_spectra_f64(_p(I_), _p(co), _p(lp), _p(rf), _p(fr), _i64(co.shape[0]), _i64(co.shape[1]),
+                                _i64(fr.shape[0]), _p(out))
+    assert rc == 0
+    return out
+
+
+def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gauss_shape, frequency):
+    """africanus/rime/wsclean_predict.py:11-120."""
+    st = np.asarray(source_type)
+    if not np.all((st == "POINT") | (st == "GAUSSIAN")):
+        raise ValueError("source_type must be POINT or GAUSSIAN")
+    spec = _c(spectra(flux, coeffs, log_poly, ref_freq, frequency), np.float64)
+    uvw_, lm_, gs_, fr_ = (_c(a, np.float64) for a in (uvw, lm, gauss_shape, frequency))
+    isg = _c(st == "GAUSSIAN", np.uint8)
+    nsrc, nrow, nchan = lm_.shape[0], uvw_.shape[0], fr_.shape[0]
+    out = np.empty((nrow, nchan, 1), dtype=np.complex128)
+    rc = _lib().orc_wsclean_predict_f64(_p(uvw_), _p(lm_), _p(isg), _p(gs_), _p(fr_), _p(spec), _i64(nsrc),
+                                        _i64(nrow), _i64(nchan), _p(out))
+    assert rc == 0
+    return out
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None,
                 dde2_jones=None, die1_jones=None, base_vis=None, die2_jones=None):
     """africanus/rime/predict.py:466-619 (checks are NOT restated here: the

@@ -6,6 +6,7 @@
  *   africanus/rime/predict.py:56-373,574-617 -> orc_predict_vis_{f64,f32}
  *   africanus/dft/kernels.py:33-67         -> orc_im_to_vis_f64
  *   africanus/dft/kernels.py:104-146       -> orc_vis_to_im_f64
+ *   africanus/rime/wsclean_predict.py:11-84 -> orc_wsclean_predict_f64
  *   africanus/rime/fast_beam_cubes.py:10-54  -> orc_freq_grid_interp_{f64,f32}
  *   africanus/rime/fast_beam_cubes.py:57-240 -> orc_beam_cube_dde_{f64,f32}
  *   africanus/constants/consts.py:6-9      -> ORC_*_TWO_PI_OVER_C
@@ -170,6 +171,115 @@ int orc_vis_to_im_f64(const double *vis, const double *uvw, const double *lm, co
             }
         }
     }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * wsclean_predict_main: africanus/rime/wsclean_predict.py:11-84.
+ *   fwhm = 2 sqrt(2 ln 2); gauss_scale = (1/fwhm) sqrt(2) pi / c (:13-15)
+ *   n = sqrt(1 - l^2 - m^2) - 1 (:32); real_phase = two_pi_over_c*(u*l + v*m + w*n) (:40,61): CASA sign
+ *   POINT:    vis[r,f] += cos(p)*spec + i sin(p)*spec                       (:42-47)
+ *   GAUSSIAN: el = emaj sin(angle), em = emaj cos(angle), er = emin/(emaj or 1) (:49-54)
+ *             u1 = (u*em - v*el)*er, v1 = u*el + v*em (:64-65)
+ *             shape = exp(-(fu1^2 + fv1^2)), fu1 = u1*scaled_freq[f] (:73-75); re,im *= shape (:76-77)
+ * is_gaussian: (nsrc) bytes; gauss_shape (nsrc,3); spectrum (nsrc,nchan); out (nrow,nchan) complex128.
+ * ---------------------------------------------------------------------- */
+/* numba's float ** int lowering: exponentiation by squaring (numba/cpython/numbers.py int_power_impl) */
+static double orc_ipow(double a, int64_t b)
+{
+    double r = 1.0;
+    int invert = b < 0;
+    int64_t e = invert ? -b : b;
+    if (e > 0x10000) return pow(a, (double)b);
+    while (e != 0) {
+        if (e & 1) r *= a;
+        e >>= 1;
+        a *= a;
+    }
+    return invert ? 1.0 / r : r;
+}
+
+/* spectra: africanus/model/wsclean/spec_model.py:70-122.
+ *   log_poly:  I * exp(sum_c coeffs[c] * log(nu/rf)^(c+1))   (:101-112)
+ *   ordinary:  I + sum_c coeffs[c] * (nu/rf - 1)^(c+1)       (:113-124) */
+int orc_spectra_f64(const double *I, const double *coeffs, const unsigned char *log_poly, const double *ref_freq,
+                    const double *frequency, int64_t nsrc, int64_t ncoeffs, int64_t nchan, double *out)
+{
+    for (int64_t s = 0; s < nsrc; ++s) {
+        double rf = ref_freq[s];
+        if (log_poly[s]) {
+            for (int64_t f = 0; f < nchan; ++f) {
+                double nu = frequency[f];
+                double acc = 0.0;
+                for (int64_t c = 0; c < ncoeffs; ++c) acc += coeffs[s * ncoeffs + c] * orc_ipow(log(nu / rf), c + 1);
+                out[s * nchan + f] = I[s] * exp(acc);
+            }
+        } else {
+            for (int64_t f = 0; f < nchan; ++f) {
+                double nu = frequency[f];
+                double acc = I[s];
+                for (int64_t c = 0; c < ncoeffs; ++c) {
+                    double term = coeffs[s * ncoeffs + c];
+                    term *= orc_ipow(nu / rf - 1.0, c + 1);
+                    acc += term;
+                }
+                out[s * nchan + f] = acc;
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_wsclean_predict_f64(const double *uvw, const double *lm, const unsigned char *is_gaussian,
+                            const double *gauss_shape, const double *frequency, const double *spectrum,
+                            int64_t nsrc, int64_t nrow, int64_t nchan, double *out)
+{
+    const double fwhm = 2.0 * sqrt(2.0 * log(2.0));
+    const double fwhminv = 1.0 / fwhm;
+    const double gauss_scale = fwhminv * sqrt(2.0) * 3.141592653589793 / ORC_LIGHTSPEED;
+    double *scaled_freq = (double *)malloc(sizeof(double) * (size_t)(nchan > 0 ? nchan : 1));
+    if (!scaled_freq) return ORC_ENOMEM;
+    for (int64_t f = 0; f < nchan; ++f) scaled_freq[f] = frequency[f] * gauss_scale;
+    memset(out, 0, sizeof(double) * 2 * (size_t)(nrow * nchan));
+    for (int64_t s = 0; s < nsrc; ++s) {
+        double l = lm[2 * s], m = lm[2 * s + 1];
+        double n = sqrt(1.0 - l * l - m * m) - 1.0;
+        if (!is_gaussian[s]) {
+            for (int64_t r = 0; r < nrow; ++r) {
+                double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+                double real_phase = ORC_TWO_PI_OVER_C * (u * l + v * m + w * n);
+                for (int64_t f = 0; f < nchan; ++f) {
+                    double p = real_phase * frequency[f];
+                    double re = cos(p) * spectrum[s * nchan + f];
+                    double im = sin(p) * spectrum[s * nchan + f];
+                    out[2 * (r * nchan + f)] += re;
+                    out[2 * (r * nchan + f) + 1] += im;
+                }
+            }
+        } else {
+            double emaj = gauss_shape[3 * s], emin = gauss_shape[3 * s + 1], angle = gauss_shape[3 * s + 2];
+            double el = emaj * sin(angle), em = emaj * cos(angle);
+            double er = emin / (emaj == 0.0 ? 1.0 : emaj);
+            for (int64_t r = 0; r < nrow; ++r) {
+                double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+                double real_phase = ORC_TWO_PI_OVER_C * (u * l + v * m + w * n);
+                double u1 = (u * em - v * el) * er;
+                double v1 = u * el + v * em;
+                for (int64_t f = 0; f < nchan; ++f) {
+                    double p = real_phase * frequency[f];
+                    double re = cos(p) * spectrum[s * nchan + f];
+                    double im = sin(p) * spectrum[s * nchan + f];
+                    double fu1 = u1 * scaled_freq[f], fv1 = v1 * scaled_freq[f];
+                    double shape = exp(-(fu1 * fu1 + fv1 * fv1));
+                    re *= shape;
+                    im *= shape;
+                    out[2 * (r * nchan + f)] += re;
+                    out[2 * (r * nchan + f) + 1] += im;
+                }
+            }
+        }
+    }
+    free(scaled_freq);
     return ORC_OK;
 }
 

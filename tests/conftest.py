@@ -44,6 +44,11 @@ def g5():
     return load_golden("g5_chain_c1.npz")
 
 
+@pytest.fixture(scope="session")
+def g7():
+    return load_golden("g7_wsclean.npz")
+
+
 def has_gpu():
     try:
         import torch

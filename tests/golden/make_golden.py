@@ -16,6 +16,7 @@ Each .npz holds the inputs and the reference's outputs for one group:
   g3_im_to_vis.npz     im_to_vis        (africanus/dft/kernels.py:14)
   g4_beam.npz          freq_grid_interp / beam_cube_dde (africanus/rime/fast_beam_cubes.py:10,57)
   g6_vis_to_im.npz     vis_to_im        (africanus/dft/kernels.py:72), flags / real vis / shapes
+  g7_wsclean.npz       wsclean_predict  (africanus/rime/wsclean_predict.py:86), point + Gaussian components
   g5_chain_c1.npz      BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr): sampled rows + checksums
 """
 import os
@@ -291,9 +292,47 @@ def g6_vis_to_im():
     save("g6_vis_to_im.npz", **out)
 
 
+# ----------------------------------------------------------------------------
+def g7_wsclean():
+    """wsclean_predict (africanus/rime/wsclean_predict.py:86) and spectra
+    (africanus/model/wsclean/spec_model.py:70), recipe of rime/tests/test_wsclean_predict.py:26-60
+    with realistic baselines / source sizes so that the Gaussian envelope is not ~1 or ~0."""
+    from africanus.rime.wsclean_predict import wsclean_predict
+    from africanus.model.wsclean.spec_model import spectra
+    rs = np.random.RandomState(42)
+    out = {}
+    for tag, (row, src, chan) in dict(small=(10, 21, 5), big=(130, 37, 70)).items():
+        source_sel = rs.randint(0, 2, src).astype(np.bool_)
+        source_type = np.where(source_sel, "POINT", "GAUSSIAN")
+        gauss_shape = np.stack([np.abs(rs.normal(size=src)) * 2e-4, np.abs(rs.normal(size=src)) * 1e-4,
+                                rs.uniform(0, np.pi, src)], axis=1)
+        uvw = rs.normal(size=(row, 3)) * 1500.0
+        uvw[:, 2] *= 0.1
+        lm = rs.normal(size=(src, 2)) * 1e-2
+        flux = rs.normal(size=src)
+        ncoeff = 2 if tag == "small" else 4
+        coeffs = rs.normal(size=(src, ncoeff)) * np.array([1.0, 0.5, 0.2, 0.1])[:ncoeff]
+        log_poly = rs.randint(0, 2, src).astype(np.bool_)
+        flux[log_poly] = np.abs(flux[log_poly])
+        coeffs[log_poly] = np.abs(coeffs[log_poly])
+        freq = np.linspace(0.856e9, 2 * 0.856e9, chan)
+        ref_freq = np.full(src, freq[freq.shape[0] // 2])
+        vis = wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gauss_shape, freq)
+        out.update({tag + "_uvw": uvw, tag + "_lm": lm, tag + "_is_gauss": ~source_sel, tag + "_flux": flux,
+                    tag + "_coeffs": coeffs, tag + "_log_poly": log_poly, tag + "_ref_freq": ref_freq,
+                    tag + "_gauss_shape": gauss_shape, tag + "_freq": freq, tag + "_vis": vis,
+                    tag + "_spectrum": spectra(flux, coeffs, log_poly, ref_freq, freq)})
+        if tag == "small":
+            fnu = freq * (1 + 0.01 * rs.random_sample(chan))
+            out["small_freq_nonuniform"] = fnu
+            out["small_vis_nonuniform"] = wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq,
+                                                          gauss_shape, fnu)
+    save("g7_wsclean.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1,
-               g6=g6_vis_to_im)
+               g6=g6_vis_to_im, g7=g7_wsclean)
     for w in which:
         fns[w]()

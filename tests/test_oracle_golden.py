@@ -307,3 +307,42 @@ def test_vis_to_im_adjointness():
     lhs = np.vdot(gamma_vis, oracle.im_to_vis(gamma_im, uvw, lm, frequency)).real
     rhs = np.vdot(oracle.vis_to_im(gamma_vis, uvw, lm, frequency, flag), gamma_im)
     assert abs(lhs - rhs) < 1e-13 * max(1.0, abs(lhs))
+
+
+# ---- wsclean_predict / spectra (fused term producers) -------------------------------------
+def _wsc_args(g7, tag, freq_key=None):
+    st = np.where(g7[tag + "_is_gauss"], "GAUSSIAN", "POINT")
+    return (g7[tag + "_uvw"], g7[tag + "_lm"], st, g7[tag + "_flux"], g7[tag + "_coeffs"], g7[tag + "_log_poly"],
+            g7[tag + "_ref_freq"], g7[tag + "_gauss_shape"], g7[freq_key or tag + "_freq"])
+
+
+@pytest.mark.parametrize("tag", ["small", "big"])
+def test_wsclean_spectra_and_predict_bit_exact(g7, tag):
+    """oracle vs africanus.model.wsclean.spectra / africanus.rime.wsclean_predict run here
+    (tests/golden/make_golden.py g7): bit for bit, 2 and 4 spectral coefficients."""
+    a = _wsc_args(g7, tag)
+    assert_array_equal(oracle.spectra(a[3], a[4], a[5], a[6], a[8]), g7[tag + "_spectrum"])
+    out = oracle.wsclean_predict(*a)
+    assert out.shape == g7[tag + "_vis"].shape and out.dtype == np.complex128
+    assert_array_equal(out, g7[tag + "_vis"])
+
+
+def test_wsclean_predict_nonuniform_and_errors(g7):
+    assert_array_equal(oracle.wsclean_predict(*_wsc_args(g7, "small", "small_freq_nonuniform")),
+                       g7["small_vis_nonuniform"])
+    a = list(_wsc_args(g7, "small"))
+    a[2] = np.where(np.arange(a[2].shape[0]) == 3, "DISK", a[2])
+    with pytest.raises(ValueError, match="POINT or GAUSSIAN"):
+        oracle.wsclean_predict(*a)
+    with pytest.raises(ValueError, match="don't match"):
+        oracle.spectra(a[3][:-1], a[4], a[5], a[6], a[8])
+
+
+def test_wsclean_point_sources_equal_casa_dft(g7):
+    """a point-only component list is im_to_vis(spectrum[..., None], convention='casa') term by term
+    (africanus/rime/wsclean_predict.py:42-47 against africanus/dft/kernels.py:57-67)."""
+    a = list(_wsc_args(g7, "small"))
+    a[2] = np.full(a[2].shape, "POINT")
+    spec = oracle.spectra(a[3], a[4], a[5], a[6], a[8])
+    dft = oracle.im_to_vis(spec[:, :, None].copy(), a[0], a[1], a[8], convention="casa")
+    assert np.abs(oracle.wsclean_predict(*a) - dft).max() < 1e-13
