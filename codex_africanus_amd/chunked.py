@@ -97,6 +97,30 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=np.flo
     return _cat(chan_blocks, 1)
 
 
+def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gauss_shape, frequency, chunks=None):
+    """Blockwise wsclean_predict over (source, row, chan) chunks, summed over the source chunks
+    (africanus/rime/dask_predict.py:609-658: ``vis.sum(axis=0)``)."""
+    from .rime.wsclean_predict import wsclean_predict as _wsclean_predict
+    chunks = chunks or {}
+    nsrc = lm.shape[0]
+    sb = _bounds(normalize_chunks(chunks.get("source"), nsrc, "source")) if nsrc else [(0, 0)]
+    rb = _bounds(normalize_chunks(chunks.get("row"), uvw.shape[0], "row"))
+    cb = _bounds(normalize_chunks(chunks.get("chan"), frequency.shape[0], "chan"))
+    lp = np.broadcast_to(np.asarray(log_poly), (nsrc,))
+    row_blocks = []
+    for (r0, r1) in rb:
+        chan_blocks = []
+        for (c0, c1) in cb:
+            acc = None
+            for (s0, s1) in sb:
+                part = _wsclean_predict(uvw[r0:r1], lm[s0:s1], source_type[s0:s1], flux[s0:s1], coeffs[s0:s1],
+                                        lp[s0:s1], ref_freq[s0:s1], gauss_shape[s0:s1], frequency[c0:c1])
+                acc = part if acc is None else acc + part
+            chan_blocks.append(acc)
+        row_blocks.append(_cat(chan_blocks, 1))
+    return _cat(row_blocks, 0)
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None, dde2_jones=None,
                 die1_jones=None, base_vis=None, die2_jones=None, streams=None, chunks=None):
     """

@@ -20,6 +20,7 @@ except ImportError as e:  # pragma: no cover - depends on the environment
 from .phase import phase_delay as _np_phase_delay
 from .predict import predict_vis as _np_predict_vis, predict_checks
 from .fast_beam_cubes import beam_cube_dde as _np_beam_cube_dde
+from .wsclean_predict import wsclean_predict as _np_wsclean_predict
 
 
 def _need_dask():
@@ -44,6 +45,25 @@ def phase_delay(lm, uvw, frequency, convention="fourier"):
     dtype = np.result_type(np.complex64, lm.dtype, uvw.dtype, frequency.dtype)
     return da.blockwise(_phase_block, ("s", "r", "c"), lm, ("s", "x"), uvw, ("r", "y"),
                         frequency, ("c",), convention=convention, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------- wsclean_predict
+def _wsclean_block(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gauss_shape, frequency):
+    return _np_wsclean_predict(_first(uvw), _first(lm), source_type, flux, _first(coeffs), log_poly, ref_freq,
+                               _first(gauss_shape), frequency)[None]
+
+
+def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gauss_shape, frequency):
+    """africanus/rime/dask_predict.py:609-658: one block per (source, row, chan) chunk, summed over the
+    source chunks.  Spectrum and predict of a block are one fused device call."""
+    _need_dask()
+    dtype = np.result_type(np.complex64, uvw.dtype, lm.dtype, flux.dtype, coeffs.dtype, ref_freq.dtype,
+                           frequency.dtype)
+    vis = da.blockwise(_wsclean_block, ("source", "row", "chan", "corr"), uvw, ("row", "uvw"), lm, ("source", "lm"),
+                       source_type, ("source",), flux, ("source",), coeffs, ("source", "comp"),
+                       log_poly, ("source",), ref_freq, ("source",), gauss_shape, ("source", "gauss"),
+                       frequency, ("chan",), adjust_chunks={"source": 1}, new_axes={"corr": 1}, dtype=dtype)
+    return vis.sum(axis=0)
 
 
 # ---------------------------------------------------------------------------- beam_cube_dde
