@@ -18,6 +18,7 @@ AF_OK, AF_EINVAL, AF_ENOMEM, AF_ENOTSUP, AF_EHIP_BASE = 0, 1, 2, 3, 1000
 CONVENTION = {"fourier": -1, "casa": 1}
 AF_DFT_AUTO, AF_DFT_EXACT, AF_DFT_RECURRENCE = 0, 1, 2
 AF_DFT_CLAMP_N = 0x100
+AF_DFT_VALU_ONLY = 0x200
 AF_JONES_DIAG, AF_JONES_2X2 = 1, 2
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t

@@ -35,6 +35,7 @@
 #include "af_common.h"
 #include "af_sincos.h"
 #include "af_dft_device.h"
+#include "af_dft_mfma.h"
 
 namespace {
 
@@ -191,7 +192,7 @@ __global__ void dft_pack_lgroups(const double *__restrict__ lmn, int64_t nsrc, i
 __global__ __launch_bounds__(64) void dft_colstate(const double *__restrict__ image, int W, int64_t nsrc,
                                                    int64_t nchan, int64_t ncorr, int64_t ntile, int CT,
                                                    const int *__restrict__ srcbad, int *__restrict__ colstate,
-                                                   int *__restrict__ tilestate, int nchunk)
+                                                   int *__restrict__ tilestate, int nchunk, int *__restrict__ flags)
 {
     const int64_t i = blockIdx.x;  // column (padded chan, corr)
     const int64_t c = i % ncorr, ch = i / ncorr;
@@ -209,7 +210,10 @@ __global__ __launch_bounds__(64) void dft_colstate(const double *__restrict__ im
     }
     if (threadIdx.x == 0) {
         colstate[i] = state;
-        if (state) atomicOr(&tilestate[(ch / CT) * nchunk + c / MAXNC], state);
+        if (state) {
+            atomicOr(&tilestate[(ch / CT) * nchunk + c / MAXNC], state);
+            atomicOr(&flags[2], state);  // any special column at all
+        }
     }
 }
 
@@ -630,6 +634,7 @@ struct Args {
     double *out;
     int64_t nrow, nsrc, nchan, ncorr;
     int chunk, mode;
+    bool mfma;  // the MFMA-accumulator kernels own the one-spacing band; only the fallbacks are launched here
     double constant;
     hipStream_t st;
 };
@@ -653,8 +658,14 @@ int launch_chunk(const Args &a)
         // Tiles in groups of four run the shared-phasor kernel when the whole band has one channel
         // spacing (flags[1] == 1) and the per-tile kernel otherwise; leftover tiles always run the
         // per-tile kernel.  Which of the launches does the work is decided on the device.
-        const int quads = (int)(L.ntile / 4), rest = (int)(L.ntile - 4 * (int64_t)quads);
-        if (quads > 0) {
+        const int quads = a.mfma ? 0 : (int)(L.ntile / 4), rest = (int)(L.ntile - 4 * (int64_t)quads);
+        if (a.mfma) {
+            // af_dft_mfma_run covers flags[1] == 1; the per-tile kernel covers per-tile spacings
+            hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), grid, block, 0, a.st, a.uvw, records,
+                               tilef, flags, colstate, tilestate, a.out, a.nrow, (int)a.nsrc, (int)L.nsrc_pad,
+                               a.nchan, a.ncorr, corr0, a.chunk, (int)L.nchunk, 0, 1, 0);
+            AF_LAUNCH_CHECK();
+        } else if (quads > 0) {
             dim3 g4((unsigned)af_cdiv(a.nrow, 64), (unsigned)quads);
             if (a.chunk == 0) af_prof_begin(a.st);  // measurement hook: the dominant kernel only
             hipLaunchKernelGGL((dft_recurrence_dpp4_kernel<CT, NC, CPLX, 7>), g4, block, 0, a.st, a.uvw, records,
@@ -668,7 +679,7 @@ int launch_chunk(const Args &a)
                                a.nchan, a.ncorr, corr0, a.chunk, (int)L.nchunk, 0, 1, 0);
             AF_LAUNCH_CHECK();
         }
-        if (rest > 0) {
+        if (!a.mfma && rest > 0) {
             dim3 gr((unsigned)af_cdiv(a.nrow, ROWS_PER_BLOCK), (unsigned)rest);
             if (a.chunk == 0 && quads == 0) af_prof_begin(a.st);
             hipLaunchKernelGGL((dft_recurrence_dpp_kernel<CT, NC, CPLX, 7>), gr, block, 0, a.st, a.uvw, records,
@@ -720,6 +731,8 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
         if (!ws_layout(L, nsrc, nchan, ncorr, image_is_complex, cands[k])) return 0;
         if (L.total > m) m = L.total;
     }
+    if (af_dft_mfma_eligible(nchan, ncorr, image_is_complex != 0))
+        m += af_dft_mfma_workspace_bytes(af_cdiv(nsrc > 0 ? nsrc : 1, 4) * 4, nchan);
     return m;
 }
 
@@ -731,7 +744,8 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
                "convention not in ('fourier', 'casa')");
     const int clamp_n = (mode & AF_DFT_CLAMP_N) ? 1 : 0;
-    mode &= ~AF_DFT_CLAMP_N;
+    const bool valu_only = (mode & AF_DFT_VALU_ONLY) != 0;
+    mode &= ~(AF_DFT_CLAMP_N | AF_DFT_VALU_ONLY);
     AF_REQUIRE(mode == AF_DFT_AUTO || mode == AF_DFT_EXACT || mode == AF_DFT_RECURRENCE,
                "af_im_to_vis_f64: unknown mode %d", mode);
     AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_im_to_vis_f64: negative extent");
@@ -749,8 +763,10 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     const int ct = choose_ct(nchan, (int)(ncorr < MAXNC ? ncorr : MAXNC), cplx);
     WsLayout L;
     ws_layout(L, nsrc, nchan, ncorr, image_is_complex, ct);
-    AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total,
-               "af_im_to_vis_f64: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    const bool mfma = !valu_only && mode != AF_DFT_EXACT && af_dft_mfma_eligible(nchan, ncorr, cplx);
+    const size_t need = L.total + (mfma ? af_dft_mfma_workspace_bytes(L.nsrc_pad, nchan) : 0);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= need,
+               "af_im_to_vis_f64: workspace too small (%zu < %zu)", workspace_bytes, need);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_im_to_vis_f64: workspace must be 256-byte aligned");
     AF_REQUIRE(L.ntile <= 65535, "af_im_to_vis_f64: too many channels");
     char *ws = static_cast<char *>(workspace);
@@ -790,13 +806,22 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
         hipLaunchKernelGGL(dft_colstate, dim3((unsigned)ncol), dim3(64), 0, st, image, W, nsrc, nchan, ncorr,
                            L.ntile, ct, reinterpret_cast<const int *>(ws + L.srcbad),
                            reinterpret_cast<int *>(ws + L.colstate), reinterpret_cast<int *>(ws + L.tilestate),
-                           (int)L.nchunk);
+                           (int)L.nchunk, reinterpret_cast<int *>(ws + L.flags));
         AF_LAUNCH_CHECK();
     }
     Args a;
     a.L = &L; a.ws = ws; a.uvw = uvw; a.out = out;
     a.nrow = nrow; a.nsrc = nsrc; a.nchan = nchan; a.ncorr = ncorr;
-    a.mode = mode; a.st = st;
+    a.mode = mode; a.st = st; a.mfma = mfma;
+    if (mfma) {
+        int rc = af_dft_mfma_run(image, uvw, frequency, reinterpret_cast<const double *>(ws + L.lmn),
+                                 reinterpret_cast<const int *>(ws + L.srcbad),
+                                 reinterpret_cast<const double *>(ws + L.tilef),
+                                 reinterpret_cast<const int *>(ws + L.flags),
+                                 reinterpret_cast<const int *>(ws + L.colstate), convention, out, nrow, nsrc,
+                                 L.nsrc_pad, nchan, ws + L.total, st);
+        if (rc != AF_OK) return rc;
+    }
     a.constant = convention == AF_CONVENTION_FOURIER ? AF_MINUS_TWO_PI_OVER_C : AF_TWO_PI_OVER_C;
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
         a.chunk = chunk;

@@ -1,0 +1,298 @@
+// im_to_vis, MFMA-accumulator path for gfx950: real images with 4 correlations on a uniformly spaced band.
+//
+// Same sum as af_im_to_vis.hip (africanus/dft/kernels.py:33-67), mapped so that the 4 correlations
+// are the N dimension of v_mfma_f64_4x4x4_4b and the accumulators live in the MFMA C/D registers:
+//   * a wave owns 16 rows x a tile of CT channels (CT = 64: 2 x 64 accumulators = all 256 AGPRs);
+//     one MFMA step contracts 4 sources:  D[row, corr] += sum_k Y[row, src k] * I[src k, corr]
+//     per channel, once for Re(Y) and once for Im(Y).  Lane layout of the instruction (measured,
+//     tools/probe_mfma_f64.hip): A lane = 16 k + (row & 15), B lane = 16 k + 4 b + corr (the same
+//     value for the four row blocks b), D lane = 16 (row & 3) + 4 (row >> 2) + corr.
+//   * so every lane owns ONE (row, source) pair of the step and its VALU work is that pair's phasor
+//     only: path difference, two quarter-turn sincos (tile start, channel step), then the
+//     three-term recurrence over the tile, run as four independent chains (re/im x even/odd
+//     channels, step 2 delta) one 8-channel group ahead of the MFMAs that consume it, re-anchored
+//     every 16 channels at y0 * d^16 (d^16 by four squarings) so that the recurrence error stays that
+//     of a 16-channel tile.  fp64 MFMA and fp64 VALU share one pipe on this chip (measured), so the
+//     gain over the VALU kernels is not rate but registers: with the accumulators out of the
+//     arch VGPRs a tile holds 64 channels instead of 13 and the per-tile setup is amortised 5x better.
+//   * the image pixels of a 4-source step (CT x 4 x 4 doubles) and the step's (l,m,n) come as one
+//     contiguous record, copied global -> LDS by global_load_lds_dwordx4 one step ahead (two LDS
+//     stages, one barrier per step) and read as ds_read_b128 (two channels per read).
+#include "af_dft_mfma.h"
+#include "af_sincos.h"
+
+namespace {
+
+constexpr int ANCHOR = 16;          // channels between re-anchored phasors
+constexpr int THREADS = 256;        // 4 waves x 16 rows
+
+__host__ __device__ constexpr int stage_doubles(int ct) { return (ct + 1) * 16; }
+
+// record of (tile, step): [ (l,m,n,0) x 4 sources | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ]
+__global__ void mfma_pack_records(const double *__restrict__ image, const double *__restrict__ lmn,
+                                  const int *__restrict__ srcbad, int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0,
+                                  int CT, double *__restrict__ rec)
+{
+    const int64_t per = stage_doubles(CT);
+    const int64_t total = nit * per;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t it = i / per, idx = i - it * per;
+        double v = 0.0;
+        if (idx < 16) {
+            const int64_t s = 4 * it + idx / 4;
+            if (s < nsrc && (idx & 3) < 3) v = lmn[4 * s + (idx & 3)];
+        } else {
+            const int64_t e = idx - 16, pair = e / 32, r = e - pair * 32;
+            const int64_t kn = r >> 1, j = 2 * pair + (r & 1);
+            const int64_t s = 4 * it + (kn >> 2), ch = c0 + j;
+            if (s < nsrc && ch < nchan && !srcbad[s]) v = image[(s * nchan + ch) * 4 + (kn & 3)];
+        }
+        rec[i] = v;
+    }
+}
+
+// quarter turns per metre at the first channel of every tile of the launch
+__global__ void mfma_tile_f0(const double *__restrict__ freq, int64_t nchan, int64_t c0, int CT, int ntile, int sign,
+                             double *__restrict__ f0)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntile) f0[t] = 4.0 * (double)sign * freq[c0 + (int64_t)t * CT] / AF_LIGHTSPEED;
+}
+
+// grid: (ceil(nrow/64), tiles of the launch); block: 4 waves, wave w on rows 64 bx + 16 w ...
+template <int CT>
+__global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
+    const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tile_f0,
+    const double *__restrict__ tilef, const int *__restrict__ flags, double *__restrict__ out, int64_t nrow,
+    int nit, int64_t nchan, int64_t c0_first)
+{
+    if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
+    constexpr int STAGE = stage_doubles(CT);
+    constexpr int UNITS = STAGE / 2;              // 16-byte units of a stage
+    __shared__ double smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = lane >> 4;                      // the source of a step this lane computes the phasor of
+    const int tile = blockIdx.y;
+    const int64_t c0 = c0_first + (int64_t)tile * CT;
+    const double *__restrict__ rec = records + (int64_t)tile * nit * STAGE;
+    int64_t row = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    if (row >= nrow) row = nrow - 1;
+    const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
+    const double F0 = tile_f0[tile], FD = tilef[1];
+    const int boff = (k * 4 + (lane & 3)) * 2;    // B operand: pixel of (source k, corr lane & 3)
+
+    double are[CT], aim[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) are[j] = aim[j] = 0.0;
+
+    // global -> LDS copy of one stage; issued from asm so that hipcc does not drain it (vmcnt(0)) in
+    // front of the LDS reads of the stage being computed; retired by the explicit wait below.
+    auto stage_load = [&](int it, int buf) {
+        const double *src = rec + (int64_t)it * STAGE;
+#pragma unroll
+        for (int e0 = 0; e0 < UNITS; e0 += THREADS) {
+            const int ebase = e0 + wave * 64;     // wave-uniform: LDS destination = base + lane * 16
+            if (ebase + lane < UNITS) {
+                const double *g = src + (ebase + lane) * 2;
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(smem + buf * STAGE + ebase * 2));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            }
+        }
+    };
+    stage_load(0, 0);
+    asm volatile("" :: "v"(u), "v"(v), "v"(w), "s"(F0), "s"(FD));  // hipcc's own waits land here, not in the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int GP = 4;                         // channel pairs per B register group (8 channels)
+    constexpr int NGRP = CT / 2 / GP;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nit) stage_load(it + 1, cur ^ 1);
+        const double *S = smem + cur * STAGE;
+        const double2 lm_ = *reinterpret_cast<const double2 *>(S + 4 * k);
+        const double n = S[4 * k + 2];
+        const double q = fma(n, w, fma(lm_.y, v, __dmul_rn(lm_.x, u)));  // path difference in metres
+        double dr, di, anr, ani;
+        sincos_quarter_turns<7>(__dmul_rn(q, FD), dr, di);    // channel-step phasor d
+        sincos_quarter_turns<7>(__dmul_rn(q, F0), anr, ani);  // phasor at the tile's first channel
+        double ar = dr, ai = di;                              // d^16
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double nr = fma(ar, ar, -__dmul_rn(ai, ai)), ni = __dmul_rn(__dadd_rn(ar, ar), ai);
+            ar = nr; ai = ni;
+        }
+        const double kk = __dadd_rn(dr, dr), k2 = fma(kk, kk, -2.0);  // 2 cos(delta), 2 cos(2 delta)
+        const double2 *B = reinterpret_cast<const double2 *>(S + 16 + boff);
+        double2 bg[2][GP];
+        double yr[2][8], yi[2][8];
+        auto start_segment = [&](double (&Yr)[8], double (&Yi)[8]) {
+            Yr[0] = anr; Yi[0] = ani;
+            Yr[1] = fma(anr, dr, -__dmul_rn(ani, di)); Yi[1] = fma(anr, di, __dmul_rn(ani, dr));
+            Yr[2] = fma(kk, Yr[1], -Yr[0]); Yi[2] = fma(kk, Yi[1], -Yi[0]);
+            Yr[3] = fma(kk, Yr[2], -Yr[1]); Yi[3] = fma(kk, Yi[2], -Yi[1]);
+#pragma unroll
+            for (int t = 4; t < 8; ++t) { Yr[t] = fma(k2, Yr[t - 2], -Yr[t - 4]); Yi[t] = fma(k2, Yi[t - 2], -Yi[t - 4]); }
+        };
+        auto continue_segment = [&](double (&Yr)[8], double (&Yi)[8], const double (&Pr)[8], const double (&Pi)[8]) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double r2 = t >= 2 ? Yr[t - 2] : Pr[t + 6], r4 = t >= 4 ? Yr[t - 4] : Pr[t + 4];
+                const double i2 = t >= 2 ? Yi[t - 2] : Pi[t + 6], i4 = t >= 4 ? Yi[t - 4] : Pi[t + 4];
+                Yr[t] = fma(k2, r2, -r4); Yi[t] = fma(k2, i2, -i4);
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < GP; ++p) bg[0][p] = B[p * 16];
+        start_segment(yr[0], yi[0]);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP) {  // pixels and phasors of the next 8 channels
+#pragma unroll
+                for (int p = 0; p < GP; ++p) bg[(g + 1) & 1][p] = B[((g + 1) * GP + p) * 16];
+                if (((g + 1) * 8) % ANCHOR == 0) {
+                    const double tr = fma(anr, ar, -__dmul_rn(ani, ai)), ti = fma(anr, ai, __dmul_rn(ani, ar));
+                    anr = tr; ani = ti;
+                    start_segment(yr[(g + 1) & 1], yi[(g + 1) & 1]);
+                } else {
+                    continue_segment(yr[(g + 1) & 1], yi[(g + 1) & 1], yr[g & 1], yi[g & 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = g * 8 + jj;
+                const double b = (jj & 1) ? bg[g & 1][jj >> 1].y : bg[g & 1][jj >> 1].x;
+                are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], b, are[j], 0, 0, 0);
+                aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], b, aim[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed in LDS
+        __syncthreads();
+    }
+
+    // D lane = 16 i + 4 b + corr holds row 4 b + i: a wave store covers 16 rows x 64 contiguous bytes,
+    // consecutive channels complete the 128-byte lines
+    const int orow = 4 * ((lane >> 2) & 3) + (lane >> 4), ocorr = lane & 3;
+    const int64_t r = (int64_t)blockIdx.x * 64 + wave * 16 + orow;
+    if (r >= nrow) return;
+    const int nvalid = (int)((nchan - c0 < CT) ? (nchan - c0) : CT);  // block-uniform: the band's last tile may be short
+    double2 *__restrict__ o = reinterpret_cast<double2 *>(out) + (r * nchan + c0) * 4 + ocorr;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        if (j < nvalid) o[j * 4] = make_double2(are[j], aim[j]);
+    }
+}
+
+// The reference skips zero pixels (`if image[s,nu,c]:`, kernels.py:64): an all-zero (chan, corr) column
+// stays exactly 0 and a non-finite source poisons only the columns where its pixel is nonzero.  The
+// main kernel accumulates zeros for both; this pass rewrites the (rare) special columns.  One thread
+// per (row, special column candidate); returns at once when dft_colstate found none (flags[2] == 0).
+__global__ void mfma_fix_columns(const int *__restrict__ flags, const int *__restrict__ colstate,
+                                 double *__restrict__ out, int64_t nrow, int64_t nchan)
+{
+    if (flags[0] != 1 || flags[1] != 1 || flags[2] == 0) return;
+    const int64_t ncol = nchan * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrow * ncol) return;
+    const int st = colstate[i % ncol];
+    if (st == 0) return;
+    const double v = st == 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+    reinterpret_cast<double2 *>(out)[i] = make_double2(v, v);
+}
+
+struct Plan {
+    int64_t nfull;       // tiles of 64 channels (a last partial tile wider than 32 channels counts)
+    int tail_ct;         // 0, 16 or 32: width of the last tile when narrower
+    int64_t tail_c0;
+    size_t f0_off, rec_off, tail_rec_off, total;
+};
+
+Plan make_plan(int64_t nsrc_pad, int64_t nchan)
+{
+    Plan p;
+    const int64_t nit = nsrc_pad / 4, rem = nchan % 64;
+    p.nfull = nchan / 64 + (rem > 32 ? 1 : 0);
+    p.tail_ct = (rem == 0 || rem > 32) ? 0 : (rem <= 16 ? 16 : 32);
+    p.tail_c0 = (nchan / 64) * 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    p.f0_off = take((size_t)(p.nfull + 1) * sizeof(double));
+    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(64) * sizeof(double));
+    p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct) : 0) * sizeof(double));
+    p.total = o;
+    return p;
+}
+
+template <int CT>
+int run_tiles(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
+              const double *tilef, const int *flags, int sign, double *out, int64_t nrow,
+              int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0, int64_t ntile, double *f0, double *rec, bool prof,
+              hipStream_t st)
+{
+    for (int64_t t = 0; t < ntile; ++t) {
+        int64_t blocks = af_cdiv(nit * stage_doubles(CT), 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(mfma_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, lmn, srcbad, nsrc, nit,
+                           nchan, c0 + t * CT, CT, rec + t * nit * stage_doubles(CT));
+        AF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(mfma_tile_f0, dim3((unsigned)af_cdiv(ntile, 64)), dim3(64), 0, st, frequency, nchan, c0, CT,
+                       (int)ntile, sign, f0);
+    AF_LAUNCH_CHECK();
+    if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
+    hipLaunchKernelGGL((dft_mfma_kernel<CT>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
+                       uvw, rec, f0, tilef, flags, out, nrow, (int)nit, nchan, c0);
+    if (prof) af_prof_end(st);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+
+}  // namespace
+
+bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex)
+{
+    return !image_is_complex && ncorr == 4 && nchan >= 14 && nchan / 64 + 1 <= 65535;
+}
+
+size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan)
+{
+    return make_plan(nsrc_pad, nchan).total;
+}
+
+int af_dft_mfma_run(const double *image, const double *uvw, const double *frequency, const double *lmn,
+                    const int *srcbad, const double *tilef, const int *flags, const int *colstate, int sign,
+                    double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
+                    hipStream_t st)
+{
+    const Plan p = make_plan(nsrc_pad, nchan);
+    char *ws = static_cast<char *>(workspace);
+    double *f0 = reinterpret_cast<double *>(ws + p.f0_off);
+    const int64_t nit = nsrc_pad / 4;
+    int rc = AF_OK;
+    if (p.nfull > 0)
+        rc = run_tiles<64>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                           0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+    if (rc != AF_OK) return rc;
+    double *trec = reinterpret_cast<double *>(ws + p.tail_rec_off);
+    if (p.tail_ct == 32)
+        rc = run_tiles<32>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                           p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+    else if (p.tail_ct == 16)
+        rc = run_tiles<16>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                           p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+    if (rc != AF_OK) return rc;
+    // grid sized for every (row, column); the blocks return at once unless a special column exists
+    const int64_t nel = nrow * nchan * 4;
+    AF_REQUIRE(af_cdiv(nel, 256) < (1LL << 31), "af_im_to_vis_f64: too many visibilities for one call");
+    hipLaunchKernelGGL(mfma_fix_columns, dim3((unsigned)af_cdiv(nel, 256)), dim3(256), 0, st, flags, colstate, out, nrow,
+                       nchan);
+    AF_LAUNCH_CHECK();
+    return rc;
+}

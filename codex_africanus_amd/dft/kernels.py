@@ -6,7 +6,8 @@ import numpy as np
 from .. import _lib
 from .._device import Call, np_dtype_of
 
-_MODES = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE}
+_MODES = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE,
+          "valu": _lib.AF_DFT_AUTO | _lib.AF_DFT_VALU_ONLY}
 _mode = os.environ.get("AFHIP_DFT_MODE", "auto")
 if _mode not in _MODES:
     raise ValueError("AFHIP_DFT_MODE must be one of %s" % sorted(_MODES))
@@ -15,7 +16,8 @@ if _mode not in _MODES:
 def set_mode(mode):
     """Phasor evaluation: 'auto' (channel recurrence when ``frequency`` is uniformly
     spaced, decided on the device; otherwise the exact path), 'exact' (reference operation
-    order + full-accuracy sincos per (row, source, chan)), 'recurrence' (force)."""
+    order + full-accuracy sincos per (row, source, chan)), 'recurrence' (force), 'valu' ('auto' with
+    im_to_vis kept on the VALU recurrence kernels instead of the MFMA-accumulator ones)."""
     global _mode
     if mode not in _MODES:
         raise ValueError("mode must be one of %s" % sorted(_MODES))
@@ -106,5 +108,6 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
         ws_bytes = int(_lib.load().af_vis_to_im_workspace_bytes(nsrc, nrow, nchan, ncorr))
         p_ws = c.scratch(ws_bytes)
         _lib.call("af_vis_to_im_f64", p_vis, p_uvw, p_lm, p_fr, p_fl, nsrc, nrow, nchan, ncorr,
-                  _lib.CONVENTION[convention], _MODES[_mode], p_out, p_ws, max(ws_bytes, 256), c.stream)
+                  _lib.CONVENTION[convention], _MODES[_mode] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws,
+                  max(ws_bytes, 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.float64 else out_dtype)

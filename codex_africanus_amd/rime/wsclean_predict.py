@@ -97,5 +97,5 @@ def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gaus
         ws_bytes = int(_lib.load().af_wsclean_predict_workspace_bytes(nsrc, nchan))
         p_ws = c.scratch(ws_bytes)
         _lib.call("af_wsclean_predict_f64", p_uvw, p_lm, p_isg, p_fl, p_co, p_lp, p_rf, p_gs, p_fr, nsrc, nrow,
-                  nchan, ncoeffs, _dft._MODES[_dft.get_mode()], p_out, p_ws, max(ws_bytes, 256), c.stream)
+                  nchan, ncoeffs, _dft._MODES[_dft.get_mode()] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws, max(ws_bytes, 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)

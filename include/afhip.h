@@ -48,6 +48,9 @@ extern "C" {
  * (africanus/rime/phase.py:42-43) instead of im_to_vis' unclamped form: the
  * phase_delay -> einsum -> predict_vis chain without materialising the coherencies */
 #define AF_DFT_CLAMP_N 0x100
+/* OR-able into `mode`: keep real 4-correlation images on the VALU recurrence kernels instead of
+ * the MFMA-accumulator kernels (same results to rounding; for comparison and tests) */
+#define AF_DFT_VALU_ONLY 0x200
 
 /* Jones layouts: africanus/rime/predict.py:10-12 */
 #define AF_JONES_DIAG 1 /* JONES_1_OR_2: corr shape (1,) or (2,), element-wise products */

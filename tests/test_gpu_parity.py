@@ -161,7 +161,7 @@ def _scale(img):
     return float(np.abs(img).sum(axis=0).max())
 
 
-@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11), ("valu", 1e-11)])
 @pytest.mark.parametrize("ncorr", [1, 2, 4])
 @pytest.mark.parametrize("kind", ["r", "c"])
 @pytest.mark.parametrize("conv", ["fourier", "casa"])
@@ -174,7 +174,7 @@ def test_im_to_vis_golden(g3, dft_mode, mode, rtol, ncorr, kind, conv):
     assert maxabs(out, ref) <= rtol * _scale(img)
 
 
-@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11)])
+@pytest.mark.parametrize("mode, rtol", [("exact", 1e-14), ("auto", 1e-11), ("valu", 1e-11)])
 @pytest.mark.parametrize("key, img, freq", [
     ("vis_r4_nonuniform", "img_r4", "frequency_nonuniform"),
     ("vis_c2_nonuniform", "img_c2", "frequency_nonuniform"),
@@ -195,7 +195,7 @@ def test_im_to_vis_nonuniform_auto_takes_exact_path(g3, dft_mode):
     assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["exact", "auto"])
+@pytest.mark.parametrize("mode", ["exact", "auto", "valu"])
 def test_im_to_vis_nan_source_semantics(g3, dft_mode, mode):
     """A source outside the unit disc poisons only its non-zero pixels' columns (kernels.py:54,64)."""
     dft_mode(mode)
@@ -296,6 +296,54 @@ def test_im_to_vis_linearity_and_row_independence(dft_mode):
     assert_array_equal(part, a[1234:2345])
     ref = oracle.im_to_vis(img, d["uvw"][:300], d["lm"], d["frequency"])
     assert maxabs(a[:300], ref) < 1e-8
+
+
+@pytest.mark.parametrize("nchan", [14, 16, 17, 32, 33, 48, 64, 65, 96, 100, 130])
+def test_im_to_vis_mfma_channel_tilings(dft_mode, nchan):
+    """real 4-correlation images on a uniform band take the MFMA-accumulator kernels: every tile
+    combination (64-wide tiles, 16- and 32-wide last tiles, ragged ends), row counts that do not fill
+    a 64-row block and source counts that do not fill a 4-source step; against the oracle and
+    against the VALU kernels."""
+    rng = np.random.default_rng(nchan)
+    nrow, nsrc = 203, 37
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    freq = np.linspace(0.9e9, 1.7e9, nchan)
+    img = rng.standard_normal((nsrc, nchan, 4))
+    ref = oracle.im_to_vis(img, uvw, lm, freq)
+    dft_mode("auto")
+    out = dft.im_to_vis(img, uvw, lm, freq)
+    dft_mode("valu")
+    valu = dft.im_to_vis(img, uvw, lm, freq)
+    assert maxabs(out, ref) <= 1e-11 * _scale(img)
+    assert maxabs(valu, ref) <= 1e-11 * _scale(img)
+    dft_mode("auto")
+    assert_array_equal(dft.im_to_vis(img, uvw[50:117], lm, freq), out[50:117])   # row independence
+    casa = dft.im_to_vis(img, uvw, lm, freq, convention="casa")
+    assert_array_equal(casa, np.conj(out))
+
+
+def test_im_to_vis_mfma_special_columns(dft_mode):
+    """zero-pixel and NaN-source semantics (kernels.py:54,64) on the MFMA path, 70 channels"""
+    rng = np.random.default_rng(5)
+    nrow, nsrc, nchan = 130, 11, 70
+    uvw = rng.standard_normal((nrow, 3)) * 1000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.05
+    lm[4] = [0.9, 0.8]                         # outside the unit disc: n is NaN
+    freq = np.linspace(1.0e9, 1.5e9, nchan)
+    img = rng.standard_normal((nsrc, nchan, 4))
+    img[:, 5, 1] = 0.0                         # an all-zero column stays exactly zero
+    img[4, 40:, :] = 0.0                       # the NaN source only poisons channels < 40 ...
+    img[4, :, 3] = 0.0                         # ... and not correlation 3
+    uvw[17] = np.nan                           # a NaN row poisons its non-zero columns only
+    ref = oracle.im_to_vis(img, uvw, lm, freq)
+    for mode in ("auto", "valu"):
+        dft_mode(mode)
+        out = dft.im_to_vis(img, uvw, lm, freq)
+        assert_array_equal(np.isnan(out), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert maxabs(out[ok], ref[ok]) <= 1e-11 * _scale(np.nan_to_num(img))
+        assert (out[:, 5, 1] == 0).all()
 
 
 # ---------------------------------------------------------------------------- beams
