@@ -15,10 +15,10 @@ on 8 GPUs).  Metric: Mvis/s = rows x chans / second / 1e6 (whole job).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  "roofline"     for the dominant kernel (dft_recurrence_kernel): algorithmic HBM bytes per
-                 launch / its average duration measured with HIP events on its own stream,
-                 against the 8 TB/s HBM peak -- plus the fp64-VALU fraction that actually
-                 bounds it (DESIGN.md, "Rooflines");
+  "roofline"     for the dominant kernel (dft_mfma_kernel<64>): algorithmic fp64 flops per launch /
+                 its average duration measured with HIP events on its own stream, against the
+                 fp64 peak (MFMA and VALU f64 share one 78.6 TFLOP/s pipe) -- plus, under "hbm",
+                 the algorithmic HBM bytes against the 8 TB/s peak (DESIGN.md, "Rooflines");
   "cpu_baseline" the CPU oracle (C restatement of the numba loop, OpenMP over rows) timed on
                  this box's host cores on a bounded row sample of the same workload.
 """
@@ -36,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+FP64_PEAK_TFLOPS = 78.6        # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz, vector or matrix
 
 
 def parse():
@@ -257,23 +257,28 @@ def main():
     if rank == 0:
         total_vis = world * nrow * nchan
         ms_per_step = elapsed / args.steps * 1e3
-        # algorithmic HBM bytes of one dft kernel launch: 64 B written per vis +
-        # uvw 24 B/row + packed real image + lmn; the kernel reads nothing else from HBM
-        # The pass is tiled in 13-channel tiles; with one channel spacing for the band the tiles go
-        # four at a time to dft_recurrence_dpp4_kernel (the dominant launch, the one the library's
-        # measurement hook brackets) and the remainder to dft_recurrence_dpp_kernel.
-        ct = 13
-        ntile = -(-nchan // ct)
-        dom_chans = nchan if args.mode == "exact" or ntile < 4 else min(nchan, (ntile // 4) * 4 * ct)
-        # algorithmic HBM bytes of that launch: 64 B written per vis + uvw 24 B/row +
-        # its tiles' records (512 B per tile and source); it reads nothing else from HBM
-        alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + (dom_chans // ct) * nsrc * 512
+        # Dominant kernel = the one the library's measurement hook brackets.  Real 4-correlation images
+        # on a one-spacing band run dft_mfma_kernel<64>: every 64-channel tile in ONE launch (C2: all
+        # 64 channels).  --mode exact runs dft_exact_kernel over all channels.
+        mfma = args.mode != "exact" and ncorr == 4 and nchan >= 14
+        if mfma:
+            ntile = nchan // 64 + (1 if nchan % 64 > 32 else 0)
+            dom_chans = min(nchan, ntile * 64) if ntile else nchan
+            kernel_name = "dft_mfma_kernel<64>" if ntile else "dft_mfma_kernel<%d>" % (16 if nchan <= 16 else 32)
+            nstep = -(-nsrc // 4)
+            # algorithmic HBM bytes of that launch: 64 B written per vis + uvw 24 B/row +
+            # its records ((64 + 1) x 16 doubles per tile and 4-source step); it reads nothing else from HBM
+            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + max(ntile, 1) * nstep * 65 * 16 * 8
+        else:
+            ct = 13
+            ntile = -(-nchan // ct)
+            dom_chans = nchan
+            kernel_name = "dft_exact_kernel<13,4,false>"
+            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + ntile * nsrc * 512
         # algorithmic flops: per (row, chan, src) one complex phasor step (recurrence, 2 FMA) +
-        # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop
+        # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop; the MACs are fp64 MFMA
+        # (v_mfma_f64_4x4x4_4b), the recurrence fp64 VALU -- one shared fp64 pipe on this chip
         alg_flops = float(nrow) * dom_chans * nsrc * (2 + 2 * ncorr) * 2
-        kernel_name = ("dft_exact_kernel<13,4,false>" if args.mode == "exact" else
-                       "dft_recurrence_dpp4_kernel<13,4,false,7>" if ntile >= 4 else
-                       "dft_recurrence_dpp_kernel<13,4,false,7>")
         workload = "im_to_vis DFT predict (BASELINE configs[1])"
         if args.workload == "fused_dde":
             # + indices 12 B/row, beam cube + |beam| + parangles/pointing/scaling; ~150 flop
@@ -313,14 +318,22 @@ def main():
             "fp64_max_abs_err": max_err,
             "roofline": {
                 "kernel": kernel_name,
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
+                # im_to_vis: fp64 MFMA bound.  fused_dde (beam gathers + VALU Jones algebra): priced against HBM.
+                "bound": "mfma" if args.workload == "dft" else "hbm",
+                "achieved": alg_flops / kernel_s / 1e12 if args.workload == "dft" else achieved,
+                "peak": FP64_PEAK_TFLOPS if args.workload == "dft" else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if args.workload == "dft" else "GB/s",
+                "frac": (alg_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS if args.workload == "dft"
+                         else achieved / HBM_PEAK_GBS),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": kernel_s * 1e3, "algorithmic_flops": alg_flops,
                 "channels_in_kernel": dom_chans if args.workload == "dft" else nchan,
-                "note": "fp64-VALU-bound, not HBM-bound: nsrc=1000 phasors per 64-byte visibility",
-                "fp64_valu": {"achieved": alg_flops / kernel_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": alg_flops / kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                              "algorithmic_flops": alg_flops},
+                "note": "fp64-pipe bound (MFMA f64 and VALU f64 share it; 78.6 TFLOP/s spec for either), not "
+                        "HBM-bound: nsrc=1000 phasors per 64-byte visibility",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes": alg_bytes},
+                "fp64": {"achieved": alg_flops / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": alg_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS},
             },
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "dft":
