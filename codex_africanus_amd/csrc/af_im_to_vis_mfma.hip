@@ -15,9 +15,12 @@
 //     of a 16-channel tile.  fp64 MFMA and fp64 VALU share one pipe on this chip (measured), so the
 //     gain over the VALU kernels is not rate but registers: with the accumulators out of the
 //     arch VGPRs a tile holds 64 channels instead of 13 and the per-tile setup is amortised 5x better.
-//   * the image pixels of a 4-source step (CT x 4 x 4 doubles) and the step's (l,m,n) come as one
+//   * the image pixels of a 4-source step (CT x 4 x 4 doubles) and the NEXT step's (l,m,n) come as one
 //     contiguous record, copied global -> LDS by global_load_lds_dwordx4 one step ahead (two LDS
-//     stages, one barrier per step) and read as ds_read_b128 (two channels per read).
+//     stages, one barrier per step) and read as ds_read_b128 (two channels per read) in the shadow of
+//     the MFMAs; the set-up of step it+1 (sincos, d^16) is sliced over the channel groups of step it.
+//   * measured (tools/microbench_issue.hip): a lone wave issues an fp64 VALU op every ~5.5 cycles and an
+//     fp64 MFMA 4x4x4 every 16.4; per step 128 MFMAs + ~220 VALU ops = ~3300 cycles against 3500 measured.
 #include "af_dft_mfma.h"
 #include "af_sincos.h"
 
@@ -28,7 +31,7 @@ constexpr int THREADS = 256;        // 4 waves x 16 rows
 
 __host__ __device__ constexpr int stage_doubles(int ct) { return (ct + 1) * 16; }
 
-// record of (tile, step): [ (l,m,n,0) x 4 sources | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ]
+// record of (tile, step): [ (l,m,n,0) x 4 sources of step+1 | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ]
 __global__ void mfma_pack_records(const double *__restrict__ image, const double *__restrict__ lmn,
                                   const int *__restrict__ srcbad, int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0,
                                   int CT, double *__restrict__ rec)
@@ -40,8 +43,8 @@ __global__ void mfma_pack_records(const double *__restrict__ image, const double
     for (; i < total; i += stride) {
         const int64_t it = i / per, idx = i - it * per;
         double v = 0.0;
-        if (idx < 16) {
-            const int64_t s = 4 * it + idx / 4;
+        if (idx < 16) {  // (l,m,n) of the NEXT step: its set-up runs during this one
+            const int64_t s = 4 * (it + 1) + idx / 4;
             if (s < nsrc && (idx & 3) < 3) v = lmn[4 * s + (idx & 3)];
         } else {
             const int64_t e = idx - 16, pair = e / 32, r = e - pair * 32;
@@ -65,8 +68,8 @@ __global__ void mfma_tile_f0(const double *__restrict__ freq, int64_t nchan, int
 template <int CT>
 __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tile_f0,
-    const double *__restrict__ tilef, const int *__restrict__ flags, double *__restrict__ out, int64_t nrow,
-    int nit, int64_t nchan, int64_t c0_first)
+    const double *__restrict__ tilef, const int *__restrict__ flags, const double *__restrict__ lmn,
+    double *__restrict__ out, int64_t nrow, int nsrc, int nit, int64_t nchan, int64_t c0_first)
 {
     if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
     constexpr int STAGE = stage_doubles(CT);
@@ -110,59 +113,107 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
 
     constexpr int GP = 4;                         // channel pairs per B register group (8 channels)
     constexpr int NGRP = CT / 2 / GP;
+
+    // Phasor set-up of one (row, source) pair, cut into 8 slices so that the set-up of step it+1 can be
+    // spread over the channel groups of step it (its dependent chains then hide behind the MFMAs):
+    //   0 (l,m,n) from LDS   1 path difference, range reductions   2,3 polynomial halves
+    //   4 quadrant fix-up -> d = (dr,di), y0   5 d^16 by four squarings, 2cos(delta), 2cos(2 delta)
+    //   7 first 8 phasors of the tile (three-term recurrence, 4 independent chains)
+    struct Setup {
+        double l, m, n;
+        SinCosStage sd, s0;
+        double dr, di, y0r, y0i, ar, ai, kk, k2;
+    };
+    auto first_segment = [](const Setup &P, double (&Yr)[8], double (&Yi)[8]) {
+        Yr[0] = P.y0r; Yi[0] = P.y0i;
+        Yr[1] = fma(P.y0r, P.dr, -__dmul_rn(P.y0i, P.di)); Yi[1] = fma(P.y0r, P.di, __dmul_rn(P.y0i, P.dr));
+        Yr[2] = fma(P.kk, Yr[1], -Yr[0]); Yi[2] = fma(P.kk, Yi[1], -Yi[0]);
+        Yr[3] = fma(P.kk, Yr[2], -Yr[1]); Yi[3] = fma(P.kk, Yi[2], -Yi[1]);
+#pragma unroll
+        for (int t = 4; t < 8; ++t) { Yr[t] = fma(P.k2, Yr[t - 2], -Yr[t - 4]); Yi[t] = fma(P.k2, Yi[t - 2], -Yi[t - 4]); }
+    };
+    auto setup_slice = [&](Setup &P, int slice, const double *hdr, double (&Yr)[8], double (&Yi)[8]) {
+        switch (slice) {
+        case 0: {
+            const double2 lm_ = *reinterpret_cast<const double2 *>(hdr + 4 * k);
+            P.l = lm_.x; P.m = lm_.y; P.n = hdr[4 * k + 2];
+            break;
+        }
+        case 1: {
+            const double q = fma(P.n, w, fma(P.m, v, __dmul_rn(P.l, u)));  // path difference in metres
+            sincos_qt_reduce(P.sd, __dmul_rn(q, FD));
+            sincos_qt_reduce(P.s0, __dmul_rn(q, F0));
+            break;
+        }
+        case 2: sincos_qt_horner<5, 3>(P.sd); sincos_qt_horner<5, 3>(P.s0); break;
+        case 3: sincos_qt_horner<2, 0>(P.sd); sincos_qt_horner<2, 0>(P.s0); break;
+        case 4: sincos_qt_finish(P.sd, P.dr, P.di); sincos_qt_finish(P.s0, P.y0r, P.y0i); break;
+        case 5: {
+            double ar = P.dr, ai = P.di;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double nr = fma(ar, ar, -__dmul_rn(ai, ai)), ni = __dmul_rn(__dadd_rn(ar, ar), ai);
+                ar = nr; ai = ni;
+            }
+            P.ar = ar; P.ai = ai;
+            P.kk = __dadd_rn(P.dr, P.dr);
+            P.k2 = fma(P.kk, P.kk, -2.0);
+            break;
+        }
+        case 7: first_segment(P, Yr, Yi); break;
+        default: break;
+        }
+    };
+
+    double yr[2][8], yi[2][8];
+    Setup cur_, nxt_;
+    {   // step 0 is set up in one piece from the global (l,m,n)
+        double hdr0[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) hdr0[t] = 0.0;
+        if (k < nsrc) { hdr0[0] = lmn[4 * k]; hdr0[1] = lmn[4 * k + 1]; hdr0[2] = lmn[4 * k + 2]; }
+        cur_.l = hdr0[0]; cur_.m = hdr0[1]; cur_.n = hdr0[2];
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) setup_slice(cur_, sl, nullptr, yr[0], yi[0]);
+    }
+    nxt_ = cur_;
+
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
         if (it + 1 < nit) stage_load(it + 1, cur ^ 1);
-        const double *S = smem + cur * STAGE;
-        const double2 lm_ = *reinterpret_cast<const double2 *>(S + 4 * k);
-        const double n = S[4 * k + 2];
-        const double q = fma(n, w, fma(lm_.y, v, __dmul_rn(lm_.x, u)));  // path difference in metres
-        double dr, di, anr, ani;
-        sincos_quarter_turns<7>(__dmul_rn(q, FD), dr, di);    // channel-step phasor d
-        sincos_quarter_turns<7>(__dmul_rn(q, F0), anr, ani);  // phasor at the tile's first channel
-        double ar = dr, ai = di;                              // d^16
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double nr = fma(ar, ar, -__dmul_rn(ai, ai)), ni = __dmul_rn(__dadd_rn(ar, ar), ai);
-            ar = nr; ai = ni;
-        }
-        const double kk = __dadd_rn(dr, dr), k2 = fma(kk, kk, -2.0);  // 2 cos(delta), 2 cos(2 delta)
+        const double *S = smem + cur * STAGE;     // header: (l,m,n) of step it + 1
         const double2 *B = reinterpret_cast<const double2 *>(S + 16 + boff);
         double2 bg[2][GP];
-        double yr[2][8], yi[2][8];
-        auto start_segment = [&](double (&Yr)[8], double (&Yi)[8]) {
-            Yr[0] = anr; Yi[0] = ani;
-            Yr[1] = fma(anr, dr, -__dmul_rn(ani, di)); Yi[1] = fma(anr, di, __dmul_rn(ani, dr));
-            Yr[2] = fma(kk, Yr[1], -Yr[0]); Yi[2] = fma(kk, Yi[1], -Yi[0]);
-            Yr[3] = fma(kk, Yr[2], -Yr[1]); Yi[3] = fma(kk, Yi[2], -Yi[1]);
-#pragma unroll
-            for (int t = 4; t < 8; ++t) { Yr[t] = fma(k2, Yr[t - 2], -Yr[t - 4]); Yi[t] = fma(k2, Yi[t - 2], -Yi[t - 4]); }
-        };
-        auto continue_segment = [&](double (&Yr)[8], double (&Yi)[8], const double (&Pr)[8], const double (&Pi)[8]) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const double r2 = t >= 2 ? Yr[t - 2] : Pr[t + 6], r4 = t >= 4 ? Yr[t - 4] : Pr[t + 4];
-                const double i2 = t >= 2 ? Yi[t - 2] : Pi[t + 6], i4 = t >= 4 ? Yi[t - 4] : Pi[t + 4];
-                Yr[t] = fma(k2, r2, -r4); Yi[t] = fma(k2, i2, -i4);
-            }
-        };
+        double anr = cur_.y0r, ani = cur_.y0i;    // phasor at the current 16-channel anchor
 #pragma unroll
         for (int p = 0; p < GP; ++p) bg[0][p] = B[p * 16];
-        start_segment(yr[0], yi[0]);
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
-            if (g + 1 < NGRP) {  // pixels and phasors of the next 8 channels
-#pragma unroll
-                for (int p = 0; p < GP; ++p) bg[(g + 1) & 1][p] = B[((g + 1) * GP + p) * 16];
+            if (g + 1 < NGRP) {  // phasors of the next 8 channels
+                double (&Yr)[8] = yr[(g + 1) & 1], (&Yi)[8] = yi[(g + 1) & 1];
+                const double (&Pr)[8] = yr[g & 1], (&Pi)[8] = yi[g & 1];
                 if (((g + 1) * 8) % ANCHOR == 0) {
-                    const double tr = fma(anr, ar, -__dmul_rn(ani, ai)), ti = fma(anr, ai, __dmul_rn(ani, ar));
+                    const double tr = fma(anr, cur_.ar, -__dmul_rn(ani, cur_.ai));
+                    const double ti = fma(anr, cur_.ai, __dmul_rn(ani, cur_.ar));
                     anr = tr; ani = ti;
-                    start_segment(yr[(g + 1) & 1], yi[(g + 1) & 1]);
+                    Setup A = cur_;
+                    A.y0r = anr; A.y0i = ani;
+                    first_segment(A, Yr, Yi);
                 } else {
-                    continue_segment(yr[(g + 1) & 1], yi[(g + 1) & 1], yr[g & 1], yi[g & 1]);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const double r2 = t >= 2 ? Yr[t - 2] : Pr[t + 6], r4 = t >= 4 ? Yr[t - 4] : Pr[t + 4];
+                        const double i2 = t >= 2 ? Yi[t - 2] : Pi[t + 6], i4 = t >= 4 ? Yi[t - 4] : Pi[t + 4];
+                        Yr[t] = fma(cur_.k2, r2, -r4); Yi[t] = fma(cur_.k2, i2, -i4);
+                    }
                 }
             }
+            // slices of the next step's set-up that belong to this group (slice 7 writes yr[0], free since
+            // the MFMAs of group NGRP-2 were issued)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl)
+                if (sl * NGRP / 8 == g) setup_slice(nxt_, sl, S, yr[0], yi[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
@@ -170,9 +221,16 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
                 const double b = (jj & 1) ? bg[g & 1][jj >> 1].y : bg[g & 1][jj >> 1].x;
                 are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], b, are[j], 0, 0, 0);
                 aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], b, aim[j], 0, 0, 0);
+                // pixels of the next 8 channels: LDS reads issue in the shadow of the 16-cycle MFMAs
+                if (g + 1 < NGRP && (jj & 1)) {
+                    bg[(g + 1) & 1][jj >> 1] = B[((g + 1) * GP + (jj >> 1)) * 16];
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        cur_ = nxt_;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed in LDS
         __syncthreads();
     }
@@ -248,7 +306,7 @@ int run_tiles(const double *image, const double *uvw, const double *frequency, c
     AF_LAUNCH_CHECK();
     if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
     hipLaunchKernelGGL((dft_mfma_kernel<CT>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
-                       uvw, rec, f0, tilef, flags, out, nrow, (int)nit, nchan, c0);
+                       uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0);
     if (prof) af_prof_end(st);
     AF_LAUNCH_CHECK();
     return AF_OK;

@@ -46,6 +46,54 @@ __device__ __forceinline__ void sincos_quarter_turns(double t4, double &c_out, d
 }
 
 
+// The same evaluation (7 terms) cut into stages, for kernels that spread one sincos over several
+// scheduling regions: reduce -> horner<5,3> -> horner<2,0> -> finish gives bit-identical results to
+// sincos_quarter_turns<7>.
+struct SinCosStage {
+    double f, z, ps, pc;
+    int q;
+};
+namespace af_sincos_detail {
+__device__ constexpr double S7[7] = {0x1.921fb54442d18p+0, -0x1.4abbce625be41p-1, 0x1.466bc677587f8p-4,
+                                     -0x1.32d2cce2e5b19p-8, 0x1.50782fda12d96p-13, -0x1.e30071afc3e59p-19,
+                                     0x1.e3f38399551bfp-25};
+__device__ constexpr double C7[7] = {0x1.0000000000000p+0, -0x1.3bd3cc9be458bp+0, 0x1.03c1f081b0780p-2,
+                                     -0x1.55d3c7dbfd139p-6, 0x1.e1f4fb60281f6p-11, -0x1.a6c9c1be9eb49p-16,
+                                     0x1.f3dbcea61b1a4p-22};
+}  // namespace af_sincos_detail
+__device__ __forceinline__ void sincos_qt_reduce(SinCosStage &s, double t4)
+{
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double a = __dadd_rn(t4, MAGIC);
+    s.q = __double2loint(a);
+    const double r = __dsub_rn(a, MAGIC);
+    s.f = __dsub_rn(t4, r);
+    s.z = __dmul_rn(s.f, s.f);
+    s.ps = af_sincos_detail::S7[6];
+    s.pc = af_sincos_detail::C7[6];
+}
+template <int HI, int LO>
+__device__ __forceinline__ void sincos_qt_horner(SinCosStage &s)
+{
+#pragma unroll
+    for (int i = HI; i >= LO; --i) {
+        s.ps = fma(s.ps, s.z, af_sincos_detail::S7[i]);
+        s.pc = fma(s.pc, s.z, af_sincos_detail::C7[i]);
+    }
+}
+__device__ __forceinline__ void sincos_qt_finish(const SinCosStage &s, double &c_out, double &s_out)
+{
+    const double ps = __dmul_rn(s.ps, s.f);
+    const bool swap = s.q & 1;
+    const double cc = swap ? ps : s.pc;
+    const double ss = swap ? s.pc : ps;
+    const int chi = __double2hiint(cc) ^ (((s.q + 1) & 2) << 30);
+    const int shi = __double2hiint(ss) ^ ((s.q & 2) << 30);
+    c_out = __hiloint2double(chi, __double2loint(cc));
+    s_out = __hiloint2double(shi, __double2loint(ss));
+}
+
+
 // (cos, sin)(p) for p in RADIANS, for the kernels that must keep the reference's phase p bit for bit
 // (phase_delay).  Cody-Waite reduction p = k*(pi/2) + r with pi/2 split in three parts (33 + 33 + 53
 // bits, fdlibm's pio2_1/pio2_2/pio2_3): k*part is exact for |k| < 2^20 and each step is one FMA, so

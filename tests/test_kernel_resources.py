@@ -17,11 +17,15 @@ CSRC = os.path.join(ROOT, "codex_africanus_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.parametrize("source, kernels", [
-    ("af_im_to_vis.hip", ("dft_recurrence_dpp_kernel", "dft_recurrence_dpp4_kernel")),
-    ("af_vis_to_im.hip", ("v2i_recurrence_kernel",)),
+@pytest.mark.parametrize("source, kernels, min_seen, reg_cap", [
+    ("af_im_to_vis.hip", ("dft_recurrence_dpp_kernel", "dft_recurrence_dpp4_kernel"), 8, 256),
+    ("af_vis_to_im.hip", ("v2i_recurrence_kernel",), 8, 256),
+    ("af_wsclean_predict.hip", ("wsc_recurrence_kernel",), 5, 512),
+    # MFMA-accumulator kernels: the 64-channel tile is one wave per SIMD by design (256 AGPRs of
+    # accumulators + arch VGPRs); its global -> LDS copies are asm-issued and hand-waited as well
+    ("af_im_to_vis_mfma.hip", ("dft_mfma_kernel",), 3, 512),
 ])
-def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels):
+def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels, min_seen, reg_cap):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
@@ -41,5 +45,5 @@ def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels):
         vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         assert scratch == 0 and vspill == 0 and sspill == 0, (name, scratch, vspill, sspill)
-        assert vgprs + agprs <= 256, (name, vgprs, agprs)   # two waves per SIMD
-    assert seen >= 8, "expected the template instantiations, found %d" % seen
+        assert vgprs + agprs <= reg_cap, (name, vgprs, agprs)   # 256: two waves per SIMD
+    assert seen >= min_seen, "expected the template instantiations, found %d" % seen
