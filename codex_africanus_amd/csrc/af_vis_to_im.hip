@@ -24,6 +24,7 @@
 #include "af_common.h"
 #include "af_sincos.h"
 #include "af_dft_device.h"
+#include "af_v2i_mfma.h"
 
 namespace {
 
@@ -64,7 +65,7 @@ bool vws_layout(VWs &L, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr
     const int64_t pmax = af_cdiv(nrow > 0 ? nrow : 1, 64);
     if (p > pmax) p = pmax;
     if (p < 1) p = 1;
-    L.rows_per_part = af_cdiv(nrow > 0 ? nrow : 1, p);
+    L.rows_per_part = af_cdiv(af_cdiv(nrow > 0 ? nrow : 1, p), 4) * 4;  // whole 4-row steps (MFMA path)
     L.npart = af_cdiv(nrow > 0 ? nrow : 1, L.rows_per_part);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
@@ -81,7 +82,13 @@ bool vws_layout(VWs &L, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr
         L.chunk_off[k] = rec;
         rec += L.ntile * nrow * (int64_t)L.chunk_groups[k] * GROUP;
     }
-    L.records = take((size_t)rec * sizeof(double));
+    // one record region: either these records or the MFMA path's (af_vis_to_im_mfma.hip) are built
+    size_t rec_bytes = (size_t)rec * sizeof(double);
+    if (af_v2i_mfma_eligible(nchan, ncorr)) {
+        const size_t mb = af_v2i_mfma_workspace_bytes(nrow, nchan);
+        if (mb > rec_bytes) rec_bytes = mb;
+    }
+    L.records = take(rec_bytes);
     L.partial = take((size_t)L.npart * nsrc * nchan * ncorr * sizeof(double));
     L.total = o;
     return true;
@@ -132,8 +139,9 @@ __global__ void v2i_prep_freq(const double *__restrict__ freq, int64_t nchan, in
 __global__ void v2i_pack_records(const double2 *__restrict__ vis, const unsigned char *__restrict__ vflags,
                                  const double *__restrict__ uvw, int64_t nrow, int64_t nchan, int64_t ncorr,
                                  int64_t ntile, int CT, int corr0, int nc, int groups, double *__restrict__ rec,
-                                 int *__restrict__ chan_any)
+                                 int *__restrict__ chan_any, const int *__restrict__ flags)
 {
+    if (flags[3] == 1) return;  // the MFMA path owns this call and has filled the record region
     const int64_t per = (int64_t)groups * GROUP;
     const int64_t total = ntile * nrow * per;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(SRC_PER_BLOCK) void v2i_recurrence_kernel(
     const int *__restrict__ flags, double *__restrict__ partial, int64_t nsrc, int64_t nrow,
     int64_t rows_per_part, int64_t nchan, int64_t ncorr, int64_t corr0, int want_uniform)
 {
-    if (flags[0] != want_uniform) return;
+    if (flags[0] != want_uniform || flags[3] == 1) return;  // flags[3]: the MFMA path did the work
     constexpr int NG = record_groups(CT, NC, 2);
     constexpr int NSLOT = 4 + CT * NC * 2;
     constexpr int PER_CHAN = NC * 2;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(SRC_PER_BLOCK) void v2i_exact_kernel(
     const int *__restrict__ flags, double *__restrict__ partial, int64_t nsrc, int64_t nrow,
     int64_t rows_per_part, int64_t nchan, int64_t ncorr, int64_t corr0, int want_uniform, double constant)
 {
-    if (want_uniform >= 0 && flags[0] != want_uniform) return;
+    if (flags[3] == 1 || (want_uniform >= 0 && flags[0] != want_uniform)) return;
     constexpr int NG = record_groups(CT, NC, 2);
     const int tile = blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
@@ -424,6 +432,15 @@ AF_EXPORT int af_vis_to_im_f64(const double *vis, const double *uvw, const doubl
                        reinterpret_cast<double *>(ws + L.freq), reinterpret_cast<int *>(ws + L.flags));
     AF_LAUNCH_CHECK();
     if (mode == AF_DFT_RECURRENCE) AF_HIP(hipMemsetAsync(ws + L.flags, 1, 1, st));
+    if (mode != AF_DFT_EXACT && af_v2i_mfma_eligible(nchan, ncorr)) {
+        // flags[3] = 1: the MFMA path owns the call unless its frequency test clears the flag on the device
+        AF_HIP(hipMemsetAsync(ws + L.flags + 3 * sizeof(int), 1, 1, st));
+        int rc = af_v2i_mfma_run(vis, flags, uvw, frequency, reinterpret_cast<const double *>(ws + L.lmn),
+                                 reinterpret_cast<int *>(ws + L.flags), reinterpret_cast<int *>(ws + L.chan_any),
+                                 -convention, reinterpret_cast<double *>(ws + L.partial), nsrc, nrow, nchan, L.npart,
+                                 L.rows_per_part, mode == AF_DFT_RECURRENCE, ws + L.records, st);
+        if (rc != AF_OK) return rc;
+    }
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
         const int64_t total = L.ntile * nrow * (int64_t)L.chunk_groups[chunk] * GROUP;
         int64_t blocks = af_cdiv(total, 256);
@@ -432,7 +449,7 @@ AF_EXPORT int af_vis_to_im_f64(const double *vis, const double *uvw, const doubl
                            reinterpret_cast<const double2 *>(vis), flags, uvw, nrow, nchan, ncorr, L.ntile, ct,
                            chunk * MAXNC, L.chunk_nc[chunk], L.chunk_groups[chunk],
                            reinterpret_cast<double *>(ws + L.records) + L.chunk_off[chunk],
-                           reinterpret_cast<int *>(ws + L.chan_any));
+                           reinterpret_cast<int *>(ws + L.chan_any), reinterpret_cast<const int *>(ws + L.flags));
         AF_LAUNCH_CHECK();
     }
     VArgs a;

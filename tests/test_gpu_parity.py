@@ -346,6 +346,41 @@ def test_im_to_vis_mfma_special_columns(dft_mode):
         assert (out[:, 5, 1] == 0).all()
 
 
+@pytest.mark.parametrize("nchan", [14, 16, 33, 64, 70, 100, 130])
+def test_vis_to_im_mfma_channel_tilings(dft_mode, nchan):
+    """4-correlation vis_to_im on a uniform band takes the MFMA-accumulator kernels: 64/32/16-wide
+    tiles, rows that do not fill a 4-row step or a partition, sources that do not fill a wave; flags,
+    a NaN row (flagged in some channels only) and a source outside the unit disc; against the oracle."""
+    rng = np.random.default_rng(100 + nchan)
+    nrow, nsrc = 1003, 37
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    freq = np.linspace(0.9e9, 1.7e9, nchan)
+    vis = rng.standard_normal((nrow, nchan, 4)) + 1j * rng.standard_normal((nrow, nchan, 4))
+    flags = rng.random((nrow, nchan, 4)) < 0.05
+    flags[:, 3, :] = True                       # a channel with no unflagged row stays exactly 0
+    ref = oracle.vis_to_im(vis, uvw, lm, freq, flags)
+    scale = np.abs(vis).sum(axis=0).max()
+    for conv in ("fourier", "casa"):
+        dft_mode("auto")
+        out = dft.vis_to_im(vis, uvw, lm, freq, flags, convention=conv)
+        r = ref if conv == "fourier" else oracle.vis_to_im(vis, uvw, lm, freq, flags, convention="casa")
+        assert out.shape == r.shape and maxabs(out, r) <= 1e-11 * scale
+        assert (out[:, 3, :] == 0).all()
+    # NaN semantics: a non-finite row poisons exactly the channels where it is unflagged; a source
+    # outside the unit disc is NaN wherever a channel has an unflagged row
+    uvw2, lm2, flags2 = uvw.copy(), lm.copy(), flags.copy()
+    uvw2[11] = np.nan
+    flags2[11, : nchan // 2, :] = True
+    flags2[11, nchan // 2:, :] = False
+    lm2[5] = [0.9, 0.8]
+    ref2 = oracle.vis_to_im(vis, uvw2, lm2, freq, flags2)
+    out2 = dft.vis_to_im(vis, uvw2, lm2, freq, flags2)
+    assert_array_equal(np.isnan(out2), np.isnan(ref2))
+    ok = ~np.isnan(ref2)
+    assert maxabs(out2[ok], ref2[ok]) <= 1e-11 * scale
+
+
 # ---------------------------------------------------------------------------- beams
 def _beam_args(g4, lm=None, beam=None, dtype=None):
     args = [g4["beam"] if beam is None else beam, g4["extents"], g4["beam_freq_map"],
