@@ -22,11 +22,10 @@
 //   * measured (tools/microbench_issue.hip): a lone wave issues an fp64 VALU op every ~5.5 cycles and an
 //     fp64 MFMA 4x4x4 every 16.4; per step 128 MFMAs + ~220 VALU ops = ~3300 cycles against 3500 measured.
 #include "af_dft_mfma.h"
-#include "af_sincos.h"
+#include "af_mfma_phasor.h"
 
 namespace {
 
-constexpr int ANCHOR = 16;          // channels between re-anchored phasors
 constexpr int THREADS = 256;        // 4 waves x 16 rows
 
 __host__ __device__ constexpr int stage_doubles(int ct) { return (ct + 1) * 16; }
@@ -90,23 +89,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
 #pragma unroll
     for (int j = 0; j < CT; ++j) are[j] = aim[j] = 0.0;
 
-    // global -> LDS copy of one stage; issued from asm so that hipcc does not drain it (vmcnt(0)) in
-    // front of the LDS reads of the stage being computed; retired by the explicit wait below.
-    auto stage_load = [&](int it, int buf) {
-        const double *src = rec + (int64_t)it * STAGE;
-#pragma unroll
-        for (int e0 = 0; e0 < UNITS; e0 += THREADS) {
-            const int ebase = e0 + wave * 64;     // wave-uniform: LDS destination = base + lane * 16
-            if (ebase + lane < UNITS) {
-                const double *g = src + (ebase + lane) * 2;
-                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(smem + buf * STAGE + ebase * 2));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-            }
-        }
-    };
-    stage_load(0, 0);
+    mfma_stage_load<UNITS>(rec, smem, wave, lane);
     asm volatile("" :: "v"(u), "v"(v), "v"(w), "s"(F0), "s"(FD));  // hipcc's own waits land here, not in the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -114,74 +97,20 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     constexpr int GP = 4;                         // channel pairs per B register group (8 channels)
     constexpr int NGRP = CT / 2 / GP;
 
-    // Phasor set-up of one (row, source) pair, cut into 8 slices so that the set-up of step it+1 can be
-    // spread over the channel groups of step it (its dependent chains then hide behind the MFMAs):
-    //   0 (l,m,n) from LDS   1 path difference, range reductions   2,3 polynomial halves
-    //   4 quadrant fix-up -> d = (dr,di), y0   5 d^16 by four squarings, 2cos(delta), 2cos(2 delta)
-    //   7 first 8 phasors of the tile (three-term recurrence, 4 independent chains)
-    struct Setup {
-        double l, m, n;
-        SinCosStage sd, s0;
-        double dr, di, y0r, y0i, ar, ai, kk, k2;
-    };
-    auto first_segment = [](const Setup &P, double (&Yr)[8], double (&Yi)[8]) {
-        Yr[0] = P.y0r; Yi[0] = P.y0i;
-        Yr[1] = fma(P.y0r, P.dr, -__dmul_rn(P.y0i, P.di)); Yi[1] = fma(P.y0r, P.di, __dmul_rn(P.y0i, P.dr));
-        Yr[2] = fma(P.kk, Yr[1], -Yr[0]); Yi[2] = fma(P.kk, Yi[1], -Yi[0]);
-        Yr[3] = fma(P.kk, Yr[2], -Yr[1]); Yi[3] = fma(P.kk, Yi[2], -Yi[1]);
-#pragma unroll
-        for (int t = 4; t < 8; ++t) { Yr[t] = fma(P.k2, Yr[t - 2], -Yr[t - 4]); Yi[t] = fma(P.k2, Yi[t - 2], -Yi[t - 4]); }
-    };
-    auto setup_slice = [&](Setup &P, int slice, const double *hdr, double (&Yr)[8], double (&Yi)[8]) {
-        switch (slice) {
-        case 0: {
-            const double2 lm_ = *reinterpret_cast<const double2 *>(hdr + 4 * k);
-            P.l = lm_.x; P.m = lm_.y; P.n = hdr[4 * k + 2];
-            break;
-        }
-        case 1: {
-            const double q = fma(P.n, w, fma(P.m, v, __dmul_rn(P.l, u)));  // path difference in metres
-            sincos_qt_reduce(P.sd, __dmul_rn(q, FD));
-            sincos_qt_reduce(P.s0, __dmul_rn(q, F0));
-            break;
-        }
-        case 2: sincos_qt_horner<5, 3>(P.sd); sincos_qt_horner<5, 3>(P.s0); break;
-        case 3: sincos_qt_horner<2, 0>(P.sd); sincos_qt_horner<2, 0>(P.s0); break;
-        case 4: sincos_qt_finish(P.sd, P.dr, P.di); sincos_qt_finish(P.s0, P.y0r, P.y0i); break;
-        case 5: {
-            double ar = P.dr, ai = P.di;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double nr = fma(ar, ar, -__dmul_rn(ai, ai)), ni = __dmul_rn(__dadd_rn(ar, ar), ai);
-                ar = nr; ai = ni;
-            }
-            P.ar = ar; P.ai = ai;
-            P.kk = __dadd_rn(P.dr, P.dr);
-            P.k2 = fma(P.kk, P.kk, -2.0);
-            break;
-        }
-        case 7: first_segment(P, Yr, Yi); break;
-        default: break;
-        }
-    };
-
     double yr[2][8], yi[2][8];
-    Setup cur_, nxt_;
+    PhasorSetup cur_, nxt_;
     {   // step 0 is set up in one piece from the global (l,m,n)
-        double hdr0[16];
+        cur_.a0 = cur_.a1 = cur_.a2 = 0.0;
+        if (k < nsrc) { cur_.a0 = lmn[4 * k]; cur_.a1 = lmn[4 * k + 1]; cur_.a2 = lmn[4 * k + 2]; }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) hdr0[t] = 0.0;
-        if (k < nsrc) { hdr0[0] = lmn[4 * k]; hdr0[1] = lmn[4 * k + 1]; hdr0[2] = lmn[4 * k + 2]; }
-        cur_.l = hdr0[0]; cur_.m = hdr0[1]; cur_.n = hdr0[2];
-#pragma unroll
-        for (int sl = 1; sl < 8; ++sl) setup_slice(cur_, sl, nullptr, yr[0], yi[0]);
+        for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, u, v, w, F0, FD, yr[0], yi[0]);
     }
     nxt_ = cur_;
 
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nit) stage_load(it + 1, cur ^ 1);
+        if (it + 1 < nit) mfma_stage_load<UNITS>(rec + (int64_t)(it + 1) * STAGE, smem + (cur ^ 1) * STAGE, wave, lane);
         const double *S = smem + cur * STAGE;     // header: (l,m,n) of step it + 1
         const double2 *B = reinterpret_cast<const double2 *>(S + 16 + boff);
         double2 bg[2][GP];
@@ -191,29 +120,20 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             if (g + 1 < NGRP) {  // phasors of the next 8 channels
-                double (&Yr)[8] = yr[(g + 1) & 1], (&Yi)[8] = yi[(g + 1) & 1];
-                const double (&Pr)[8] = yr[g & 1], (&Pi)[8] = yi[g & 1];
-                if (((g + 1) * 8) % ANCHOR == 0) {
+                if (((g + 1) * 8) % MFMA_ANCHOR == 0) {
                     const double tr = fma(anr, cur_.ar, -__dmul_rn(ani, cur_.ai));
                     const double ti = fma(anr, cur_.ai, __dmul_rn(ani, cur_.ar));
                     anr = tr; ani = ti;
-                    Setup A = cur_;
-                    A.y0r = anr; A.y0i = ani;
-                    first_segment(A, Yr, Yi);
+                    phasor_first_segment(cur_, anr, ani, yr[(g + 1) & 1], yi[(g + 1) & 1]);
                 } else {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const double r2 = t >= 2 ? Yr[t - 2] : Pr[t + 6], r4 = t >= 4 ? Yr[t - 4] : Pr[t + 4];
-                        const double i2 = t >= 2 ? Yi[t - 2] : Pi[t + 6], i4 = t >= 4 ? Yi[t - 4] : Pi[t + 4];
-                        Yr[t] = fma(cur_.k2, r2, -r4); Yi[t] = fma(cur_.k2, i2, -i4);
-                    }
+                    phasor_next_segment(cur_, yr[(g + 1) & 1], yi[(g + 1) & 1], yr[g & 1], yi[g & 1]);
                 }
             }
             // slices of the next step's set-up that belong to this group (slice 7 writes yr[0], free since
             // the MFMAs of group NGRP-2 were issued)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl)
-                if (sl * NGRP / 8 == g) setup_slice(nxt_, sl, S, yr[0], yi[0]);
+                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, yr[0], yi[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
