@@ -3,11 +3,11 @@
 #pragma once
 #include "af_common.h"
 
-// real image, exactly 4 correlations, enough channels to fill a 16-channel tile
+// exactly 4 correlations (real or complex pixels), enough channels to fill a 16-channel tile
 bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex);
 
 // bytes of workspace the path needs behind the common prep arrays (256-byte aligned start)
-size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan);
+size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex);
 
 // Packs the records and launches the kernels on `st`.  The kernels do the work iff the prep pass
 // found one channel spacing for the whole band (flags[0] == 1 and flags[1] == 1); otherwise they
@@ -15,7 +15,7 @@ size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan);
 //   lmn     (nsrc,4)  cleaned (l, m, n, 0) of dft_prep_src         srcbad (nsrc) non-finite sources
 //   tilef   [1] = channel step in quarter turns per metre           flags  device flags, [2] = any special column
 //   colstate (chan, 4) zero-column / NaN-source overrides of the reference's `if image[s,nu,c]:`
-int af_dft_mfma_run(const double *image, const double *uvw, const double *frequency, const double *lmn,
+int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw, const double *frequency, const double *lmn,
                     const int *srcbad, const double *tilef, const int *flags, const int *colstate, int sign,
                     double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
                     hipStream_t st);

@@ -732,7 +732,7 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
         if (L.total > m) m = L.total;
     }
     if (af_dft_mfma_eligible(nchan, ncorr, image_is_complex != 0))
-        m += af_dft_mfma_workspace_bytes(af_cdiv(nsrc > 0 ? nsrc : 1, 4) * 4, nchan);
+        m += af_dft_mfma_workspace_bytes(af_cdiv(nsrc > 0 ? nsrc : 1, 4) * 4, nchan, image_is_complex != 0);
     return m;
 }
 
@@ -764,7 +764,7 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     WsLayout L;
     ws_layout(L, nsrc, nchan, ncorr, image_is_complex, ct);
     const bool mfma = !valu_only && mode != AF_DFT_EXACT && af_dft_mfma_eligible(nchan, ncorr, cplx);
-    const size_t need = L.total + (mfma ? af_dft_mfma_workspace_bytes(L.nsrc_pad, nchan) : 0);
+    const size_t need = L.total + (mfma ? af_dft_mfma_workspace_bytes(L.nsrc_pad, nchan, cplx) : 0);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= need,
                "af_im_to_vis_f64: workspace too small (%zu < %zu)", workspace_bytes, need);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_im_to_vis_f64: workspace must be 256-byte aligned");
@@ -814,7 +814,7 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     a.nrow = nrow; a.nsrc = nsrc; a.nchan = nchan; a.ncorr = ncorr;
     a.mode = mode; a.st = st; a.mfma = mfma;
     if (mfma) {
-        int rc = af_dft_mfma_run(image, uvw, frequency, reinterpret_cast<const double *>(ws + L.lmn),
+        int rc = af_dft_mfma_run(image, (int)cplx, uvw, frequency, reinterpret_cast<const double *>(ws + L.lmn),
                                  reinterpret_cast<const int *>(ws + L.srcbad),
                                  reinterpret_cast<const double *>(ws + L.tilef),
                                  reinterpret_cast<const int *>(ws + L.flags),

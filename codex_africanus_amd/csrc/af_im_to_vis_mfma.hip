@@ -28,14 +28,17 @@ namespace {
 
 constexpr int THREADS = 256;        // 4 waves x 16 rows
 
-__host__ __device__ constexpr int stage_doubles(int ct) { return (ct + 1) * 16; }
+// doubles of one (tile, step) record: header + CT channels x 16 (source k, corr) x 1 (real pixel) or 3 (Re, Im, -Im)
+__host__ __device__ constexpr int stage_doubles(int ct, bool cplx) { return (ct * (cplx ? 3 : 1) + 1) * 16; }
 
-// record of (tile, step): [ (l,m,n,0) x 4 sources of step+1 | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ]
-__global__ void mfma_pack_records(const double *__restrict__ image, const double *__restrict__ lmn,
+// record of (tile, step): [ (l,m,n,0) x 4 sources of step+1 | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ];
+// complex images: ... x 2 channels x (Re, Im, -Im) -- the -Im copy lets Re(Y I) = ReY ReI + ImY (-ImI) run as
+// two plain MFMAs (the instruction has no operand negation)
+__global__ void mfma_pack_records(const double *__restrict__ image, int cplx, const double *__restrict__ lmn,
                                   const int *__restrict__ srcbad, int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0,
                                   int CT, double *__restrict__ rec)
 {
-    const int64_t per = stage_doubles(CT);
+    const int64_t per = stage_doubles(CT, cplx != 0);
     const int64_t total = nit * per;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -45,11 +48,19 @@ __global__ void mfma_pack_records(const double *__restrict__ image, const double
         if (idx < 16) {  // (l,m,n) of the NEXT step: its set-up runs during this one
             const int64_t s = 4 * (it + 1) + idx / 4;
             if (s < nsrc && (idx & 3) < 3) v = lmn[4 * s + (idx & 3)];
-        } else {
+        } else if (!cplx) {
             const int64_t e = idx - 16, pair = e / 32, r = e - pair * 32;
             const int64_t kn = r >> 1, j = 2 * pair + (r & 1);
             const int64_t s = 4 * it + (kn >> 2), ch = c0 + j;
             if (s < nsrc && ch < nchan && !srcbad[s]) v = image[(s * nchan + ch) * 4 + (kn & 3)];
+        } else {
+            const int64_t e = idx - 16, pair = e / 96, r = e - pair * 96;
+            const int64_t kn = r / 6, t = r - kn * 6, j = 2 * pair + (t >= 3), comp = t % 3;
+            const int64_t s = 4 * it + (kn >> 2), ch = c0 + j;
+            if (s < nsrc && ch < nchan && !srcbad[s]) {
+                const double *px = image + ((s * nchan + ch) * 4 + (kn & 3)) * 2;
+                v = comp == 0 ? px[0] : (comp == 1 ? px[1] : -px[1]);
+            }
         }
         rec[i] = v;
     }
@@ -64,14 +75,14 @@ __global__ void mfma_tile_f0(const double *__restrict__ freq, int64_t nchan, int
 }
 
 // grid: (ceil(nrow/64), tiles of the launch); block: 4 waves, wave w on rows 64 bx + 16 w ...
-template <int CT>
+template <int CT, bool CPLX>
 __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tile_f0,
     const double *__restrict__ tilef, const int *__restrict__ flags, const double *__restrict__ lmn,
     double *__restrict__ out, int64_t nrow, int nsrc, int nit, int64_t nchan, int64_t c0_first)
 {
     if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
-    constexpr int STAGE = stage_doubles(CT);
+    constexpr int STAGE = stage_doubles(CT, CPLX);
     constexpr int UNITS = STAGE / 2;              // 16-byte units of a stage
     __shared__ double smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     if (row >= nrow) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
     const double F0 = tile_f0[tile], FD = tilef[1];
-    const int boff = (k * 4 + (lane & 3)) * 2;    // B operand: pixel of (source k, corr lane & 3)
+    const int boff = (k * 4 + (lane & 3)) * (CPLX ? 6 : 2);  // B operand: pixel(s) of (source k, corr lane & 3)
 
     double are[CT], aim[CT];
 #pragma unroll
@@ -113,10 +124,25 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         if (it + 1 < nit) mfma_stage_load<UNITS>(rec + (int64_t)(it + 1) * STAGE, smem + (cur ^ 1) * STAGE, wave, lane);
         const double *S = smem + cur * STAGE;     // header: (l,m,n) of step it + 1
         const double2 *B = reinterpret_cast<const double2 *>(S + 16 + boff);
-        double2 bg[2][GP];
+        constexpr int BPG = CPLX ? 12 : GP;       // 16-byte B reads per group of 8 channels
+        constexpr int BSTRIDE = CPLX ? 48 : 16;   // double2 units between channel pairs
+        double2 bg[2][BPG];
         double anr = cur_.y0r, ani = cur_.y0i;    // phasor at the current 16-channel anchor
+        auto load_b = [&](int g, int t) {         // t-th read of group g
+            if constexpr (CPLX) bg[g & 1][t] = B[(g * GP + t / 3) * BSTRIDE + (t % 3)];
+            else bg[g & 1][t] = B[(g * GP + t) * BSTRIDE];
+        };
+        // pixel components of channel jj of group g: real image -> b; complex -> (br, bi, -bi)
+        auto pix = [&](int g, int jj, int comp) -> double {
+            if constexpr (CPLX) {
+                const int f = (jj >> 1) * 6 + (jj & 1) * 3 + comp;  // position among the pair's 6 doubles
+                return (f & 1) ? bg[g & 1][f >> 1].y : bg[g & 1][f >> 1].x;
+            } else {
+                return (jj & 1) ? bg[g & 1][jj >> 1].y : bg[g & 1][jj >> 1].x;
+            }
+        };
 #pragma unroll
-        for (int p = 0; p < GP; ++p) bg[0][p] = B[p * 16];
+        for (int t = 0; t < BPG; ++t) load_b(0, t);
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             if (g + 1 < NGRP) {  // phasors of the next 8 channels
@@ -135,17 +161,39 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
             for (int sl = 0; sl < 8; ++sl)
                 if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, yr[0], yi[0]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!CPLX) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = g * 8 + jj;
-                const double b = (jj & 1) ? bg[g & 1][jj >> 1].y : bg[g & 1][jj >> 1].x;
-                are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], b, are[j], 0, 0, 0);
-                aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], b, aim[j], 0, 0, 0);
-                // pixels of the next 8 channels: LDS reads issue in the shadow of the 16-cycle MFMAs
-                if (g + 1 < NGRP && (jj & 1)) {
-                    bg[(g + 1) & 1][jj >> 1] = B[((g + 1) * GP + (jj >> 1)) * 16];
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = g * 8 + jj;
+                    const double b = pix(g, jj, 0);
+                    are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], b, are[j], 0, 0, 0);
+                    aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], b, aim[j], 0, 0, 0);
+                    // pixels of the next 8 channels: LDS reads issue in the shadow of the 16-cycle MFMAs
+                    if (g + 1 < NGRP && (jj & 1)) {
+                        load_b(g + 1, jj >> 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                    }
+                }
+            } else {
+                // vis += (yr + i yi)(br + i bi): four MFMAs per channel on two accumulators; the four passes
+                // keep MFMAs on the same accumulator 16 instructions apart
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = g * 8 + jj;
+                        if (pass == 0) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], pix(g, jj, 0), are[j], 0, 0, 0);
+                        if (pass == 1) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], pix(g, jj, 1), aim[j], 0, 0, 0);
+                        if (pass == 2) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], pix(g, jj, 2), are[j], 0, 0, 0);
+                        if (pass == 3) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], pix(g, jj, 0), aim[j], 0, 0, 0);
+                        const int t = pass * 8 + jj;
+                        if (g + 1 < NGRP && t < BPG) {
+                            load_b(g + 1, t);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +240,7 @@ struct Plan {
     size_t f0_off, rec_off, tail_rec_off, total;
 };
 
-Plan make_plan(int64_t nsrc_pad, int64_t nchan)
+Plan make_plan(int64_t nsrc_pad, int64_t nchan, bool cplx)
 {
     Plan p;
     const int64_t nit = nsrc_pad / 4, rem = nchan % 64;
@@ -202,30 +250,30 @@ Plan make_plan(int64_t nsrc_pad, int64_t nchan)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
     p.f0_off = take((size_t)(p.nfull + 1) * sizeof(double));
-    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(64) * sizeof(double));
-    p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct) : 0) * sizeof(double));
+    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(64, cplx) * sizeof(double));
+    p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct, cplx) : 0) * sizeof(double));
     p.total = o;
     return p;
 }
 
-template <int CT>
+template <int CT, bool CPLX>
 int run_tiles(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
               const double *tilef, const int *flags, int sign, double *out, int64_t nrow,
               int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0, int64_t ntile, double *f0, double *rec, bool prof,
               hipStream_t st)
 {
     for (int64_t t = 0; t < ntile; ++t) {
-        int64_t blocks = af_cdiv(nit * stage_doubles(CT), 256);
+        int64_t blocks = af_cdiv(nit * stage_doubles(CT, CPLX), 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(mfma_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, lmn, srcbad, nsrc, nit,
-                           nchan, c0 + t * CT, CT, rec + t * nit * stage_doubles(CT));
+        hipLaunchKernelGGL(mfma_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, (int)CPLX, lmn, srcbad, nsrc,
+                           nit, nchan, c0 + t * CT, CT, rec + t * nit * stage_doubles(CT, CPLX));
         AF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(mfma_tile_f0, dim3((unsigned)af_cdiv(ntile, 64)), dim3(64), 0, st, frequency, nchan, c0, CT,
                        (int)ntile, sign, f0);
     AF_LAUNCH_CHECK();
     if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
-    hipLaunchKernelGGL((dft_mfma_kernel<CT>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
                        uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0);
     if (prof) af_prof_end(st);
     AF_LAUNCH_CHECK();
@@ -236,35 +284,37 @@ int run_tiles(const double *image, const double *uvw, const double *frequency, c
 
 bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex)
 {
-    return !image_is_complex && ncorr == 4 && nchan >= 14 && nchan / 64 + 1 <= 65535;
+    (void)image_is_complex;  // complex pixels: four MFMAs per channel instead of two
+    return ncorr == 4 && nchan >= 14 && nchan / 64 + 1 <= 65535;
 }
 
-size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan)
+size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex)
 {
-    return make_plan(nsrc_pad, nchan).total;
+    return make_plan(nsrc_pad, nchan, image_is_complex).total;
 }
 
-int af_dft_mfma_run(const double *image, const double *uvw, const double *frequency, const double *lmn,
-                    const int *srcbad, const double *tilef, const int *flags, const int *colstate, int sign,
-                    double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
-                    hipStream_t st)
+namespace {
+template <bool CPLX>
+int run_all(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
+            const double *tilef, const int *flags, const int *colstate, int sign, double *out, int64_t nrow, int64_t nsrc,
+            int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st)
 {
-    const Plan p = make_plan(nsrc_pad, nchan);
+    const Plan p = make_plan(nsrc_pad, nchan, CPLX);
     char *ws = static_cast<char *>(workspace);
     double *f0 = reinterpret_cast<double *>(ws + p.f0_off);
     const int64_t nit = nsrc_pad / 4;
     int rc = AF_OK;
     if (p.nfull > 0)
-        rc = run_tiles<64>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                           0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+        rc = run_tiles<64, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
     if (rc != AF_OK) return rc;
     double *trec = reinterpret_cast<double *>(ws + p.tail_rec_off);
     if (p.tail_ct == 32)
-        rc = run_tiles<32>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                           p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+        rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
     else if (p.tail_ct == 16)
-        rc = run_tiles<16>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                           p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+        rc = run_tiles<16, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
     if (rc != AF_OK) return rc;
     // grid sized for every (row, column); the blocks return at once unless a special column exists
     const int64_t nel = nrow * nchan * 4;
@@ -273,4 +323,16 @@ int af_dft_mfma_run(const double *image, const double *uvw, const double *freque
                        nchan);
     AF_LAUNCH_CHECK();
     return rc;
+}
+}  // namespace
+
+int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw, const double *frequency,
+                    const double *lmn, const int *srcbad, const double *tilef, const int *flags, const int *colstate,
+                    int sign, double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
+                    hipStream_t st)
+{
+    return image_is_complex ? run_all<true>(image, uvw, frequency, lmn, srcbad, tilef, flags, colstate, sign, out, nrow,
+                                            nsrc, nsrc_pad, nchan, workspace, st)
+                            : run_all<false>(image, uvw, frequency, lmn, srcbad, tilef, flags, colstate, sign, out, nrow,
+                                             nsrc, nsrc_pad, nchan, workspace, st);
 }

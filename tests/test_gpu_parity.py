@@ -321,6 +321,14 @@ def test_im_to_vis_mfma_channel_tilings(dft_mode, nchan):
     assert_array_equal(dft.im_to_vis(img, uvw[50:117], lm, freq), out[50:117])   # row independence
     casa = dft.im_to_vis(img, uvw, lm, freq, convention="casa")
     assert_array_equal(casa, np.conj(out))
+    # complex pixels: four MFMAs per channel
+    cimg = img + 1j * rng.standard_normal((nsrc, nchan, 4))
+    cref = oracle.im_to_vis(cimg, uvw, lm, freq)
+    cout = dft.im_to_vis(cimg, uvw, lm, freq)
+    dft_mode("valu")
+    cvalu = dft.im_to_vis(cimg, uvw, lm, freq)
+    assert maxabs(cout, cref) <= 1e-11 * _scale(cimg)
+    assert maxabs(cvalu, cref) <= 1e-11 * _scale(cimg)
 
 
 def test_im_to_vis_mfma_special_columns(dft_mode):
@@ -336,14 +344,15 @@ def test_im_to_vis_mfma_special_columns(dft_mode):
     img[4, 40:, :] = 0.0                       # the NaN source only poisons channels < 40 ...
     img[4, :, 3] = 0.0                         # ... and not correlation 3
     uvw[17] = np.nan                           # a NaN row poisons its non-zero columns only
-    ref = oracle.im_to_vis(img, uvw, lm, freq)
-    for mode in ("auto", "valu"):
-        dft_mode(mode)
-        out = dft.im_to_vis(img, uvw, lm, freq)
-        assert_array_equal(np.isnan(out), np.isnan(ref))
-        ok = ~np.isnan(ref)
-        assert maxabs(out[ok], ref[ok]) <= 1e-11 * _scale(np.nan_to_num(img))
-        assert (out[:, 5, 1] == 0).all()
+    for image in (img, img + 1j * np.where(img != 0, rng.standard_normal(img.shape), 0.0)):
+        ref = oracle.im_to_vis(image, uvw, lm, freq)
+        for mode in ("auto", "valu"):
+            dft_mode(mode)
+            out = dft.im_to_vis(image, uvw, lm, freq)
+            assert_array_equal(np.isnan(out), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            assert maxabs(out[ok], ref[ok]) <= 1e-11 * _scale(np.nan_to_num(image))
+            assert (out[:, 5, 1] == 0).all()
 
 
 @pytest.mark.parametrize("nchan", [14, 16, 33, 64, 70, 100, 130])
