@@ -70,8 +70,12 @@ __global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restric
         double wv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m[k] = model[i + k * stride];
-            d[k] = data[i + k * stride];
+            // streamed once: non-temporal loads keep the sweep out of L2's way
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d mv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(model + i + k * stride));
+            const v2d dv = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(data + i + k * stride));
+            m[k] = make_double2(mv.x, mv.y);
+            d[k] = make_double2(dv.x, dv.y);
             if (HAS_WEIGHT) wv[k] = weight[i + k * stride];
         }
 #pragma unroll

@@ -219,18 +219,19 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
 // The reference skips zero pixels (`if image[s,nu,c]:`, kernels.py:64): an all-zero (chan, corr) column
 // stays exactly 0 and a non-finite source poisons only the columns where its pixel is nonzero.  The
 // main kernel accumulates zeros for both; this pass rewrites the (rare) special columns.  One thread
-// per (row, special column candidate); returns at once when dft_colstate found none (flags[2] == 0).
+// per (row, column), grid-stride; returns at once when dft_colstate found no special column (flags[2] == 0).
 __global__ void mfma_fix_columns(const int *__restrict__ flags, const int *__restrict__ colstate,
                                  double *__restrict__ out, int64_t nrow, int64_t nchan)
 {
     if (flags[0] != 1 || flags[1] != 1 || flags[2] == 0) return;
-    const int64_t ncol = nchan * 4;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrow * ncol) return;
-    const int st = colstate[i % ncol];
-    if (st == 0) return;
-    const double v = st == 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
-    reinterpret_cast<double2 *>(out)[i] = make_double2(v, v);
+    const int64_t ncol = nchan * 4, total = nrow * ncol;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int st = colstate[i % ncol];
+        if (st == 0) continue;
+        const double v = st == 1 ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+        reinterpret_cast<double2 *>(out)[i] = make_double2(v, v);
+    }
 }
 
 struct Plan {
@@ -316,11 +317,10 @@ int run_all(const double *image, const double *uvw, const double *frequency, con
         rc = run_tiles<16, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
                                  p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
     if (rc != AF_OK) return rc;
-    // grid sized for every (row, column); the blocks return at once unless a special column exists
-    const int64_t nel = nrow * nchan * 4;
-    AF_REQUIRE(af_cdiv(nel, 256) < (1LL << 31), "af_im_to_vis_f64: too many visibilities for one call");
-    hipLaunchKernelGGL(mfma_fix_columns, dim3((unsigned)af_cdiv(nel, 256)), dim3(256), 0, st, flags, colstate, out, nrow,
-                       nchan);
+    // grid-stride sweep; its blocks return at once unless a special column exists
+    int64_t fix_blocks = af_cdiv(nrow * nchan * 4, 256);
+    if (fix_blocks > 2048) fix_blocks = 2048;
+    hipLaunchKernelGGL(mfma_fix_columns, dim3((unsigned)fix_blocks), dim3(256), 0, st, flags, colstate, out, nrow, nchan);
     AF_LAUNCH_CHECK();
     return rc;
 }
