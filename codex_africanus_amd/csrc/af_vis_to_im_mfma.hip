@@ -82,7 +82,7 @@ __global__ void v2i_mfma_pack(const double2 *__restrict__ vis, const unsigned ch
                     const double2 x = vis[(r * nchan + ch) * 4 + (kn & 3)];
                     v = (rr & 1) ? -x.y : x.x;
                     if (!(isfinite(a) && isfinite(b) && isfinite(c))) v = __longlong_as_double(0x7ff8000000000000LL);
-                    if (rr == 0) chan_any[ch] = 1;  // benign race: every writer stores 1
+                    if ((rr & 7) == 0) chan_any[ch] = 1;  // once per unflagged (row, chan); benign race: all store 1
                 }
             }
         }

@@ -390,6 +390,27 @@ def test_vis_to_im_mfma_channel_tilings(dft_mode, nchan):
     assert maxabs(out2[ok], ref2[ok]) <= 1e-11 * scale
 
 
+@pytest.mark.parametrize("nrow, nsrc", [(1, 1), (3, 2), (5, 3), (63, 4), (65, 5), (129, 9)])
+def test_mfma_paths_tiny_extents(dft_mode, nrow, nsrc):
+    """fewer rows than a wave's 16, fewer sources than one 4-source step: im_to_vis and vis_to_im"""
+    rng = np.random.default_rng(1000 * nrow + nsrc)
+    nchan = 64
+    uvw = rng.standard_normal((nrow, 3)) * 2000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.02
+    freq = np.linspace(1.0e9, 1.4e9, nchan)
+    img = rng.standard_normal((nsrc, nchan, 4))
+    dft_mode("auto")
+    out = dft.im_to_vis(img, uvw, lm, freq)
+    assert maxabs(out, oracle.im_to_vis(img, uvw, lm, freq)) <= 1e-11 * max(_scale(img), 1.0)
+    cimg = img + 1j * rng.standard_normal(img.shape)
+    assert maxabs(dft.im_to_vis(cimg, uvw, lm, freq), oracle.im_to_vis(cimg, uvw, lm, freq)) <= 1e-11 * _scale(cimg)
+    vis = rng.standard_normal((nrow, nchan, 4)) + 1j * rng.standard_normal((nrow, nchan, 4))
+    flags = rng.random((nrow, nchan, 4)) < 0.1
+    got = dft.vis_to_im(vis, uvw, lm, freq, flags)
+    ref = oracle.vis_to_im(vis, uvw, lm, freq, flags)
+    assert maxabs(got, ref) <= 1e-11 * max(np.abs(vis).sum(axis=0).max(), 1.0)
+
+
 # ---------------------------------------------------------------------------- beams
 def _beam_args(g4, lm=None, beam=None, dtype=None):
     args = [g4["beam"] if beam is None else beam, g4["extents"], g4["beam_freq_map"],
