@@ -1,0 +1,145 @@
+"""Seeded random-shape sweeps of the HIP entry points against the oracle: extents that straddle every tile /
+step / partition boundary, random flags and zero pixels, both conventions, every phasor mode."""
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd import dft, rime
+
+pytestmark = pytest.mark.gpu
+
+MODES = ("auto", "valu", "exact")
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    m = dft.get_mode()
+    yield
+    dft.set_mode(m)
+
+
+def _freq(rng, nchan, uniform):
+    f = np.linspace(0.9e9, 0.9e9 + 6.5e6 * max(nchan - 1, 1), nchan)
+    if not uniform and nchan > 2:
+        f = f * (1 + 1e-3 * rng.random(nchan))
+    return f
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_im_to_vis_random_shapes(seed):
+    rng = np.random.default_rng(seed)
+    nrow, nsrc = int(rng.integers(1, 400)), int(rng.integers(1, 40))
+    nchan = int(rng.choice([1, 2, 7, 13, 14, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 80, 97, 128, 129]))
+    ncorr = int(rng.choice([1, 2, 4, 4, 4]))
+    cplx = bool(rng.integers(0, 2))
+    uniform = bool(rng.integers(0, 4))
+    mode = MODES[seed % 3]
+    conv = ("fourier", "casa")[seed % 2]
+    uvw = rng.standard_normal((nrow, 3)) * rng.choice([10.0, 1000.0, 8000.0])
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    img = rng.standard_normal((nsrc, nchan, ncorr))
+    if cplx:
+        img = img + 1j * rng.standard_normal(img.shape)
+    img[rng.random(img.shape) < 0.1] = 0.0
+    freq = _freq(rng, nchan, uniform)
+    dft.set_mode(mode)
+    out = dft.im_to_vis(img, uvw, lm, freq, convention=conv)
+    ref = oracle.im_to_vis(img, uvw, lm, freq, convention=conv)
+    scale = max(float(np.abs(img).sum(axis=0).max()), 1e-300)
+    tol = 1e-14 if (mode == "exact" or not uniform) else 1e-11
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= tol * scale, (nrow, nsrc, nchan, ncorr, cplx, uniform, mode)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_vis_to_im_random_shapes(seed):
+    rng = np.random.default_rng(100 + seed)
+    nrow, nsrc = int(rng.integers(1, 700)), int(rng.integers(1, 90))
+    nchan = int(rng.choice([1, 3, 13, 14, 16, 17, 32, 33, 48, 64, 65, 96, 130]))
+    ncorr = int(rng.choice([1, 2, 4, 4, 4]))
+    uniform = bool(rng.integers(0, 4))
+    mode = ("auto", "exact", "auto")[seed % 3]
+    conv = ("fourier", "casa")[seed % 2]
+    uvw = rng.standard_normal((nrow, 3)) * rng.choice([10.0, 1000.0, 8000.0])
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    vis = rng.standard_normal((nrow, nchan, ncorr)) + 1j * rng.standard_normal((nrow, nchan, ncorr))
+    flags = rng.random((nrow, nchan, ncorr)) < rng.choice([0.0, 0.05, 0.6])
+    freq = _freq(rng, nchan, uniform)
+    dft.set_mode(mode)
+    out = dft.vis_to_im(vis, uvw, lm, freq, flags, convention=conv)
+    ref = oracle.vis_to_im(vis, uvw, lm, freq, flags, convention=conv)
+    scale = max(float(np.abs(vis).sum(axis=0).max()), 1.0)
+    tol = 1e-14 if (mode == "exact" or not uniform) else 1e-11
+    assert np.abs(out - ref).max() <= tol * scale, (nrow, nsrc, nchan, ncorr, uniform, mode)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wsclean_predict_random_shapes(seed):
+    rng = np.random.default_rng(200 + seed)
+    nrow, nsrc = int(rng.integers(1, 300)), int(rng.integers(1, 60))
+    nchan = int(rng.choice([1, 2, 8, 9, 16, 24, 25, 40, 41, 64, 81]))
+    ncoeff = int(rng.integers(1, 5))
+    uniform = bool(rng.integers(0, 4))
+    mode = ("auto", "exact")[seed % 2]
+    isg = rng.random(nsrc) < rng.choice([0.0, 0.5, 1.0])
+    st = np.where(isg, "GAUSSIAN", "POINT")
+    uvw = rng.standard_normal((nrow, 3)) * 1500.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.02
+    flux = rng.uniform(0.1, 2.0, nsrc)
+    coeffs = rng.standard_normal((nsrc, ncoeff)) * (0.5 ** np.arange(1, ncoeff + 1))
+    log_poly = rng.random(nsrc) < 0.5
+    gshape = np.stack([rng.uniform(0, 3e-4, nsrc), rng.uniform(0, 2e-4, nsrc), rng.uniform(0, np.pi, nsrc)], axis=1)
+    freq = _freq(rng, nchan, uniform)
+    ref_freq = np.full(nsrc, float(freq[nchan // 2]))
+    args = (uvw, lm, st, flux, coeffs, log_poly, ref_freq, gshape, freq)
+    dft.set_mode(mode)
+    out = rime.wsclean_predict(*args)
+    ref = oracle.wsclean_predict(*args)
+    scale = max(float(np.abs(oracle.spectra(flux, coeffs, log_poly, ref_freq, freq)).sum(axis=0).max()), 1.0)
+    tol = 1e-13 if (mode == "exact" or not uniform) else 1e-11
+    assert np.abs(out - ref).max() <= tol * scale, (nrow, nsrc, nchan, ncoeff, uniform, mode)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_predict_vis_random_shapes_bit_exact(seed):
+    rng = np.random.default_rng(300 + seed)
+    nsrc, ntime, nant, nchan = int(rng.integers(1, 6)), int(rng.integers(1, 5)), int(rng.integers(2, 9)), int(rng.integers(1, 20))
+    corr = [(1,), (2,), (2, 2)][seed % 3]
+    a1, a2 = np.triu_indices(nant, 1)
+    nbl = a1.shape[0]
+    time_index = np.repeat(np.arange(ntime), nbl) + int(rng.integers(0, 50))
+    ant1, ant2 = np.tile(a1, ntime), np.tile(a2, ntime)
+    nrow = time_index.shape[0]
+    rc = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    have = rng.integers(0, 2, 4).astype(bool)
+    dde = rc(nsrc, ntime, nant, nchan, *corr) if have[0] else None
+    coh = rc(nsrc, nrow, nchan, *corr) if (have[1] or not have[0]) else None
+    die = rc(ntime, nant, nchan, *corr) if have[2] else None
+    bv = rc(nrow, nchan, *corr) if have[3] else None
+    idx_t = (np.int32, np.int64)[seed % 2]
+    args = (time_index.astype(idx_t), ant1.astype(idx_t), ant2.astype(idx_t), dde, coh, dde, die, bv, die)
+    out = rime.predict_vis(*args)
+    ref = oracle.predict_vis(*args)
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_piecewise_uniform_bands_take_the_per_tile_kernels():
+    """two sub-bands with different channel spacings: every VALU tile (13 / 16 channels) is uniform but
+    the MFMA tiles are not -- the device-side flags must route the call to the per-tile recurrence kernels"""
+    rng = np.random.default_rng(7)
+    nrow, nsrc = 150, 21
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    # im_to_vis tiles are 13 channels wide: 2 x 13 channels
+    f13 = np.concatenate([1.0e9 + 1e6 * np.arange(13), 1.2e9 + 3e6 * np.arange(13)])
+    img = rng.standard_normal((nsrc, 26, 4))
+    dft.set_mode("auto")
+    out = dft.im_to_vis(img, uvw, lm, f13)
+    assert np.abs(out - oracle.im_to_vis(img, uvw, lm, f13)).max() <= 1e-11 * np.abs(img).sum(axis=0).max()
+    # vis_to_im VALU tiles are 16 wide: 2 x 16 channels
+    f16 = np.concatenate([1.0e9 + 1e6 * np.arange(16), 1.2e9 + 3e6 * np.arange(16)])
+    vis = rng.standard_normal((nrow, 32, 4)) + 1j * rng.standard_normal((nrow, 32, 4))
+    flags = rng.random((nrow, 32, 4)) < 0.05
+    got = dft.vis_to_im(vis, uvw, lm, f16, flags)
+    ref = oracle.vis_to_im(vis, uvw, lm, f16, flags)
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(vis).sum(axis=0).max()
