@@ -66,10 +66,11 @@ _SIGNATURES = {
                                   _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "af_freq_grid_interp_f64": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "af_freq_grid_interp_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "af_beam_cube_dde_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _int]),
     "af_beam_cube_dde_c128": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp,
-                                     _vp, _vp, _i64, _vp, _vp, _vp]),
+                                     _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "af_beam_cube_dde_c64": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp,
-                                    _vp, _vp, _i64, _vp, _vp, _vp]),
+                                    _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "af_fused_plan_rows": (_int, [_vp, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
     "af_fused_predict_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "af_fused_predict_c128": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,

@@ -4,9 +4,10 @@
 //   freq_grid_interp :10-54   (binary search of each channel in beam_freq_map)
 //   beam_cube_dde    :57-240  (rotate/scale lm, trilinear 8-voxel interpolation of the complex
 //                              cube AND of its amplitude, amplitude-preserving normalisation)
-// One lane owns one output Jones (source, time, antenna, channel) with the channel axis
-// fastest, so stores are coalesced; the cube gathers hit L2/Infinity Cache (the whole cube
-// is read-only and resident).  Arithmetic keeps the reference's operation order with
+// One lane owns one correlation of one output Jones (source, time, antenna, channel), channel and
+// correlation fastest, so stores are coalesced and the lanes of a Jones gather adjacent records; the
+// cube and its amplitude (computed once per call: the reference takes |.| of every gathered voxel) are
+// read-only and L2/Infinity-Cache resident.  Arithmetic keeps the reference's operation order with
 // explicitly rounded operations (no contraction).
 #include "af_common.h"
 #include "af_beam_device.h"
@@ -51,18 +52,78 @@ __global__ void freq_grid_interp_kernel(const T *__restrict__ frequency, int64_t
     freq_data[3 * f + 2] = pos;
 }
 
-// fast_beam_cubes.py:110-238; grid: ceil(nsrc*ntime*nant*nchan / 256)
+// One record (re, im, |.|, 0) per (voxel, correlation), built once per call: the reference takes np.abs of
+// every gathered voxel (fast_beam_cubes.py:187-222: 8 x ncorr hypot per Jones), the cube has far fewer voxels than
+// the call has samples, and a sample then needs ONE 4-element gather per voxel instead of two.
+template <typename T>
+__global__ void beam_pack_kernel(const typename BeamOps<T>::vec2 *__restrict__ beam, int64_t n, T *__restrict__ rec)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const typename BeamOps<T>::vec2 b = beam[i];
+        rec[4 * i + 0] = b.x;
+        rec[4 * i + 1] = b.y;
+        rec[4 * i + 2] = BeamOps<T>::hypot_(b.x, b.y);
+        rec[4 * i + 3] = (T)0.0;
+    }
+}
+
+// beam_sample_corr (af_beam_device.h) reading the packed records: same operations in the same order
+template <typename T>
+__device__ __forceinline__ typename BeamOps<T>::vec2 beam_sample_rec(const T *__restrict__ rec,
+                                                                     const BeamVoxels<T, int64_t> &vx, int c)
+{
+    using O = BeamOps<T>;
+    using V2 = typename O::vec2;
+    struct alignas(4 * sizeof(T)) V4 { T x, y, z, w; };
+    const T zero = (T)0.0;
+    V4 b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = *reinterpret_cast<const V4 *>(rec + 4 * (vx.off[k] + c));
+    T cre = zero, cim = zero, absc = zero;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const T wgt = vx.wt[k];
+        absc = O::add(absc, O::mul(wgt, b[k].z));
+        const T pre = O::sub(O::mul(wgt, b[k].x), O::mul(zero, b[k].y));
+        const T pim = O::add(O::mul(wgt, b[k].y), O::mul(zero, b[k].x));
+        cre = O::add(cre, pre);
+        cim = O::add(cim, pim);
+    }
+    const T div = O::hypot_(cre, cim);
+    const T sc = (div == zero) ? absc : O::div(absc, div);
+    V2 r;
+    r.x = O::sub(O::mul(cre, sc), O::mul(cim, zero));
+    r.y = O::add(O::mul(cre, zero), O::mul(cim, sc));
+    return r;
+}
+
+// (sin, cos) of every parallactic angle once per call (:118-119)
+template <typename T>
+__global__ void beam_parangle_kernel(const T *__restrict__ parangles, int64_t n, T *__restrict__ sc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) BeamOps<T>::sincos_(parangles[i], &sc[2 * i], &sc[2 * i + 1]);
+}
+
+// fast_beam_cubes.py:110-238; one lane per (Jones, correlation): grid ceil(nsrc*ntime*nant*nchan*ncorr / 256).
+// The gathers are request-rate bound: the ncorr lanes of a Jones read ncorr adjacent 32-byte records of a
+// voxel (one cache line at ncorr = 4) and store adjacent outputs; the voxel set-up is recomputed per lane
+// (cheaper than exchanging 16 values).
 template <typename T>
 __global__ __launch_bounds__(256) void beam_cube_dde_kernel(
-    const T *__restrict__ beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int ncorr,
-    const T *__restrict__ lm_ext, const T *__restrict__ lm, int64_t nsrc, const T *__restrict__ parangles,
+    const T *__restrict__ vrec, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int ncorr,
+    const T *__restrict__ lm_ext, const T *__restrict__ lm, int64_t nsrc, const T *__restrict__ pa_sc,
     int64_t ntime, int64_t nant, const T *__restrict__ point_errors, const T *__restrict__ antenna_scaling,
     const T *__restrict__ freq_data, int64_t nchan, T *__restrict__ out)
 {
     using O = B<T>;
     using V2 = typename O::vec2;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t lane_idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = nsrc * ntime * nant * nchan;
+    const int64_t idx = lane_idx / ncorr;
+    const int c = (int)(lane_idx - idx * ncorr);
     if (idx >= total) return;
     const int64_t f = idx % nchan;
     const int64_t a = (idx / nchan) % nant;
@@ -70,16 +131,13 @@ __global__ __launch_bounds__(256) void beam_cube_dde_kernel(
     const int64_t s = idx / (nchan * nant * ntime);
 
     const BeamGrid<T> grid = beam_grid<T>(lm_ext, beam_lw, beam_mh, beam_nud);
-    T sin_pa, cos_pa;
-    O::sincos_(parangles[t * nant + a], &sin_pa, &cos_pa);
+    const T sin_pa = pa_sc[2 * (t * nant + a)], cos_pa = pa_sc[2 * (t * nant + a) + 1];
     const T *pe = point_errors + ((t * nant + a) * nchan + f) * 2;
     const T *as = antenna_scaling + (a * nchan + f) * 2;
     BeamVoxels<T> vx;
     beam_voxels<T, int64_t>(grid, lm[2 * s], lm[2 * s + 1], sin_pa, cos_pa, pe[0], pe[1], as[0], as[1], freq_data[3 * f + 0],
                    freq_data[3 * f + 1], (int)freq_data[3 * f + 2], ncorr, vx);
-    const V2 *fbeam = reinterpret_cast<const V2 *>(beam);
-    V2 *o = reinterpret_cast<V2 *>(out) + idx * ncorr;
-    for (int c = 0; c < ncorr; ++c) o[c] = beam_sample_corr<T, int64_t, false>(fbeam, nullptr, vx, c);
+    reinterpret_cast<V2 *>(out)[lane_idx] = beam_sample_rec<T>(vrec, vx, c);
 }
 
 template <typename T>
@@ -96,11 +154,30 @@ int freq_grid_interp(const T *frequency, int64_t nchan, const T *beam_freq_map, 
 }
 
 template <typename T>
+struct BeamWs {
+    size_t freq_data, pa_sc, babs, total;
+};
+
+template <typename T>
+BeamWs<T> beam_ws(int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int64_t ncorr, int64_t ntime, int64_t nant,
+                  int64_t nchan)
+{
+    BeamWs<T> w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    w.freq_data = take((size_t)nchan * 3 * sizeof(T));
+    w.pa_sc = take((size_t)ntime * nant * 2 * sizeof(T));
+    w.babs = take((size_t)beam_lw * beam_mh * beam_nud * ncorr * 4 * sizeof(T));  // (re, im, |.|, 0) records
+    w.total = o;
+    return w;
+}
+
+template <typename T>
 int beam_cube_dde(const T *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int ncorr,
                   const T *beam_lm_extents, const T *beam_freq_map, const T *lm, int64_t nsrc,
                   const T *parallactic_angles, int64_t ntime, int64_t nant, const T *point_errors,
-                  const T *antenna_scaling, const T *frequency, int64_t nchan, T *out, T *freq_data_ws,
-                  void *stream)
+                  const T *antenna_scaling, const T *frequency, int64_t nchan, T *out, void *workspace,
+                  size_t workspace_bytes, void *stream)
 {
     AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
     AF_REQUIRE(ncorr >= 1, "af_beam_cube_dde: ncorr must be >= 1");
@@ -108,15 +185,33 @@ int beam_cube_dde(const T *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_
     const int64_t total = nsrc * ntime * nant * nchan;
     if (total == 0) return AF_OK;
     AF_REQUIRE(beam && beam_lm_extents && beam_freq_map && lm && parallactic_angles && point_errors &&
-                   antenna_scaling && frequency && out && freq_data_ws,
+                   antenna_scaling && frequency && out,
                "af_beam_cube_dde: NULL array");
-    int rc = freq_grid_interp<T>(frequency, nchan, beam_freq_map, beam_nud, freq_data_ws, stream);
+    const BeamWs<T> W = beam_ws<T>(beam_lw, beam_mh, beam_nud, ncorr, ntime, nant, nchan);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= W.total, "af_beam_cube_dde: workspace too small (%zu < %zu)",
+               workspace_bytes, W.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_beam_cube_dde: workspace must be 256-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    T *freq_data = reinterpret_cast<T *>(ws + W.freq_data);
+    T *pa_sc = reinterpret_cast<T *>(ws + W.pa_sc);
+    T *babs = reinterpret_cast<T *>(ws + W.babs);
+    hipStream_t st = af_stream(stream);
+    int rc = freq_grid_interp<T>(frequency, nchan, beam_freq_map, beam_nud, freq_data, stream);
     if (rc != AF_OK) return rc;
-    const int64_t blocks = af_cdiv(total, 256);
+    const int64_t nvox = beam_lw * beam_mh * beam_nud * ncorr;
+    int64_t ablocks = af_cdiv(nvox, 256);
+    if (ablocks > 8192) ablocks = 8192;
+    hipLaunchKernelGGL((beam_pack_kernel<T>), dim3((unsigned)ablocks), dim3(256), 0, st,
+                       reinterpret_cast<const typename BeamOps<T>::vec2 *>(beam), nvox, babs);
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((beam_parangle_kernel<T>), dim3((unsigned)af_cdiv(ntime * nant, 256)), dim3(256), 0, st,
+                       parallactic_angles, ntime * nant, pa_sc);
+    AF_LAUNCH_CHECK();
+    const int64_t blocks = af_cdiv(total * ncorr, 256);
     AF_REQUIRE(blocks < (1LL << 31), "af_beam_cube_dde: problem too large for one launch");
-    hipLaunchKernelGGL((beam_cube_dde_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, af_stream(stream), beam,
-                       beam_lw, beam_mh, beam_nud, ncorr, beam_lm_extents, lm, nsrc, parallactic_angles, ntime,
-                       nant, point_errors, antenna_scaling, freq_data_ws, nchan, out);
+    hipLaunchKernelGGL((beam_cube_dde_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, babs, beam_lw, beam_mh,
+                       beam_nud, ncorr, beam_lm_extents, lm, nsrc, pa_sc, ntime, nant, point_errors, antenna_scaling,
+                       freq_data, nchan, out);
     AF_LAUNCH_CHECK();
     return AF_OK;
 }
@@ -140,21 +235,29 @@ AF_EXPORT int af_beam_cube_dde_c128(const double *beam, int64_t beam_lw, int64_t
                                     const double *lm, int64_t nsrc, const double *parallactic_angles,
                                     int64_t ntime, int64_t nant, const double *point_errors,
                                     const double *antenna_scaling, const double *frequency, int64_t nchan,
-                                    double *out, double *freq_data_ws, void *stream)
+                                    double *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     return beam_cube_dde<double>(beam, beam_lw, beam_mh, beam_nud, ncorr, beam_lm_extents, beam_freq_map, lm, nsrc,
                                  parallactic_angles, ntime, nant, point_errors, antenna_scaling, frequency, nchan,
-                                 out, freq_data_ws, stream);
+                                 out, workspace, workspace_bytes, stream);
+}
+
+AF_EXPORT size_t af_beam_cube_dde_workspace_bytes(int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int64_t ncorr,
+                                                  int64_t ntime, int64_t nant, int64_t nchan, int is_f32)
+{
+    if (beam_lw < 0 || beam_mh < 0 || beam_nud < 0 || ncorr < 0 || ntime < 0 || nant < 0 || nchan < 0) return 0;
+    return is_f32 ? beam_ws<float>(beam_lw, beam_mh, beam_nud, ncorr, ntime, nant, nchan).total
+                  : beam_ws<double>(beam_lw, beam_mh, beam_nud, ncorr, ntime, nant, nchan).total;
 }
 
 AF_EXPORT int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
                                    int ncorr, const float *beam_lm_extents, const float *beam_freq_map,
                                    const float *lm, int64_t nsrc, const float *parallactic_angles, int64_t ntime,
                                    int64_t nant, const float *point_errors, const float *antenna_scaling,
-                                   const float *frequency, int64_t nchan, float *out, float *freq_data_ws,
-                                   void *stream)
+                                   const float *frequency, int64_t nchan, float *out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
 {
     return beam_cube_dde<float>(beam, beam_lw, beam_mh, beam_nud, ncorr, beam_lm_extents, beam_freq_map, lm, nsrc,
                                 parallactic_angles, ntime, nant, point_errors, antenna_scaling, frequency, nchan,
-                                out, freq_data_ws, stream);
+                                out, workspace, workspace_bytes, stream);
 }

@@ -61,7 +61,9 @@ def beam_cube_dde(beam, beam_lm_extents, beam_freq_map, lm, parallactic_angles, 
         p_lm, p_pa = c.inp(lm, rt), c.inp(parallactic_angles, rt)
         p_pe, p_as, p_fr = c.inp(point_errors, rt), c.inp(antenna_scaling, rt), c.inp(frequency, rt)
         p_out, h = c.out((nsrc, ntime, nant, nchan) + corrs, ct)
-        p_ws = c.scratch(nchan * 3 * np.dtype(rt).itemsize)
+        ws_bytes = int(_lib.load().af_beam_cube_dde_workspace_bytes(beam_lw, beam_mh, beam_nud, ncorr, ntime, nant,
+                                                                    nchan, int(rt == np.float32)))
+        p_ws = c.scratch(ws_bytes)
         _lib.call(fn, p_beam, beam_lw, beam_mh, beam_nud, ncorr, p_ext, p_map, p_lm, nsrc, p_pa, ntime, nant,
-                  p_pe, p_as, p_fr, nchan, p_out, p_ws, c.stream)
+                  p_pe, p_as, p_fr, nchan, p_out, p_ws, max(ws_bytes, 256), c.stream)
         return c.result(h)

@@ -182,19 +182,23 @@ int af_freq_grid_interp_f32(const float *frequency, int64_t nchan, const float *
  *   beam_freq_map (beam_nud); lm (nsrc,2); parallactic_angles (ntime,nant);
  *   point_errors (ntime,nant,nchan,2); antenna_scaling (nant,nchan,2);
  *   frequency (nchan) -> out (nsrc,ntime,nant,nchan,ncorr) complex.
- * `freq_data_ws`: device scratch for nchan*3 reals. */
+ * `workspace`: 256-byte aligned device scratch of af_beam_cube_dde_workspace_bytes(...) bytes
+ * (frequency grid, (sin, cos) of the parallactic angles and |beam|, all built once per call). */
+size_t af_beam_cube_dde_workspace_bytes(int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int64_t ncorr,
+                                        int64_t ntime, int64_t nant, int64_t nchan, int is_f32);
 int af_beam_cube_dde_c128(const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
                           int ncorr, const double *beam_lm_extents, const double *beam_freq_map,
                           const double *lm, int64_t nsrc, const double *parallactic_angles,
                           int64_t ntime, int64_t nant, const double *point_errors,
                           const double *antenna_scaling, const double *frequency, int64_t nchan,
-                          double *out, double *freq_data_ws, void *stream);
+                          double *out, void *workspace, size_t workspace_bytes, void *stream);
 int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
                          int ncorr, const float *beam_lm_extents, const float *beam_freq_map,
                          const float *lm, int64_t nsrc, const float *parallactic_angles,
                          int64_t ntime, int64_t nant, const float *point_errors,
                          const float *antenna_scaling, const float *frequency, int64_t nchan,
-                         float *out, float *freq_data_ws, void *stream);
+                         float *out, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ---- fused predict with beam-cube DDEs -------------------------------------------
  * The reference's chain phase_delay -> einsum("srf,sfij->srfij", phase, brightness) ->
