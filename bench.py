@@ -109,6 +109,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
             dist.init_process_group("gloo")
+        # build the communicator now (RCCL sets its rings up lazily, at the first collective): the timed
+        # region must not pay for it even when --warmup is 0
+        warm = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(dev)
 
     from codex_africanus_amd import _lib
     from codex_africanus_amd.testing import synthetic_inputs, real_image
