@@ -236,6 +236,21 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
 int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
                  int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream);
 
+/* ---- term producers ---------------------------------------------------------------
+ * Replaces africanus.rime.feed_rotation (africanus/rime/feeds.py:14-73): parallactic_angles (n) real ->
+ * out (n,2,2) complex of the same precision; AF_FEED_LINEAR [[c, s], [-s, c]], AF_FEED_CIRCULAR
+ * diag(e^{-i pa}, e^{+i pa}).  Any other feed_type is AF_EINVAL ("Invalid feed_type"). */
+#define AF_FEED_LINEAR 0
+#define AF_FEED_CIRCULAR 1
+int af_feed_rotation_f64(const double *parallactic_angles, int64_t n, int feed_type, double *out, void *stream);
+int af_feed_rotation_f32(const float *parallactic_angles, int64_t n, int feed_type, float *out, void *stream);
+/* Replaces africanus.model.shape.gaussian (africanus/model/shape/gaussian_shape.py:11-62): uvw (nrow,3),
+ * frequency (nchan), shape_params (nsrc,3) = (major, minor, orientation) [rad] -> out (nsrc,nrow,nchan)
+ * float64.  `workspace`: nsrc*32 bytes of device scratch. */
+int af_gaussian_shape_f64(const double *uvw, const double *frequency, const double *shape_params, int64_t nsrc,
+                          int64_t nrow, int64_t nchan, double *out, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

@@ -168,6 +168,31 @@ def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gaus
     return out
 
 
+def feed_rotation(parallactic_angles, feed_type="linear"):
+    """africanus/rime/feeds.py:50-73."""
+    if feed_type not in ("linear", "circular"):
+        raise ValueError("Invalid feed_type '%s'" % feed_type)
+    pa = np.asarray(parallactic_angles)
+    if pa.dtype not in (np.float32, np.float64):
+        raise ValueError("parallactic_angles has none-floating point type %s" % pa.dtype)
+    pa64 = _c(pa, np.float64)
+    out = np.empty(pa.shape + (2, 2), dtype=np.complex128)
+    rc = _lib().orc_feed_rotation_f64(_p(pa64), _i64(pa64.size), ctypes.c_int(0 if feed_type == "linear" else 1),
+                                      _p(out))
+    assert rc == 0
+    return out if pa.dtype == np.float64 else out.astype(np.complex64)
+
+
+def gaussian_shape(uvw, frequency, shape_params):
+    """africanus/model/shape/gaussian_shape.py:11-62."""
+    uvw_, fr_, sp_ = (_c(a, np.float64) for a in (uvw, frequency, shape_params))
+    nsrc, nrow, nchan = sp_.shape[0], uvw_.shape[0], fr_.shape[0]
+    out = np.empty((nsrc, nrow, nchan), dtype=np.float64)
+    rc = _lib().orc_gaussian_shape_f64(_p(uvw_), _p(fr_), _p(sp_), _i64(nsrc), _i64(nrow), _i64(nchan), _p(out))
+    assert rc == 0
+    return out
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None,
                 dde2_jones=None, die1_jones=None, base_vis=None, die2_jones=None):
     """africanus/rime/predict.py:466-619 (checks are NOT restated here: the

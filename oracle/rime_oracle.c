@@ -7,6 +7,8 @@
  *   africanus/dft/kernels.py:33-67         -> orc_im_to_vis_f64
  *   africanus/dft/kernels.py:104-146       -> orc_vis_to_im_f64
  *   africanus/rime/wsclean_predict.py:11-84 -> orc_wsclean_predict_f64
+ *   africanus/rime/feeds.py:14-47           -> orc_feed_rotation_f64
+ *   africanus/model/shape/gaussian_shape.py:21-62 -> orc_gaussian_shape_f64
  *   africanus/rime/fast_beam_cubes.py:10-54  -> orc_freq_grid_interp_{f64,f32}
  *   africanus/rime/fast_beam_cubes.py:57-240 -> orc_beam_cube_dde_{f64,f32}
  *   africanus/constants/consts.py:6-9      -> ORC_*_TWO_PI_OVER_C
@@ -276,6 +278,60 @@ int orc_wsclean_predict_f64(const double *uvw, const double *lm, const unsigned 
                     out[2 * (r * nchan + f)] += re;
                     out[2 * (r * nchan + f) + 1] += im;
                 }
+            }
+        }
+    }
+    free(scaled_freq);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * feed_rotation: africanus/rime/feeds.py:14-47.  feed_type 0 = linear [[c, s], [-s, c]] (:21-32),
+ * 1 = circular diag(e^{-i pa}, e^{+i pa}) (:35-45).  out (n,2,2) complex128.
+ * ---------------------------------------------------------------------- */
+int orc_feed_rotation_f64(const double *pa, int64_t n, int feed_type, double *out)
+{
+    if (feed_type != 0 && feed_type != 1) return ORC_EINVAL;
+    for (int64_t i = 0; i < n; ++i) {
+        const double c = cos(pa[i]), s = sin(pa[i]);
+        double *o = out + 8 * i;
+        if (feed_type == 0) {
+            o[0] = c;  o[1] = 0.0; o[2] = s; o[3] = 0.0;
+            o[4] = -s; o[5] = 0.0; o[6] = c; o[7] = 0.0;
+        } else {
+            o[0] = c;   o[1] = -s;  o[2] = 0.0; o[3] = 0.0;
+            o[4] = 0.0; o[5] = 0.0; o[6] = c;   o[7] = s;
+        }
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * gaussian shape: africanus/model/shape/gaussian_shape.py:21-62.
+ *   shape[s,r,f] = exp(-(fu1^2 + fv1^2)), fu1 = u1*scaled_freq[f], u1 = (u*em - v*el)*er, v1 = u*el + v*em,
+ *   el = emaj sin(angle), em = emaj cos(angle), er = emin / (emaj or 1)   (:45-60)
+ * out (nsrc,nrow,nchan) float64.
+ * ---------------------------------------------------------------------- */
+int orc_gaussian_shape_f64(const double *uvw, const double *frequency, const double *shape_params, int64_t nsrc,
+                           int64_t nrow, int64_t nchan, double *out)
+{
+    const double fwhm = 2.0 * sqrt(2.0 * log(2.0));
+    const double fwhminv = 1.0 / fwhm;
+    const double gauss_scale = fwhminv * sqrt(2.0) * 3.141592653589793 / ORC_LIGHTSPEED;
+    double *scaled_freq = (double *)malloc(sizeof(double) * (size_t)(nchan > 0 ? nchan : 1));
+    if (!scaled_freq) return ORC_ENOMEM;
+    for (int64_t f = 0; f < nchan; ++f) scaled_freq[f] = frequency[f] * gauss_scale;
+    for (int64_t s = 0; s < nsrc; ++s) {
+        const double emaj = shape_params[3 * s], emin = shape_params[3 * s + 1], angle = shape_params[3 * s + 2];
+        const double el = emaj * sin(angle), em = emaj * cos(angle);
+        const double er = emin / (emaj == 0.0 ? 1.0 : emaj);
+        for (int64_t r = 0; r < nrow; ++r) {
+            const double u = uvw[3 * r], v = uvw[3 * r + 1];
+            const double u1 = (u * em - v * el) * er;
+            const double v1 = u * el + v * em;
+            for (int64_t f = 0; f < nchan; ++f) {
+                const double fu1 = u1 * scaled_freq[f], fv1 = v1 * scaled_freq[f];
+                out[(s * nrow + r) * nchan + f] = exp(-(fu1 * fu1 + fv1 * fv1));
             }
         }
     }

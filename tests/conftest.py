@@ -49,6 +49,11 @@ def g7():
     return load_golden("g7_wsclean.npz")
 
 
+@pytest.fixture(scope="session")
+def g8():
+    return load_golden("g8_producers.npz")
+
+
 def has_gpu():
     try:
         import torch

@@ -330,9 +330,28 @@ def g7_wsclean():
     save("g7_wsclean.npz", **out)
 
 
+# ----------------------------------------------------------------------------
+def g8_producers():
+    """feed_rotation (africanus/rime/feeds.py:50) and the Gaussian shape function
+    (africanus/model/shape/gaussian_shape.py:11), recipes of rime/tests/test_rime.py:50-77 and
+    model/shape/tests/test_gaussian_shape.py:11-24 with realistic source sizes / baselines."""
+    from africanus.rime import feed_rotation
+    from africanus.model.shape import gaussian
+    rs = np.random.RandomState(8)
+    pa = rs.uniform(-np.pi, np.pi, (5, 7))
+    uvw = rs.normal(size=(40, 3)) * 1500.0
+    freq = np.linspace(0.856e9, 2 * 0.856e9, 16)
+    shape_params = np.stack([np.abs(rs.normal(size=9)) * 2e-4, np.abs(rs.normal(size=9)) * 1e-4,
+                             rs.uniform(0, np.pi, 9)], axis=1)
+    shape_params[3, 0] = 0.0      # emaj == 0: er = emin / 1
+    save("g8_producers.npz", pa=pa, feed_linear=feed_rotation(pa, "linear"), feed_circular=feed_rotation(pa, "circular"),
+         feed_linear_f32=feed_rotation(pa.astype(np.float32), "linear"),
+         uvw=uvw, freq=freq, shape_params=shape_params, gauss=gaussian(uvw, freq, shape_params))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1,
-               g6=g6_vis_to_im, g7=g7_wsclean)
+               g6=g6_vis_to_im, g7=g7_wsclean, g8=g8_producers)
     for w in which:
         fns[w]()

@@ -1,0 +1,83 @@
+"""GPU parity of the term producers: rime.feed_rotation and model.shape.gaussian against
+the reference's golden vectors (tests/golden/g8_producers.npz) and the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd import rime
+from codex_africanus_amd.model.shape import gaussian
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("feed_type", ["linear", "circular"])
+def test_feed_rotation_golden(g8, feed_type):
+    out = rime.feed_rotation(g8["pa"], feed_type)
+    ref = g8["feed_" + feed_type]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.abs(out - ref).max() <= 2e-16          # device sincos within 1 ulp of libm's
+    # structure is exact: zeros and the repeated / negated entries
+    if feed_type == "linear":
+        assert (out.imag == 0).all() and (out[..., 0, 0] == out[..., 1, 1]).all() and (out[..., 0, 1] == -out[..., 1, 0]).all()
+    else:
+        assert (out[..., 0, 1] == 0).all() and (out[..., 1, 0] == 0).all() and (out[..., 1, 1] == np.conj(out[..., 0, 0])).all()
+
+
+def test_feed_rotation_dtypes_and_errors(g8):
+    out = rime.feed_rotation(g8["pa"].astype(np.float32), "linear")
+    assert out.dtype == np.complex64 and np.abs(out - g8["feed_linear_f32"]).max() <= 2e-7
+    with pytest.raises(ValueError, match="Invalid feed_type 'bob'"):
+        rime.feed_rotation(g8["pa"], "bob")
+    with pytest.raises(ValueError, match="none-floating point type"):
+        rime.feed_rotation(np.arange(4), "linear")
+    assert rime.feed_rotation(np.zeros((0, 3)), "circular").shape == (0, 3, 2, 2)
+    import torch
+    t = torch.from_numpy(g8["pa"]).to("cuda:0")
+    dev = rime.feed_rotation(t, "circular")
+    assert isinstance(dev, torch.Tensor) and dev.shape == (5, 7, 2, 2)
+    np.testing.assert_array_equal(dev.cpu().numpy(), rime.feed_rotation(g8["pa"], "circular"))
+
+
+def test_gaussian_shape_golden(g8):
+    out = gaussian(g8["uvw"], g8["freq"], g8["shape_params"])
+    ref = g8["gauss"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    # exp / sin / cos on the device are within 1 ulp of libm's; the exponent reaches ~80
+    assert np.abs(out - ref).max() <= 1e-13
+    assert np.all(np.abs(out - ref) <= 2e-13 * np.abs(ref) + 1e-300)
+    # the reference's own test recipe (model/shape/tests/test_gaussian_shape.py:11-24)
+    rng = np.random.default_rng(1)
+    uvw, freq = rng.random((10, 3)), np.linspace(0.856e9, 2 * 0.856e9, 16)
+    sp = np.array([[0.4, 0.3, 0.2], [0.4, 0.3, 0.2]])
+    got = gaussian(uvw, freq, sp)
+    assert got.shape == (2, 10, 16)
+    np.testing.assert_allclose(got, oracle.gaussian_shape(uvw, freq, sp), rtol=1e-12, atol=1e-300)
+    out32 = gaussian(g8["uvw"].astype(np.float32), g8["freq"].astype(np.float32), g8["shape_params"].astype(np.float32))
+    assert out32.dtype == np.float32
+
+
+def test_producers_feed_the_predict(g8):
+    """the chain of africanus/rime/examples/predict.py:404-472: a DDE term times the feed rotation, Gaussian
+    coherencies = phase x shape x brightness, through predict_vis -- every stage on the device"""
+    rng = np.random.default_rng(3)
+    nsrc, ntime, nant, nchan = 4, 3, 5, 6
+    a1, a2 = np.triu_indices(nant, 1)
+    nbl = a1.shape[0]
+    time_index = np.repeat(np.arange(ntime), nbl)
+    ant1, ant2 = np.tile(a1, ntime).astype(np.int32), np.tile(a2, ntime).astype(np.int32)
+    nrow = time_index.shape[0]
+    uvw = rng.standard_normal((nrow, 3)) * 1500.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.01
+    freq = np.linspace(0.9e9, 1.1e9, nchan)
+    sp = np.stack([rng.uniform(0, 3e-4, nsrc), rng.uniform(0, 2e-4, nsrc), rng.uniform(0, np.pi, nsrc)], axis=1)
+    B = rng.standard_normal((nsrc, nchan, 2, 2)) + 1j * rng.standard_normal((nsrc, nchan, 2, 2))
+    dde0 = rng.standard_normal((nsrc, ntime, nant, nchan, 2, 2)) + 1j * rng.standard_normal((nsrc, ntime, nant, nchan, 2, 2))
+    pa = rng.uniform(-1, 1, (ntime, nant))
+    frot = rime.feed_rotation(pa, "linear")
+    dde = np.einsum("stafij,tajk->stafik", dde0, frot)
+    coh = np.einsum("srf,srf,sfij->srfij", rime.phase_delay(lm, uvw, freq), gaussian(uvw, freq, sp), B)
+    vis = rime.predict_vis(time_index, ant1, ant2, dde, coh, dde, None, None, None)
+    rdde = np.einsum("stafij,tajk->stafik", dde0, oracle.feed_rotation(pa, "linear"))
+    rcoh = np.einsum("srf,srf,sfij->srfij", oracle.phase_delay(lm, uvw, freq), oracle.gaussian_shape(uvw, freq, sp), B)
+    ref = oracle.predict_vis(time_index, ant1, ant2, rdde, rcoh, rdde, None, None, None)
+    assert np.abs(vis - ref).max() <= 1e-12 * np.abs(ref).max()

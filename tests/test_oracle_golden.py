@@ -346,3 +346,27 @@ def test_wsclean_point_sources_equal_casa_dft(g7):
     spec = oracle.spectra(a[3], a[4], a[5], a[6], a[8])
     dft = oracle.im_to_vis(spec[:, :, None].copy(), a[0], a[1], a[8], convention="casa")
     assert np.abs(oracle.wsclean_predict(*a) - dft).max() < 1e-13
+
+
+# ---- term producers: feed_rotation, Gaussian shape ---------------------------------------------------------
+def test_feed_rotation_and_gaussian_shape_bit_exact(g8):
+    """oracle vs africanus.rime.feed_rotation / africanus.model.shape.gaussian run here (make_golden.py g8)"""
+    assert_array_equal(oracle.feed_rotation(g8["pa"], "linear"), g8["feed_linear"])
+    assert_array_equal(oracle.feed_rotation(g8["pa"], "circular"), g8["feed_circular"])
+    f32 = oracle.feed_rotation(g8["pa"].astype(np.float32), "linear")
+    assert f32.dtype == np.complex64 and np.abs(f32 - g8["feed_linear_f32"]).max() < 2e-7
+    assert_array_equal(oracle.gaussian_shape(g8["uvw"], g8["freq"], g8["shape_params"]), g8["gauss"])
+    with pytest.raises(ValueError, match="Invalid feed_type"):
+        oracle.feed_rotation(g8["pa"], "elliptical")
+
+
+def test_feed_rotation_reference_kat():
+    """africanus/rime/tests/test_rime.py:50-77: the matrices spelled out"""
+    pa = np.random.default_rng(0).random((10, 5))
+    fr = oracle.feed_rotation(pa, "linear")
+    assert_array_equal(fr, np.array([[np.cos(pa), np.sin(pa)], [-np.sin(pa), np.cos(pa)]]).transpose(2, 3, 0, 1))
+    fc = oracle.feed_rotation(pa, "circular")
+    ref = np.zeros(pa.shape + (2, 2), np.complex128)
+    ref[..., 0, 0] = np.cos(pa) - 1j * np.sin(pa)
+    ref[..., 1, 1] = np.cos(pa) + 1j * np.sin(pa)
+    assert_array_equal(fc, ref)
