@@ -184,7 +184,7 @@ def main():
         def predict():
             _lib.call("af_fused_predict_c128", P(fd["items"]), n_items.value, P(fd["a1"]), P(fd["a2"]), nrow,
                       P(d_lm), P(d_uvw), P(d_freq), P(fd["X"]), nsrc, nchan, P(fd["beam"]), 257, 257, 33,
-                      P(fd["ext"]), P(fd["fmap"]), P(fd["pa"]), ntime, nant, P(fd["pe"]), P(fd["asc"]),
+                      P(fd["ext"]), P(fd["fmap"]), P(fd["pa"]), ntime, nant, P(fd["pe"]), P(fd["asc"]), None, None,
                       _lib.CONVENTION["fourier"], P(d_vis), P(d_fws), fws_bytes, stream)
 
     # "observed" data for the chi^2: the model itself plus a fixed perturbation (one extra predict)

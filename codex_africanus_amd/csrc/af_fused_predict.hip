@@ -31,7 +31,7 @@ constexpr int THREADS = 512;
 constexpr int RPT = 4;  // rows per lane
 
 struct FusedWs {
-    size_t lmn, f4, freq_data, babs, total;
+    size_t lmn, f4, freq_data, gauss, babs, total;
 };
 
 FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud)
@@ -42,6 +42,7 @@ FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, 
     w.lmn = take((size_t)nsrc * 4 * sizeof(double));
     w.f4 = take((size_t)nchan * sizeof(double));
     w.freq_data = take((size_t)nchan * 3 * sizeof(double));
+    w.gauss = take((size_t)nsrc * 4 * sizeof(double));  // (el*gs, em*gs, er, is_extended) per source
     w.babs = take((size_t)beam_lw * beam_mh * beam_nud * 16 * sizeof(double));  // 128-B voxel records
     w.total = o;
     return w;
@@ -66,6 +67,25 @@ __global__ void fused_prep_freq(const double *__restrict__ freq, int64_t nchan, 
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < nchan) f4[c] = 4.0 * (double)sign * freq[c] / AF_LIGHTSPEED;
+}
+
+// Gaussian source shapes (africanus/model/shape/gaussian_shape.py:45-50): el = emaj sin(pa), em = emaj cos(pa),
+// er = emin / (emaj or 1), with the frequency scale gs folded into el and em; a source with emaj == emin == 0
+// (or no shape array at all) is a point source: its shape factor is exactly 1 and is skipped.
+__global__ void fused_prep_gauss(const double *__restrict__ shape_params, int64_t nsrc, double gs,
+                                 double *__restrict__ gp)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    double el = 0.0, em = 0.0, er = 0.0, ext = 0.0;
+    if (shape_params != nullptr) {
+        const double emaj = shape_params[3 * s], emin = shape_params[3 * s + 1], angle = shape_params[3 * s + 2];
+        el = emaj * sin(angle) * gs;
+        em = emaj * cos(angle) * gs;
+        er = emin / (emaj == 0.0 ? 1.0 : emaj);
+        ext = (emaj != 0.0 || emin != 0.0) ? 1.0 : 0.0;
+    }
+    gp[4 * s + 0] = el; gp[4 * s + 1] = em; gp[4 * s + 2] = er; gp[4 * s + 3] = ext;
 }
 
 // One 128-byte record per voxel, once per call: for each of the 4 correlations (re, im, |.|, 0).
@@ -147,14 +167,16 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
 }
 
 // grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * nant double2 (E then G) + 6 * nant doubles.
+template <bool FEED, bool GAUSS>
 __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
     const double2 *__restrict__ brightness, const double *__restrict__ vrec,
     int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
     const double *__restrict__ freq_data, const double *__restrict__ parangles,
-    const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling, int nsrc, int64_t nchan,
-    int64_t ntime, int nant, int st, double2 *__restrict__ out)
+    const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling,
+    const double2 *__restrict__ feed_rot, const double *__restrict__ gauss, const double *__restrict__ freq, int nsrc,
+    int64_t nchan, int64_t ntime, int nant, int st, double2 *__restrict__ out)
 {
     extern __shared__ double2 lds[];
     double2 *ldsE = lds;                            // [st][4][nant]
@@ -180,11 +202,15 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
     }
-    const double F4 = f4[f];
+    const double F4 = f4[f], NU = freq[f];
 
     // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
-    // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m)
+    // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m); ldsR[a] = the antenna's 2x2 feed rotation (optional)
     double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * nant);
+    double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
+    constexpr bool have_feed = FEED;
+    if (have_feed)
+        for (int i = tid; i < 4 * nant; i += THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
     for (int a = tid; a < nant; a += THREADS) {
         double sp, cp;
         sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
@@ -225,7 +251,22 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
             Eme.re = e.x; Eme.im = e.y;
             Emate.re = __shfl_xor(e.x, 1, 64);
             Emate.im = __shfl_xor(e.y, 1, 64);
-            const C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
+            C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
+            if constexpr (have_feed) {
+                // E <- E . R(t, antenna)  (einsum "stafij,tajk->stafik", rime/examples/predict.py:472):
+                // this lane's component (i, j = e_corr & 1) is E[i,0] R[0,j] + E[i,1] R[1,j]
+                const double2 r0 = ldsR[4 * e_ant + (e_corr & 1)], r1 = ldsR[4 * e_ant + 2 + (e_corr & 1)];
+                C2 R0, R1;
+                R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
+                C2 Er = cmul(E0, R0);
+                cmac(Er, E1, R1);
+                e = make_double2(Er.re, Er.im);
+                Eme = Er;
+                Emate.re = __shfl_xor(Er.re, 1, 64);
+                Emate.im = __shfl_xor(Er.im, 1, 64);
+                E0 = (e_corr & 1) ? Emate : Eme;
+                E1 = (e_corr & 1) ? Eme : Emate;
+            }
             // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]   (G = E.B, row-major 2x2)
             const double2 *bp = brightness + ((int64_t)sc * nchan + f) * 4;
             const double2 b0 = bp[e_corr & 1], b1 = bp[2 + (e_corr & 1)];
@@ -244,12 +285,30 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
         for (int sl = 0; sl < nb; ++sl) {
             const double l = lmn[4 * (s0 + sl)], m = lmn[4 * (s0 + sl) + 1], n = lmn[4 * (s0 + sl) + 2];
+            // Gaussian shape factors exp(-(u1^2 + v1^2) (nu gs)^2) of this lane's rows (gaussian_shape.py:52-60);
+            // computed ahead of the row loop so that exp's temporaries do not overlap the Jones algebra
+            double shape[RPT];
+            bool extended = false;
+            if constexpr (GAUSS) {
+                const double gel = gauss[4 * (s0 + sl)], gem = gauss[4 * (s0 + sl) + 1], ger = gauss[4 * (s0 + sl) + 2];
+                extended = gauss[4 * (s0 + sl) + 3] != 0.0;  // block-uniform
+                if (extended) {
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const double u1 = (u[k] * gem - v[k] * gel) * ger * NU, v1 = (u[k] * gel + v[k] * gem) * NU;
+                        shape[k] = exp(-(u1 * u1 + v1 * v1));
+                    }
+                }
+            }
             const double2 *pE = ldsE + (size_t)sl * 4 * nant, *pG = ldsG + (size_t)sl * 4 * nant;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const double q = fma(n, w[k], fma(m, v[k], __dmul_rn(l, u[k])));
                 C2 y;
                 sincos_quarter_turns<7>(__dmul_rn(q, F4), y.re, y.im);
+                if constexpr (GAUSS) {
+                    if (extended) { y.re *= shape[k]; y.im *= shape[k]; }
+                }
                 C2 Gp[4], Eq[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -328,7 +387,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
                                     const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
                                     const double *beam_lm_extents, const double *beam_freq_map,
                                     const double *parallactic_angles, int64_t ntime, int64_t nant,
-                                    const double *point_errors, const double *antenna_scaling, int convention,
+                                    const double *point_errors, const double *antenna_scaling,
+                                    const double *feed_rotation, const double *gauss_shape, int convention,
                                     double *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
@@ -337,7 +397,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_REQUIRE(nitems >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_c128: negative extent");
     // one time step's Jones of a source batch + per-antenna constants live in LDS (160 KiB per workgroup)
-    AF_REQUIRE(nant <= 930, "af_fused_predict_c128: more than 930 antennas");
+    AF_REQUIRE(nant <= 680, "af_fused_predict_c128: more than 680 antennas");
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nitems < (1LL << 31), "af_fused_predict_c128: too large");
     hipStream_t st_ = af_stream(stream);
     if (nrow == 0 || nchan == 0) return AF_OK;
@@ -364,6 +424,14 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_LAUNCH_CHECK();
     int rc = af_freq_grid_interp_f64(frequency, nchan, beam_freq_map, beam_nud, freq_data, stream);
     if (rc != AF_OK) return rc;
+    double *gp = reinterpret_cast<double *>(ws + W.gauss);
+    {
+        const double fwhm = 2.0 * sqrt(2.0 * log(2.0));  // gaussian_shape.py:23-25
+        const double gs = (1.0 / fwhm) * sqrt(2.0) * 3.141592653589793 / AF_LIGHTSPEED;
+        hipLaunchKernelGGL(fused_prep_gauss, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st_, gauss_shape, nsrc, gs,
+                           gp);
+        AF_LAUNCH_CHECK();
+    }
     {
         const int64_t nvox = beam_lw * beam_mh * beam_nud;
         AF_REQUIRE(nvox < (1LL << 31), "af_fused_predict_c128: beam cube too large");
@@ -374,21 +442,31 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         AF_LAUNCH_CHECK();
     }
     // sources per batch: as many as fit 128 KB of LDS (E and G: 128 bytes per (source, antenna))
-    int st = (int)(1024 / nant);
+    // (E and G: 128 bytes per (source, antenna); 112 bytes of constants per antenna; 160 KiB per workgroup)
+    int st = (int)((160 * 1024 - 112 * nant) / (128 * nant));
+    if (st > 1024 / nant) st = (int)(1024 / nant);
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double);
+    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
+                             (size_t)nant * 4 * sizeof(double2);  // E, G, per-antenna constants, feed rotation
     AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_c128: %zu bytes of LDS needed (nant = %lld)", lds_bytes,
                (long long)nant);
-    AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_predict_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    af_prof_begin(st_);
-    hipLaunchKernelGGL(fused_predict_kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(THREADS), lds_bytes, st_,
-                       items, antenna1, antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness),
-                       babs, beam_lw, beam_mh, beam_nud, beam_lm_extents,
-                       freq_data, parallactic_angles, point_errors, antenna_scaling, (int)nsrc, nchan, ntime,
-                       (int)nant, st, reinterpret_cast<double2 *>(out));
-    AF_LAUNCH_CHECK();
+    const bool feed = feed_rotation != nullptr, gauss = gauss_shape != nullptr;
+    auto launch = [&](auto kernel) -> int {
+        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+        af_prof_begin(st_);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(THREADS), lds_bytes, st_, items, antenna1,
+                           antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), babs, beam_lw, beam_mh,
+                           beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
+                           reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc, nchan, ntime,
+                           (int)nant, st, reinterpret_cast<double2 *>(out));
+        AF_LAUNCH_CHECK();
+        return AF_OK;
+    };
+    rc = feed ? (gauss ? launch(fused_predict_kernel<true, true>) : launch(fused_predict_kernel<true, false>))
+              : (gauss ? launch(fused_predict_kernel<false, true>) : launch(fused_predict_kernel<false, false>));
+    if (rc != AF_OK) return rc;
     af_prof_end(st_);
     return AF_OK;
 }

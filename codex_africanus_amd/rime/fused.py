@@ -27,7 +27,8 @@ def _host(a):
 def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
                       beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
                       point_errors=None, antenna_scaling=None,
-                      die1_jones=None, base_vis=None, die2_jones=None, convention="fourier"):
+                      die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
+                      feed_rotation=None, gauss_shape=None):
     """
     ``V_pq = G_p ( B_pq + sum_s E_ps (K_pqs X_s) E_qs^H ) G_q^H`` from source-level inputs.
 
@@ -36,7 +37,11 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     frequency -- the per-source coherency matrix X_s (africanus.model.coherency.convert output);
     optional beam cube arguments exactly as ``beam_cube_dde`` (all or none); optional
     ``die{1,2}_jones`` (time, ant, chan, 2, 2) and ``base_vis`` (row, chan, 2, 2) exactly as
-    ``predict_vis``.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    ``predict_vis``; optional ``feed_rotation`` (time, ant, 2, 2) multiplied onto the beam term,
+    ``E <- E R`` (the ``einsum("stafij,tajk->stafik")`` of africanus/rime/examples/predict.py:472; needs the
+    beam arguments) and ``gauss_shape`` (source, 3) = (major, minor, orientation) in radians, the Gaussian
+    shape function of africanus/model/shape/gaussian_shape.py multiplied onto the phase term (rows of zeros
+    are point sources).  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
     ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
     per-antenna Jones terms on the device.  float64 / complex128 only.
     """
@@ -49,6 +54,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                          "antenna_scaling must all be present or all absent")
     if (die1_jones is None) != (die2_jones is None):
         raise ValueError("Both die1_jones and die2_jones must be present or absent")
+    if feed_rotation is not None and not have_beam:
+        raise ValueError("feed_rotation multiplies the beam term: pass the beam arguments as well")
     nsrc, nrow, nchan = int(lm.shape[0]), int(uvw.shape[0]), int(frequency.shape[0])
     if tuple(lm.shape) != (nsrc, 2) or tuple(uvw.shape) != (nrow, 3):
         raise ValueError("lm must be (source, 2) and uvw (row, 3)")
@@ -63,7 +70,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         if tuple(a.shape) != (nrow,):
             raise ValueError("%s must have shape (row,)" % name)
 
-    with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, *beam_args) as c:
+    if gauss_shape is not None and tuple(gauss_shape.shape) != (nsrc, 3):
+        raise ValueError("gauss_shape must have shape (source, 3)")
+    with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, feed_rotation, gauss_shape,
+              *beam_args) as c:
         if flat_spectrum:
             if _is_torch(brightness):
                 brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
@@ -73,6 +83,9 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         p_b = c.inp(brightness, np.complex128)
         p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
         conv = _lib.CONVENTION[convention]
+        if not have_beam and gauss_shape is not None:
+            raise ValueError("gauss_shape without a beam is not fused yet: multiply model.shape.gaussian into "
+                             "the coherencies, or use rime.wsclean_predict for single-correlation components")
         if not have_beam:
             # sum_s K X_s: the direct transform with a complex image and phase_delay's clamped n
             ws_bytes = int(_lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, 4, 1))
@@ -109,11 +122,15 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 c.inp(beam_freq_map, np.float64)
             p_pa, p_pe, p_as = c.inp(parallactic_angles, np.float64), c.inp(point_errors, np.float64), \
                 c.inp(antenna_scaling, np.float64)
+            if feed_rotation is not None and tuple(feed_rotation.shape) != (ntime, nant, 2, 2):
+                raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
+            p_fr_rot = c.inp(feed_rotation, np.complex128)
+            p_gs = c.inp(gauss_shape, np.float64)
             ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
             p_ws = c.scratch(ws_bytes)
             _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, p_b,
                       nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
-                      p_as, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+                      p_as, p_fr_rot, p_gs, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
         vis = c.result(h)
     if die1_jones is None and base_vis is None:
         return vis

@@ -213,6 +213,10 @@ int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, in
  *   antenna1/antenna2 (nrow) int32; lm (nsrc,2); uvw (nrow,3); frequency (nchan);
  *   brightness (nsrc,nchan,2,2) complex128; beam (lw,mh,nud,2,2) complex128 and the other
  *   beam_cube_dde arguments as in af_beam_cube_dde_c128; out (nrow,nchan,2,2) complex128.
+ *   feed_rotation (ntime,nant,2,2) complex128 or NULL: E <- E . R(t,a), the einsum
+ *       "stafij,tajk->stafik" of africanus/rime/examples/predict.py:472 (af_feed_rotation_f64 output);
+ *   gauss_shape (nsrc,3) = (major, minor, orientation) [rad] or NULL: K <- K . shape(r,s,nu), the Gaussian
+ *       shape function of africanus/model/shape/gaussian_shape.py:11-62; (0,0,.) rows are point sources.
  * DIE terms / base_vis are applied afterwards with af_predict_vis_c128 (source_coh = out). */
 int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *items_host,
                        int64_t max_items, int64_t *nitems);
@@ -224,7 +228,8 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
                           int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh,
                           int64_t beam_nud, const double *beam_lm_extents, const double *beam_freq_map,
                           const double *parallactic_angles, int64_t ntime, int64_t nant,
-                          const double *point_errors, const double *antenna_scaling, int convention,
+                          const double *point_errors, const double *antenna_scaling,
+                          const double *feed_rotation, const double *gauss_shape, int convention,
                           double *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- chi-squared ---------------------------------------------------------------

@@ -113,3 +113,38 @@ def test_fused_argument_errors():
     with pytest.raises(ValueError, match="convention"):
         rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
                                convention="x")
+
+
+@pytest.mark.parametrize("feed_type", ["linear", "circular"])
+def test_fused_with_feed_rotation_and_gaussian_sources(feed_type):
+    """the complete chain of africanus/rime/examples/predict.py:404-525: DDE = beam_cube_dde x feed_rotation,
+    coherencies = phase x Gaussian shape x brightness, all inside the fused kernel"""
+    d = _problem(11, 700, 8, 19, 9)
+    rng = np.random.default_rng(4)
+    nsrc = d["lm"].shape[0]
+    sp = np.stack([rng.uniform(0, 3e-4, nsrc), rng.uniform(0, 2e-4, nsrc), rng.uniform(0, np.pi, nsrc)], axis=1)
+    sp[::3] = 0.0                      # every third source is a point source
+    sp[1, 0] = 0.0                     # emaj == 0, emin > 0
+    frot = rime.feed_rotation(d["pa"], feed_type)
+    out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"],
+                                 d["X"], d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"],
+                                 feed_rotation=frot, gauss_shape=sp)
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"])
+    shape = oracle.gaussian_shape(d["uvw"], d["frequency"], sp)
+    coh = np.einsum("srf,srf,sfij->srfij", phase, shape, d["X"])
+    dde = oracle.beam_cube_dde(d["beam"], d["extents"], d["beam_freq_map"], d["lm"], d["pa"], d["pe"], d["as"],
+                               d["frequency"])
+    dde = np.einsum("stafij,tajk->stafik", dde, oracle.feed_rotation(d["pa"], feed_type))
+    ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, coh, dde, None, None, None)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-9 * _scale(d)
+    # each option alone
+    only_feed = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"],
+                                       d["X"], d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"],
+                                       d["as"], feed_rotation=frot)
+    coh0 = np.einsum("srf,sfij->srfij", phase, d["X"])
+    ref_feed = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, coh0, dde, None, None, None)
+    assert np.abs(only_feed - ref_feed).max() <= 1e-9 * _scale(d)
+    with pytest.raises(ValueError, match="feed_rotation multiplies the beam term"):
+        rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                               feed_rotation=frot)
