@@ -15,10 +15,12 @@ uvw[:, 0] = rng.uniform(-4000, 4000, nrow); uvw[:, 1] = rng.uniform(-4000, 4000,
 image = real_image(d)
 dft.im_to_vis(image, uvw[:1000], d["lm"], d["frequency"])          # warm-up (library load, first launch)
 ts = []
-for _ in range(3):
+for _ in range(6):
     t0 = time.perf_counter()
     vis = dft.im_to_vis(image, uvw, d["lm"], d["frequency"])
     ts.append(time.perf_counter() - t0)
 t = min(ts)
+# the first calls also page-lock their result buffers (pooled and re-used afterwards)
 print(json.dumps({"numpy_in_numpy_out_seconds": ts, "Mvis_per_s_pcie_inclusive": nrow * 64 / t / 1e6,
+                  "Mvis_per_s_first_call": nrow * 64 / ts[0] / 1e6,
                   "result_GB": vis.nbytes / 1e9}))
