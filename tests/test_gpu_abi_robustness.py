@@ -106,3 +106,31 @@ def test_entry_points_are_stream_ordered():
     assert torch.equal(a, ref)
     s2.synchronize()
     assert torch.equal(b, 2.0 * ref)
+
+
+def test_numpy_results_in_pooled_pinned_memory_are_ordinary_arrays():
+    """host mode hands results back in page-locked buffers that return to a pool on garbage collection: a
+    retained result is never overwritten by later calls, a dropped one may be re-used, and the arrays
+    behave like any numpy array (writable, sliceable, views keep the buffer alive)"""
+    import gc
+    d = synthetic_inputs(seed=2, nrow=5000, nchan=64, nsrc=10)
+    img = real_image(d)
+    a = dft.im_to_vis(img, d["uvw"], d["lm"], d["frequency"])          # 20 MB: pinned
+    assert a.flags.writeable and a.flags.c_contiguous and a.dtype == np.complex128
+    keep = a.copy()
+    b = dft.im_to_vis(2.0 * img, d["uvw"], d["lm"], d["frequency"])    # a is alive: b gets its own buffer
+    np.testing.assert_array_equal(a, keep)
+    np.testing.assert_array_equal(b, 2.0 * keep)
+    view = a[100:200, :, 1]
+    addr = a.ctypes.data
+    del a
+    gc.collect()
+    c = dft.im_to_vis(3.0 * img, d["uvw"], d["lm"], d["frequency"])    # view still pins a's buffer
+    assert c.ctypes.data != addr
+    np.testing.assert_array_equal(view, keep[100:200, :, 1])
+    del view, c
+    gc.collect()
+    e = dft.im_to_vis(img, d["uvw"], d["lm"], d["frequency"])          # a pooled buffer comes back
+    np.testing.assert_array_equal(e, keep)
+    e += 1.0                                                            # writable like any array
+    np.testing.assert_array_equal(b, 2.0 * keep)
