@@ -1,0 +1,244 @@
+// Calibration consumers of the predict path for gfx950:
+//   corrupt_vis   africanus/calibration/utils/corrupt_vis.py:10-101    vis = sum_dir G_p M_dir G_q^H
+//   residual_vis  africanus/calibration/utils/residual_vis.py:11-119   res = vis - sum_dir G_p M_dir G_q^H (unflagged)
+//   correct_vis   africanus/calibration/utils/correct_vis.py:10-115    cor = G_p^-1 vis G_q^-H            (unflagged)
+// in the three gain layouts of africanus/calibration/utils/utils.py:6-45 (DIAG_DIAG, DIAG, FULL).
+// HBM-bound streaming kernels: one lane per (row, chan) cell, directions summed in registers in the
+// reference's order with the reference's operation order (bit-identical results); the time bin of a row is
+// found by a binary search of the (normalised) bin starts instead of the reference's bin-outer loop.
+#include "af_common.h"
+
+namespace {
+
+struct C2 {
+    double re, im;
+};
+__device__ __forceinline__ C2 cmul(C2 a, C2 b)
+{
+    C2 z;
+    z.re = __dsub_rn(__dmul_rn(a.re, b.re), __dmul_rn(a.im, b.im));
+    z.im = __dadd_rn(__dmul_rn(a.re, b.im), __dmul_rn(a.im, b.re));
+    return z;
+}
+__device__ __forceinline__ C2 cadd(C2 a, C2 b) { return C2{__dadd_rn(a.re, b.re), __dadd_rn(a.im, b.im)}; }
+__device__ __forceinline__ C2 csub(C2 a, C2 b) { return C2{__dsub_rn(a.re, b.re), __dsub_rn(a.im, b.im)}; }
+__device__ __forceinline__ C2 cconj(C2 a) { return C2{a.re, -a.im}; }
+__device__ __forceinline__ C2 cneg(C2 a) { return C2{-a.re, -a.im}; }
+// CPython's _Py_c_quot, the algorithm numba lowers complex division to
+__device__ __forceinline__ C2 cdiv(C2 a, C2 b)
+{
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (fabs(b.re) >= fabs(b.im)) {
+        if (b.re == 0.0) return C2{nan, nan};
+        const double rat = __ddiv_rn(b.im, b.re), den = __dadd_rn(b.re, __dmul_rn(b.im, rat));
+        return C2{__ddiv_rn(__dadd_rn(a.re, __dmul_rn(a.im, rat)), den), __ddiv_rn(__dsub_rn(a.im, __dmul_rn(a.re, rat)), den)};
+    }
+    const double rat = __ddiv_rn(b.re, b.im), den = __dadd_rn(__dmul_rn(b.re, rat), b.im);
+    return C2{__ddiv_rn(__dadd_rn(__dmul_rn(a.re, rat), a.im), den), __ddiv_rn(__dsub_rn(__dmul_rn(a.im, rat), a.re), den)};
+}
+
+constexpr int jones_elems(int mode, int ncorr) { return mode == 0 ? ncorr : (mode == 1 ? 2 : 4); }
+constexpr int vis_elems(int mode, int ncorr) { return mode == 0 ? ncorr : 4; }
+
+// min of the bin starts (the reference normalises time_bin_indices in place, corrupt_vis.py:85)
+__global__ void calib_min_kernel(const int64_t *__restrict__ tbin_idx, int64_t ntime, int64_t *__restrict__ mn)
+{
+    __shared__ long long smin;
+    if (threadIdx.x == 0) smin = 0x7fffffffffffffffLL;
+    __syncthreads();
+    long long m = 0x7fffffffffffffffLL;
+    for (int64_t i = threadIdx.x; i < ntime; i += blockDim.x) m = tbin_idx[i] < m ? tbin_idx[i] : m;
+    atomicMin(&smin, m);
+    __syncthreads();
+    if (threadIdx.x == 0) *mn = ntime > 0 ? smin : 0;
+}
+
+// time bin of every row: the last t with start[t] <= row, if row < start[t] + count[t]; -1 otherwise
+__global__ void calib_rowbin_kernel(const int64_t *__restrict__ tbin_idx, const int64_t *__restrict__ tbin_counts,
+                                    const int64_t *__restrict__ mn, int64_t ntime, int64_t nrow, int *__restrict__ rowbin)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrow) return;
+    const int64_t off = *mn;
+    int64_t lo = 0, hi = ntime;  // first t with start[t] > row
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tbin_idx[mid] - off <= row) lo = mid + 1; else hi = mid;
+    }
+    const int64_t t = lo - 1;
+    rowbin[row] = (t >= 0 && row < tbin_idx[t] - off + tbin_counts[t]) ? (int)t : -1;
+}
+
+// acc (+/-)= sum_dir a1j[s] . model[s] . a2j[s]^H, the reference's jones_mul / subtract_model bodies
+template <int MODE, int NCORR, int SIGN>
+__device__ __forceinline__ void jones_term(int64_t ndir, const C2 *__restrict__ a1j, const C2 *__restrict__ model,
+                                           const C2 *__restrict__ a2j, C2 (&acc)[vis_elems(MODE, NCORR)])
+{
+    constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
+    for (int64_t s = 0; s < ndir; ++s) {
+        const C2 *g = a1j + s * J, *h = a2j + s * J, *m = model + s * V;
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < NCORR; ++c) {
+                const C2 t = cmul(cmul(g[c], m[c]), cconj(h[c]));
+                acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
+            }
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const C2 t = cmul(cmul(g[c >> 1], m[c]), cconj(h[c & 1]));
+                acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
+            }
+        } else {
+            const C2 tmp00 = cconj(h[0]), tmp01 = cconj(h[2]), tmp10 = cconj(h[1]), tmp11 = cconj(h[3]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const C2 t1 = cmul(g[2 * i], m[0]), t2 = cmul(g[2 * i + 1], m[2]);
+                const C2 t3 = cmul(g[2 * i], m[1]), t4 = cmul(g[2 * i + 1], m[3]);
+                const C2 o0 = cadd(cadd(cadd(cmul(t1, tmp00), cmul(t2, tmp00)), cmul(t3, tmp10)), cmul(t4, tmp10));
+                const C2 o1 = cadd(cadd(cadd(cmul(t1, tmp01), cmul(t2, tmp01)), cmul(t3, tmp11)), cmul(t4, tmp11));
+                acc[2 * i] = SIGN > 0 ? cadd(acc[2 * i], o0) : csub(acc[2 * i], o0);
+                acc[2 * i + 1] = SIGN > 0 ? cadd(acc[2 * i + 1], o1) : csub(acc[2 * i + 1], o1);
+            }
+        }
+    }
+}
+
+// OP 0 corrupt, 1 residual, 2 correct; grid: ceil(nrow*nchan / 256)
+template <int OP, int MODE, int NCORR>
+__global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
+                                                    const int64_t *__restrict__ ant2, const C2 *__restrict__ jones,
+                                                    const C2 *__restrict__ vis, const unsigned char *__restrict__ flag,
+                                                    const C2 *__restrict__ model, int64_t nrow, int64_t nant,
+                                                    int64_t nchan, int64_t ndir, C2 *__restrict__ out)
+{
+    constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= nrow * nchan) return;
+    const int64_t row = cell / nchan, nu = cell - row * nchan;
+    const int t = rowbin[row];
+    C2 acc[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) acc[c] = C2{0.0, 0.0};
+    bool active = t >= 0;
+    if (OP != 0 && active) {
+#pragma unroll
+        for (int c = 0; c < V; ++c) active = active && flag[cell * V + c] == 0;
+    }
+    if (active) {
+        const int64_t p = ant1[row], q = ant2[row];
+        const C2 *a1j = jones + (((int64_t)t * nant + p) * nchan + nu) * ndir * J;
+        const C2 *a2j = jones + (((int64_t)t * nant + q) * nchan + nu) * ndir * J;
+        if constexpr (OP == 0) {
+            jones_term<MODE, NCORR, +1>(ndir, a1j, model + cell * ndir * V, a2j, acc);
+        } else if constexpr (OP == 1) {
+#pragma unroll
+            for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
+            jones_term<MODE, NCORR, -1>(ndir, a1j, model + cell * ndir * V, a2j, acc);
+        } else {
+            const C2 *b = vis + cell * V;
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int c = 0; c < NCORR; ++c) acc[c] = cdiv(b[c], cmul(a1j[c], cconj(a2j[c])));
+            } else if constexpr (MODE == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = cdiv(b[c], cmul(a1j[c >> 1], cconj(a2j[c & 1])));
+            } else {
+                const C2 det1 = csub(cmul(a1j[0], a1j[3]), cmul(a1j[1], a1j[2]));
+                const C2 a00 = cdiv(a1j[3], det1), a01 = cdiv(cneg(a1j[1]), det1);
+                const C2 a10 = cdiv(cneg(a1j[2]), det1), a11 = cdiv(a1j[0], det1);
+                const C2 c0 = cconj(a2j[0]), c1 = cconj(a2j[1]), c2 = cconj(a2j[2]), c3 = cconj(a2j[3]);
+                const C2 det2 = csub(cmul(c0, c3), cmul(c1, c2));
+                const C2 b00 = cdiv(c3, det2), b01 = cdiv(cneg(c2), det2);
+                const C2 b10 = cdiv(cneg(c1), det2), b11 = cdiv(c0, det2);
+                C2 t1 = cmul(a00, b[0]), t2 = cmul(a01, b[2]), t3 = cmul(a00, b[1]), t4 = cmul(a01, b[3]);
+                acc[0] = cadd(cadd(cadd(cmul(t1, b00), cmul(t2, b00)), cmul(t3, b10)), cmul(t4, b10));
+                acc[1] = cadd(cadd(cadd(cmul(t1, b01), cmul(t2, b01)), cmul(t3, b11)), cmul(t4, b11));
+                t1 = cmul(a10, b[0]); t2 = cmul(a11, b[2]); t3 = cmul(a10, b[1]); t4 = cmul(a11, b[3]);
+                acc[2] = cadd(cadd(cadd(cmul(t1, b00), cmul(t2, b00)), cmul(t3, b10)), cmul(t4, b10));
+                acc[3] = cadd(cadd(cadd(cmul(t1, b01), cmul(t2, b01)), cmul(t3, b11)), cmul(t4, b11));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) out[cell * V + c] = acc[c];
+}
+
+template <int OP>
+int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, const int64_t *ant1, const int64_t *ant2,
+        const double *jones, const double *vis, const unsigned char *flag, const double *model, int64_t nrow,
+        int64_t nant, int64_t nchan, int64_t ndir, int mode, int ncorr, double *out, void *workspace,
+        size_t workspace_bytes, void *stream, const char *who)
+{
+    AF_REQUIRE(mode >= 0 && mode <= 2, "%s: mode must be 0 (DIAG_DIAG), 1 (DIAG) or 2 (FULL)", who);
+    AF_REQUIRE(ncorr == 1 || ncorr == 2, "ncorr cant be larger than 2");
+    AF_REQUIRE(mode == 0 || ncorr == 2, "%s: DIAG and FULL gains need 2x2 visibilities", who);
+    AF_REQUIRE(nrow >= 0 && nant >= 0 && nchan >= 0 && ndir >= 0 && ntime >= 0, "%s: negative extent", who);
+    AF_REQUIRE(OP != 2 || ndir <= 1, "Jones has n_dir > 1. Cannot correct for direction dependent gains");
+    AF_REQUIRE(OP != 2 || ndir == 1, "%s: jones needs one direction", who);
+    if (nrow == 0 || nchan == 0) return AF_OK;
+    AF_REQUIRE(out && ant1 && ant2 && (ntime == 0 || (tbin_idx && tbin_counts)), "%s: NULL array", who);
+    AF_REQUIRE(jones || ntime == 0, "%s: NULL jones", who);
+    AF_REQUIRE(OP == 0 || (vis && flag), "%s: NULL vis / flag", who);
+    AF_REQUIRE(OP == 2 || model || ndir == 0, "%s: NULL model", who);
+    const size_t need = 256 + (size_t)nrow * sizeof(int);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= need, "%s: workspace too small (%zu < %zu)", who,
+               workspace_bytes, need);
+    hipStream_t st = af_stream(stream);
+    int64_t *mn = static_cast<int64_t *>(workspace);
+    int *rowbin = reinterpret_cast<int *>(static_cast<char *>(workspace) + 256);
+    hipLaunchKernelGGL(calib_min_kernel, dim3(1), dim3(256), 0, st, tbin_idx, ntime, mn);
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(calib_rowbin_kernel, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, tbin_idx, tbin_counts, mn,
+                       ntime, nrow, rowbin);
+    AF_LAUNCH_CHECK();
+    const int64_t cells = nrow * nchan;
+    AF_REQUIRE(af_cdiv(cells, 256) < (1LL << 31), "%s: problem too large for one launch", who);
+    const dim3 grid((unsigned)af_cdiv(cells, 256)), block(256);
+    const C2 *jn = reinterpret_cast<const C2 *>(jones), *vs = reinterpret_cast<const C2 *>(vis);
+    const C2 *md = reinterpret_cast<const C2 *>(model);
+    C2 *o = reinterpret_cast<C2 *>(out);
+#define AF_CALIB_LAUNCH(M, N)                                                                                          \
+    hipLaunchKernelGGL((calib_kernel<OP, M, N>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow, nant, \
+                       nchan, ndir, o)
+    if (mode == 0 && ncorr == 1) AF_CALIB_LAUNCH(0, 1);
+    else if (mode == 0) AF_CALIB_LAUNCH(0, 2);
+    else if (mode == 1) AF_CALIB_LAUNCH(1, 2);
+    else AF_CALIB_LAUNCH(2, 2);
+#undef AF_CALIB_LAUNCH
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+
+}  // namespace
+
+AF_EXPORT size_t af_calibration_workspace_bytes(int64_t nrow) { return nrow < 0 ? 0 : 256 + (size_t)nrow * sizeof(int); }
+
+AF_EXPORT int af_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                                  const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                                  const double *model, int64_t nrow, int64_t nant, int64_t nchan, int64_t ndir, int mode,
+                                  int ncorr, double *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run<0>(time_bin_indices, time_bin_counts, ntime, antenna1, antenna2, jones, nullptr, nullptr, model, nrow, nant,
+                  nchan, ndir, mode, ncorr, out, workspace, workspace_bytes, stream, "af_corrupt_vis_c128");
+}
+
+AF_EXPORT int af_residual_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                                   const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                                   const double *vis, const unsigned char *flag, const double *model, int64_t nrow,
+                                   int64_t nant, int64_t nchan, int64_t ndir, int mode, int ncorr, double *out,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run<1>(time_bin_indices, time_bin_counts, ntime, antenna1, antenna2, jones, vis, flag, model, nrow, nant, nchan,
+                  ndir, mode, ncorr, out, workspace, workspace_bytes, stream, "af_residual_vis_c128");
+}
+
+AF_EXPORT int af_correct_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                                  const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                                  const double *vis, const unsigned char *flag, int64_t nrow, int64_t nant, int64_t nchan,
+                                  int64_t ndir, int mode, int ncorr, double *out, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    return run<2>(time_bin_indices, time_bin_counts, ntime, antenna1, antenna2, jones, vis, flag, nullptr, nrow, nant, nchan,
+                  ndir, mode, ncorr, out, workspace, workspace_bytes, stream, "af_correct_vis_c128");
+}

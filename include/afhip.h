@@ -256,6 +256,32 @@ int af_gaussian_shape_f64(const double *uvw, const double *frequency, const doub
                           int64_t nrow, int64_t nchan, double *out, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* ---- calibration consumers of the predict ------------------------------------------------
+ * Replace africanus.calibration.utils.corrupt_vis (calibration/utils/corrupt_vis.py:58-101), residual_vis
+ * (residual_vis.py:63-119) and correct_vis (correct_vis.py:63-115).  mode: 0 DIAG_DIAG (jones and vis carry
+ * ncorr = 1 or 2 values), 1 DIAG (jones (2), vis (2,2)), 2 FULL (jones (2,2), vis (2,2)) -- check_type of
+ * calibration/utils/utils.py:11-45.  J = ncorr | 2 | 4 gain values, V = ncorr | 4 | 4 visibility values.
+ *   time_bin_indices / time_bin_counts (ntime) int64 (bin starts are normalised by their minimum on the device,
+ *   as the reference does in place); antenna1/antenna2 (nrow) int64; jones (ntime,nant,nchan,ndir,J);
+ *   model (nrow,nchan,ndir,V); vis (nrow,nchan,V); flag (nrow,nchan,V) bytes; out (nrow,nchan,V); complex128.
+ *   Rows outside every bin and (row, chan) cells with any flagged correlation are 0 in the output of
+ *   residual / correct.  correct_vis needs ndir == 1.  workspace: af_calibration_workspace_bytes(nrow). */
+size_t af_calibration_workspace_bytes(int64_t nrow);
+int af_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                        const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                        const double *model, int64_t nrow, int64_t nant, int64_t nchan, int64_t ndir, int mode,
+                        int ncorr, double *out, void *workspace, size_t workspace_bytes, void *stream);
+int af_residual_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                         const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                         const double *vis, const unsigned char *flag, const double *model, int64_t nrow,
+                         int64_t nant, int64_t nchan, int64_t ndir, int mode, int ncorr, double *out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int af_correct_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
+                        const int64_t *antenna1, const int64_t *antenna2, const double *jones,
+                        const double *vis, const unsigned char *flag, int64_t nrow, int64_t nant, int64_t nchan,
+                        int64_t ndir, int mode, int ncorr, double *out, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

@@ -193,6 +193,79 @@ def gaussian_shape(uvw, frequency, shape_params):
     return out
 
 
+# ---- calibration consumers (africanus/calibration/utils) ------------------------------------------------
+def _calib_mode(jones, vis, vis_type):
+    """africanus/calibration/utils/utils.py:11-45 (check_type)."""
+    vis_ndim = (3, 4) if vis_type == "vis" else (4, 5)
+    if vis.ndim == vis_ndim[0]:
+        if jones.ndim != 5:
+            raise RuntimeError("Jones axes not compatible with visibility axes. Expected length 5 but got "
+                               "length %d" % jones.ndim)
+        return 0
+    if vis.ndim == vis_ndim[1]:
+        if jones.ndim == 5:
+            return 1
+        if jones.ndim == 6:
+            return 2
+        raise RuntimeError("Jones term has incorrect shape")
+    raise RuntimeError("Visibility data has incorrect shape")
+
+
+def _calib_common(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, arrays):
+    for a in (jones,) + tuple(arrays):
+        if a.shape[-1] > 2:
+            raise ValueError("ncorr cant be larger than 2")
+    tbi = _c(time_bin_indices, np.int64)
+    tbi = tbi - tbi.min() if tbi.size else tbi
+    return tbi, _c(time_bin_counts, np.int64), _c(antenna1, np.int64), _c(antenna2, np.int64)
+
+
+def corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model):
+    """africanus/calibration/utils/corrupt_vis.py:58-101."""
+    mode = _calib_mode(jones, model, "model")
+    tbi, tbc, a1, a2 = _calib_common(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, (model,))
+    jn, md = _c(jones, np.complex128), _c(model, np.complex128)
+    nrow, nchan, ndir = md.shape[:3]
+    out = np.empty(md.shape[:2] + md.shape[3:], dtype=np.complex128)
+    rc = _lib().orc_corrupt_vis_c128(_p(tbi), _p(tbc), _i64(tbi.shape[0]), _p(a1), _p(a2), _p(jn), _p(md), _i64(nrow),
+                                     _i64(jn.shape[1]), _i64(nchan), _i64(ndir), ctypes.c_int(mode),
+                                     ctypes.c_int(md.shape[-1]), _p(out))
+    assert rc == 0
+    return out
+
+
+def residual_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag, model):
+    """africanus/calibration/utils/residual_vis.py:63-119."""
+    mode = _calib_mode(jones, vis, "vis")
+    tbi, tbc, a1, a2 = _calib_common(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, (vis, model))
+    jn, md, vs = _c(jones, np.complex128), _c(model, np.complex128), _c(vis, np.complex128)
+    fl = _c(np.asarray(flag) != 0, np.uint8)
+    nrow, nchan, ndir = md.shape[:3]
+    out = np.empty(vs.shape, dtype=np.complex128)
+    rc = _lib().orc_residual_vis_c128(_p(tbi), _p(tbc), _i64(tbi.shape[0]), _p(a1), _p(a2), _p(jn), _p(vs), _p(fl),
+                                      _p(md), _i64(nrow), _i64(jn.shape[1]), _i64(nchan), _i64(ndir),
+                                      ctypes.c_int(mode), ctypes.c_int(vs.shape[-1]), _p(out))
+    assert rc == 0
+    return out
+
+
+def correct_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag):
+    """africanus/calibration/utils/correct_vis.py:63-115."""
+    mode = _calib_mode(jones, vis, "vis")
+    tbi, tbc, a1, a2 = _calib_common(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, (vis,))
+    if jones.shape[3] > 1:
+        raise ValueError("Jones has n_dir > 1. Cannot correct for direction dependent gains")
+    jn, vs = _c(jones, np.complex128), _c(vis, np.complex128)
+    fl = _c(np.asarray(flag) != 0, np.uint8)
+    nrow, nchan = vs.shape[:2]
+    out = np.empty(vs.shape, dtype=np.complex128)
+    rc = _lib().orc_correct_vis_c128(_p(tbi), _p(tbc), _i64(jn.shape[0]), _p(a1), _p(a2), _p(jn), _p(vs), _p(fl),
+                                     _i64(nrow), _i64(jn.shape[1]), _i64(nchan), ctypes.c_int(mode),
+                                     ctypes.c_int(vs.shape[-1]), _p(out))
+    assert rc == 0
+    return out
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None,
                 dde2_jones=None, die1_jones=None, base_vis=None, die2_jones=None):
     """africanus/rime/predict.py:466-619 (checks are NOT restated here: the

@@ -54,6 +54,11 @@ def g8():
     return load_golden("g8_producers.npz")
 
 
+@pytest.fixture(scope="session")
+def g9():
+    return load_golden("g9_calibration.npz")
+
+
 def has_gpu():
     try:
         import torch

@@ -349,9 +349,39 @@ def g8_producers():
          uvw=uvw, freq=freq, shape_params=shape_params, gauss=gaussian(uvw, freq, shape_params))
 
 
+# ----------------------------------------------------------------------------
+def g9_calibration():
+    """corrupt_vis / residual_vis / correct_vis (africanus/calibration/utils/{corrupt,residual,correct}_vis.py)
+    for the four (corr, jones) layouts of calibration/utils/tests/test_utils.py:10-18, seeded; time bins as
+    produced by chunkify_rows (utils.py:48-61)."""
+    from africanus.calibration.utils import corrupt_vis, residual_vis, correct_vis, chunkify_rows
+    rs = np.random.RandomState(9)
+    ntime, nant, nchan, ndir = 5, 4, 6, 3
+    a1, a2 = np.triu_indices(nant, 1)
+    nbl = a1.shape[0]
+    time = np.repeat(np.arange(ntime, dtype=np.float64) * 10.0, nbl)
+    ant1, ant2 = np.tile(a1, ntime).astype(np.int32), np.tile(a2, ntime).astype(np.int32)
+    nrow = time.shape[0]
+    _, tbi, tbc = chunkify_rows(time, ntime)
+    rc = lambda *sh: rs.normal(size=sh) + 1j * rs.normal(size=sh)
+    out = dict(time=time, ant1=ant1, ant2=ant2, tbin_idx=tbi, tbin_counts=tbc)
+    for tag, corr, jcorr in (("dd1", (1,), (1,)), ("dd2", (2,), (2,)), ("diag", (2, 2), (2,)), ("full", (2, 2), (2, 2))):
+        jones = rc(ntime, nant, nchan, ndir, *jcorr) + 1.0
+        model = rc(nrow, nchan, ndir, *corr)
+        vis = corrupt_vis(tbi.copy(), tbc, ant1, ant2, jones, model)
+        data = vis + 0.1 * rc(*vis.shape)
+        flag = rs.random_sample(vis.shape) < 0.1
+        res = residual_vis(tbi.copy(), tbc, ant1, ant2, jones, data, flag, model)
+        j1 = np.ascontiguousarray(jones[:, :, :, :1])
+        cor = correct_vis(tbi.copy(), tbc, ant1, ant2, j1, data, flag)
+        out.update({tag + "_jones": jones, tag + "_model": model, tag + "_vis": vis, tag + "_data": data,
+                    tag + "_flag": flag, tag + "_residual": res, tag + "_corrected": cor})
+    save("g9_calibration.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1,
-               g6=g6_vis_to_im, g7=g7_wsclean, g8=g8_producers)
+               g6=g6_vis_to_im, g7=g7_wsclean, g8=g8_producers, g9=g9_calibration)
     for w in which:
         fns[w]()

@@ -370,3 +370,35 @@ def test_feed_rotation_reference_kat():
     ref[..., 0, 0] = np.cos(pa) - 1j * np.sin(pa)
     ref[..., 1, 1] = np.cos(pa) + 1j * np.sin(pa)
     assert_array_equal(fc, ref)
+
+
+# ---- calibration consumers: corrupt_vis, residual_vis, correct_vis -------------------------------------------
+CALIB_TAGS = ["dd1", "dd2", "diag", "full"]
+
+
+@pytest.mark.parametrize("tag", CALIB_TAGS)
+def test_calibration_utils_bit_exact(g9, tag):
+    """oracle vs africanus.calibration.utils.{corrupt,residual,correct}_vis run here (make_golden.py g9), the
+    four layouts of calibration/utils/tests/test_utils.py:10-18"""
+    a = (g9["tbin_idx"], g9["tbin_counts"], g9["ant1"], g9["ant2"])
+    assert_array_equal(oracle.corrupt_vis(*a, g9[tag + "_jones"], g9[tag + "_model"]), g9[tag + "_vis"])
+    assert_array_equal(oracle.residual_vis(*a, g9[tag + "_jones"], g9[tag + "_data"], g9[tag + "_flag"],
+                                           g9[tag + "_model"]), g9[tag + "_residual"])
+    j1 = np.ascontiguousarray(g9[tag + "_jones"][:, :, :, :1])
+    assert_array_equal(oracle.correct_vis(*a, j1, g9[tag + "_data"], g9[tag + "_flag"]), g9[tag + "_corrected"])
+
+
+@pytest.mark.parametrize("tag", CALIB_TAGS)
+def test_corrupt_vis_equals_predict_vis(g9, tag):
+    """africanus/calibration/utils/tests/test_utils.py:21-78: corrupt_vis == predict_vis on transposed arrays"""
+    jones, model = g9[tag + "_jones"], g9[tag + "_model"]
+    if tag == "diag":
+        full = np.zeros(jones.shape[:4] + (2, 2), np.complex128)
+        full[..., 0, 0], full[..., 1, 1] = jones[..., 0], jones[..., 1]
+        jones = full
+    nd = jones.ndim
+    jt = np.ascontiguousarray(np.transpose(jones, [3, 0, 1, 2] + list(range(4, nd))))
+    mt = np.ascontiguousarray(np.transpose(model, [2, 0, 1] + list(range(3, model.ndim))))
+    time_index = np.unique(g9["time"], return_inverse=True)[1]
+    ref = oracle.predict_vis(time_index, g9["ant1"], g9["ant2"], jt, mt, jt, None, None, None)
+    assert_array_almost_equal(ref, g9[tag + "_vis"], decimal=10)
