@@ -282,6 +282,23 @@ int af_correct_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin
                         int64_t ndir, int mode, int ncorr, double *out, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* ---- convolutional degridding ---------------------------------------------------------------
+ * Replaces africanus.gridding.perleypolyhedron.degridder.degridder (gridding/perleypolyhedron/degridder.py:79-175)
+ * with the gather convolution policies (policies/convolution_policies.py:188-323; packed != 0:
+ * "conv_1d_axisymmetric_packed_gather", else "..._unpacked_gather"), baseline_transform_policy "None", the facet
+ * phase rotation (phase_rotate != 0: "phase_rotate", policies/phase_transform_policies.py:9-35) and the
+ * Stokes -> correlation policy given as ncorr (2 or 4) complex per-correlation factors
+ * (policies/stokes_conversion_policies.py:8-137), corr_factors (ncorr) complex128 DEVICE.
+ *   uvw (nrow,3); gridstack (nband,npix,npix) complex128; wavelengths (nchan); chanmap (nchan) int64 band of
+ *   every channel; cell [arcsec]; image_centre / phase_centre (ra, dec) [rad] HOST pointers;
+ *   convolution_kernel (oversampling * (width + 2)) float64 as made by kernels.pack_kernel / the unpacked form;
+ *   out (nrow,nchan,ncorr) complex128. */
+int af_degridder_c128(const double *uvw, const double *gridstack, const double *wavelengths,
+                      const int64_t *chanmap, double cell, const double *image_centre_host,
+                      const double *phase_centre_host, const double *convolution_kernel, int64_t kernel_width,
+                      int64_t kernel_oversampling, int phase_rotate, const double *corr_factors, int ncorr,
+                      int packed, int64_t nrow, int64_t nchan, int64_t npix, double *out, void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

@@ -193,6 +193,49 @@ def gaussian_shape(uvw, frequency, shape_params):
     return out
 
 
+# ---- convolutional degridder (africanus/gridding/perleypolyhedron) --------------------------------------
+# stokes2corr policies as per-correlation factors (policies/stokes_conversion_policies.py:8-137)
+STOKES2CORR = {
+    "XXYY_FROM_I": [1, 1], "XXXYYXYY_FROM_I": [1, 0, 0, 1], "RRLL_FROM_I": [1, 1], "RRRLLRLL_FROM_I": [1, 0, 0, 1],
+    "XXYY_FROM_Q": [1, -1], "XXXYYXYY_FROM_Q": [1, 0, 0, -1], "RLLR_FROM_Q": [1, 1], "RRRLLRLL_FROM_Q": [0, 1, 1, 0],
+    "XYYX_FROM_U": [1, 1], "XXXYYXYY_FROM_U": [0, 1, 1, 0], "RLLR_FROM_U": [1j, -1j],
+    "RRRLLRLL_FROM_U": [0, 1j, -1j, 0], "XYYX_FROM_V": [1j, -1j], "XXXYYXYY_FROM_V": [0, 1j, -1j, 0],
+    "RRLL_FROM_V": [1, -1], "RRRLLRLL_FROM_V": [1, 0, 0, -1],
+}
+
+
+def degridder(uvw, gridstack, wavelengths, chanmap, cell, image_centre, phase_centre, convolution_kernel,
+              convolution_kernel_width, convolution_kernel_oversampling, baseline_transform_policy,
+              phase_transform_policy, stokes_conversion_policy, convolution_policy, vis_dtype=np.complex128):
+    """africanus/gridding/perleypolyhedron/degridder.py:79-175 (gather policies; 'None' / 'wlinapprox' baseline
+    transforms)."""
+    if np.size(chanmap) != np.size(wavelengths):
+        raise ValueError("Chanmap and corresponding wavelengths must match in shape")
+    if gridstack.shape[1] != gridstack.shape[2]:
+        raise ValueError("Grid must be square")
+    chanmap = _c(np.ravel(chanmap), np.int64)
+    wl = _c(np.ravel(wavelengths), np.float64)
+    if gridstack.shape[0] < chanmap.max() + 1:
+        raise ValueError("Not enough channel bands in grid stack to match mfs band mapping")
+    if uvw.shape[1] != 3:
+        raise ValueError("UVW array must be array of tripples")
+    bpol = {"None": 0, "wlinapprox": 1}[baseline_transform_policy]
+    ppol = {"None": 0, None: 0, "phase_rotate": 1}[phase_transform_policy]
+    cpol = {"conv_1d_axisymmetric_packed_gather": 0, "conv_1d_axisymmetric_unpacked_gather": 1}[convolution_policy]
+    coef = _c(np.asarray(STOKES2CORR[stokes_conversion_policy], dtype=np.complex128), np.complex128)
+    uvw_, g = _c(uvw, np.float64), _c(gridstack, np.complex128)
+    k = _c(convolution_kernel, np.float64)
+    ic, pc = _c(image_centre, np.float64), _c(phase_centre, np.float64)
+    nrow, nchan, npix = uvw_.shape[0], wl.shape[0], g.shape[1]
+    out = np.empty((nrow, nchan, coef.shape[0]), dtype=np.complex128)
+    rc = _lib().orc_degridder_c128(_p(uvw_), _p(g), _p(wl), _p(chanmap), ctypes.c_double(cell), _p(ic), _p(pc), _p(k),
+                                   _i64(convolution_kernel_width), _i64(convolution_kernel_oversampling),
+                                   ctypes.c_int(bpol), ctypes.c_int(ppol), _p(coef), ctypes.c_int(coef.shape[0]),
+                                   ctypes.c_int(cpol), _i64(nrow), _i64(nchan), _i64(npix), _p(out))
+    assert rc == 0
+    return out.astype(vis_dtype, copy=False)
+
+
 # ---- calibration consumers (africanus/calibration/utils) ------------------------------------------------
 def _calib_mode(jones, vis, vis_type):
     """africanus/calibration/utils/utils.py:11-45 (check_type)."""

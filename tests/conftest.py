@@ -59,6 +59,11 @@ def g9():
     return load_golden("g9_calibration.npz")
 
 
+@pytest.fixture(scope="session")
+def g10():
+    return load_golden("g10_degridder.npz")
+
+
 def has_gpu():
     try:
         import torch

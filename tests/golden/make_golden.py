@@ -379,9 +379,44 @@ def g9_calibration():
     save("g9_calibration.npz", **out)
 
 
+# ----------------------------------------------------------------------------
+def g10_degridder():
+    """Perley-polyhedron convolutional degridder (africanus/gridding/perleypolyhedron/degridder.py:178
+    degridder_serial) with the kernels of kernels.py (kbsinc, pack_kernel), recipe of
+    gridding/perleypolyhedron/tests/test_ppgridder.py:180-376: W = 7 taps, oversampling 9."""
+    from africanus.gridding.perleypolyhedron import kernels
+    from africanus.gridding.perleypolyhedron.degridder import degridder_serial
+    rs = np.random.RandomState(10)
+    npix, nrow, nchan, W, OS = 64, 60, 5, 7, 9
+    cell = 4.0                                      # arcsec
+    wavelengths = 299792458.0 / np.linspace(1.0e9, 1.4e9, nchan)
+    umax = 0.45 * 1.0 / np.deg2rad(cell / 3600.0) * wavelengths.min()
+    uvw = rs.uniform(-1, 1, (nrow, 3)) * umax
+    uvw[:, 2] *= 0.05
+    uvw[0] = [0.0, 0.0, 0.0]
+    uvw[1, :2] = [umax * 1.3, -umax * 1.3]         # taps that fall off the grid
+    grid = rs.normal(size=(2, npix, npix)) + 1j * rs.normal(size=(2, npix, npix))
+    chanmap = np.array([0, 0, 1, 1, 1])
+    kern = kernels.kbsinc(W, oversample=OS)
+    pkern = kernels.pack_kernel(kern, W, oversample=OS)
+    pc = np.array([0.3, -0.5])
+    ic = np.array([0.3 + 0.01, -0.5 + 0.008])
+    out = dict(uvw=uvw, grid=grid, wavelengths=wavelengths, chanmap=chanmap, cell=cell, kern=kern, pkern=pkern,
+               phase_centre=pc, image_centre=ic, W=W, OS=OS)
+    cases = [("packed_I4", "None", "None", "XXXYYXYY_FROM_I", "conv_1d_axisymmetric_packed_gather", pkern, pc),
+             ("unpacked_I2", "None", "None", "XXYY_FROM_I", "conv_1d_axisymmetric_unpacked_gather", kern, pc),
+             ("packed_V4_rot", "None", "phase_rotate", "XXXYYXYY_FROM_V", "conv_1d_axisymmetric_packed_gather", pkern, ic),
+             ("packed_Q2_rot", "None", "phase_rotate", "XXYY_FROM_Q", "conv_1d_axisymmetric_packed_gather", pkern, ic),
+             ("unpacked_U4", "None", "None", "RRRLLRLL_FROM_U", "conv_1d_axisymmetric_unpacked_gather", kern, pc)]
+    for tag, bpol, ppol, spol, cpol, k, centre in cases:
+        out[tag] = degridder_serial(uvw.copy(), grid, wavelengths, chanmap, cell, (centre[0], centre[1]),
+                                    (pc[0], pc[1]), k, W, OS, bpol, ppol, spol, cpol)
+    save("g10_degridder.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = dict(g1=g1_phase_delay, g2=g2_predict_vis, g3=g3_im_to_vis, g4=g4_beam, g5=g5_chain_c1,
-               g6=g6_vis_to_im, g7=g7_wsclean, g8=g8_producers, g9=g9_calibration)
+               g6=g6_vis_to_im, g7=g7_wsclean, g8=g8_producers, g9=g9_calibration, g10=g10_degridder)
     for w in which:
         fns[w]()

@@ -402,3 +402,37 @@ def test_corrupt_vis_equals_predict_vis(g9, tag):
     time_index = np.unique(g9["time"], return_inverse=True)[1]
     ref = oracle.predict_vis(time_index, g9["ant1"], g9["ant2"], jt, mt, jt, None, None, None)
     assert_array_almost_equal(ref, g9[tag + "_vis"], decimal=10)
+
+
+# ---- convolutional degridder (Perley polyhedron, BASELINE configs[4]) -----------------------------------------
+DEGRID_CASES = [
+    ("packed_I4", "None", "XXXYYXYY_FROM_I", "conv_1d_axisymmetric_packed_gather", "pkern", "phase_centre"),
+    ("unpacked_I2", "None", "XXYY_FROM_I", "conv_1d_axisymmetric_unpacked_gather", "kern", "phase_centre"),
+    ("packed_V4_rot", "phase_rotate", "XXXYYXYY_FROM_V", "conv_1d_axisymmetric_packed_gather", "pkern", "image_centre"),
+    ("packed_Q2_rot", "phase_rotate", "XXYY_FROM_Q", "conv_1d_axisymmetric_packed_gather", "pkern", "image_centre"),
+    ("unpacked_U4", "None", "RRRLLRLL_FROM_U", "conv_1d_axisymmetric_unpacked_gather", "kern", "phase_centre"),
+]
+
+
+@pytest.mark.parametrize("tag, ppol, spol, cpol, kern, centre", DEGRID_CASES)
+def test_degridder_oracle_vs_reference(g10, tag, ppol, spol, cpol, kern, centre):
+    """oracle vs africanus.gridding.perleypolyhedron.degridder.degridder_serial run here (make_golden.py g10).
+    The reference is compiled with fastmath=True, so agreement is to rounding: 1e-14 without the facet phase
+    rotation, 1e-10 with it (a phase of ~1e4 rad re-associated)."""
+    out = oracle.degridder(g10["uvw"], g10["grid"], g10["wavelengths"], g10["chanmap"], float(g10["cell"]), g10[centre],
+                           g10["phase_centre"], g10[kern], int(g10["W"]), int(g10["OS"]), "None", ppol, spol, cpol)
+    ref = g10[tag]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= (1e-10 if ppol == "phase_rotate" else 1e-14) * np.abs(ref).max()
+
+
+def test_degridder_kernels_match_reference(g10):
+    """numpy kernel generators against the reference's kbsinc / pack_kernel outputs stored with the golden"""
+    from codex_africanus_amd.gridding.perleypolyhedron import kernels
+    W, OS = int(g10["W"]), int(g10["OS"])
+    k = kernels.kbsinc(W, oversample=OS)
+    np.testing.assert_allclose(k, g10["kern"], rtol=1e-13, atol=1e-16)
+    assert_array_equal(kernels.pack_kernel(g10["kern"], W, OS), g10["pkern"])
+    assert_array_equal(kernels.unpack_kernel(g10["pkern"], W, OS), g10["kern"])
+    assert kernels.uspace(W, OS).shape == (OS * (W + 2),)
+    assert abs(kernels.sinc(W, OS).sum() - 1) < 1e-14 and abs(kernels.hanningsinc(W, oversample=OS).sum() - 1) < 1e-14
