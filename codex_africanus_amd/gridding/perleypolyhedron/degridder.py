@@ -65,7 +65,9 @@ def degridder(uvw, gridstack, wavelengths, chanmap, cell, image_centre, phase_ce
         p_uvw, p_wl, p_k = c.inp(uvw, np.float64), c.inp(wavelengths, np.float64), c.inp(convolution_kernel, np.float64)
         p_g, p_cm, p_cf = c.inp(gridstack, np.complex128), c.inp(chanmap, np.int64), c.inp(coef, np.complex128)
         p_out, h = c.out((nrow, nchan, ncorr), np.complex128)
+        ws_bytes = int(_lib.load().af_degridder_workspace_bytes(nrow))
+        p_ws = c.scratch(ws_bytes)
         _lib.call("af_degridder_c128", p_uvw, p_g, p_wl, p_cm, float(cell), ic.ctypes.data, pc.ctypes.data, p_k, W, OS,
                   int(phase_transform_policy == "phase_rotate"), p_cf, ncorr, _CONV[convolution_policy], nrow, nchan,
-                  npix, p_out, c.stream)
+                  npix, p_out, p_ws, max(ws_bytes, 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)

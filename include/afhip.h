@@ -292,12 +292,16 @@ int af_correct_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin
  *   uvw (nrow,3); gridstack (nband,npix,npix) complex128; wavelengths (nchan); chanmap (nchan) int64 band of
  *   every channel; cell [arcsec]; image_centre / phase_centre (ra, dec) [rad] HOST pointers;
  *   convolution_kernel (oversampling * (width + 2)) float64 as made by kernels.pack_kernel / the unpacked form;
- *   out (nrow,nchan,ncorr) complex128. */
+ *   out (nrow,nchan,ncorr) complex128.  workspace (optional, af_degridder_workspace_bytes(nrow), 256-byte
+ *   aligned): lets the call process the rows in uv-tile order (a counting sort of their mid-band position),
+ *   which keeps the gathers of concurrent waves inside one cache-sized neighbourhood; results are unchanged. */
+size_t af_degridder_workspace_bytes(int64_t nrow);
 int af_degridder_c128(const double *uvw, const double *gridstack, const double *wavelengths,
                       const int64_t *chanmap, double cell, const double *image_centre_host,
                       const double *phase_centre_host, const double *convolution_kernel, int64_t kernel_width,
                       int64_t kernel_oversampling, int phase_rotate, const double *corr_factors, int ncorr,
-                      int packed, int64_t nrow, int64_t nchan, int64_t npix, double *out, void *stream);
+                      int packed, int64_t nrow, int64_t nchan, int64_t npix, double *out, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and

@@ -106,3 +106,21 @@ def test_degridder_errors(g10):
         call(a13="conv_nn_scatter")
     with pytest.raises(ValueError, match="no defined result"):
         call(a10="rotate")
+
+
+def test_degridder_uv_tile_order_is_transparent():
+    """>= 4096 rows: the call processes the rows in uv-tile order (counting sort of their mid-band position);
+    every row must still land in its own output slot -- including rows off the grid and NaN coordinates"""
+    rng = np.random.default_rng(11)
+    npix, nrow, nchan, W, OS = 128, 6001, 4, 7, 9
+    wl = 299792458.0 / np.linspace(1.0e9, 1.3e9, nchan)
+    umax = 0.6 / np.deg2rad(5.0 / 3600.0) * wl.min()
+    uvw = rng.uniform(-1, 1, (nrow, 3)) * umax
+    grid = rng.standard_normal((2, npix, npix)) + 1j * rng.standard_normal((2, npix, npix))
+    k = kernels.pack_kernel(kernels.kbsinc(W, oversample=OS), W, OS)
+    args = (uvw, grid, wl, np.array([0, 1, 1, 0]), 5.0, (0.2, 0.1), (0.19, 0.11), k, W, OS, "None", "phase_rotate",
+            "XXXYYXYY_FROM_Q", "conv_1d_axisymmetric_packed_gather")
+    out, ref = degridder(*args), oracle.degridder(*args)
+    assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+    part = degridder(uvw[:1000], *args[1:])                  # < 4096 rows: natural order
+    np.testing.assert_array_equal(part, out[:1000])
