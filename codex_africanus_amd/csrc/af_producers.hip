@@ -58,7 +58,59 @@ __global__ __launch_bounds__(256) void gaussian_shape_kernel(const double *__res
     out[i] = exp(-__dadd_rn(__dmul_rn(fu1, fu1), __dmul_rn(fv1, fv1)));
 }
 
+// float ** int as numba lowers it: exponentiation by squaring
+__device__ __forceinline__ double ipow_sq(double a, int e)
+{
+    double r = 1.0;
+    while (e != 0) {
+        if (e & 1) r = __dmul_rn(r, a);
+        e >>= 1;
+        a = __dmul_rn(a, a);
+    }
+    return r;
+}
+
+// spectral_model (spec_model.py:173-213): one lane per (source, chan, pol), pol fastest
+__global__ void spectral_model_kernel(const double *__restrict__ stokes, const double *__restrict__ spi,
+                                      const double *__restrict__ ref_freq, const double *__restrict__ frequency,
+                                      const int *__restrict__ base, int64_t nsrc, int64_t nspi, int64_t npol,
+                                      int64_t nchan, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsrc * nchan * npol) return;
+    const int64_t p = i % npol, f = (i / npol) % nchan, s = i / (npol * nchan);
+    const double ratio = frequency[f] / ref_freq[s];
+    const int b = base[p];
+    double v;
+    if (b == 0) {
+        v = stokes[s * npol + p];
+        for (int64_t si = 0; si < nspi; ++si) v = __dmul_rn(v, pow(ratio, spi[(s * nspi + si) * npol + p]));
+    } else {
+        const double lr = b == 1 ? log(ratio) : log10(ratio);
+        double acc = 0.0;
+        for (int64_t si = 0; si < nspi; ++si)
+            acc = __dadd_rn(acc, __dmul_rn(spi[(s * nspi + si) * npol + p], ipow_sq(lr, (int)si + 1)));
+        v = __dmul_rn(stokes[s * npol + p], b == 1 ? exp(acc) : pow(10.0, acc));
+    }
+    out[i] = v;
+}
+
 }  // namespace
+
+AF_EXPORT int af_spectral_model_f64(const double *stokes, const double *spi, const double *ref_freq,
+                                    const double *frequency, const int *base, int64_t nsrc, int64_t nspi, int64_t npol,
+                                    int64_t nchan, double *out, void *stream)
+{
+    AF_REQUIRE(nsrc >= 0 && nspi >= 0 && npol >= 1 && nchan >= 0, "af_spectral_model_f64: bad extents");
+    if (nsrc == 0 || nchan == 0) return AF_OK;
+    AF_REQUIRE(stokes && ref_freq && frequency && base && out && (spi || nspi == 0), "af_spectral_model_f64: NULL array");
+    const int64_t total = nsrc * nchan * npol;
+    AF_REQUIRE(af_cdiv(total, 256) < (1LL << 31), "af_spectral_model_f64: problem too large for one launch");
+    hipLaunchKernelGGL(spectral_model_kernel, dim3((unsigned)af_cdiv(total, 256)), dim3(256), 0, af_stream(stream), stokes,
+                       spi, ref_freq, frequency, base, nsrc, nspi, npol, nchan, out);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
 
 AF_EXPORT int af_feed_rotation_f64(const double *parallactic_angles, int64_t n, int feed_type, double *out, void *stream)
 {

@@ -303,6 +303,14 @@ int af_degridder_c128(const double *uvw, const double *gridstack, const double *
                       int packed, int64_t nrow, int64_t nchan, int64_t npix, double *out, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* Replaces africanus.model.spectral.spectral_model (africanus/model/spectral/spec_model.py:102-236):
+ * stokes (nsrc,npol), spi (nsrc,nspi,npol), ref_freq (nsrc), frequency (nchan), base (npol) int32 DEVICE array of
+ * 0 "std"  I prod_i (nu/nu0)^spi_i, 1 "log"  I exp(sum_i spi_i ln(nu/nu0)^(i+1)), 2 "log10" (same in base 10)
+ * -> out (nsrc,nchan,npol) float64. */
+int af_spectral_model_f64(const double *stokes, const double *spi, const double *ref_freq, const double *frequency,
+                          const int *base, int64_t nsrc, int64_t nspi, int64_t npol, int64_t nchan, double *out,
+                          void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

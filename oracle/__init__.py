@@ -168,6 +168,33 @@ def wsclean_predict(uvw, lm, source_type, flux, coeffs, log_poly, ref_freq, gaus
     return out
 
 
+_BASES = {0: 0, 1: 1, 2: 2, "std": 0, "log": 1, "log10": 2}
+
+
+def spectral_model(stokes, spi, ref_freq, frequency, base=0):
+    """africanus/model/spectral/spec_model.py:102-236."""
+    stokes, spi = np.asarray(stokes), np.asarray(spi)
+    if spi.ndim - 2 != stokes.ndim - 1:
+        raise ValueError("Dimensions on stokes and spi don't agree")
+    pol_shape = stokes.shape[1:]
+    npol = int(np.prod(pol_shape, dtype=np.int64)) if pol_shape else 1
+    if npol != (int(np.prod(spi.shape[2:], dtype=np.int64)) if spi.shape[2:] else 1):
+        raise ValueError("Correlations on stokes and spi don't agree")
+    bl = list(base) if isinstance(base, (list, tuple)) else [base] * npol
+    bl = bl + [bl[-1]] * (npol - len(bl))
+    try:
+        b = _c(np.array([_BASES[x] for x in bl[:npol]]), np.int32)
+    except KeyError:
+        raise ValueError("Invalid base")
+    st, sp = _c(stokes.reshape(stokes.shape[0], npol), np.float64), _c(spi.reshape(spi.shape[0], spi.shape[1], npol), np.float64)
+    rf, fr = _c(ref_freq, np.float64), _c(frequency, np.float64)
+    out = np.empty((st.shape[0], fr.shape[0], npol), dtype=np.float64)
+    rc = _lib().orc_spectral_model_f64(_p(st), _p(sp), _p(rf), _p(fr), _p(b), _i64(st.shape[0]), _i64(sp.shape[1]),
+                                       _i64(npol), _i64(fr.shape[0]), _p(out))
+    assert rc == 0
+    return out.reshape((st.shape[0], fr.shape[0]) + tuple(pol_shape))
+
+
 def feed_rotation(parallactic_angles, feed_type="linear"):
     """africanus/rime/feeds.py:50-73."""
     if feed_type not in ("linear", "circular"):

@@ -339,6 +339,38 @@ int orc_gaussian_shape_f64(const double *uvw, const double *frequency, const dou
     return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------
+ * spectral_model: africanus/model/spectral/spec_model.py:102-236.  stokes (nsrc,npol), spi (nsrc,nspi,npol),
+ * base (npol) ints: 0 std  I * prod_i (nu/nu0)^spi_i (:173-185), 1 log  I * exp(sum_i spi_i ln(nu/nu0)^(i+1))
+ * (:187-199), 2 log10  I * 10^(sum_i spi_i log10(nu/nu0)^(i+1)) (:201-213); out (nsrc,nchan,npol).
+ * float ** float -> pow(); float ** int -> exponentiation by squaring (orc_ipow); 10 ** float -> pow(10, x).
+ * ---------------------------------------------------------------------- */
+int orc_spectral_model_f64(const double *stokes, const double *spi, const double *ref_freq, const double *frequency,
+                           const int *base, int64_t nsrc, int64_t nspi, int64_t npol, int64_t nchan, double *out)
+{
+    for (int64_t p = 0; p < npol; ++p) {
+        if (base[p] < 0 || base[p] > 2) return ORC_EINVAL;
+        for (int64_t s = 0; s < nsrc; ++s) {
+            const double rf = ref_freq[s];
+            for (int64_t f = 0; f < nchan; ++f) {
+                double v;
+                if (base[p] == 0) {
+                    const double ratio = frequency[f] / rf;
+                    v = stokes[s * npol + p];
+                    for (int64_t si = 0; si < nspi; ++si) v *= pow(ratio, spi[(s * nspi + si) * npol + p]);
+                } else {
+                    const double lr = base[p] == 1 ? log(frequency[f] / rf) : log10(frequency[f] / rf);
+                    double acc = 0.0;
+                    for (int64_t si = 0; si < nspi; ++si) acc += spi[(s * nspi + si) * npol + p] * orc_ipow(lr, si + 1);
+                    v = stokes[s * npol + p] * (base[p] == 1 ? exp(acc) : pow(10.0, acc));
+                }
+                out[(s * nchan + f) * npol + p] = v;
+            }
+        }
+    }
+    return ORC_OK;
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -344,7 +344,17 @@ def g8_producers():
     shape_params = np.stack([np.abs(rs.normal(size=9)) * 2e-4, np.abs(rs.normal(size=9)) * 1e-4,
                              rs.uniform(0, np.pi, 9)], axis=1)
     shape_params[3, 0] = 0.0      # emaj == 0: er = emin / 1
-    save("g8_producers.npz", pa=pa, feed_linear=feed_rotation(pa, "linear"), feed_circular=feed_rotation(pa, "circular"),
+    from africanus.model.spectral import spectral_model
+    stokes = rs.normal(size=(11, 4))
+    stokes[:, 0] = np.abs(stokes[:, 0]) + 0.5
+    spi = rs.normal(size=(11, 3, 4)) * np.array([0.7, 0.2, 0.05])[None, :, None]
+    ref_freq = rs.uniform(1.0e9, 1.4e9, 11)
+    spec = {"spec_std": spectral_model(stokes, spi, ref_freq, freq, base=0),
+            "spec_log": spectral_model(stokes, spi, ref_freq, freq, base=1),
+            "spec_log10": spectral_model(stokes, spi, ref_freq, freq, base=2),
+            "spec_list": spectral_model(stokes, spi, ref_freq, freq, base=[0, 1, 2]),
+            "spec_nopol": spectral_model(stokes[:, 0].copy(), spi[:, :, 0].copy(), ref_freq, freq, base="log")}
+    save("g8_producers.npz", stokes=stokes, spi=spi, spec_ref_freq=ref_freq, **spec, pa=pa, feed_linear=feed_rotation(pa, "linear"), feed_circular=feed_rotation(pa, "circular"),
          feed_linear_f32=feed_rotation(pa.astype(np.float32), "linear"),
          uvw=uvw, freq=freq, shape_params=shape_params, gauss=gaussian(uvw, freq, shape_params))
 

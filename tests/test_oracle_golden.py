@@ -436,3 +436,13 @@ def test_degridder_kernels_match_reference(g10):
     assert_array_equal(kernels.unpack_kernel(g10["pkern"], W, OS), g10["kern"])
     assert kernels.uspace(W, OS).shape == (OS * (W + 2),)
     assert abs(kernels.sinc(W, OS).sum() - 1) < 1e-14 and abs(kernels.hanningsinc(W, oversample=OS).sum() - 1) < 1e-14
+
+
+def test_spectral_model_bit_exact(g8):
+    """oracle vs africanus.model.spectral.spectral_model run here (make_golden.py g8): the three bases, a
+    per-polarisation list, and the no-polarisation form"""
+    a = (g8["stokes"], g8["spi"], g8["spec_ref_freq"], g8["freq"])
+    for key, base in (("spec_std", 0), ("spec_log", 1), ("spec_log10", 2), ("spec_list", [0, 1, 2])):
+        assert_array_equal(oracle.spectral_model(*a, base=base), g8[key])
+    assert_array_equal(oracle.spectral_model(g8["stokes"][:, 0].copy(), g8["spi"][:, :, 0].copy(), g8["spec_ref_freq"],
+                                             g8["freq"], base="log"), g8["spec_nopol"])
