@@ -21,6 +21,7 @@ from .phase import phase_delay as _np_phase_delay
 from .predict import predict_vis as _np_predict_vis, predict_checks
 from .fast_beam_cubes import beam_cube_dde as _np_beam_cube_dde
 from .wsclean_predict import wsclean_predict as _np_wsclean_predict
+from .feeds import feed_rotation as _np_feed_rotation
 
 
 def _need_dask():
@@ -45,6 +46,16 @@ def phase_delay(lm, uvw, frequency, convention="fourier"):
     dtype = np.result_type(np.complex64, lm.dtype, uvw.dtype, frequency.dtype)
     return da.blockwise(_phase_block, ("s", "r", "c"), lm, ("s", "x"), uvw, ("r", "y"),
                         frequency, ("c",), convention=convention, dtype=dtype)
+
+
+# ---------------------------------------------------------------------------- feed_rotation
+def feed_rotation(parallactic_angles, feed_type="linear"):
+    """africanus/rime/dask.py:144-163: one block per chunk of parallactic angles."""
+    _need_dask()
+    pa_dims = tuple("pa-%d" % i for i in range(parallactic_angles.ndim))
+    dtype = np.result_type(parallactic_angles.dtype, np.complex64)
+    return da.blockwise(_np_feed_rotation, pa_dims + ("corr-1", "corr-2"), parallactic_angles, pa_dims,
+                        feed_type=feed_type, new_axes={"corr-1": 2, "corr-2": 2}, dtype=dtype)
 
 
 # ---------------------------------------------------------------------------- wsclean_predict

@@ -100,3 +100,45 @@ def test_dask_vis_to_im():
         ddask.vis_to_im(da.from_array(g6["vis70"], chunks=(r, c, 4)), da.from_array(g6["uvw300"], chunks=(r, 3)),
                         da.from_array(g6["lm"], chunks=(11, 2)), da.from_array(g6["frequency70"], chunks=c),
                         da.from_array(g6["flags70"], chunks=(r, (70,), 4)))
+
+
+def test_dask_producers_and_calibration():
+    """dask front-ends of the producers / calibration consumers (africanus/rime/dask.py:144-163,
+    model/shape/dask.py, model/spectral/dask.py, calibration/utils/dask.py) against the array-level calls"""
+    da = pytest.importorskip("dask.array")
+    from conftest import load_golden
+    from codex_africanus_amd.rime import dask as rdask, feed_rotation
+    from codex_africanus_amd.model.shape import gaussian
+    from codex_africanus_amd.model.shape import dask as sdask
+    from codex_africanus_amd.model.spectral import spectral_model
+    from codex_africanus_amd.model.spectral import dask as pdask
+    from codex_africanus_amd.calibration import utils as cu
+    from codex_africanus_amd.calibration.utils import dask as cdask
+    g8, g9 = load_golden("g8_producers.npz"), load_golden("g9_calibration.npz")
+    out = rdask.feed_rotation(da.from_array(g8["pa"], chunks=(2, 3)), "circular").compute(scheduler="sync")
+    assert_array_equal(out, feed_rotation(g8["pa"], "circular"))
+    out = sdask.gaussian(da.from_array(g8["uvw"], chunks=(13, 3)), da.from_array(g8["freq"], chunks=5),
+                         da.from_array(g8["shape_params"], chunks=(9, 3))).compute(scheduler="sync")
+    assert_array_equal(out, gaussian(g8["uvw"], g8["freq"], g8["shape_params"]))
+    out = pdask.spectral_model(da.from_array(g8["stokes"], chunks=(4, 4)), da.from_array(g8["spi"], chunks=(4, 3, 4)),
+                               da.from_array(g8["spec_ref_freq"], chunks=4), da.from_array(g8["freq"], chunks=7),
+                               base=[0, 1, 2]).compute(scheduler="sync")
+    assert_array_equal(out, spectral_model(g8["stokes"], g8["spi"], g8["spec_ref_freq"], g8["freq"], base=[0, 1, 2]))
+    # calibration: 5 time bins of 6 rows, chunked 2 + 2 + 1 bins (chunkify_rows), chunk-local bin starts
+    row_chunks, tbi, tbc = cu.chunkify_rows(g9["time"], 2)
+    tchunks = (2, 2, 1)
+    d = lambda x, c: da.from_array(x, chunks=c)
+    jones, model = g9["full_jones"], g9["full_model"]
+    dj = d(jones, (tchunks,) + jones.shape[1:])
+    dm = d(model, (row_chunks,) + model.shape[1:])
+    idx = [d(tbi, (tchunks,)), d(tbc, (tchunks,)), d(g9["ant1"], (row_chunks,)), d(g9["ant2"], (row_chunks,))]
+    vis = cdask.corrupt_vis(*idx, dj, dm).compute(scheduler="sync")
+    assert_array_equal(vis, g9["full_vis"])
+    dv, df = d(g9["full_data"], (row_chunks,) + vis.shape[1:]), d(g9["full_flag"], (row_chunks,) + vis.shape[1:])
+    res = cdask.residual_vis(*idx, dj, dv, df, dm).compute(scheduler="sync")
+    assert_array_equal(res, g9["full_residual"])
+    j1 = np.ascontiguousarray(jones[:, :, :, :1])
+    cor = cdask.correct_vis(*idx, d(j1, (tchunks,) + j1.shape[1:]), dv, df).compute(scheduler="sync")
+    assert_array_equal(cor, g9["full_corrected"])
+    with pytest.raises(ValueError, match="Cannot chunk jones over antenna"):
+        cdask.corrupt_vis(*idx, d(jones, (tchunks, 2) + jones.shape[2:]), dm)
