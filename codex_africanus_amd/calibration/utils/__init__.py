@@ -87,6 +87,34 @@ def corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, mo
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
 
 
+def compute_and_corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model, uvw, freq, lm):
+    """
+    ``corrupt_vis`` with the model coherencies of a time-variable point-source model formed on the fly:
+    ``source_vis = model[t,chan,dir] exp(-2 pi i nu/c (u l + v m + w (n-1))) / n``.  Same contract as
+    ``africanus.calibration.utils.compute_and_corrupt_vis``
+    (africanus/calibration/utils/compute_and_corrupt_vis.py:73-152): ``model`` (time, chan, dir, corr[, corr]),
+    ``uvw`` (row, 3), ``freq`` (chan,), ``lm`` (time, dir, 2) -> (row, chan, corr[, corr]) of ``jones``'s dtype.
+    """
+    mode, ncorr = _prepare(jones, (model,), model, "model")
+    ntime, nant = int(jones.shape[0]), int(jones.shape[1])
+    nrow, nchan, ndir = int(uvw.shape[0]), int(model.shape[1]), int(model.shape[2])
+    if tuple(int(s) for s in lm.shape) != (int(model.shape[0]), ndir, 2) or int(freq.shape[0]) != nchan:
+        raise ValueError("model (time, chan, dir, corr...), lm (time, dir, 2) and freq (chan,) disagree")
+    out_shape = (nrow, nchan) + tuple(int(s) for s in model.shape[3:])
+    out_dtype = np_dtype_of(jones)
+    with Call(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model, uvw, freq, lm) as c:
+        p_tbi, p_tbc = c.inp(time_bin_indices, np.int64), c.inp(time_bin_counts, np.int64)
+        p_a1, p_a2 = c.inp(antenna1, np.int64), c.inp(antenna2, np.int64)
+        p_j, p_m = c.inp(jones, np.complex128), c.inp(model, np.complex128)
+        p_uvw, p_fr, p_lm = c.inp(uvw, np.float64), c.inp(freq, np.float64), c.inp(lm, np.float64)
+        p_out, h = c.out(out_shape, np.complex128)
+        ws = int(_lib.load().af_calibration_workspace_bytes(nrow))
+        p_ws = c.scratch(ws)
+        _lib.call("af_compute_and_corrupt_vis_c128", p_tbi, p_tbc, int(time_bin_indices.shape[0]), p_a1, p_a2, p_j, p_m,
+                  p_uvw, p_fr, p_lm, nrow, nant, nchan, ndir, mode, ncorr, p_out, p_ws, max(ws, 256), c.stream)
+        return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
+
+
 def residual_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag, model):
     """
     ``residual = vis - sum_dir G_p model_dir G_q^H`` where no correlation of the (row, chan) cell is flagged,

@@ -104,13 +104,17 @@ __device__ __forceinline__ void jones_term(int64_t ndir, const C2 *__restrict__ 
     }
 }
 
-// OP 0 corrupt, 1 residual, 2 correct; grid: ceil(nrow*nchan / 256)
+// OP 0 corrupt, 1 residual, 2 correct, 3 compute-and-corrupt (model per time bin, phase computed here);
+// grid: ceil(nrow*nchan / 256)
 template <int OP, int MODE, int NCORR>
 __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
                                                     const int64_t *__restrict__ ant2, const C2 *__restrict__ jones,
                                                     const C2 *__restrict__ vis, const unsigned char *__restrict__ flag,
                                                     const C2 *__restrict__ model, int64_t nrow, int64_t nant,
-                                                    int64_t nchan, int64_t ndir, C2 *__restrict__ out)
+                                                    int64_t nchan, int64_t ndir, C2 *__restrict__ out,
+                                                    const double *__restrict__ uvw = nullptr,
+                                                    const double *__restrict__ freq = nullptr,
+                                                    const double *__restrict__ lm = nullptr)
 {
     constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
     const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[c] = C2{0.0, 0.0};
     bool active = t >= 0;
-    if (OP != 0 && active) {
+    if ((OP == 1 || OP == 2) && active) {
 #pragma unroll
         for (int c = 0; c < V; ++c) active = active && flag[cell * V + c] == 0;
     }
@@ -131,6 +135,24 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
         const C2 *a2j = jones + (((int64_t)t * nant + q) * nchan + nu) * ndir * J;
         if constexpr (OP == 0) {
             jones_term<MODE, NCORR, +1>(ndir, a1j, model + cell * ndir * V, a2j, acc);
+        } else if constexpr (OP == 3) {
+            // compute_and_corrupt_vis.py:14-22: source_vis = model[t,nu,s] * exp(1j * real_phase) / n, n = sqrt(1 - l^2 - m^2)
+            const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2], nuf = freq[nu];
+            const C2 *mt = model + ((int64_t)t * nchan + nu) * ndir * V;
+            for (int64_t s = 0; s < ndir; ++s) {
+                const double l = lm[((int64_t)t * ndir + s) * 2], m = lm[((int64_t)t * ndir + s) * 2 + 1];
+                const double n = __dsqrt_rn(__dsub_rn(__dsub_rn(1.0, __dmul_rn(l, l)), __dmul_rn(m, m)));
+                const double real_phase = __dmul_rn(
+                    __dmul_rn(AF_MINUS_TWO_PI_OVER_C, nuf),
+                    __dadd_rn(__dadd_rn(__dmul_rn(u, l), __dmul_rn(v, m)), __dmul_rn(w, __dsub_rn(n, 1.0))));
+                double sp, cp;
+                sincos(real_phase, &sp, &cp);
+                const C2 ph{cp, sp}, nn{n, 0.0};
+                C2 sv[V];
+#pragma unroll
+                for (int c = 0; c < V; ++c) sv[c] = cdiv(cmul(mt[s * V + c], ph), nn);
+                jones_term<MODE, NCORR, +1>(1, a1j + s * J, sv, a2j + s * J, acc);
+            }
         } else if constexpr (OP == 1) {
 #pragma unroll
             for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
@@ -168,7 +190,8 @@ template <int OP>
 int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, const int64_t *ant1, const int64_t *ant2,
         const double *jones, const double *vis, const unsigned char *flag, const double *model, int64_t nrow,
         int64_t nant, int64_t nchan, int64_t ndir, int mode, int ncorr, double *out, void *workspace,
-        size_t workspace_bytes, void *stream, const char *who)
+        size_t workspace_bytes, void *stream, const char *who, const double *uvw = nullptr, const double *freq = nullptr,
+        const double *lm = nullptr)
 {
     AF_REQUIRE(mode >= 0 && mode <= 2, "%s: mode must be 0 (DIAG_DIAG), 1 (DIAG) or 2 (FULL)", who);
     AF_REQUIRE(ncorr == 1 || ncorr == 2, "ncorr cant be larger than 2");
@@ -179,7 +202,8 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     if (nrow == 0 || nchan == 0) return AF_OK;
     AF_REQUIRE(out && ant1 && ant2 && (ntime == 0 || (tbin_idx && tbin_counts)), "%s: NULL array", who);
     AF_REQUIRE(jones || ntime == 0, "%s: NULL jones", who);
-    AF_REQUIRE(OP == 0 || (vis && flag), "%s: NULL vis / flag", who);
+    AF_REQUIRE(OP == 0 || OP == 3 || (vis && flag), "%s: NULL vis / flag", who);
+    AF_REQUIRE(OP != 3 || (uvw && freq && (lm || ndir == 0)), "%s: NULL uvw / freq / lm", who);
     AF_REQUIRE(OP == 2 || model || ndir == 0, "%s: NULL model", who);
     const size_t need = 256 + (size_t)nrow * sizeof(int);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= need, "%s: workspace too small (%zu < %zu)", who,
@@ -200,7 +224,7 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     C2 *o = reinterpret_cast<C2 *>(out);
 #define AF_CALIB_LAUNCH(M, N)                                                                                          \
     hipLaunchKernelGGL((calib_kernel<OP, M, N>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow, nant, \
-                       nchan, ndir, o)
+                       nchan, ndir, o, uvw, freq, lm)
     if (mode == 0 && ncorr == 1) AF_CALIB_LAUNCH(0, 1);
     else if (mode == 0) AF_CALIB_LAUNCH(0, 2);
     else if (mode == 1) AF_CALIB_LAUNCH(1, 2);
@@ -241,4 +265,16 @@ AF_EXPORT int af_correct_vis_c128(const int64_t *time_bin_indices, const int64_t
 {
     return run<2>(time_bin_indices, time_bin_counts, ntime, antenna1, antenna2, jones, vis, flag, nullptr, nrow, nant, nchan,
                   ndir, mode, ncorr, out, workspace, workspace_bytes, stream, "af_correct_vis_c128");
+}
+
+AF_EXPORT int af_compute_and_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts,
+                                              int64_t ntime, const int64_t *antenna1, const int64_t *antenna2,
+                                              const double *jones, const double *model, const double *uvw,
+                                              const double *frequency, const double *lm, int64_t nrow, int64_t nant,
+                                              int64_t nchan, int64_t ndir, int mode, int ncorr, double *out,
+                                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run<3>(time_bin_indices, time_bin_counts, ntime, antenna1, antenna2, jones, nullptr, nullptr, model, nrow, nant,
+                  nchan, ndir, mode, ncorr, out, workspace, workspace_bytes, stream, "af_compute_and_corrupt_vis_c128", uvw,
+                  frequency, lm);
 }

@@ -311,6 +311,17 @@ int af_spectral_model_f64(const double *stokes, const double *spi, const double 
                           const int *base, int64_t nsrc, int64_t nspi, int64_t npol, int64_t nchan, double *out,
                           void *stream);
 
+/* Replaces africanus.calibration.utils.compute_and_corrupt_vis (calibration/utils/compute_and_corrupt_vis.py:73-152):
+ * corrupt_vis with the model coherencies formed on the fly from a time-variable point-source model,
+ *   source_vis = model[t,nu,dir] * exp(-2 pi i nu/c (u l + v m + w (n - 1))) / n,  n = sqrt(1 - l^2 - m^2),
+ * model (ntime,nchan,ndir,V), lm (ntime,ndir,2), uvw (nrow,3), frequency (nchan); the rest as af_corrupt_vis_c128. */
+int af_compute_and_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts,
+                                    int64_t ntime, const int64_t *antenna1, const int64_t *antenna2,
+                                    const double *jones, const double *model, const double *uvw,
+                                    const double *frequency, const double *lm, int64_t nrow, int64_t nant,
+                                    int64_t nchan, int64_t ndir, int mode, int ncorr, double *out,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

@@ -304,6 +304,21 @@ def corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, mo
     return out
 
 
+def compute_and_corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model, uvw, freq, lm):
+    """africanus/calibration/utils/compute_and_corrupt_vis.py:73-152."""
+    mode = _calib_mode(jones, model, "model")
+    tbi, tbc, a1, a2 = _calib_common(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, (model,))
+    jn, md = _c(jones, np.complex128), _c(model, np.complex128)
+    uvw_, fr, lm_ = _c(uvw, np.float64), _c(freq, np.float64), _c(lm, np.float64)
+    nrow, nchan, ndir = uvw_.shape[0], md.shape[1], md.shape[2]
+    out = np.empty((nrow, fr.shape[0]) + md.shape[3:], dtype=np.complex128)
+    rc = _lib().orc_compute_and_corrupt_vis_c128(_p(tbi), _p(tbc), _i64(tbi.shape[0]), _p(a1), _p(a2), _p(jn), _p(md),
+                                                 _p(uvw_), _p(fr), _p(lm_), _i64(nrow), _i64(jn.shape[1]), _i64(nchan),
+                                                 _i64(ndir), ctypes.c_int(mode), ctypes.c_int(md.shape[-1]), _p(out))
+    assert rc == 0
+    return out
+
+
 def residual_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag, model):
     """africanus/calibration/utils/residual_vis.py:63-119."""
     mode = _calib_mode(jones, vis, "vis")

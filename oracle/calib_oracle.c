@@ -71,6 +71,28 @@ static void jones_term(int mode, int ncorr, int64_t ndir, const cplx *a1j, const
     }
 }
 
+/* compute_and_corrupt_vis.py:11-71: source_vis = model[s] * exp(1j * real_phase) / n per direction, then the
+ * jones_mul body; model (ndir, V) of the row's time bin, lm (ndir, 2) of the time bin */
+static void jones_term_computed(int mode, int ncorr, int64_t ndir, const cplx *a1j, const cplx *model, const cplx *a2j,
+                                const double *uvw, double freq, const double *lm, cplx *acc)
+{
+    const double m2pioc = -2 * 3.141592653589793 / 2.99792458e8;
+    const int V = mode == 0 ? ncorr : 4;
+    for (int64_t s = 0; s < ndir; ++s) {
+        const double l = lm[2 * s], m = lm[2 * s + 1];
+        const double n = sqrt(1 - l * l - m * m);
+        const double real_phase = m2pioc * freq * (uvw[0] * l + uvw[1] * m + uvw[2] * (n - 1));
+        /* 1.0j * real_phase = (0*x - 1*0, 0*0 + 1*x); np.exp of it = exp(re) * (cos, sin) */
+        const double ere = exp(0.0 * real_phase - 1.0 * 0.0), eim = 0.0 * 0.0 + 1.0 * real_phase;
+        const cplx ph = { ere * cos(eim), ere * sin(eim) };
+        const cplx nn = { n, 0.0 };
+        cplx sv[4];
+        for (int c = 0; c < V; ++c) sv[c] = cdiv(cmul(model[s * V + c], ph), nn);
+        jones_term(mode, ncorr, 1, a1j + s * (mode == 0 ? ncorr : (mode == 1 ? 2 : 4)), sv,
+                   a2j + s * (mode == 0 ? ncorr : (mode == 1 ? 2 : 4)), +1, acc);
+    }
+}
+
 static int jones_elems(int mode, int ncorr) { return mode == 0 ? ncorr : (mode == 1 ? 2 : 4); }
 static int vis_elems(int mode, int ncorr) { return mode == 0 ? ncorr : 4; }
 
@@ -162,6 +184,27 @@ int orc_correct_vis_c128(const int64_t *tbin_idx, const int64_t *tbin_counts, in
                     r[3] = cadd(cadd(cadd(cmul(t1, b01), cmul(t2, b01)), cmul(t3, b11)), cmul(t4, b11));
                 }
             }
+        }
+    return 0;
+}
+
+/* compute_and_corrupt_vis.py:73-152: model (ntime,nchan,ndir,V), lm (ntime,ndir,2), uvw (nrow,3), freq (nchan) */
+int orc_compute_and_corrupt_vis_c128(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime,
+                                     const int64_t *ant1, const int64_t *ant2, const double *jones, const double *model,
+                                     const double *uvw, const double *freq, const double *lm, int64_t nrow, int64_t nant,
+                                     int64_t nchan, int64_t ndir, int mode, int ncorr, double *out)
+{
+    const int J = jones_elems(mode, ncorr), V = vis_elems(mode, ncorr);
+    const cplx *jn = (const cplx *)jones, *md = (const cplx *)model;
+    cplx *o = (cplx *)out;
+    memset(out, 0, sizeof(double) * 2 * (size_t)(nrow * nchan * V));
+    for (int64_t t = 0; t < ntime; ++t)
+        for (int64_t row = tbin_idx[t]; row < tbin_idx[t] + tbin_counts[t]; ++row) {
+            const int64_t p = ant1[row], q = ant2[row];
+            for (int64_t nu = 0; nu < nchan; ++nu)
+                jones_term_computed(mode, ncorr, ndir, jn + ((t * nant + p) * nchan + nu) * ndir * J,
+                                    md + (t * nchan + nu) * ndir * V, jn + ((t * nant + q) * nchan + nu) * ndir * J,
+                                    uvw + 3 * row, freq[nu], lm + t * ndir * 2, o + (row * nchan + nu) * V);
         }
     return 0;
 }

@@ -365,6 +365,7 @@ def g9_calibration():
     for the four (corr, jones) layouts of calibration/utils/tests/test_utils.py:10-18, seeded; time bins as
     produced by chunkify_rows (utils.py:48-61)."""
     from africanus.calibration.utils import corrupt_vis, residual_vis, correct_vis, chunkify_rows
+    from africanus.calibration.utils import compute_and_corrupt_vis
     rs = np.random.RandomState(9)
     ntime, nant, nchan, ndir = 5, 4, 6, 3
     a1, a2 = np.triu_indices(nant, 1)
@@ -374,7 +375,10 @@ def g9_calibration():
     nrow = time.shape[0]
     _, tbi, tbc = chunkify_rows(time, ntime)
     rc = lambda *sh: rs.normal(size=sh) + 1j * rs.normal(size=sh)
-    out = dict(time=time, ant1=ant1, ant2=ant2, tbin_idx=tbi, tbin_counts=tbc)
+    cc_uvw = rs.normal(size=(nrow, 3)) * 800.0
+    cc_freq = np.linspace(1.0e9, 1.2e9, nchan)
+    cc_lm = rs.normal(size=(ntime, ndir, 2)) * 0.02
+    out = dict(time=time, ant1=ant1, ant2=ant2, tbin_idx=tbi, tbin_counts=tbc, cc_uvw=cc_uvw, cc_freq=cc_freq, cc_lm=cc_lm)
     for tag, corr, jcorr in (("dd1", (1,), (1,)), ("dd2", (2,), (2,)), ("diag", (2, 2), (2,)), ("full", (2, 2), (2, 2))):
         jones = rc(ntime, nant, nchan, ndir, *jcorr) + 1.0
         model = rc(nrow, nchan, ndir, *corr)
@@ -384,6 +388,9 @@ def g9_calibration():
         res = residual_vis(tbi.copy(), tbc, ant1, ant2, jones, data, flag, model)
         j1 = np.ascontiguousarray(jones[:, :, :, :1])
         cor = correct_vis(tbi.copy(), tbc, ant1, ant2, j1, data, flag)
+        tmodel = rc(ntime, nchan, ndir, *corr)
+        out[tag + "_tmodel"] = tmodel
+        out[tag + "_ccvis"] = compute_and_corrupt_vis(tbi.copy(), tbc, ant1, ant2, jones, tmodel, cc_uvw, cc_freq, cc_lm)
         out.update({tag + "_jones": jones, tag + "_model": model, tag + "_vis": vis, tag + "_data": data,
                     tag + "_flag": flag, tag + "_residual": res, tag + "_corrected": cor})
     save("g9_calibration.npz", **out)

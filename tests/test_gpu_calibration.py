@@ -85,3 +85,26 @@ def test_calibration_torch_device_resident(g9):
                        T(g9["full_data"]), T(g9["full_flag"]), T(g9["full_model"]))
     assert isinstance(out, torch.Tensor) and out.is_cuda
     assert_array_equal(out.cpu().numpy(), g9["full_residual"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_compute_and_corrupt_vis_golden(g9, tag):
+    """the predict (phase x time-variable model / n) fused into corrupt_vis; device sin/cos are within 1 ulp of
+    libm's, everything else is the reference's operation order"""
+    from codex_africanus_amd.calibration.utils import compute_and_corrupt_vis
+    a = (g9["tbin_idx"], g9["tbin_counts"], g9["ant1"], g9["ant2"])
+    out = compute_and_corrupt_vis(*a, g9[tag + "_jones"], g9[tag + "_tmodel"], g9["cc_uvw"], g9["cc_freq"], g9["cc_lm"])
+    ref = g9[tag + "_ccvis"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.abs(out - ref).max() <= 1e-14 * np.abs(ref).max()
+    # equals corrupt_vis on the materialised coherencies (compute_and_corrupt_vis.py:14-22)
+    uvw, freq, lm, tm = g9["cc_uvw"], g9["cc_freq"], g9["cc_lm"], g9[tag + "_tmodel"]
+    tidx = np.repeat(np.arange(5), 6)
+    l, m = lm[..., 0], lm[..., 1]
+    n = np.sqrt(1 - l**2 - m**2)
+    ph = -2 * np.pi / 299792458.0 * freq[None, :, None] * (uvw[:, 0, None, None] * l[tidx][:, None, :]
+                                                            + uvw[:, 1, None, None] * m[tidx][:, None, :]
+                                                            + uvw[:, 2, None, None] * (n[tidx][:, None, :] - 1))
+    extra = (None,) * (tm.ndim - 3)
+    model = tm[tidx] * (np.exp(1j * ph) / n[tidx][:, None, :])[(..., ) + extra]
+    np.testing.assert_allclose(out, corrupt_vis(*a, g9[tag + "_jones"], model), rtol=1e-12, atol=1e-12)

@@ -446,3 +446,11 @@ def test_spectral_model_bit_exact(g8):
         assert_array_equal(oracle.spectral_model(*a, base=base), g8[key])
     assert_array_equal(oracle.spectral_model(g8["stokes"][:, 0].copy(), g8["spi"][:, :, 0].copy(), g8["spec_ref_freq"],
                                              g8["freq"], base="log"), g8["spec_nopol"])
+
+
+@pytest.mark.parametrize("tag", CALIB_TAGS)
+def test_compute_and_corrupt_vis_bit_exact(g9, tag):
+    """oracle vs africanus.calibration.utils.compute_and_corrupt_vis run here (make_golden.py g9)"""
+    a = (g9["tbin_idx"], g9["tbin_counts"], g9["ant1"], g9["ant2"])
+    out = oracle.compute_and_corrupt_vis(*a, g9[tag + "_jones"], g9[tag + "_tmodel"], g9["cc_uvw"], g9["cc_freq"], g9["cc_lm"])
+    assert_array_equal(out, g9[tag + "_ccvis"])
