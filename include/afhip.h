@@ -322,6 +322,22 @@ int af_compute_and_corrupt_vis_c128(const int64_t *time_bin_indices, const int64
                                     int64_t nchan, int64_t ndir, int mode, int ncorr, double *out,
                                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Replaces africanus.gridding.perleypolyhedron.gridder.gridder (gridding/perleypolyhedron/gridder.py:12-117), the
+ * adjoint of the degridder: conv_policy 0 "conv_1d_axisymmetric_unpacked_scatter", 1 "..._packed_scatter",
+ * 2 "conv_nn_scatter" (policies/convolution_policies.py:6-185); corr_factors (ncorr) complex128 DEVICE = the
+ * corr2stokes policy (policies/stokes_conversion_policies.py:143-180) as per-correlation factors; phase_rotate != 0
+ * applies the facet phase rotation with sign +1 first; do_normalize divides every band by its summed tap weights
+ * + 1e-8.  vis (nrow,nchan,ncorr) complex128 (not modified); gridstack (nband,npix,npix) complex128, zeroed by the
+ * call; the adds are hardware fp64 atomics, so results are reproducible to rounding only.
+ * workspace: af_gridder_workspace_bytes(nrow, nband). */
+size_t af_gridder_workspace_bytes(int64_t nrow, int64_t nband);
+int af_gridder_c128(const double *uvw, const double *vis, const double *wavelengths, const int64_t *chanmap,
+                    int64_t npix, double cell, const double *image_centre_host, const double *phase_centre_host,
+                    const double *convolution_kernel, int64_t kernel_width, int64_t kernel_oversampling,
+                    int phase_rotate, const double *corr_factors, int ncorr, int conv_policy, int do_normalize,
+                    int64_t nrow, int64_t nchan, int64_t nband, double *gridstack, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 /* ---- WSClean component-list predict ------------------------------------------------
  * Replaces africanus.model.wsclean.spectra (africanus/model/wsclean/spec_model.py:70-126) and
  * africanus.rime.wsclean_predict (africanus/rime/wsclean_predict.py:11-120):

@@ -263,6 +263,53 @@ def degridder(uvw, gridstack, wavelengths, chanmap, cell, image_centre, phase_ce
     return out.astype(vis_dtype, copy=False)
 
 
+# corr2stokes policies as per-correlation factors (policies/stokes_conversion_policies.py:143-180)
+CORR2STOKES = {
+    "I_FROM_XXYY": [.5, .5], "I_FROM_XXXYYXYY": [.5, 0, 0, .5], "I_FROM_RRLL": [.5, .5], "I_FROM_RRRLLRLL": [.5, 0, 0, .5],
+    "Q_FROM_XXYY": [.5, -.5], "Q_FROM_XXXYYXYY": [.5, 0, 0, -.5], "Q_FROM_RRRLLRLL": [0, .5, .5, 0],
+    "U_FROM_XYYX": [.5, .5], "U_FROM_XXXYYXYY": [0, .5, .5, 0], "U_FROM_RLLR": [-.5j, .5j],
+    "U_FROM_RRRLLRLL": [0, -.5j, .5j, 0], "V_FROM_RRLL": [.5, -.5], "V_FROM_RRRLLRLL": [.5, 0, 0, -.5],
+    "V_FROM_XYYX": [-.5j, .5j], "V_FROM_XXXYYXYY": [0, -.5j, .5j, 0],
+}
+
+
+def gridder(uvw, vis, wavelengths, chanmap, npix, cell, image_centre, phase_centre, convolution_kernel,
+            convolution_kernel_width, convolution_kernel_oversampling, baseline_transform_policy,
+            phase_transform_policy, stokes_conversion_policy, convolution_policy, grid_dtype=np.complex128,
+            do_normalize=False):
+    """africanus/gridding/perleypolyhedron/gridder.py:12-117 (scatter policies; 'None' baseline transform)."""
+    if np.size(chanmap) != np.size(wavelengths):
+        raise ValueError("Chanmap and corresponding wavelengths must match in shape")
+    chanmap = _c(np.ravel(chanmap), np.int64)
+    wl = _c(np.ravel(wavelengths), np.float64)
+    if uvw.shape[1] != 3:
+        raise ValueError("UVW array must be array of tripples")
+    if uvw.shape[0] != vis.shape[0]:
+        raise ValueError("UVW array must have same number of rows as vis array")
+    if vis.shape[1] != wl.size:
+        raise ValueError("Chanmap must correspond to visibility channels")
+    assert baseline_transform_policy == "None"
+    ppol = {"None": 0, None: 0, "phase_rotate": 1}[phase_transform_policy]
+    cpol = {"conv_1d_axisymmetric_unpacked_scatter": 0, "conv_1d_axisymmetric_packed_scatter": 1,
+            "conv_nn_scatter": 2}[convolution_policy]
+    coef = _c(np.asarray(CORR2STOKES[stokes_conversion_policy], dtype=np.complex128), np.complex128)
+    if coef.shape[0] != vis.shape[2]:
+        raise ValueError("stokes_conversion_policy does not fit the correlations of vis")
+    nband = int(chanmap.max()) + 1
+    uvw_, vs = _c(uvw, np.float64), _c(vis, np.complex128)
+    k = _c(convolution_kernel, np.float64)
+    ic, pc = _c(image_centre, np.float64), _c(phase_centre, np.float64)
+    out = np.empty((nband, npix, npix), dtype=np.complex128)
+    wt = np.empty(nband, dtype=np.float64)
+    rc = _lib().orc_gridder_c128(_p(uvw_), _p(vs), _p(wl), _p(chanmap), _i64(npix), ctypes.c_double(cell), _p(ic), _p(pc),
+                                 _p(k), _i64(convolution_kernel_width), _i64(convolution_kernel_oversampling),
+                                 ctypes.c_int(ppol), _p(coef), ctypes.c_int(coef.shape[0]), ctypes.c_int(cpol),
+                                 ctypes.c_int(int(bool(do_normalize))), _i64(uvw_.shape[0]), _i64(wl.shape[0]),
+                                 _i64(nband), _p(out), _p(wt))
+    assert rc == 0
+    return out.astype(grid_dtype, copy=False)
+
+
 # ---- calibration consumers (africanus/calibration/utils) ------------------------------------------------
 def _calib_mode(jones, vis, vis_type):
     """africanus/calibration/utils/utils.py:11-45 (check_type)."""

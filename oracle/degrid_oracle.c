@@ -89,3 +89,87 @@ int orc_degridder_c128(const double *uvw, const double *grid, const double *wave
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * gridder: africanus/gridding/perleypolyhedron/gridder.py:12-117 with the scatter policies
+ * (policies/convolution_policies.py:6-185: unpacked 0, packed 1, nearest neighbour 2) and corr2stokes given as
+ * per-correlation complex factors (policies/stokes_conversion_policies.py:143-180).  The facet phase rotation is
+ * applied with phasesign +1 before gridding (:81-91); the tap weights of a visibility are summed over ALL taps,
+ * on or off the grid (:57-67), per band; do_normalize divides every band by its weight sum + 1e-8 (:114-116).
+ * vis (nrow,nchan,ncorr) complex128; out grid (nband,npix,npix) complex128.
+ * ---------------------------------------------------------------------- */
+int orc_gridder_c128(const double *uvw, const double *vis, const double *wavelengths, const int64_t *chanmap,
+                     int64_t npix, double cell, const double *image_centre, const double *phase_centre,
+                     const double *kernel, int64_t W, int64_t os, int phase_policy, const double *coef, int ncorr,
+                     int conv_policy, int do_normalize, int64_t nrow, int64_t nchan, int64_t nband, double *out,
+                     double *wt_out)
+{
+    const cplx *vs = (const cplx *)vis;
+    cplx *g = (cplx *)out;
+    const double ra0 = phase_centre[0], dec0 = phase_centre[1], ra = image_centre[0], dec = image_centre[1];
+    const double scale_factor = npix * cell / 3600.0 * 3.141592653589793 / 180.0;
+    const int64_t klen = os * (W + 2);
+    const double d_ra = ra - ra0, c_d_ra = cos(d_ra), s_d_ra = sin(d_ra);
+    const double c_new = cos(dec), c_old = cos(dec0), s_new = sin(dec), s_old = sin(dec0);
+    const double ll = c_new * s_d_ra, mm = s_new * c_old - c_new * s_old * c_d_ra;
+    const double nn = -(1 - sqrt(1 - ll * ll - mm * mm));
+    memset(out, 0, sizeof(double) * 2 * (size_t)(nband * npix * npix));
+    for (int64_t b = 0; b < nband; ++b) wt_out[b] = 0.0;
+    for (int64_t r = 0; r < nrow; ++r) {
+        const double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+        for (int64_t c = 0; c < nchan; ++c) {
+            double pr = 1.0, pi_ = 0.0;
+            if (phase_policy == 1) {
+                const double x = 1.0 * 2 * 3.141592653589793 * (u * ll + v * mm + w * nn) / wavelengths[c];
+                pr = cos(x); pi_ = sin(x);
+            }
+            cplx s = {0.0, 0.0};
+            for (int k = 0; k < ncorr; ++k) {
+                const cplx x = vs[(r * nchan + c) * ncorr + k];
+                const double xr = x.re * pr - x.im * pi_, xi = x.re * pi_ + x.im * pr;   /* vis *= phase */
+                s.re += coef[2 * k] * xr - coef[2 * k + 1] * xi;
+                s.im += coef[2 * k] * xi + coef[2 * k + 1] * xr;
+            }
+            const double su = u * scale_factor / wavelengths[c], sv = v * scale_factor / wavelengths[c];
+            cplx *gb = g + chanmap[c] * npix * npix;
+            const double offset_u = su + npix / 2, offset_v = sv + npix / 2;
+            const int64_t disc_u = py_round_i(offset_u), disc_v = py_round_i(offset_v);
+            if (conv_policy == 2) {
+                if (disc_u >= 0 && disc_u < npix && disc_v >= 0 && disc_v < npix) {
+                    gb[disc_v * npix + disc_u].re += s.re;
+                    gb[disc_v * npix + disc_u].im += s.im;
+                }
+                wt_out[chanmap[c]] += 1.0;
+                continue;
+            }
+            const int64_t frac_u = (int64_t)((-offset_u + disc_u) * os), frac_v = (int64_t)((-offset_v + disc_v) * os);
+            const int64_t fo_u = frac_u < 0 ? 0 : 1, fo_v = frac_v < 0 ? 0 : 1;
+            double cw = 0.0;
+            for (int64_t tv = 0; tv < W; ++tv) {
+                int64_t iv = conv_policy == 1 ? tv + fo_v + frac_v * (W + 2) : (tv + 1) * os + frac_v;
+                if (iv < 0) iv += klen;
+                const double conv_v = kernel[iv];
+                const int64_t gv = disc_v + tv - W / 2;
+                for (int64_t tu = 0; tu < W; ++tu) {
+                    int64_t iu = conv_policy == 1 ? tu + fo_u + frac_u * (W + 2) : (tu + 1) * os + frac_u;
+                    if (iu < 0) iu += klen;
+                    const double conv_u = kernel[iu];
+                    const int64_t gu = disc_u + tu - W / 2;
+                    if (gv >= 0 && gv < npix && gu >= 0 && gu < npix) {
+                        gb[gv * npix + gu].re += conv_v * conv_u * s.re;
+                        gb[gv * npix + gu].im += conv_v * conv_u * s.im;
+                    }
+                    cw += conv_v * conv_u;
+                }
+            }
+            wt_out[chanmap[c]] += cw;
+        }
+    }
+    if (do_normalize)
+        for (int64_t b = 0; b < nband; ++b)
+            for (int64_t i = 0; i < npix * npix; ++i) {
+                g[b * npix * npix + i].re /= wt_out[b] + 1.0e-8;
+                g[b * npix * npix + i].im /= wt_out[b] + 1.0e-8;
+            }
+    return 0;
+}

@@ -428,6 +428,23 @@ def g10_degridder():
     for tag, bpol, ppol, spol, cpol, k, centre in cases:
         out[tag] = degridder_serial(uvw.copy(), grid, wavelengths, chanmap, cell, (centre[0], centre[1]),
                                     (pc[0], pc[1]), k, W, OS, bpol, ppol, spol, cpol)
+    # the adjoint: gridder.py:12-117 with the scatter policies
+    from africanus.gridding.perleypolyhedron.gridder import gridder
+    vis2 = rs.normal(size=(nrow, nchan, 2)) + 1j * rs.normal(size=(nrow, nchan, 2))
+    vis4 = rs.normal(size=(nrow, nchan, 4)) + 1j * rs.normal(size=(nrow, nchan, 4))
+    out.update(gvis2=vis2, gvis4=vis4)
+    gcases = [("grid_unpacked_I2", vis2, "None", "I_FROM_XXYY", "conv_1d_axisymmetric_unpacked_scatter", kern, pc, False),
+              ("grid_packed_V4_rot_norm", vis4, "phase_rotate", "V_FROM_XXXYYXYY", "conv_1d_axisymmetric_packed_scatter",
+               pkern, ic, True),
+              ("grid_packed_Q2_rot", vis2, "phase_rotate", "Q_FROM_XXYY", "conv_1d_axisymmetric_packed_scatter", pkern, ic,
+               False),
+              ("grid_nn_U4", vis4, "None", "U_FROM_RRRLLRLL", "conv_nn_scatter", kern, pc, True)]
+    inside = np.abs(uvw[:, :2]).max(axis=1) < umax          # conv_nn_scatter has no bounds check in the reference
+    out["grid_nn_rows"] = inside
+    for tag, v, ppol, spol, cpol, k, centre, norm in gcases:
+        rows = inside if cpol == "conv_nn_scatter" else np.ones(nrow, bool)
+        out[tag] = gridder(uvw[rows].copy(), v[rows].copy(), wavelengths, chanmap, npix, cell, (centre[0], centre[1]),
+                           (pc[0], pc[1]), k, W, OS, "None", ppol, spol, cpol, do_normalize=norm)
     save("g10_degridder.npz", **out)
 
 

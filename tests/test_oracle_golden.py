@@ -454,3 +454,26 @@ def test_compute_and_corrupt_vis_bit_exact(g9, tag):
     a = (g9["tbin_idx"], g9["tbin_counts"], g9["ant1"], g9["ant2"])
     out = oracle.compute_and_corrupt_vis(*a, g9[tag + "_jones"], g9[tag + "_tmodel"], g9["cc_uvw"], g9["cc_freq"], g9["cc_lm"])
     assert_array_equal(out, g9[tag + "_ccvis"])
+
+
+GRID_CASES = [
+    ("grid_unpacked_I2", "gvis2", "None", "I_FROM_XXYY", "conv_1d_axisymmetric_unpacked_scatter", "kern", "phase_centre", False),
+    ("grid_packed_V4_rot_norm", "gvis4", "phase_rotate", "V_FROM_XXXYYXYY", "conv_1d_axisymmetric_packed_scatter", "pkern",
+     "image_centre", True),
+    ("grid_packed_Q2_rot", "gvis2", "phase_rotate", "Q_FROM_XXYY", "conv_1d_axisymmetric_packed_scatter", "pkern",
+     "image_centre", False),
+    ("grid_nn_U4", "gvis4", "None", "U_FROM_RRRLLRLL", "conv_nn_scatter", "kern", "phase_centre", True),
+]
+
+
+@pytest.mark.parametrize("tag, vkey, ppol, spol, cpol, kern, centre, norm", GRID_CASES)
+def test_gridder_oracle_vs_reference(g10, tag, vkey, ppol, spol, cpol, kern, centre, norm):
+    """oracle vs africanus.gridding.perleypolyhedron.gridder.gridder run here (make_golden.py g10); fastmath in the
+    reference: agreement to rounding"""
+    rows = g10["grid_nn_rows"] if cpol == "conv_nn_scatter" else np.ones(g10["uvw"].shape[0], bool)
+    out = oracle.gridder(g10["uvw"][rows], g10[vkey][rows], g10["wavelengths"], g10["chanmap"], 64, float(g10["cell"]),
+                         g10[centre], g10["phase_centre"], g10[kern], int(g10["W"]), int(g10["OS"]), "None", ppol, spol,
+                         cpol, do_normalize=norm)
+    ref = g10[tag]
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= (1e-10 if ppol == "phase_rotate" else 1e-14) * np.abs(ref).max()
