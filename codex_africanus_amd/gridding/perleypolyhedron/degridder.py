@@ -2,7 +2,7 @@
 import numpy as np
 
 from ... import _lib
-from ..._device import Call, np_dtype_of, _is_torch
+from ..._device import Call, _is_torch
 
 # stokes2corr policies as per-correlation factors (policies/stokes_conversion_policies.py:8-137)
 STOKES_TO_CORR = {

@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 
 from .. import _lib
-from .._device import Call, np_dtype_of, _is_torch
+from .._device import Call, _is_torch
 from .predict import predict_vis
 
 

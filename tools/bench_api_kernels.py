@@ -2,7 +2,7 @@
 """Achieved HBM bandwidth of the API-compatible (materialised-input) kernels on one MI355X:
 predict_vis (coh only / dde+coh+die), phase_delay, beam_cube_dde, chi2.  Device-resident torch
 tensors, HIP-event timing on torch's stream, algorithmic bytes = inputs read once + output written once."""
-import ctypes, json, sys, os
+import json, sys, os
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

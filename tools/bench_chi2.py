@@ -1,5 +1,5 @@
 import ctypes, sys, os, json
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from codex_africanus_amd import _lib
 lib = _lib.load()
