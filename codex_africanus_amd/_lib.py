@@ -95,6 +95,7 @@ _SIGNATURES = {
     "af_gridder_workspace_bytes": (_sz, [_i64, _i64]),
     "af_gridder_c128": (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _i64, _i64, _int, _vp, _int, _int,
                                _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "af_coherency_convert": (_int, [_vp, _int, _i64, _int, _int, _vp, _vp, _vp, _vp, _int, _vp]),
     "af_wsclean_spectra_f64": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "af_wsclean_predict_workspace_bytes": (_sz, [_i64, _i64]),
     "af_wsclean_predict_f64": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,

@@ -303,6 +303,30 @@ int af_degridder_c128(const double *uvw, const double *gridstack, const double *
                       int packed, int64_t nrow, int64_t nchan, int64_t npix, double *out, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* Replaces africanus.model.coherency.convert (africanus/model/coherency/conversion.py:207-216; products :18-48):
+ * Stokes <-> correlation conversion.  input (nelem, nin) of dtype `in_kind`, out (nelem, nout) of dtype `out_kind`
+ * (AF_KIND_*: same precision; complex input -> complex output; a real output admits only the two real products).
+ * Output o is the product op[o] of input columns src1[o], src2[o] (-1 = the implicit Stokes default 0,
+ * `implicit_stokes=True`), the three tables being HOST arrays of nout ints (the schema resolution is host logic):
+ *   AF_CONV_ADD  a + b + 0j   (RR, XX)      AF_CONV_SUB   a - b + 0j  (LL, YY)
+ *   AF_CONV_ADDJ a + b*1j     (RL, XY)      AF_CONV_SUBJ  a - b*1j    (LR, YX)
+ *   AF_CONV_HALF_ADD (a+b)/2  (I; Q of RL,LR)   AF_CONV_HALF_SUB (a-b)/2  (Q of XX,YY; V of RR,LL)
+ *   AF_CONV_HALF_SUB_OVER_J (a-b)/2j  (U of RL,LR; V of XY,YX)
+ * nin, nout <= 12 (a schema names each of I,Q,U,V,RR,RL,LR,LL,XX,XY,YX,YY at most once). */
+#define AF_KIND_F32 0
+#define AF_KIND_F64 1
+#define AF_KIND_C64 2
+#define AF_KIND_C128 3
+#define AF_CONV_ADD 0
+#define AF_CONV_SUB 1
+#define AF_CONV_ADDJ 2
+#define AF_CONV_SUBJ 3
+#define AF_CONV_HALF_ADD 4
+#define AF_CONV_HALF_SUB 5
+#define AF_CONV_HALF_SUB_OVER_J 6
+int af_coherency_convert(const void *input, int in_kind, int64_t nelem, int nin, int nout, const int *src1_host,
+                         const int *src2_host, const int *op_host, void *out, int out_kind, void *stream);
+
 /* Replaces africanus.model.spectral.spectral_model (africanus/model/spectral/spec_model.py:102-236):
  * stokes (nsrc,npol), spi (nsrc,nspi,npol), ref_freq (nsrc), frequency (nchan), base (npol) int32 DEVICE array of
  * 0 "std"  I prod_i (nu/nu0)^spi_i, 1 "log"  I exp(sum_i spi_i ln(nu/nu0)^(i+1)), 2 "log10" (same in base 10)

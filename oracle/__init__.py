@@ -487,3 +487,54 @@ def beam_cube_dde(beam, beam_lm_extents, beam_freq_map, lm, parallactic_angles,
                              _i64(nant), _p(pe_), _p(as_), _p(fr_), _i64(nchan), _p(out))
     assert rc == 0
     return out
+
+
+# ---- Stokes <-> correlation conversion (africanus/model/coherency/conversion.py) ---------------------------
+# the products of conversion.py:18-48, evaluated by numpy's own (complex) add / multiply / divide loops so that
+# the dtype promotion and the propagation of non-finite values are the reference's
+_PRODUCT_FN = {
+    "sum": lambda a, b: a + b + 0j, "diff": lambda a, b: a - b + 0j,
+    "sum_j": lambda a, b: a + b * 1j, "diff_j": lambda a, b: a - b * 1j,
+    "half_sum": lambda a, b: (a + b) / 2, "half_diff": lambda a, b: (a - b) / 2,
+    "half_diff_over_j": lambda a, b: (a - b) / 2j,
+}
+CONVERT_PRODUCTS = {
+    "RR": [("I", "V", "sum")], "LL": [("I", "V", "diff")], "RL": [("Q", "U", "sum_j")], "LR": [("Q", "U", "diff_j")],
+    "XX": [("I", "Q", "sum")], "YY": [("I", "Q", "diff")], "XY": [("U", "V", "sum_j")], "YX": [("U", "V", "diff_j")],
+    "I": [("XX", "YY", "half_sum"), ("RR", "LL", "half_sum")],
+    "Q": [("XX", "YY", "half_diff"), ("RL", "LR", "half_sum")],
+    "U": [("XY", "YX", "half_sum"), ("RL", "LR", "half_diff_over_j")],
+    "V": [("XY", "YX", "half_diff_over_j"), ("RR", "LL", "half_diff")],
+}
+_CASA_STOKES = ("Undefined I Q U V RR RL LR LL XX XY YX YY").split()
+
+
+def convert(input, input_schema, output_schema, implicit_stokes=False):
+    """africanus/model/coherency/conversion.py:143-216 for well-formed schemas (names or casacore ids, nested
+    lists): first candidate pair whose operands are all present (with implicit_stokes a missing Stokes operand of a
+    correlation counts as 0); result real only if every output is a real combination of real input."""
+    def names(schema):
+        arr = np.asarray(schema, dtype=object)
+        flat = [x if isinstance(x, str) else _CASA_STOKES[int(x)] for x in arr.ravel()]
+        return flat, arr.shape
+    inames, ishape = names(input_schema)
+    onames, oshape = names(output_schema)
+    x = np.asarray(input)
+    if x.dtype.kind in "biu":
+        x = x.astype(np.float64)
+    lead = x.shape[:x.ndim - len(ishape)]
+    x = x.reshape(lead + (len(inames),))
+    cols = []
+    for name in onames:
+        for n1, n2, product in CONVERT_PRODUCTS[name]:
+            corr = name not in "IQUV"
+            have1, have2 = n1 in inames, n2 in inames
+            if (have1 or (corr and implicit_stokes)) and (have2 or (corr and implicit_stokes)):
+                a = x[..., inames.index(n1)] if have1 else x.dtype.type(0)
+                b = x[..., inames.index(n2)] if have2 else x.dtype.type(0)
+                cols.append(np.broadcast_to(_PRODUCT_FN[product](a, b), lead))
+                break
+        else:
+            raise KeyError(name)
+    dtype = np.result_type(*[c.dtype for c in cols])
+    return np.stack([c.astype(dtype) for c in cols], axis=-1).reshape(lead + oshape)

@@ -64,6 +64,11 @@ def g10():
     return load_golden("g10_degridder.npz")
 
 
+@pytest.fixture(scope="session")
+def g11():
+    return load_golden("g11_convert.npz")
+
+
 def has_gpu():
     try:
         import torch

@@ -127,3 +127,35 @@ def test_constants_match_reference_bits():
     assert constants.c == 2.99792458e8
     assert constants.two_pi_over_c == 2 * math.pi / 2.99792458e8
     assert constants.minus_two_pi_over_c == -constants.two_pi_over_c
+
+
+def test_convert_schema_errors_match_reference(g11):
+    """convert's schema resolution is host logic: the same exception class and message as the reference recorded
+    for each malformed call (tests/golden/make_golden_convert.py), raised before any device work."""
+    import json
+    from codex_africanus_amd.model.coherency import conversion as C
+    bad = json.loads(str(g11["bad_cases"]))
+    assert len(bad) == len(g11["errors"]) >= 8
+    for (shape, isch, osch, implicit), rec in zip(bad, g11["errors"]):
+        cls, msg = str(rec).split("|", 1)
+        with pytest.raises(Exception) as ei:
+            C.convert_setup(np.zeros(shape), isch, osch, implicit)
+        assert type(ei.value).__name__ == cls, (isch, osch)
+        assert str(ei.value) == msg, (isch, osch)
+
+
+def test_convert_setup_resolution():
+    from codex_africanus_amd.model.coherency import conversion as C
+    x = np.zeros((3, 2, 2), np.float32)
+    mapping, ishape, oshape, dtype = C.convert_setup(x, [["XX", "XY"], ["YX", "YY"]], ["I", "Q", "U", "V"], False)
+    assert ishape == (2, 2) and oshape == (4,) and dtype == np.complex64
+    assert mapping == [(0, 3, C.HALF_ADD, 0), (0, 3, C.HALF_SUB, 1), (1, 2, C.HALF_ADD, 2), (1, 2, C.HALF_SUB_OVER_J, 3)]
+    # real products of real input stay real; integer input computes in float64
+    assert C.convert_setup(x[..., 0], ["XX", "YY"], ["I", "Q"], False)[3] == np.float32
+    assert C.convert_setup(np.zeros((3, 2), np.int32), ["XX", "YY"], ["I", "Q"], False)[3] == np.float64
+    assert C.convert_setup(np.zeros((3, 2), np.int32), ["I", "Q"], ["XX", "YY"], False)[3] == np.complex128
+    # the first candidate pair wins when both are present; defaults only under implicit_stokes
+    m = C.convert_setup(np.zeros((3, 4)), ["RL", "LR", "XX", "YY"], ["Q"], False)[0]
+    assert m == [(2, 3, C.HALF_SUB, 0)]
+    m = C.convert_setup(np.zeros((3, 1)), ["I"], ["XX", "XY"], True)[0]
+    assert m == [(0, -1, C.ADD, 0), (-1, -1, C.ADDJ, 1)]

@@ -1,0 +1,99 @@
+"""GPU parity of the Stokes <-> correlation conversion (fourth term producer) against the
+reference's golden vectors (tests/golden/g11_convert.npz) and the oracle; values must be equal (the products are
+one rounded sum and exact scalings)."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd.model.coherency import convert
+
+pytestmark = pytest.mark.gpu
+
+
+def test_convert_golden(g11):
+    cases = json.loads(str(g11["cases"]))
+    for i, (isch, osch, implicit) in enumerate(cases):
+        for kind in ("f64", "c128", "f32", "c64"):
+            ref = g11["out_%d_%s" % (i, kind)]
+            got = convert(g11["in_%d_%s" % (i, kind)], isch, osch, implicit_stokes=implicit)
+            assert got.dtype == ref.dtype and got.shape == ref.shape, (i, kind)
+            assert np.array_equal(got, ref), (i, kind, np.abs(got - ref).max())
+
+
+def test_convert_reference_kat():
+    """model/coherency/tests/test_convert.py:66-134"""
+    I, Q, U, V = 1.0 + 1j, 2.0 + 2j, 3.0 + 3j, 4.0 + 4j
+    x = np.asarray([[I, Q, U, V]])
+    lin = convert(x, ["I", "Q", "U", "V"], ["XX", "XY", "YX", "YY"])
+    assert np.all(lin == [[I + Q, U + V * 1j, U - V * 1j, I - Q]])
+    circ = convert(x, [1, 2, 3, 4], [5, 6, 7, 8])
+    assert np.all(circ == [[I + V, Q + U * 1j, Q - U * 1j, I - V]])
+    assert np.all(convert(lin, ["XX", "XY", "YX", "YY"], ["I", "Q", "U", "V"]) == x)
+    assert np.all(convert(circ, ["RR", "RL", "LR", "LL"], ["I", "Q", "U", "V"]) == x)
+    v = convert(np.asarray([I]), ["I"], ["XX", "XY", "YX", "YY"], implicit_stokes=True)
+    assert v[0] == I and v[-1] == I
+    with pytest.raises(Exception, match="can produce output 'I'"):
+        convert(np.array([1.0 + 1j]), ["XX"], ["I"], implicit_stokes=True)
+
+
+@pytest.mark.parametrize("vis_shape", [(20, 8), (14, 6), (5, 5, 5), (0, 3), ()])
+def test_convert_shapes(vis_shape, g11):
+    """model/coherency/tests/test_convert.py:59-64: output shape = leading dims + output schema shape."""
+    for isch, osch, implicit in json.loads(str(g11["cases"])):
+        ishape, oshape = np.asarray(isch).shape, np.asarray(osch).shape
+        n = int(np.prod(vis_shape + ishape))
+        vis = np.arange(1.0, n + 1.0).reshape(vis_shape + ishape)
+        out = convert(vis, isch, osch, implicit_stokes=implicit)
+        assert out.shape == vis_shape + oshape
+        assert np.array_equal(out, oracle.convert(vis, isch, osch, implicit))
+
+
+def test_convert_large_and_round_trip():
+    """size-independent properties at a visibility-sized array: Stokes -> corr -> Stokes is the identity up to one
+    rounding per sum, linear == circular Stokes, integer input, device tensors."""
+    rs = np.random.RandomState(5)
+    stokes = rs.normal(size=(20000, 64, 4)) + 1j * rs.normal(size=(20000, 64, 4))
+    sch = ["I", "Q", "U", "V"]
+    lin = convert(stokes, sch, [["XX", "XY"], ["YX", "YY"]])
+    assert lin.shape == (20000, 64, 2, 2)
+    back = convert(lin, [["XX", "XY"], ["YX", "YY"]], sch)
+    assert np.abs(back - stokes).max() < 1e-15 * 8
+    circ = convert(stokes, sch, ["RR", "RL", "LR", "LL"])
+    assert np.abs(convert(circ, ["RR", "RL", "LR", "LL"], sch) - stokes).max() < 1e-15 * 8
+    sub = slice(0, 300)
+    assert np.array_equal(lin[sub], oracle.convert(stokes[sub], sch, [["XX", "XY"], ["YX", "YY"]]))
+    ints = rs.randint(-50, 50, size=(100, 2))
+    out = convert(ints, ["XX", "YY"], ["I", "Q"])
+    assert out.dtype == np.float64 and np.array_equal(out, oracle.convert(ints, ["XX", "YY"], ["I", "Q"]))
+    import torch
+    t = torch.from_numpy(stokes[:1000]).to("cuda:0")
+    dev = convert(t, sch, ["XX", "XY", "YX", "YY"])
+    assert isinstance(dev, torch.Tensor) and dev.dtype == torch.complex128
+    assert np.array_equal(dev.cpu().numpy().reshape(1000, 64, 2, 2), lin[:1000])
+
+
+def test_convert_non_finite(g11):
+    """inf / nan / signed zeros flow through the products as numpy's complex loops propagate them in the reference"""
+    for j, (isch, osch) in enumerate(json.loads(str(g11["nf_cases"]))):
+        for kind in ("real", "cplx"):
+            got, ref = convert(g11["nf_in_" + kind], isch, osch), g11["nf_out_%d_%s" % (j, kind)]
+            assert got.dtype == ref.dtype
+            for part in (np.real, np.imag):
+                assert np.array_equal(part(got), part(ref), equal_nan=True), (isch, osch, kind, got, ref)
+
+
+def test_convert_dask(g11):
+    """model/coherency/tests/test_convert.py:143-160: chunked == unchunked"""
+    da = pytest.importorskip("dask.array")
+    from codex_africanus_amd.model.coherency.dask import convert as da_convert
+    for chunks in (((10, 5, 3), (2, 3), (3,)), ((6, 8), (3, 3), (4, 4)), ((5, 5, 5),)):
+        vis_shape = tuple(sum(c) for c in chunks)
+        for isch, osch, implicit in json.loads(str(g11["cases"]))[:11]:
+            ishape = np.asarray(isch).shape
+            n = int(np.prod(vis_shape + ishape))
+            vis = np.arange(1.0, n + 1.0).reshape(vis_shape + ishape)
+            dvis = da.from_array(vis, chunks=chunks + tuple((s,) for s in ishape))
+            got = da_convert(dvis, isch, osch).compute(scheduler="threads")
+            assert np.array_equal(got, convert(vis, isch, osch))

@@ -477,3 +477,42 @@ def test_gridder_oracle_vs_reference(g10, tag, vkey, ppol, spol, cpol, kern, cen
     ref = g10[tag]
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= (1e-10 if ppol == "phase_rotate" else 1e-14) * np.abs(ref).max()
+
+
+def test_convert_oracle_matches_reference(g11):
+    """Stokes <-> correlation convert (africanus/model/coherency/conversion.py:207): every schema pair of the
+    reference's test_convert.py:13-28 plus circular / implicit-Stokes / two-candidate cases, four input dtypes;
+    values, dtype and shape identical."""
+    import json
+    cases = json.loads(str(g11["cases"]))
+    assert len(cases) >= 22
+    for i, (isch, osch, implicit) in enumerate(cases):
+        for kind in ("f64", "c128", "f32", "c64"):
+            ref = g11["out_%d_%s" % (i, kind)]
+            got = oracle.convert(g11["in_%d_%s" % (i, kind)], isch, osch, implicit)
+            assert got.dtype == ref.dtype and got.shape == ref.shape, (i, kind)
+            assert np.array_equal(got, ref), (i, kind)
+
+
+def test_convert_oracle_non_finite(g11):
+    import json
+    with np.errstate(all="ignore"):
+        for j, (isch, osch) in enumerate(json.loads(str(g11["nf_cases"]))):
+            for kind in ("real", "cplx"):
+                got, ref = oracle.convert(g11["nf_in_" + kind], isch, osch), g11["nf_out_%d_%s" % (j, kind)]
+                for part in (np.real, np.imag):
+                    assert np.array_equal(part(got), part(ref), equal_nan=True), (isch, osch, kind)
+
+
+def test_convert_reference_kat():
+    """The known answers of model/coherency/tests/test_convert.py:66-134."""
+    I, Q, U, V = 1.0 + 1j, 2.0 + 2j, 3.0 + 3j, 4.0 + 4j
+    x = np.asarray([[I, Q, U, V]])
+    lin = oracle.convert(x, ["I", "Q", "U", "V"], ["XX", "XY", "YX", "YY"])
+    assert np.all(lin == [[I + Q, U + V * 1j, U - V * 1j, I - Q]])
+    circ = oracle.convert(x, [1, 2, 3, 4], [5, 6, 7, 8])
+    assert np.all(circ == [[I + V, Q + U * 1j, Q - U * 1j, I - V]])
+    assert np.all(oracle.convert(lin, ["XX", "XY", "YX", "YY"], ["I", "Q", "U", "V"]) == x)
+    assert np.all(oracle.convert(circ, ["RR", "RL", "LR", "LL"], ["I", "Q", "U", "V"]) == x)
+    v = oracle.convert(np.asarray([I]), ["I"], ["XX", "XY", "YX", "YY"], implicit_stokes=True)
+    assert v[0] == I and v[-1] == I

@@ -107,4 +107,17 @@ j1 = jn[:, :, :, :1].contiguous()
 dt = timeit(lambda: correct_vis(tbi, tbc, a1c, a2c, j1, vs, flg), reps=3)
 b = 2 * nrow_c * 64 * 64 + flg.numel()
 out["correct_vis FULL (1e6 rows x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+# Stokes <-> correlation conversion at the C2 visibility shape
+del jn, md, vs, flg, j1
+from codex_africanus_amd.model.coherency import convert
+vis4 = rc(1000000, 64, 4)
+for label, isch, osch in (("corr->Stokes", ["XX", "XY", "YX", "YY"], ["I", "Q", "U", "V"]),
+                          ("Stokes->corr", ["I", "Q", "U", "V"], [["XX", "XY"], ["YX", "YY"]])):
+    dt = timeit(lambda: convert(vis4, isch, osch), reps=5)
+    b = 2 * vis4.numel() * 16
+    out["convert %s c128 (1e6 rows x 64 chan x 4)" % label] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+st_real = torch.randn(1000000, 64, 4, dtype=torch.float64, device=dev)
+dt = timeit(lambda: convert(st_real, ["I", "Q", "U", "V"], ["XX", "XY", "YX", "YY"]), reps=5)
+b = st_real.numel() * 8 + st_real.numel() * 16
+out["convert Stokes->corr f64 -> c128 (1e6 rows x 64 chan x 4)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 print(json.dumps(out, indent=1))
