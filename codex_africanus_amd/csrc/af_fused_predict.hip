@@ -21,6 +21,7 @@
 // Every per-antenna Jones is computed once per (timestep, channel, source) and reused by all
 // baselines of the timestep from LDS; the output is written once.  fp64-VALU bound
 // (~70 fp64 ops per (row,chan,src) + ~15 % for the beam stage).
+#include <stdlib.h>
 #include "af_common.h"
 #include "af_beam_device.h"
 #include "af_sincos.h"
@@ -108,27 +109,67 @@ __global__ void beam_pack_kernel(const double2 *__restrict__ beam, int64_t nvox,
 // One correlation of beam_sample_corr (af_beam_device.h) from the packed records: weighted sums of
 // the 8 voxels in the reference's order (FMA-contracted: the fused path is checked to 1e-9, not bit
 // for bit), then the amplitude-preserving normalisation corr_sum * absc_sum / |corr_sum|.
-__device__ __forceinline__ double2 beam_sample1(const double *__restrict__ rec, const BeamVoxels<double, int> &vx,
-                                                int c)
+__device__ __forceinline__ double2 beam_reduce1(const double2 (&v)[8], const double (&ab)[8], const double (&wt)[8])
 {
-    double2 v[8];
-    double ab[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double *r = rec + (int64_t)vx.off[k] * VREC + c * 4;
-        v[k] = *reinterpret_cast<const double2 *>(r);
-        ab[k] = r[2];
-    }
     double cre = 0.0, cim = 0.0, absc = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        cre = fma(vx.wt[k], v[k].x, cre);
-        cim = fma(vx.wt[k], v[k].y, cim);
-        absc = fma(vx.wt[k], ab[k], absc);
+        cre = fma(wt[k], v[k].x, cre);
+        cim = fma(wt[k], v[k].y, cim);
+        absc = fma(wt[k], ab[k], absc);
     }
-    const double div = __dsqrt_rn(fma(cre, cre, __dmul_rn(cim, cim)));
-    const double sc = (div == 0.0) ? absc : __ddiv_rn(absc, div);
+    // corr_sum * absc_sum / |corr_sum|  (:227-235; absc_sum itself when corr_sum == 0): 1/|.| by v_rsq_f64 and two
+    // Newton steps (~1 ulp; the fused chain is checked to 1e-9 against the oracle, not bit for bit)
+    const double n2 = fma(cre, cre, __dmul_rn(cim, cim));
+    double y = __builtin_amdgcn_rsq(n2);
+    y = fma(__dmul_rn(0.5, y), fma(-__dmul_rn(n2, y), y, 1.0), y);
+    y = fma(__dmul_rn(0.5, y), fma(-__dmul_rn(n2, y), y, 1.0), y);
+    const double sc = (n2 == 0.0) ? absc : __dmul_rn(absc, y);
     return make_double2(__dmul_rn(cre, sc), __dmul_rn(cim, sc));
+}
+
+// Geometry of one beam sample for the packed records: beam_voxels (af_beam_device.h; reference
+// rime/fast_beam_cubes.py:130-225, same operations in the same order) with 32-bit BYTE offsets into the record
+// array: off[0..3] are the (l, m) corners on the lower frequency plane, the upper plane is +VREC*8 bytes (an
+// immediate offset of the load), so a sample costs four address computations instead of eight 64-bit ones.
+struct FusedGrid {
+    double lower_l, lower_m, lscale, mscale, lmaxf, mmaxf;
+    int lmaxi, mmaxi;
+    unsigned stride_l, stride_m;  // bytes between consecutive l / m voxels of the packed cube
+};
+struct FusedVoxels {
+    unsigned off[4];
+    double wt[8];
+};
+__device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, double m, double sin_pa, double cos_pa,
+                                             double pe_l, double pe_m, double as_l, double as_m, double freq_scale,
+                                             double nud, int gc0, FusedVoxels &vx)
+{
+    const double inv_nud = __dsub_rn(1.0, nud);
+    const double sl = __dmul_rn(l, freq_scale), sm = __dmul_rn(m, freq_scale);
+    const double tl = __dadd_rn(sl, pe_l), tm = __dadd_rn(sm, pe_m);
+    double vl = __dsub_rn(__dmul_rn(tl, cos_pa), __dmul_rn(tm, sin_pa));
+    double vm = __dadd_rn(__dmul_rn(tl, sin_pa), __dmul_rn(tm, cos_pa));
+    vl = __dmul_rn(vl, as_l);
+    vm = __dmul_rn(vm, as_m);
+    vl = __dmul_rn(g.lscale, __dsub_rn(vl, g.lower_l));
+    vm = __dmul_rn(g.mscale, __dsub_rn(vm, g.lower_m));
+    {   // max(zero, min(v, maxf)) with Python's comparison semantics (:150-151)
+        const double t1 = vl < g.lmaxf ? vl : g.lmaxf; vl = 0.0 > t1 ? 0.0 : t1;
+        const double t2 = vm < g.mmaxf ? vm : g.mmaxf; vm = 0.0 > t2 ? 0.0 : t2;
+    }
+    const double fl = floor(vl), fm = floor(vm);
+    const int gl0 = (int)fl, gm0 = (int)fm;
+    const double ld = __dsub_rn(vl, fl), md = __dsub_rn(vm, fm);
+    const double omld = __dsub_rn(1.0, ld), ommd = __dsub_rn(1.0, md);
+    const double w00 = __dmul_rn(omld, ommd), w10 = __dmul_rn(ld, ommd), w01 = __dmul_rn(omld, md), w11 = __dmul_rn(ld, md);
+    vx.wt[0] = __dmul_rn(w00, nud); vx.wt[1] = __dmul_rn(w10, nud);
+    vx.wt[2] = __dmul_rn(w01, nud); vx.wt[3] = __dmul_rn(w11, nud);
+    vx.wt[4] = __dmul_rn(w00, inv_nud); vx.wt[5] = __dmul_rn(w10, inv_nud);
+    vx.wt[6] = __dmul_rn(w01, inv_nud); vx.wt[7] = __dmul_rn(w11, inv_nud);
+    const unsigned base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m + (unsigned)gc0 * (VREC * 8u);
+    const unsigned dl = gl0 < g.lmaxi ? g.stride_l : 0u, dm = gm0 < g.mmaxi ? g.stride_m : 0u;  // upper neighbour clamped
+    vx.off[0] = base; vx.off[1] = base + dl; vx.off[2] = base + dm; vx.off[3] = base + dl + dm;
 }
 
 struct C2 {
@@ -166,8 +207,35 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
     acc.im = fma(a.im, b.re, acc.im);
 }
 
-// grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * nant double2 (E then G) + 6 * nant doubles.
-template <bool FEED, bool GAUSS>
+// exp(2 pi i x / 256) for x = q * f4 * 64 (f4 in quarter turns per metre): the nearest of 256 table phasors
+// (LDS, one 16-byte gather) times the residual rotation |theta| <= pi/256 by its Taylor series -- sin to
+// theta^5, cos to theta^6: truncation 8e-18 / 1e-20.  14 fp64 operations and no quadrant selects, against 17 + ~9
+// integer operations for the full-range polynomial pair.
+constexpr int PH_TABLE = 256;
+__device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, double x256)
+{
+    constexpr double T = 6.283185307179586476925 / PH_TABLE;
+    constexpr double S1 = T, S3 = -T * T * T / 6.0, S5 = T * T * T * T * T / 120.0;
+    constexpr double C2_ = -T * T / 2.0, C4 = T * T * T * T / 24.0, C6 = -T * T * T * T * T * T / 720.0;
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double a = __dadd_rn(x256, MAGIC);
+    const int k = __double2loint(a) & (PH_TABLE - 1);
+    const double z = __dsub_rn(x256, __dsub_rn(a, MAGIC));  // [-0.5, 0.5]
+    const double z2 = __dmul_rn(z, z);
+    const double sn = __dmul_rn(z, fma(z2, fma(z2, S5, S3), S1));
+    const double cs = fma(z2, fma(z2, fma(z2, C6, C4), C2_), 1.0);
+    const double2 tk = table[k];
+    C2 y;
+    y.re = fma(tk.x, cs, -__dmul_rn(tk.y, sn));
+    y.im = fma(tk.y, cs, __dmul_rn(tk.x, sn));
+    return y;
+}
+
+// grid: (nitems, nchan); block 512.  Dynamic LDS: 2 * st * 4 * np double2 (E then G) + 6 * nant doubles + the feed
+// rotations + the 256-entry phasor table.  NP > 0: the antenna stride np of the Jones arrays is the compile-time
+// constant NP >= nant, so that the four components of a Jones term are one address plus immediate offsets; NP = 0:
+// np = nant at run time.
+template <bool FEED, bool GAUSS, int NP>
 __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
@@ -176,11 +244,12 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const double *__restrict__ freq_data, const double *__restrict__ parangles,
     const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling,
     const double2 *__restrict__ feed_rot, const double *__restrict__ gauss, const double *__restrict__ freq, int nsrc,
-    int64_t nchan, int64_t ntime, int nant, int st, double2 *__restrict__ out)
+    int64_t nchan, int64_t ntime, int nant, int st, double2 *__restrict__ out, int only_stage)
 {
     extern __shared__ double2 lds[];
-    double2 *ldsE = lds;                            // [st][4][nant]
-    double2 *ldsG = lds + (size_t)st * 4 * nant;    // [st][4][nant]
+    const int np = NP > 0 ? NP : nant;
+    double2 *ldsE = lds;                          // [st][4][np]
+    double2 *ldsG = lds + (size_t)st * 4 * np;    // [st][4][np]
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.y;
     const int t = items[4 * blockIdx.x + 0];
@@ -202,12 +271,18 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
     }
-    const double F4 = f4[f], NU = freq[f];
+    const double F256 = f4[f] * 64.0, NU = freq[f];   // 1/256 turns per metre (exact scaling of f4)
 
     // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
     // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m); ldsR[a] = the antenna's 2x2 feed rotation (optional)
-    double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * nant);
+    double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * np);
     double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
+    double2 *ldsT = ldsR + (size_t)4 * nant;      // phasor table
+    for (int i = tid; i < PH_TABLE; i += THREADS) {
+        double c, sn;
+        sincos_quarter_turns<7>((double)i * (4.0 / PH_TABLE), c, sn);
+        ldsT[i] = make_double2(c, sn);
+    }
     constexpr bool have_feed = FEED;
     if (have_feed)
         for (int i = tid; i < 4 * nant; i += THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
@@ -220,11 +295,19 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
         ldsA[6 * a + 2] = pe[0]; ldsA[6 * a + 3] = pe[1];
         ldsA[6 * a + 4] = as[0]; ldsA[6 * a + 5] = as[1];
     }
-    const BeamGrid<double> grid = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+    FusedGrid grid;
+    {
+        const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+        grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
+        grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
+        grid.stride_m = (unsigned)beam_nud * (VREC * 8u);
+        grid.stride_l = (unsigned)beam_mh * grid.stride_m;
+    }
     const double fscale = freq_data[3 * f + 0], fnud = freq_data[3 * f + 1];
     const int fgc0 = (int)freq_data[3 * f + 2];
-    const int ntask = st * nant;           // Jones terms per batch
+    const int ntask = st * np;             // Jones slots per batch (antennas >= nant of a padded stride are skipped)
     const int e_corr = tid & 3;            // this lane's correlation in stage 1
+    const char *vrec_c = reinterpret_cast<const char *>(vrec) + e_corr * 32;   // this lane's 32 bytes of a record
     __syncthreads();
 
     for (int s0 = 0; s0 < nsrc; s0 += st) {
@@ -232,20 +315,48 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
         // Four lanes per Jones term, one per correlation: every lane gathers its own 32 bytes
         // (re, im, |.|) of each of the 8 voxel records, so a record's cache line is fetched once and no
         // cross-lane reduction is needed.  THREADS/4 terms per round.
-        for (int task0 = 0; task0 < ntask; task0 += THREADS / 4) {
+        // The round's only dependent memory chain is  voxel geometry -> 8 record gathers: the source coordinates and
+        // brightness columns of round j + 1 are fetched while round j computes (the stage is bound by the latency
+        // of these L2 reads, not by its arithmetic).
+        struct Task {
+            int e_sl, e_ant;
+            bool have_task, have;
+            double2 lm, b0, b1;
+        };
+        auto fetch = [&](int task0) {
+            Task T;
             const int task = task0 + (tid >> 2);
-            const bool have_task = task < ntask;
-            const int e_sl = have_task ? task / nant : 0, e_ant = have_task ? task % nant : 0;
-            const int s = s0 + e_sl;
-            const bool have = have_task && s < nsrc;
-            const int sc = have ? s : 0;
-            BeamVoxels<double, int> vx;
-            // voxel offsets in voxels (ncorr = 1): the packed records are indexed per voxel
-            beam_voxels<double, int>(grid, lmn[4 * sc], lmn[4 * sc + 1], ldsA[6 * e_ant + 0], ldsA[6 * e_ant + 1],
-                                     ldsA[6 * e_ant + 2], ldsA[6 * e_ant + 3], ldsA[6 * e_ant + 4],
-                                     ldsA[6 * e_ant + 5], fscale, fnud, fgc0, 1, vx);
-            double2 e = beam_sample1(vrec, vx, e_corr);
-            if (!have) e = make_double2(0.0, 0.0);
+            T.e_sl = task / np;          // NP > 0: a shift
+            T.e_ant = task - T.e_sl * np;
+            T.have_task = task < ntask && T.e_ant < nant;
+            if (!T.have_task) T.e_sl = T.e_ant = 0;
+            const int s = s0 + T.e_sl;
+            T.have = T.have_task && s < nsrc;
+            const int sc = T.have ? s : 0;
+            T.lm = *reinterpret_cast<const double2 *>(lmn + 4 * sc);
+            // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]: this lane needs column c%2 of B
+            const double2 *bp = brightness + ((int64_t)sc * nchan + f) * 4;
+            T.b0 = bp[e_corr & 1];
+            T.b1 = bp[2 + (e_corr & 1)];
+            return T;
+        };
+        Task nxt = fetch(0);
+        for (int task0 = 0; task0 < ntask && only_stage != 2; task0 += THREADS / 4) {
+            const Task T = nxt;
+            if (task0 + THREADS / 4 < ntask) nxt = fetch(task0 + THREADS / 4);
+            FusedVoxels vx;
+            fused_voxels(grid, T.lm.x, T.lm.y, ldsA[6 * T.e_ant + 0], ldsA[6 * T.e_ant + 1], ldsA[6 * T.e_ant + 2],
+                         ldsA[6 * T.e_ant + 3], ldsA[6 * T.e_ant + 4], ldsA[6 * T.e_ant + 5], fscale, fnud, fgc0, vx);
+            double2 v[8];
+            double ab[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double *r = reinterpret_cast<const double *>(vrec_c + (size_t)vx.off[k & 3]) + (k >> 2) * VREC;
+                v[k] = *reinterpret_cast<const double2 *>(r);
+                ab[k] = r[2];
+            }
+            double2 e = beam_reduce1(v, ab, vx.wt);
+            if (!T.have) e = make_double2(0.0, 0.0);
             // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
             C2 Eme, Emate;
             Eme.re = e.x; Eme.im = e.y;
@@ -255,7 +366,7 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
             if constexpr (have_feed) {
                 // E <- E . R(t, antenna)  (einsum "stafij,tajk->stafik", rime/examples/predict.py:472):
                 // this lane's component (i, j = e_corr & 1) is E[i,0] R[0,j] + E[i,1] R[1,j]
-                const double2 r0 = ldsR[4 * e_ant + (e_corr & 1)], r1 = ldsR[4 * e_ant + 2 + (e_corr & 1)];
+                const double2 r0 = ldsR[4 * T.e_ant + (e_corr & 1)], r1 = ldsR[4 * T.e_ant + 2 + (e_corr & 1)];
                 C2 R0, R1;
                 R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
                 C2 Er = cmul(E0, R0);
@@ -267,23 +378,20 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
                 E0 = (e_corr & 1) ? Emate : Eme;
                 E1 = (e_corr & 1) ? Eme : Emate;
             }
-            // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]   (G = E.B, row-major 2x2)
-            const double2 *bp = brightness + ((int64_t)sc * nchan + f) * 4;
-            const double2 b0 = bp[e_corr & 1], b1 = bp[2 + (e_corr & 1)];
             C2 B0, B1, G;
-            B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+            B0.re = T.b0.x; B0.im = T.b0.y; B1.re = T.b1.x; B1.im = T.b1.y;
             G = cmul(E0, B0);
             cmac(G, E1, B1);
-            if (have_task) {
-                ldsE[((size_t)e_sl * 4 + e_corr) * nant + e_ant] = e;
-                ldsG[((size_t)e_sl * 4 + e_corr) * nant + e_ant] = have ? make_double2(G.re, G.im)
-                                                                        : make_double2(0.0, 0.0);
+            if (T.have_task) {
+                ldsE[((size_t)T.e_sl * 4 + e_corr) * np + T.e_ant] = e;
+                ldsG[((size_t)T.e_sl * 4 + e_corr) * np + T.e_ant] = T.have ? make_double2(G.re, G.im)
+                                                                            : make_double2(0.0, 0.0);
             }
         }
         __syncthreads();
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
-        for (int sl = 0; sl < nb; ++sl) {
+        for (int sl = 0; sl < nb && only_stage != 1; ++sl) {
             const double l = lmn[4 * (s0 + sl)], m = lmn[4 * (s0 + sl) + 1], n = lmn[4 * (s0 + sl) + 2];
             // Gaussian shape factors exp(-(u1^2 + v1^2) (nu gs)^2) of this lane's rows (gaussian_shape.py:52-60);
             // computed ahead of the row loop so that exp's temporaries do not overlap the Jones algebra
@@ -300,19 +408,18 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
                     }
                 }
             }
-            const double2 *pE = ldsE + (size_t)sl * 4 * nant, *pG = ldsG + (size_t)sl * 4 * nant;
+            const double2 *pE = ldsE + (size_t)sl * 4 * np, *pG = ldsG + (size_t)sl * 4 * np;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const double q = fma(n, w[k], fma(m, v[k], __dmul_rn(l, u[k])));
-                C2 y;
-                sincos_quarter_turns<7>(__dmul_rn(q, F4), y.re, y.im);
+                C2 y = table_phasor(ldsT, __dmul_rn(q, F256));
                 if constexpr (GAUSS) {
                     if (extended) { y.re *= shape[k]; y.im *= shape[k]; }
                 }
                 C2 Gp[4], Eq[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    double2 g = pG[c * nant + a1[k]], e = pE[c * nant + a2[k]];
+                    double2 g = pG[c * np + a1[k]], e = pE[c * np + a2[k]];
                     Gp[c].re = g.x; Gp[c].im = g.y;
                     Eq[c].re = e.x; Eq[c].im = e.y;
                 }
@@ -397,7 +504,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_REQUIRE(nitems >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_c128: negative extent");
     // one time step's Jones of a source batch + per-antenna constants live in LDS (160 KiB per workgroup)
-    AF_REQUIRE(nant <= 680, "af_fused_predict_c128: more than 680 antennas");
+    AF_REQUIRE(nant <= 664, "af_fused_predict_c128: more than 664 antennas");
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nitems < (1LL << 31), "af_fused_predict_c128: too large");
     hipStream_t st_ = af_stream(stream);
     if (nrow == 0 || nchan == 0) return AF_OK;
@@ -434,7 +541,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     }
     {
         const int64_t nvox = beam_lw * beam_mh * beam_nud;
-        AF_REQUIRE(nvox < (1LL << 31), "af_fused_predict_c128: beam cube too large");
+        AF_REQUIRE(nvox < (1LL << 25), "af_fused_predict_c128: beam cube too large (32-bit byte offsets into the 128-byte "
+                                       "voxel records: fewer than 2^25 voxels)");
         int64_t blocks = af_cdiv(nvox * 4, 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(beam_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st_,
@@ -443,15 +551,22 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     }
     // sources per batch: as many as fit 128 KB of LDS (E and G: 128 bytes per (source, antenna))
     // (E and G: 128 bytes per (source, antenna); 112 bytes of constants per antenna; 160 KiB per workgroup)
-    int st = (int)((160 * 1024 - 112 * nant) / (128 * nant));
-    if (st > 1024 / nant) st = (int)(1024 / nant);
+    // antenna stride of the Jones arrays: a compile-time constant for the common array sizes
+    const int NPv = (nant > 32 && nant <= 64) ? 64 : (nant > 64 && nant <= 128) ? 128 : 0;
+    const int64_t np = NPv ? NPv : nant;
+    const int64_t fixed = 112 * nant + PH_TABLE * 16;   // per-antenna constants, feed rotation, phasor table
+    int st = (int)((160 * 1024 - fixed) / (128 * np));
+    if (st > 1024 / np) st = (int)(1024 / np);
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    const size_t lds_bytes = (size_t)2 * st * 4 * nant * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
-                             (size_t)nant * 4 * sizeof(double2);  // E, G, per-antenna constants, feed rotation
+    const size_t lds_bytes = (size_t)2 * st * 4 * np * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
+                             (size_t)nant * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
     AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_c128: %zu bytes of LDS needed (nant = %lld)", lds_bytes,
                (long long)nant);
     const bool feed = feed_rotation != nullptr, gauss = gauss_shape != nullptr;
+    // measurement hook (tools/profile_fused.sh): AFHIP_FUSED_STAGE=1 / 2 runs only the beam stage / only the
+    // accumulation stage (results are then meaningless); unset = the real kernel
+    static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
     auto launch = [&](auto kernel) -> int {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
@@ -460,12 +575,15 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
                            antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), babs, beam_lw, beam_mh,
                            beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
                            reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc, nchan, ntime,
-                           (int)nant, st, reinterpret_cast<double2 *>(out));
+                           (int)nant, st, reinterpret_cast<double2 *>(out), only_stage);
         AF_LAUNCH_CHECK();
         return AF_OK;
     };
-    rc = feed ? (gauss ? launch(fused_predict_kernel<true, true>) : launch(fused_predict_kernel<true, false>))
-              : (gauss ? launch(fused_predict_kernel<false, true>) : launch(fused_predict_kernel<false, false>));
+#define AF_FUSED_PICK(NPC)                                                                                \
+    (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC>) : launch(fused_predict_kernel<true, false, NPC>)) \
+          : (gauss ? launch(fused_predict_kernel<false, true, NPC>) : launch(fused_predict_kernel<false, false, NPC>)))
+    rc = NPv == 64 ? AF_FUSED_PICK(64) : NPv == 128 ? AF_FUSED_PICK(128) : AF_FUSED_PICK(0);
+#undef AF_FUSED_PICK
     if (rc != AF_OK) return rc;
     af_prof_end(st_);
     return AF_OK;
