@@ -8,20 +8,28 @@
 // africanus/rime/predict.py:199-212) evaluated without materialising the (src,row,chan)
 // coherencies (4.1 TB at C2) or the (src,time,ant,chan) Jones terms (130 GB at C3).
 //
-// One workgroup (512 lanes, one per CU: 237 VGPRs, up to 128 KB of LDS) owns one run of rows with
+// One workgroup (512 lanes, one per CU: <= 250 VGPRs, up to 160 KB of LDS) owns one run of rows with
 // equal time_index (<= 2048 rows: a whole 64-antenna timestep) and one channel, and walks the
 // sources in batches:
-//   stage 1  four lanes per (source of the batch, antenna), one per correlation: sample the beam cube
-//            (repacked once per call into 128-byte voxel records [corr][re, im, |.|, 0]) -> E, and G = E.B(s,nu); both go to LDS as [src][component][antenna] so that
-//            stage 2's reads are conflict-free (consecutive rows = consecutive antenna2) or
-//            broadcasts (antenna1);
-//   stage 2  lane = four rows: per source q = l u + m v + n w, the phasor by the quarter-turn
-//            polynomial sincos, M = G_p . E_q^H (one 2x2 complex product instead of two because B
-//            was folded into G per antenna), acc += K M.
+//   stage 1  (beam) super-rounds of 512 Jones terms: every lane computes the voxel geometry of one (source, antenna)
+//            term (32-bit byte offsets into the packed cube: 128-byte voxel records [corr][re, im, |.|, 0]), then four
+//            sampling rounds in which the four lanes of a quad take the geometry of quad lane i by DPP broadcast and
+//            sample one correlation each (8 x (16 + 8)-byte gathers, one cache line per voxel and quad) -> E, and
+//            G = E.B(s,nu); both go to LDS as [src][component][antenna] so that stage 2's reads are conflict-free
+//            (consecutive rows = consecutive antenna2) or broadcasts (antenna1).  The next super-round's source
+//            coordinates are fetched one super-round ahead.  Bound by the L2 -> L1 line traffic of the gathers
+//            (8 lines per Jones term: 2.1 TB at C3) and their address processing, not by arithmetic.
+//   stage 2  (accumulate) lane = four rows: per source q = l u + m v + n w, the phasor from a 256-entry LDS table
+//            times a short residual rotation, M = G_p . E_q^H (one 2x2 complex product instead of two because B
+//            was folded into G per antenna), acc += K M.  66 fp64 + ~20 other instructions per (row, source):
+//            fp64-VALU issue bound.
 // Every per-antenna Jones is computed once per (timestep, channel, source) and reused by all
-// baselines of the timestep from LDS; the output is written once.  fp64-VALU bound
-// (~70 fp64 ops per (row,chan,src) + ~15 % for the beam stage).
+// baselines of the timestep from LDS; the output is written once.  Measured at C3 (tools/profile_fused.sh,
+// AFHIP_FUSED_STAGE): stage 2 alone 159 ms, stage 1 adds ~89 ms (they run back to back, not overlapped).
 #include <stdlib.h>
+
+#include <type_traits>
+
 #include "af_common.h"
 #include "af_beam_device.h"
 #include "af_sincos.h"
@@ -172,6 +180,21 @@ __device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, doubl
     vx.off[0] = base; vx.off[1] = base + dl; vx.off[2] = base + dm; vx.off[3] = base + dl + dm;
 }
 
+// value of quad lane QL in all four lanes of the quad; the neighbour lane ^ 1 (DPP quad_perm, no LDS crossbar)
+template <int QL> __device__ __forceinline__ int quad_bcast(int x)
+{
+    return __builtin_amdgcn_mov_dpp(x, QL * 0x55, 0xf, 0xf, true);
+}
+template <int QL> __device__ __forceinline__ double quad_bcast(double x)
+{
+    return __hiloint2double(quad_bcast<QL>(__double2hiint(x)), quad_bcast<QL>(__double2loint(x)));
+}
+__device__ __forceinline__ double quad_swap1(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xf, 0xf, true));
+}
+
 struct C2 {
     double re, im;
 };
@@ -315,78 +338,95 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
         // Four lanes per Jones term, one per correlation: every lane gathers its own 32 bytes
         // (re, im, |.|) of each of the 8 voxel records, so a record's cache line is fetched once and no
         // cross-lane reduction is needed.  THREADS/4 terms per round.
-        // The round's only dependent memory chain is  voxel geometry -> 8 record gathers: the source coordinates and
-        // brightness columns of round j + 1 are fetched while round j computes (the stage is bound by the latency
-        // of these L2 reads, not by its arithmetic).
-        struct Task {
-            int e_sl, e_ant;
-            bool have_task, have;
-            double2 lm, b0, b1;
+        // Super-rounds of THREADS Jones terms: every lane first works out the voxel geometry of ONE term (its source
+        // coordinates were fetched during the previous super-round); then four sampling rounds, in round i the four
+        // lanes of a quad take the geometry of quad lane i by DPP broadcast and sample one correlation each -- the
+        // geometry (a third of the stage's instructions) is computed once per term, not once per correlation.
+        struct Own {
+            int info;      // e_sl | e_ant << 11 | have_task << 30 | have << 31
+            double2 lm;
         };
         auto fetch = [&](int task0) {
-            Task T;
-            const int task = task0 + (tid >> 2);
-            T.e_sl = task / np;          // NP > 0: a shift
-            T.e_ant = task - T.e_sl * np;
-            T.have_task = task < ntask && T.e_ant < nant;
-            if (!T.have_task) T.e_sl = T.e_ant = 0;
-            const int s = s0 + T.e_sl;
-            T.have = T.have_task && s < nsrc;
-            const int sc = T.have ? s : 0;
-            T.lm = *reinterpret_cast<const double2 *>(lmn + 4 * sc);
-            // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]: this lane needs column c%2 of B
-            const double2 *bp = brightness + ((int64_t)sc * nchan + f) * 4;
-            T.b0 = bp[e_corr & 1];
-            T.b1 = bp[2 + (e_corr & 1)];
+            Own T;
+            const int task = task0 + tid;
+            int e_sl = task / np;          // NP > 0: a shift
+            int e_ant = task - e_sl * np;
+            const bool have_task = task < ntask && e_ant < nant;
+            if (!have_task) e_sl = e_ant = 0;
+            const bool have = have_task && s0 + e_sl < nsrc;
+            T.info = e_sl | (e_ant << 11) | ((int)have_task << 30) | (int)((unsigned)have << 31);
+            T.lm = *reinterpret_cast<const double2 *>(lmn + 4 * (have ? s0 + e_sl : 0));
             return T;
         };
-        Task nxt = fetch(0);
-        for (int task0 = 0; task0 < ntask && only_stage != 2; task0 += THREADS / 4) {
-            const Task T = nxt;
-            if (task0 + THREADS / 4 < ntask) nxt = fetch(task0 + THREADS / 4);
-            FusedVoxels vx;
-            fused_voxels(grid, T.lm.x, T.lm.y, ldsA[6 * T.e_ant + 0], ldsA[6 * T.e_ant + 1], ldsA[6 * T.e_ant + 2],
-                         ldsA[6 * T.e_ant + 3], ldsA[6 * T.e_ant + 4], ldsA[6 * T.e_ant + 5], fscale, fnud, fgc0, vx);
-            double2 v[8];
-            double ab[8];
+        Own nxt = fetch(0);
+        for (int task0 = 0; task0 < ntask && only_stage != 2; task0 += THREADS) {
+            const Own own = nxt;
+            if (task0 + THREADS < ntask) nxt = fetch(task0 + THREADS);
+            FusedVoxels gx;
+            {
+                const int a = (own.info >> 11) & 1023;
+                fused_voxels(grid, own.lm.x, own.lm.y, ldsA[6 * a + 0], ldsA[6 * a + 1], ldsA[6 * a + 2], ldsA[6 * a + 3],
+                             ldsA[6 * a + 4], ldsA[6 * a + 5], fscale, fnud, fgc0, gx);
+            }
+            auto round = [&](auto lane_c) {
+                constexpr int QL = decltype(lane_c)::value;
+                const int info = quad_bcast<QL>(own.info);
+                const int e_sl = info & 2047, e_ant = (info >> 11) & 1023;
+                const bool have_task = (info >> 30) & 1, have = info < 0;
+                // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]: this lane needs column c%2 of B
+                const double2 *bp = brightness + ((int64_t)(have ? s0 + e_sl : 0) * nchan + f) * 4;
+                const double2 b0 = bp[e_corr & 1], b1 = bp[2 + (e_corr & 1)];
+                unsigned off[4];
+                double wt[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double *r = reinterpret_cast<const double *>(vrec_c + (size_t)vx.off[k & 3]) + (k >> 2) * VREC;
-                v[k] = *reinterpret_cast<const double2 *>(r);
-                ab[k] = r[2];
-            }
-            double2 e = beam_reduce1(v, ab, vx.wt);
-            if (!T.have) e = make_double2(0.0, 0.0);
-            // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
-            C2 Eme, Emate;
-            Eme.re = e.x; Eme.im = e.y;
-            Emate.re = __shfl_xor(e.x, 1, 64);
-            Emate.im = __shfl_xor(e.y, 1, 64);
-            C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
-            if constexpr (have_feed) {
-                // E <- E . R(t, antenna)  (einsum "stafij,tajk->stafik", rime/examples/predict.py:472):
-                // this lane's component (i, j = e_corr & 1) is E[i,0] R[0,j] + E[i,1] R[1,j]
-                const double2 r0 = ldsR[4 * T.e_ant + (e_corr & 1)], r1 = ldsR[4 * T.e_ant + 2 + (e_corr & 1)];
-                C2 R0, R1;
-                R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
-                C2 Er = cmul(E0, R0);
-                cmac(Er, E1, R1);
-                e = make_double2(Er.re, Er.im);
-                Eme = Er;
-                Emate.re = __shfl_xor(Er.re, 1, 64);
-                Emate.im = __shfl_xor(Er.im, 1, 64);
-                E0 = (e_corr & 1) ? Emate : Eme;
-                E1 = (e_corr & 1) ? Eme : Emate;
-            }
-            C2 B0, B1, G;
-            B0.re = T.b0.x; B0.im = T.b0.y; B1.re = T.b1.x; B1.im = T.b1.y;
-            G = cmul(E0, B0);
-            cmac(G, E1, B1);
-            if (T.have_task) {
-                ldsE[((size_t)T.e_sl * 4 + e_corr) * np + T.e_ant] = e;
-                ldsG[((size_t)T.e_sl * 4 + e_corr) * np + T.e_ant] = T.have ? make_double2(G.re, G.im)
-                                                                            : make_double2(0.0, 0.0);
-            }
+                for (int k = 0; k < 4; ++k) off[k] = (unsigned)quad_bcast<QL>((int)gx.off[k]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
+                double2 v[8];
+                double ab[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double *r = reinterpret_cast<const double *>(vrec_c + (size_t)off[k & 3]) + (k >> 2) * VREC;
+                    v[k] = *reinterpret_cast<const double2 *>(r);
+                    ab[k] = r[2];
+                }
+                double2 e = beam_reduce1(v, ab, wt);
+                if (!have) e = make_double2(0.0, 0.0);
+                // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
+                C2 Eme, Emate;
+                Eme.re = e.x; Eme.im = e.y;
+                Emate.re = quad_swap1(e.x);
+                Emate.im = quad_swap1(e.y);
+                C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
+                if constexpr (have_feed) {
+                    // E <- E . R(t, antenna)  (einsum "stafij,tajk->stafik", rime/examples/predict.py:472):
+                    // this lane's component (i, j = e_corr & 1) is E[i,0] R[0,j] + E[i,1] R[1,j]
+                    const double2 r0 = ldsR[4 * e_ant + (e_corr & 1)], r1 = ldsR[4 * e_ant + 2 + (e_corr & 1)];
+                    C2 R0, R1;
+                    R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
+                    C2 Er = cmul(E0, R0);
+                    cmac(Er, E1, R1);
+                    e = make_double2(Er.re, Er.im);
+                    Eme = Er;
+                    Emate.re = quad_swap1(Er.re);
+                    Emate.im = quad_swap1(Er.im);
+                    E0 = (e_corr & 1) ? Emate : Eme;
+                    E1 = (e_corr & 1) ? Eme : Emate;
+                }
+                C2 B0, B1, G;
+                B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                G = cmul(E0, B0);
+                cmac(G, E1, B1);
+                if (have_task) {
+                    ldsE[((size_t)e_sl * 4 + e_corr) * np + e_ant] = e;
+                    ldsG[((size_t)e_sl * 4 + e_corr) * np + e_ant] = have ? make_double2(G.re, G.im)
+                                                                          : make_double2(0.0, 0.0);
+                }
+            };
+            round(std::integral_constant<int, 0>{});
+            round(std::integral_constant<int, 1>{});
+            round(std::integral_constant<int, 2>{});
+            round(std::integral_constant<int, 3>{});
         }
         __syncthreads();
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------

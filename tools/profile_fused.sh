@@ -37,4 +37,4 @@ for st in glob.glob("gpurun_out/prof_fused/stats/**/*kernel_stats.csv", recursiv
 json.dump(out, open("gpurun_out/prof_fused/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-tail -2 "$OUT"/*.log | tail -20
+for f in "$OUT"/*.log; do tail -n 2 "$f"; done
