@@ -69,38 +69,71 @@ __global__ void calib_rowbin_kernel(const int64_t *__restrict__ tbin_idx, const 
     rowbin[row] = (t >= 0 && row < tbin_idx[t] - off + tbin_counts[t]) ? (int)t : -1;
 }
 
-// acc (+/-)= sum_dir a1j[s] . model[s] . a2j[s]^H, the reference's jones_mul / subtract_model bodies
+// acc (+/-)= g . m . h^H for ONE direction, the reference's jones_mul / subtract_model bodies
 template <int MODE, int NCORR, int SIGN>
-__device__ __forceinline__ void jones_term(int64_t ndir, const C2 *__restrict__ a1j, const C2 *__restrict__ model,
-                                           const C2 *__restrict__ a2j, C2 (&acc)[vis_elems(MODE, NCORR)])
+__device__ __forceinline__ void jones_term(const C2 *__restrict__ g, const C2 *__restrict__ m, const C2 *__restrict__ h,
+                                           C2 (&acc)[vis_elems(MODE, NCORR)])
 {
-    constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
-    for (int64_t s = 0; s < ndir; ++s) {
-        const C2 *g = a1j + s * J, *h = a2j + s * J, *m = model + s * V;
-        if constexpr (MODE == 0) {
+    if constexpr (MODE == 0) {
 #pragma unroll
-            for (int c = 0; c < NCORR; ++c) {
-                const C2 t = cmul(cmul(g[c], m[c]), cconj(h[c]));
-                acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
-            }
-        } else if constexpr (MODE == 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const C2 t = cmul(cmul(g[c >> 1], m[c]), cconj(h[c & 1]));
-                acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
-            }
-        } else {
-            const C2 tmp00 = cconj(h[0]), tmp01 = cconj(h[2]), tmp10 = cconj(h[1]), tmp11 = cconj(h[3]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const C2 t1 = cmul(g[2 * i], m[0]), t2 = cmul(g[2 * i + 1], m[2]);
-                const C2 t3 = cmul(g[2 * i], m[1]), t4 = cmul(g[2 * i + 1], m[3]);
-                const C2 o0 = cadd(cadd(cadd(cmul(t1, tmp00), cmul(t2, tmp00)), cmul(t3, tmp10)), cmul(t4, tmp10));
-                const C2 o1 = cadd(cadd(cadd(cmul(t1, tmp01), cmul(t2, tmp01)), cmul(t3, tmp11)), cmul(t4, tmp11));
-                acc[2 * i] = SIGN > 0 ? cadd(acc[2 * i], o0) : csub(acc[2 * i], o0);
-                acc[2 * i + 1] = SIGN > 0 ? cadd(acc[2 * i + 1], o1) : csub(acc[2 * i + 1], o1);
-            }
+        for (int c = 0; c < NCORR; ++c) {
+            const C2 t = cmul(cmul(g[c], m[c]), cconj(h[c]));
+            acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
         }
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const C2 t = cmul(cmul(g[c >> 1], m[c]), cconj(h[c & 1]));
+            acc[c] = SIGN > 0 ? cadd(acc[c], t) : csub(acc[c], t);
+        }
+    } else {
+        const C2 tmp00 = cconj(h[0]), tmp01 = cconj(h[2]), tmp10 = cconj(h[1]), tmp11 = cconj(h[3]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const C2 t1 = cmul(g[2 * i], m[0]), t2 = cmul(g[2 * i + 1], m[2]);
+            const C2 t3 = cmul(g[2 * i], m[1]), t4 = cmul(g[2 * i + 1], m[3]);
+            const C2 o0 = cadd(cadd(cadd(cmul(t1, tmp00), cmul(t2, tmp00)), cmul(t3, tmp10)), cmul(t4, tmp10));
+            const C2 o1 = cadd(cadd(cadd(cmul(t1, tmp01), cmul(t2, tmp01)), cmul(t3, tmp11)), cmul(t4, tmp11));
+            acc[2 * i] = SIGN > 0 ? cadd(acc[2 * i], o0) : csub(acc[2 * i], o0);
+            acc[2 * i + 1] = SIGN > 0 ? cadd(acc[2 * i + 1], o1) : csub(acc[2 * i + 1], o1);
+        }
+    }
+}
+
+// The per-antenna gain of a lane's (row, chan) cell is a J*16-byte record that the lane's neighbours do not share a
+// cache line with (record stride ndir*J*16 bytes along the channel axis, other antennas elsewhere): read lane by lane,
+// every 16-byte load instruction touches 64 lines, and the CU's address / tag path -- not HBM -- bounds the kernel
+// (tools/microbench_gather.hip: 2.8 TB/s against 4.6 TB/s).  Instead J lanes fetch one record together (a full
+// 64 / 32-byte segment per record and instruction) and the wave transposes through a private LDS region: slot
+// 64 k + lane on the way in, an XOR-swizzled slot on the way out so that both directions are free of bank conflicts.
+// `rec` is the lane's record index (units of J*16 bytes); every lane of the wave must call.
+template <int J>
+__device__ __forceinline__ void gather_gain(const C2 *__restrict__ jones, int rec, C2 (&g)[J], double2 *lds_wave)
+{
+    if constexpr (J == 1) {
+        g[0] = jones[rec];
+    } else {
+        const int lane = threadIdx.x & 63;
+        constexpr int CPI = 64 / J;   // cells per load instruction
+        const double2 *src = reinterpret_cast<const double2 *>(jones);
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+            const int c = k * CPI + lane / J, h = lane % J;
+            const int rec_c = __shfl(rec, c, 64);
+            const int hs = J == 4 ? (h ^ ((c >> 1) & 3)) : h;
+            lds_wave[k * 64 + lane] = src[(int64_t)rec_c * J + hs];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int slot = J == 4 ? (j ^ ((lane >> 1) & 3)) : j;
+            const double2 v = lds_wave[lane * J + slot];
+            g[j] = C2{v.x, v.y};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -117,10 +150,13 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                                                     const double *__restrict__ lm = nullptr)
 {
     constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
-    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (cell >= nrow * nchan) return;
+    __shared__ double2 lds_gain[4][J > 1 ? 64 * J : 1];
+    double2 *lds_wave = lds_gain[threadIdx.x >> 6];
+    const int64_t cell_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = cell_raw < nrow * nchan;      // out-of-range lanes still take part in the wave's gathers
+    const int64_t cell = in_range ? cell_raw : 0;
     const int64_t row = cell / nchan, nu = cell - row * nchan;
-    const int t = rowbin[row];
+    const int t = in_range ? rowbin[row] : -1;
     C2 acc[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[c] = C2{0.0, 0.0};
@@ -129,18 +165,54 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
 #pragma unroll
         for (int c = 0; c < V; ++c) active = active && flag[cell * V + c] == 0;
     }
+    // record indices of the two gains of direction 0 (inactive lanes: record 0, fetched and ignored)
+    int rec1 = 0, rec2 = 0;
     if (active) {
         const int64_t p = ant1[row], q = ant2[row];
-        const C2 *a1j = jones + (((int64_t)t * nant + p) * nchan + nu) * ndir * J;
-        const C2 *a2j = jones + (((int64_t)t * nant + q) * nchan + nu) * ndir * J;
-        if constexpr (OP == 0) {
-            jones_term<MODE, NCORR, +1>(ndir, a1j, model + cell * ndir * V, a2j, acc);
-        } else if constexpr (OP == 3) {
-            // compute_and_corrupt_vis.py:14-22: source_vis = model[t,nu,s] * exp(1j * real_phase) / n, n = sqrt(1 - l^2 - m^2)
-            const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2], nuf = freq[nu];
-            const C2 *mt = model + ((int64_t)t * nchan + nu) * ndir * V;
-            for (int64_t s = 0; s < ndir; ++s) {
-                const double l = lm[((int64_t)t * ndir + s) * 2], m = lm[((int64_t)t * ndir + s) * 2 + 1];
+        rec1 = (int)((((int64_t)t * nant + p) * nchan + nu) * ndir);
+        rec2 = (int)((((int64_t)t * nant + q) * nchan + nu) * ndir);
+    }
+    // inactive lanes borrow the record of the wave's first active lane (a valid address whatever the extents are);
+    // a wave without any active lane skips the gathers
+    const unsigned long long act_mask = __ballot(active);
+    const bool any_active = act_mask != 0;   // wave-uniform
+    {
+        const int first = any_active ? __ffsll((unsigned long long)act_mask) - 1 : 0;
+        const int b1 = __shfl(rec1, first, 64), b2 = __shfl(rec2, first, 64);
+        if (!active) { rec1 = b1; rec2 = b2; }
+    }
+    C2 g1[J], g2[J];
+    if constexpr (OP == 0 || OP == 1) {
+        if constexpr (OP == 1) {
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
+            }
+        }
+        for (int64_t s = 0; s < ndir; ++s) {
+            C2 m[V];
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < V; ++c) m[c] = model[(cell * ndir + s) * V + c];
+            }
+            if (any_active) {
+                gather_gain<J>(jones, rec1 + (int)s, g1, lds_wave);
+                gather_gain<J>(jones, rec2 + (int)s, g2, lds_wave);
+            }
+            if (active) jones_term<MODE, NCORR, OP == 0 ? +1 : -1>(g1, m, g2, acc);
+        }
+    } else if constexpr (OP == 3) {
+        // compute_and_corrupt_vis.py:14-22: source_vis = model[t,nu,s] * exp(1j * real_phase) / n, n = sqrt(1 - l^2 - m^2)
+        const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2], nuf = freq[nu];
+        const int tt = active ? t : 0;
+        const C2 *mt = model + ((int64_t)tt * nchan + nu) * ndir * V;
+        for (int64_t s = 0; s < ndir; ++s) {
+            if (any_active) {
+                gather_gain<J>(jones, rec1 + (int)s, g1, lds_wave);
+                gather_gain<J>(jones, rec2 + (int)s, g2, lds_wave);
+            }
+            if (active) {
+                const double l = lm[((int64_t)tt * ndir + s) * 2], m = lm[((int64_t)tt * ndir + s) * 2 + 1];
                 const double n = __dsqrt_rn(__dsub_rn(__dsub_rn(1.0, __dmul_rn(l, l)), __dmul_rn(m, m)));
                 const double real_phase = __dmul_rn(
                     __dmul_rn(AF_MINUS_TWO_PI_OVER_C, nuf),
@@ -151,13 +223,16 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                 C2 sv[V];
 #pragma unroll
                 for (int c = 0; c < V; ++c) sv[c] = cdiv(cmul(mt[s * V + c], ph), nn);
-                jones_term<MODE, NCORR, +1>(1, a1j + s * J, sv, a2j + s * J, acc);
+                jones_term<MODE, NCORR, +1>(g1, sv, g2, acc);
             }
-        } else if constexpr (OP == 1) {
-#pragma unroll
-            for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
-            jones_term<MODE, NCORR, -1>(ndir, a1j, model + cell * ndir * V, a2j, acc);
-        } else {
+        }
+    } else {
+        if (any_active) {
+            gather_gain<J>(jones, rec1, g1, lds_wave);
+            gather_gain<J>(jones, rec2, g2, lds_wave);
+        }
+        if (active) {
+            const C2 *a1j = g1, *a2j = g2;
             const C2 *b = vis + cell * V;
             if constexpr (MODE == 0) {
 #pragma unroll
@@ -182,6 +257,7 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
             }
         }
     }
+    if (!in_range) return;
 #pragma unroll
     for (int c = 0; c < V; ++c) out[cell * V + c] = acc[c];
 }
@@ -199,6 +275,8 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     AF_REQUIRE(nrow >= 0 && nant >= 0 && nchan >= 0 && ndir >= 0 && ntime >= 0, "%s: negative extent", who);
     AF_REQUIRE(OP != 2 || ndir <= 1, "Jones has n_dir > 1. Cannot correct for direction dependent gains");
     AF_REQUIRE(OP != 2 || ndir == 1, "%s: jones needs one direction", who);
+    AF_REQUIRE((double)ntime * (double)nant * (double)nchan * (double)(ndir > 0 ? ndir : 1) < 2147483648.0,
+               "%s: more than 2^31 gain records (time x ant x chan x dir)", who);
     if (nrow == 0 || nchan == 0) return AF_OK;
     AF_REQUIRE(out && ant1 && ant2 && (ntime == 0 || (tbin_idx && tbin_counts)), "%s: NULL array", who);
     AF_REQUIRE(jones || ntime == 0, "%s: NULL jones", who);

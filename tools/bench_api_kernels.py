@@ -27,7 +27,8 @@ def rc(*shape):
 
 out = {}
 # predict_vis, coh only: (src=16, row=262144, chan=64, 2, 2) c128 = 17.2 GB read, 1.07 GB written
-s, r, c, t, a = 16, 262144, 64, 130, 64
+# (AF_BENCH_ROWS overrides the row count: 262144 rows make every source slab exactly 2^30 bytes)
+s, r, c, t, a = 16, int(os.environ.get("AF_BENCH_ROWS", 262144)), 64, 130, 64
 nbl = a * (a - 1) // 2
 ti = torch.arange(r, device=dev, dtype=torch.int32) // nbl
 a1 = torch.randint(0, a, (r,), device=dev, dtype=torch.int32)
@@ -35,7 +36,7 @@ a2 = torch.randint(0, a, (r,), device=dev, dtype=torch.int32)
 coh = rc(s, r, c, 2, 2)
 dt = timeit(lambda: rime.predict_vis(ti, a1, a2, None, coh, None, None, None, None))
 b = coh.numel() * 16 + r * c * 64
-out["predict_vis coh-only c128 (16 src x 262144 rows x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+out["predict_vis coh-only c128 (16 src x %d rows x 64 chan)" % r] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 ntime = int(ti.max().item()) + 1
 dde = rc(s, ntime, a, c, 2, 2)
 die = rc(ntime, a, c, 2, 2)
@@ -49,6 +50,8 @@ dt = timeit(lambda: rime.predict_vis(ti, a1, a2, None, coh64, None, None, None, 
 b = coh64.numel() * 8 + r * c * 32
 out["predict_vis coh-only c64"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 del coh64
+if os.environ.get("AF_BENCH_ONLY_PREDICT"):
+    print(json.dumps(out, indent=1)); sys.exit(0)
 # phase_delay: (100 src, 100k rows, 64 chan) c128 = 10.2 GB written
 lm = (torch.rand(100, 2, dtype=torch.float64, device=dev) - 0.5) * 0.1
 uvw = (torch.rand(100000, 3, dtype=torch.float64, device=dev) - 0.5) * 8000
