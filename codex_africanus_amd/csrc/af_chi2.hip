@@ -5,7 +5,8 @@
 // row-sharded multi-GPU predict (BASELINE config 4) reduces exactly this quantity across
 // GPUs with one RCCL all-reduce of an (nchan,) vector.  HBM-bound: reads model and data
 // once (2 x 16 B per cell), fully coalesced; per-lane partial sums in registers over the
-// rows of the block, one double atomicAdd per (block, column).
+// rows of the block, the correlations of a channel added up across neighbouring lanes, one double
+// atomicAdd per (wave, channel): with one per lane the 64-odd accumulators serialised 30 % of the run time.
 #include "af_common.h"
 
 namespace {
@@ -49,7 +50,15 @@ __global__ __launch_bounds__(256) void chi2_kernel(const double2 *__restrict__ m
             const double a = fma(dr, dr, di * di);
             acc[0] = HAS_WEIGHT ? fma(weight[i], a, acc[0]) : acc[0] + a;
         }
-        atomicAdd(&chi2[col / ncorr], (acc[0] + acc[1]) + (acc[2] + acc[3]));
+        // the ncorr lanes of a channel are neighbours and in range together: one atomic per channel, not per lane
+        double total = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (ncorr == 4 || ncorr == 2) {
+            total += __shfl_xor(total, 1, 64);
+            if (ncorr == 4) total += __shfl_xor(total, 2, 64);
+            if ((threadIdx.x & (ncorr - 1)) == 0) atomicAdd(&chi2[col / ncorr], total);
+        } else {
+            atomicAdd(&chi2[col / ncorr], total);
+        }
     }
 }
 
@@ -91,7 +100,16 @@ __global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restric
         const double a = fma(dr, dr, di * di);
         acc[0] = HAS_WEIGHT ? fma(weight[i], a, acc[0]) : acc[0] + a;
     }
-    atomicAdd(&chi2[col / ncorr], (acc[0] + acc[1]) + (acc[2] + acc[3]));
+    // the ncorr lanes of a channel are neighbours (256 and ncol are multiples of ncorr): add them up in registers so
+    // that the 64-odd channel accumulators see one atomic per channel and wave, not one per lane
+    double total = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (ncorr == 4 || ncorr == 2) {
+        total += __shfl_xor(total, 1, 64);
+        if (ncorr == 4) total += __shfl_xor(total, 2, 64);
+        if ((threadIdx.x & (ncorr - 1)) == 0) atomicAdd(&chi2[col / ncorr], total);
+    } else {
+        atomicAdd(&chi2[col / ncorr], total);
+    }
 }
 
 }  // namespace
