@@ -230,27 +230,16 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
     acc.im = fma(a.im, b.re, acc.im);
 }
 
-// exp(2 pi i x / 256) for x = q * f4 * 64 (f4 in quarter turns per metre): the nearest of 256 table phasors
-// (LDS, one 16-byte gather) times the residual rotation |theta| <= pi/256 by its Taylor series -- sin to
-// theta^5, cos to theta^6: truncation 8e-18 / 1e-20.  14 fp64 operations and no quadrant selects, against 17 + ~9
-// integer operations for the full-range polynomial pair.
-constexpr int PH_TABLE = 256;
+// exp(2 pi i x / 256) for x = q * f4 * 64 (f4 in quarter turns per metre): table phasor of af_sincos.h in one piece
+constexpr int PH_TABLE = PHASOR_TABLE;
 __device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, double x256)
 {
-    constexpr double T = 6.283185307179586476925 / PH_TABLE;
-    constexpr double S1 = T, S3 = -T * T * T / 6.0, S5 = T * T * T * T * T / 120.0;
-    constexpr double C2_ = -T * T / 2.0, C4 = T * T * T * T / 24.0, C6 = -T * T * T * T * T * T / 720.0;
-    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
-    const double a = __dadd_rn(x256, MAGIC);
-    const int k = __double2loint(a) & (PH_TABLE - 1);
-    const double z = __dsub_rn(x256, __dsub_rn(a, MAGIC));  // [-0.5, 0.5]
-    const double z2 = __dmul_rn(z, z);
-    const double sn = __dmul_rn(z, fma(z2, fma(z2, S5, S3), S1));
-    const double cs = fma(z2, fma(z2, fma(z2, C6, C4), C2_), 1.0);
-    const double2 tk = table[k];
+    TablePhasorStage st;
+    table_phasor_reduce(st, table, x256);
+    table_phasor_sin(st);
+    table_phasor_cos(st);
     C2 y;
-    y.re = fma(tk.x, cs, -__dmul_rn(tk.y, sn));
-    y.im = fma(tk.y, cs, __dmul_rn(tk.x, sn));
+    table_phasor_finish(st, y.re, y.im);
     return y;
 }
 
@@ -301,11 +290,7 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * np);
     double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
     double2 *ldsT = ldsR + (size_t)4 * nant;      // phasor table
-    for (int i = tid; i < PH_TABLE; i += THREADS) {
-        double c, sn;
-        sincos_quarter_turns<7>((double)i * (4.0 / PH_TABLE), c, sn);
-        ldsT[i] = make_double2(c, sn);
-    }
+    table_phasor_init(ldsT, tid, THREADS);
     constexpr bool have_feed = FEED;
     if (have_feed)
         for (int i = tid; i < 4 * nant; i += THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     constexpr int STAGE = stage_doubles(CT, CPLX);
     constexpr int UNITS = STAGE / 2;              // 16-byte units of a stage
     __shared__ double smem[2 * STAGE];
+    __shared__ double2 ptab[PHASOR_TABLE];   // exp(2 pi i k / 256): af_sincos.h table phasor
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = lane >> 4;                      // the source of a step this lane computes the phasor of
     const int tile = blockIdx.y;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     int64_t row = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
     if (row >= nrow) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
-    const double F0 = tile_f0[tile], FD = tilef[1];
+    const double F0 = 64.0 * tile_f0[tile], FD = 64.0 * tilef[1];   // quarter turns -> 1/256 turns per metre (exact)
     const int boff = (k * 4 + (lane & 3)) * (CPLX ? 6 : 2);  // B operand: pixel(s) of (source k, corr lane & 3)
 
     double are[CT], aim[CT];
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     for (int j = 0; j < CT; ++j) are[j] = aim[j] = 0.0;
 
     mfma_stage_load<UNITS>(rec, smem, wave, lane);
+    table_phasor_init(ptab, tid, THREADS);
     asm volatile("" :: "v"(u), "v"(v), "v"(w), "s"(F0), "s"(FD));  // hipcc's own waits land here, not in the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         cur_.a0 = cur_.a1 = cur_.a2 = 0.0;
         if (k < nsrc) { cur_.a0 = lmn[4 * k]; cur_.a1 = lmn[4 * k + 1]; cur_.a2 = lmn[4 * k + 2]; }
 #pragma unroll
-        for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, u, v, w, F0, FD, yr[0], yi[0]);
+        for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, u, v, w, F0, FD, ptab, yr[0], yi[0]);
     }
     nxt_ = cur_;
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
             // the MFMAs of group NGRP-2 were issued)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl)
-                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, yr[0], yi[0]);
+                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, ptab, yr[0], yi[0]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!CPLX) {
 #pragma unroll

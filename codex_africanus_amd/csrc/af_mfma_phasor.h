@@ -31,7 +31,7 @@ __device__ __forceinline__ void mfma_stage_load(const double *src, double *lds_s
 // header ((l,m,n) in im_to_vis, (u,v,w) in vis_to_im); the lane-side triple is passed in.
 struct PhasorSetup {
     double a0, a1, a2;
-    SinCosStage sd, s0;
+    TablePhasorStage sd, s0;
     double dr, di, y0r, y0i;  // channel-step phasor d, phasor at the tile's first channel
     double ar, ai;            // d^16
     double kk, k2;            // 2 cos(delta), 2 cos(2 delta)
@@ -64,10 +64,14 @@ __device__ __forceinline__ void phasor_next_segment(const PhasorSetup &P, double
 
 // The set-up cut into 8 slices, so that the set-up of step it+1 can be spread over the channel groups of
 // step it (its dependent chains then hide behind the MFMAs):
-//   0 header triple from LDS   1 path difference, range reductions   2,3 polynomial halves
-//   4 quadrant fix-up -> d, y0   5 d^16 by four squarings, 2cos(delta), 2cos(2 delta)   7 first 8 phasors
+//   0 header triple from LDS   1 path difference, range reductions + table reads   2 residual sines   3 residual
+//   cosines   4 table entry x residual rotation -> d, y0   5 d^16 by four squarings, 2cos(delta), 2cos(2 delta)
+//   7 first 8 phasors
+// F0, FD: the tile's first-channel frequency and the channel step in 1/256 turns per metre (quarter turns x 64);
+// `table`: the block's PHASOR_TABLE-entry phasor table in LDS (table_phasor_init).
 __device__ __forceinline__ void phasor_setup_slice(PhasorSetup &P, int slice, const double *hdr4, double c0, double c1,
-                                                   double c2, double F0, double FD, double (&Yr)[8], double (&Yi)[8])
+                                                   double c2, double F0, double FD, const double2 *table,
+                                                   double (&Yr)[8], double (&Yi)[8])
 {
     switch (slice) {
     case 0: {
@@ -77,13 +81,13 @@ __device__ __forceinline__ void phasor_setup_slice(PhasorSetup &P, int slice, co
     }
     case 1: {
         const double q = fma(P.a2, c2, fma(P.a1, c1, __dmul_rn(P.a0, c0)));  // path difference in metres
-        sincos_qt_reduce(P.sd, __dmul_rn(q, FD));
-        sincos_qt_reduce(P.s0, __dmul_rn(q, F0));
+        table_phasor_reduce(P.sd, table, __dmul_rn(q, FD));
+        table_phasor_reduce(P.s0, table, __dmul_rn(q, F0));
         break;
     }
-    case 2: sincos_qt_horner<5, 3>(P.sd); sincos_qt_horner<5, 3>(P.s0); break;
-    case 3: sincos_qt_horner<2, 0>(P.sd); sincos_qt_horner<2, 0>(P.s0); break;
-    case 4: sincos_qt_finish(P.sd, P.dr, P.di); sincos_qt_finish(P.s0, P.y0r, P.y0i); break;
+    case 2: table_phasor_sin(P.sd); table_phasor_sin(P.s0); break;
+    case 3: table_phasor_cos(P.sd); table_phasor_cos(P.s0); break;
+    case 4: table_phasor_finish(P.sd, P.dr, P.di); table_phasor_finish(P.s0, P.y0r, P.y0i); break;
     case 5: {
         double ar = P.dr, ai = P.di;
 #pragma unroll

@@ -94,6 +94,53 @@ __device__ __forceinline__ void sincos_qt_finish(const SinCosStage &s, double &c
 }
 
 
+// exp(2 pi i x / 256) from a 256-entry table of exp(2 pi i k / 256) (LDS: one 16-byte gather) times the residual
+// rotation |theta| <= pi/256 by its Taylor series -- sin to theta^5, cos to theta^6: truncation 8e-18 / 1e-20; the
+// result carries the table entry's and four products' roundings (~2e-16).  x in units of 1/256 turn (a
+// quarter-turn argument times 64: an exact scaling).  14 fp64 operations + 2 integer operations and no quadrant
+// selects, against 17 + ~9 for sincos_quarter_turns<7>.  Cut into stages like the polynomial pair above:
+// reduce (issues the table read) -> sin -> cos -> finish.
+constexpr int PHASOR_TABLE = 256;
+struct TablePhasorStage {
+    double z, z2, sn, cs;
+    double2 tk;
+};
+// fill `table` (PHASOR_TABLE entries) with a block of `nthreads` lanes; the caller synchronises
+__device__ __forceinline__ void table_phasor_init(double2 *table, int tid, int nthreads)
+{
+    for (int i = tid; i < PHASOR_TABLE; i += nthreads) {
+        double c, sn;
+        sincos_quarter_turns<7>((double)i * (4.0 / PHASOR_TABLE), c, sn);
+        table[i] = make_double2(c, sn);
+    }
+}
+__device__ __forceinline__ void table_phasor_reduce(TablePhasorStage &s, const double2 *table, double x256)
+{
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double a = __dadd_rn(x256, MAGIC);
+    s.tk = table[__double2loint(a) & (PHASOR_TABLE - 1)];
+    s.z = __dsub_rn(x256, __dsub_rn(a, MAGIC));  // [-0.5, 0.5]
+    s.z2 = __dmul_rn(s.z, s.z);
+}
+__device__ __forceinline__ void table_phasor_sin(TablePhasorStage &s)
+{
+    constexpr double T = 6.283185307179586476925 / PHASOR_TABLE;
+    constexpr double S1 = T, S3 = -T * T * T / 6.0, S5 = T * T * T * T * T / 120.0;
+    s.sn = __dmul_rn(s.z, fma(s.z2, fma(s.z2, S5, S3), S1));
+}
+__device__ __forceinline__ void table_phasor_cos(TablePhasorStage &s)
+{
+    constexpr double T = 6.283185307179586476925 / PHASOR_TABLE;
+    constexpr double C2 = -T * T / 2.0, C4 = T * T * T * T / 24.0, C6 = -T * T * T * T * T * T / 720.0;
+    s.cs = fma(s.z2, fma(s.z2, fma(s.z2, C6, C4), C2), 1.0);
+}
+__device__ __forceinline__ void table_phasor_finish(const TablePhasorStage &s, double &c_out, double &s_out)
+{
+    c_out = fma(s.tk.x, s.cs, -__dmul_rn(s.tk.y, s.sn));
+    s_out = fma(s.tk.y, s.cs, __dmul_rn(s.tk.x, s.sn));
+}
+
+
 // (cos, sin)(p) for p in RADIANS, for the kernels that must keep the reference's phase p bit for bit
 // (phase_delay).  Cody-Waite reduction p = k*(pi/2) + r with pi/2 split in three parts (33 + 33 + 53
 // bits, fdlibm's pio2_1/pio2_2/pio2_3): k*part is exact for |k| < 2^20 and each step is one FMA, so

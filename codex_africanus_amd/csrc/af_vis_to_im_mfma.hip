@@ -101,6 +101,7 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
     constexpr int STAGE = v_stage_doubles(CT);
     constexpr int UNITS = STAGE / 2;
     __shared__ double smem[2 * STAGE];
+    __shared__ double2 ptab[PHASOR_TABLE];   // exp(2 pi i k / 256): af_sincos.h table phasor
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = lane >> 4;  // the row of a step this lane computes the phasor of
     const int tile = blockIdx.y;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
     int64_t src = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
     if (src >= nsrc) src = nsrc - 1;
     const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
-    const double F0 = tilef[2 * tile], FD = tilef[2 * tile + 1];
+    const double F0 = 64.0 * tilef[2 * tile], FD = 64.0 * tilef[2 * tile + 1];   // quarter turns -> 1/256 turns per metre (exact)
     const int64_t it0 = (int64_t)blockIdx.z * steps_per_part;
     const int64_t it1 = (it0 + steps_per_part < nstep) ? it0 + steps_per_part : nstep;
     const int boff = k * 4 + (lane & 3);  // B operand (Re V, -Im V) of (row k, corr lane & 3)
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
     for (int j = 0; j < CT; ++j) acc[j] = 0.0;
 
     mfma_stage_load<UNITS>(rec + it0 * STAGE, smem, wave, lane);
+    table_phasor_init(ptab, threadIdx.x, blockDim.x);
     asm volatile("" :: "v"(l), "v"(m), "v"(n), "s"(F0), "s"(FD));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
         if (!(isfinite(a) && isfinite(b) && isfinite(c))) { a = 0.0; b = 0.0; c = 0.0; }
         cur_.a0 = a; cur_.a1 = b; cur_.a2 = c;
 #pragma unroll
-        for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, l, m, n, F0, FD, yr[0], yi[0]);
+        for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, l, m, n, F0, FD, ptab, yr[0], yi[0]);
     }
     nxt_ = cur_;
 
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
             }
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl)
-                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, l, m, n, F0, FD, yr[0], yi[0]);
+                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, l, m, n, F0, FD, ptab, yr[0], yi[0]);
             __builtin_amdgcn_sched_barrier(0);
             // two MFMAs per channel on ONE accumulator: all Re products of the group first, then all
             // Im products, so that dependent MFMAs are 8 instructions apart
