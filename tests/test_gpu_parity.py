@@ -273,6 +273,46 @@ def test_im_to_vis_phase_centre(dft_mode):
     assert np.abs(vis - Inu[None, :, None]).max() < 1e-13
 
 
+@pytest.mark.parametrize("mode", ["exact", "auto"])
+def test_im_to_vis_analytic_sum(dft_mode, mode):
+    """africanus/dft/tests/test_dft.py:45-84: several channels and sources, one correlation, against the phasor
+    sum written out with numpy's complex exponential (decimal=14 there)."""
+    from codex_africanus_amd.constants import minus_two_pi_over_c
+    dft_mode(mode)
+    rng = np.random.default_rng(123)
+    nrow, nchan, nsource = 100, 3, 5
+    uvw = rng.random((nrow, 3))
+    frequency = np.linspace(1.0e9, 2.0e9, nchan)
+    image = (rng.standard_normal(nsource)[:, None] * (frequency / frequency[nchan // 2]) ** (-0.7))[:, :, None]
+    lm = 0.001 + 0.1 * rng.random((nsource, 2))
+    vis = dft.im_to_vis(image, uvw, lm, frequency)[..., 0]
+    n = np.sqrt(1.0 - lm[:, 0] ** 2 - lm[:, 1] ** 2)
+    path = uvw[:, 0, None] * lm[None, :, 0] + uvw[:, 1, None] * lm[None, :, 1] + uvw[:, 2, None] * (n[None, :] - 1)
+    expect = np.einsum("rsf,sf->rf", np.exp(1j * minus_two_pi_over_c * path[:, :, None] * frequency[None, None, :]),
+                       image[:, :, 0])
+    np.testing.assert_array_almost_equal(vis, expect, decimal=13 if mode == "auto" else 14)
+
+
+def test_symmetric_covariance(dft_mode):
+    """africanus/dft/tests/test_dft.py:297-331: the image-plane precision matrix R^H R sampled at the source
+    positions (im_to_vis of a unit source followed by vis_to_im) is symmetric."""
+    dft_mode("auto")
+    rng = np.random.default_rng(123)
+    nsource, nrows = 25, 1000
+    lm = -0.05 + 0.1 * rng.random((nsource, 2))
+    uvw = rng.standard_normal((nrows, 3)) * 1000
+    uvw[:, 2] = 0.0
+    freq = np.array([1.0e9])
+    flags = np.zeros((nrows, 1, 1), dtype=np.bool_)
+    unit = np.ones((1, 1, 1))
+    psf = np.zeros((nsource, nsource))
+    for j in range(nsource):
+        k = dft.im_to_vis(unit, uvw, lm[j:j + 1], freq)
+        psf[:, j] = dft.vis_to_im(k, uvw, lm, freq, flags)[:, 0, 0]
+    assert np.abs(psf - psf.T).max() < 1e-13 * nrows      # entries are sums of `nrows` unit phasors
+    assert np.abs(np.diag(psf) - nrows).max() < 1e-10
+
+
 @pytest.mark.parametrize("mode, tol", [("exact", 2e-12), ("auto", 1e-8)])
 def test_im_to_vis_c1_golden(g5, dft_mode, mode, tol):
     """BASELINE config C1 (10k rows, 16 chan, 100 src, 4 corr) against the reference's rows."""
