@@ -25,7 +25,8 @@
 //            fp64-VALU issue bound.
 // Every per-antenna Jones is computed once per (timestep, channel, source) and reused by all
 // baselines of the timestep from LDS; the output is written once.  Measured at C3 (tools/profile_fused.sh,
-// AFHIP_FUSED_STAGE): stage 2 alone 159 ms, stage 1 adds ~89 ms (they run back to back, not overlapped).
+// AFHIP_FUSED_STAGE): 8-wave kernel 243 ms (stage 2 alone 159 ms, stage 1 adds ~89 ms back to back); wave-specialised
+// kernel (WS: 8 accumulating + 4 sampling waves, double-buffered Jones; the default) 217 ms.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -247,8 +248,12 @@ __device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, do
 // rotations + the 256-entry phasor table.  NP > 0: the antenna stride np of the Jones arrays is the compile-time
 // constant NP >= nant, so that the four components of a Jones term are one address plus immediate offsets; NP = 0:
 // np = nant at run time.
-template <bool FEED, bool GAUSS, int NP>
-__global__ __launch_bounds__(THREADS) void fused_predict_kernel(
+// WS (wave-specialised): 12 waves -- the 8 waves of lanes 0..511 only accumulate (stage 2), the 4 waves of lanes
+// 512..767 only sample the beam (stage 1), one batch ahead, into the other half of a double-buffered Jones region;
+// one barrier per batch.  Each SIMD then holds two accumulating waves (fp64 issue bound) and one sampling wave
+// (L1-fill bound), whose stalls the other two fill.
+template <bool FEED, bool GAUSS, int NP, bool WS>
+__global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
     const double2 *__restrict__ brightness, const double *__restrict__ vrec,
@@ -260,9 +265,12 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
 {
     extern __shared__ double2 lds[];
     const int np = NP > 0 ? NP : nant;
-    double2 *ldsE = lds;                          // [st][4][np]
-    double2 *ldsG = lds + (size_t)st * 4 * np;    // [st][4][np]
+    constexpr int NBUF = WS ? 2 : 1;              // Jones buffers: E then G, each [st][4][np]
+    constexpr int NTHREADS = WS ? THREADS + THREADS / 2 : THREADS;
+    constexpr int PLANES = WS ? THREADS / 2 : THREADS;   // lanes that sample the beam
     const int tid = threadIdx.x;
+    const bool consumer = !WS || tid < THREADS;
+    const int ptid = WS ? tid - THREADS : tid;    // lane number among the sampling lanes
     const int64_t f = blockIdx.y;
     const int t = items[4 * blockIdx.x + 0];
     const int64_t r0 = items[4 * blockIdx.x + 1];
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int rl = tid + k * THREADS;
-        live[k] = rl < rc;
+        live[k] = consumer && rl < rc;
         const int64_t r = r0 + (live[k] ? rl : 0);
         u[k] = uvw[3 * r]; v[k] = uvw[3 * r + 1]; w[k] = uvw[3 * r + 2];
         a1[k] = ant1[r]; a2[k] = ant2[r];
@@ -287,14 +295,14 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
 
     // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
     // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m); ldsR[a] = the antenna's 2x2 feed rotation (optional)
-    double *ldsA = reinterpret_cast<double *>(lds + (size_t)2 * st * 4 * np);
+    double *ldsA = reinterpret_cast<double *>(lds + (size_t)NBUF * 2 * st * 4 * np);
     double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
     double2 *ldsT = ldsR + (size_t)4 * nant;      // phasor table
-    table_phasor_init(ldsT, tid, THREADS);
+    table_phasor_init(ldsT, tid, NTHREADS);
     constexpr bool have_feed = FEED;
     if (have_feed)
-        for (int i = tid; i < 4 * nant; i += THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
-    for (int a = tid; a < nant; a += THREADS) {
+        for (int i = tid; i < 4 * nant; i += NTHREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
+    for (int a = tid; a < nant; a += NTHREADS) {
         double sp, cp;
         sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
         const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
     const char *vrec_c = reinterpret_cast<const char *>(vrec) + e_corr * 32;   // this lane's 32 bytes of a record
     __syncthreads();
 
-    for (int s0 = 0; s0 < nsrc; s0 += st) {
+    auto stage1 = [&](int s0, double2 *ldsE, double2 *ldsG) {
         // ---- stage 1: E and G = E.B for the batch's (source, antenna) pairs -> LDS ------------------
         // Four lanes per Jones term, one per correlation: every lane gathers its own 32 bytes
         // (re, im, |.|) of each of the 8 voxel records, so a record's cache line is fetched once and no
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
         };
         auto fetch = [&](int task0) {
             Own T;
-            const int task = task0 + tid;
+            const int task = task0 + ptid;
             int e_sl = task / np;          // NP > 0: a shift
             int e_ant = task - e_sl * np;
             const bool have_task = task < ntask && e_ant < nant;
@@ -344,38 +352,49 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
             return T;
         };
         Own nxt = fetch(0);
-        for (int task0 = 0; task0 < ntask && only_stage != 2; task0 += THREADS) {
+        for (int task0 = 0; task0 < ntask && only_stage != 2; task0 += PLANES) {
             const Own own = nxt;
-            if (task0 + THREADS < ntask) nxt = fetch(task0 + THREADS);
+            if (task0 + PLANES < ntask) nxt = fetch(task0 + PLANES);
             FusedVoxels gx;
             {
                 const int a = (own.info >> 11) & 1023;
                 fused_voxels(grid, own.lm.x, own.lm.y, ldsA[6 * a + 0], ldsA[6 * a + 1], ldsA[6 * a + 2], ldsA[6 * a + 3],
                              ldsA[6 * a + 4], ldsA[6 * a + 5], fscale, fnud, fgc0, gx);
             }
-            auto round = [&](auto lane_c) {
+            // One sampling round in two halves: gathers issued, then consumed.
+            struct Round {
+                int info;
+                double2 b0, b1, v[8];
+                double ab[8], wt[8];
+            };
+            auto issue = [&](auto lane_c, Round &R) {
                 constexpr int QL = decltype(lane_c)::value;
                 const int info = quad_bcast<QL>(own.info);
-                const int e_sl = info & 2047, e_ant = (info >> 11) & 1023;
-                const bool have_task = (info >> 30) & 1, have = info < 0;
+                R.info = info;
+                const int e_sl = info & 2047;
+                const bool have = info < 0;
                 // G[c] = E[2(c/2)] . B[c%2] + E[2(c/2)+1] . B[2 + c%2]: this lane needs column c%2 of B
                 const double2 *bp = brightness + ((int64_t)(have ? s0 + e_sl : 0) * nchan + f) * 4;
-                const double2 b0 = bp[e_corr & 1], b1 = bp[2 + (e_corr & 1)];
+                R.b0 = bp[e_corr & 1];
+                R.b1 = bp[2 + (e_corr & 1)];
                 unsigned off[4];
-                double wt[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) off[k] = (unsigned)quad_bcast<QL>((int)gx.off[k]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
-                double2 v[8];
-                double ab[8];
+                for (int k = 0; k < 8; ++k) R.wt[k] = quad_bcast<QL>(gx.wt[k]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const double *r = reinterpret_cast<const double *>(vrec_c + (size_t)off[k & 3]) + (k >> 2) * VREC;
-                    v[k] = *reinterpret_cast<const double2 *>(r);
-                    ab[k] = r[2];
+                    R.v[k] = *reinterpret_cast<const double2 *>(r);
+                    R.ab[k] = r[2];
                 }
-                double2 e = beam_reduce1(v, ab, wt);
+            };
+            auto finish = [&](const Round &R) {
+                const int info = R.info;
+                const int e_sl = info & 2047, e_ant = (info >> 11) & 1023;
+                const bool have_task = (info >> 30) & 1, have = info < 0;
+                const double2 b0 = R.b0, b1 = R.b1;
+                double2 e = beam_reduce1(R.v, R.ab, R.wt);
                 if (!have) e = make_double2(0.0, 0.0);
                 // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
                 C2 Eme, Emate;
@@ -408,12 +427,20 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
                                                                           : make_double2(0.0, 0.0);
                 }
             };
-            round(std::integral_constant<int, 0>{});
-            round(std::integral_constant<int, 1>{});
-            round(std::integral_constant<int, 2>{});
-            round(std::integral_constant<int, 3>{});
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            // (two rounds in flight were measured: no gain -- the stage is bound by the gathers' throughput, not their
+            // latency -- and the second round's 48 registers spill in every variant)
+            Round R;
+            issue(I0{}, R); finish(R);
+            issue(I1{}, R); finish(R);
+            issue(I2{}, R); finish(R);
+            issue(I3{}, R); finish(R);
         }
-        __syncthreads();
+    };
+    auto stage2 = [&](int s0, const double2 *ldsE, const double2 *ldsG) {
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
         for (int sl = 0; sl < nb && only_stage != 1; ++sl) {
@@ -459,7 +486,37 @@ __global__ __launch_bounds__(THREADS) void fused_predict_kernel(
                 cmac(acc[k][3], y, M3);
             }
         }
-        __syncthreads();
+    };
+    const size_t buf_elems = (size_t)2 * st * 4 * np;   // one buffer: E then G
+    if constexpr (!WS) {
+        for (int s0 = 0; s0 < nsrc; s0 += st) {
+            stage1(s0, lds, lds + (size_t)st * 4 * np);
+            __syncthreads();
+            stage2(s0, lds, lds + (size_t)st * 4 * np);
+            __syncthreads();
+        }
+    } else {
+        // producer: sample batch b, barrier b; consumer: barrier b, accumulate batch b.  When the producer passes
+        // barrier b the consumers have finished batch b - 1, whose buffer batch b + 1 overwrites.  Two separate
+        // loops: the accumulators must not be live in the sampling waves' code (168 registers at 3 waves per SIMD).
+        if (!consumer) {
+            // the lone sampling wave of a SIMD runs dependent chains behind memory latency: let it issue whenever it
+            // is ready, ahead of the two accumulating waves (which always have independent work)
+            __builtin_amdgcn_s_setprio(3);
+            int b = 0;
+            for (int s0 = 0; s0 < nsrc; s0 += st, ++b) {
+                double2 *E = lds + (size_t)(b & 1) * buf_elems;
+                stage1(s0, E, E + (size_t)st * 4 * np);
+                __syncthreads();
+            }
+            return;
+        }
+        int b = 0;
+        for (int s0 = 0; s0 < nsrc; s0 += st, ++b) {
+            const double2 *E = lds + (size_t)(b & 1) * buf_elems;
+            __syncthreads();
+            stage2(s0, E, E + (size_t)st * 4 * np);
+        }
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -580,11 +637,17 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     const int NPv = (nant > 32 && nant <= 64) ? 64 : (nant > 64 && nant <= 128) ? 128 : 0;
     const int64_t np = NPv ? NPv : nant;
     const int64_t fixed = 112 * nant + PH_TABLE * 16;   // per-antenna constants, feed rotation, phasor table
-    int st = (int)((160 * 1024 - fixed) / (128 * np));
+    // wave-specialised variant (12 waves, double-buffered Jones): the default when two buffers of >= 2 sources fit
+    // and no Gaussian shapes are folded in (that variant needs more than the 168 registers of 3 waves per SIMD);
+    // AFHIP_FUSED_WS=0 selects the 8-wave kernel
+    static const int ws_env = getenv("AFHIP_FUSED_WS") ? atoi(getenv("AFHIP_FUSED_WS")) : 1;
+    const bool ws_mode = ws_env != 0 && gauss_shape == nullptr && (160 * 1024 - fixed) / (256 * np) >= 2;
+    const int nbuf = ws_mode ? 2 : 1;
+    int st = (int)((160 * 1024 - fixed) / (128 * nbuf * np));
     if (st > 1024 / np) st = (int)(1024 / np);
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    const size_t lds_bytes = (size_t)2 * st * 4 * np * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
+    const size_t lds_bytes = (size_t)nbuf * 2 * st * 4 * np * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
                              (size_t)nant * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
     AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_c128: %zu bytes of LDS needed (nant = %lld)", lds_bytes,
                (long long)nant);
@@ -592,11 +655,11 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // measurement hook (tools/profile_fused.sh): AFHIP_FUSED_STAGE=1 / 2 runs only the beam stage / only the
     // accumulation stage (results are then meaningless); unset = the real kernel
     static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
-    auto launch = [&](auto kernel) -> int {
+    auto launch = [&](auto kernel, int nthreads) -> int {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
         af_prof_begin(st_);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(THREADS), lds_bytes, st_, items, antenna1,
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(nthreads), lds_bytes, st_, items, antenna1,
                            antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), babs, beam_lw, beam_mh,
                            beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
                            reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc, nchan, ntime,
@@ -604,9 +667,13 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         AF_LAUNCH_CHECK();
         return AF_OK;
     };
-#define AF_FUSED_PICK(NPC)                                                                                \
-    (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC>) : launch(fused_predict_kernel<true, false, NPC>)) \
-          : (gauss ? launch(fused_predict_kernel<false, true, NPC>) : launch(fused_predict_kernel<false, false, NPC>)))
+#define AF_FUSED_PICK(NPC)                                                                                               \
+    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true>, THREADS + THREADS / 2)                          \
+                     : launch(fused_predict_kernel<false, false, NPC, true>, THREADS + THREADS / 2))                        \
+             : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false>, THREADS)                               \
+                              : launch(fused_predict_kernel<true, false, NPC, false>, THREADS))                             \
+                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, false>, THREADS)                              \
+                              : launch(fused_predict_kernel<false, false, NPC, false>, THREADS))))
     rc = NPv == 64 ? AF_FUSED_PICK(64) : NPv == 128 ? AF_FUSED_PICK(128) : AF_FUSED_PICK(0);
 #undef AF_FUSED_PICK
     if (rc != AF_OK) return rc;
