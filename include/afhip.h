@@ -217,7 +217,9 @@ int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, in
  *       "stafij,tajk->stafik" of africanus/rime/examples/predict.py:472 (af_feed_rotation_f64 output);
  *   gauss_shape (nsrc,3) = (major, minor, orientation) [rad] or NULL: K <- K . shape(r,s,nu), the Gaussian
  *       shape function of africanus/model/shape/gaussian_shape.py:11-62; (0,0,.) rows are point sources.
- * DIE terms / base_vis are applied afterwards with af_predict_vis_c128 (source_coh = out). */
+ * DIE terms / base_vis are applied afterwards with af_predict_vis_c128 (source_coh = out).
+ * Limits (AF_EINVAL beyond them): nant <= 664 (one time step's Jones of a source in LDS), beam cube < 2^25 voxels
+ * (32-bit byte offsets into its 128-byte voxel records), nchan <= 65535. */
 int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *items_host,
                        int64_t max_items, int64_t *nitems);
 size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
