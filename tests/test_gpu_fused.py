@@ -53,7 +53,10 @@ def _scale(d):
     return np.abs(d["X"]).sum(axis=0).max()
 
 
-@pytest.mark.parametrize("nant, nrow", [(7, 300), (12, 1000), (5, 37)])
+# antenna counts on every Jones-stride variant of the kernel: run-time stride (<= 32 and > 128 antennas), the
+# compile-time strides 64 and 128, exactly full (64) and padded (40, 70) -- with rows spanning several timesteps
+@pytest.mark.parametrize("nant, nrow", [(7, 300), (12, 1000), (5, 37), (40, 1700), (64, 2100), (70, 2600),
+                                        (130, 9000)])
 def test_fused_with_beam_matches_chain(nant, nrow):
     d = _problem(3, nrow, 8, 23, nant)
     out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"],
