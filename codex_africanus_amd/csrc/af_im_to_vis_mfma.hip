@@ -10,15 +10,15 @@
 //   * so every lane owns ONE (row, source) pair of the step and its VALU work is that pair's phasor
 //     only: path difference, two quarter-turn sincos (tile start, channel step), then the
 //     three-term recurrence over the tile, run as four independent chains (re/im x even/odd
-//     channels, step 2 delta) one 8-channel group ahead of the MFMAs that consume it, re-anchored
-//     every 16 channels at y0 * d^16 (d^16 by four squarings) so that the recurrence error stays that
-//     of a 16-channel tile.  fp64 MFMA and fp64 VALU share one pipe on this chip (measured), so the
+//     channels, step 2 delta) one 8-channel group ahead of the MFMAs that consume it (error growth
+//     (j/2)^2 eps <= 4e-13 at the end of a 64-channel tile: no re-anchoring, MFMA_ANCHOR = 64).
+//     fp64 MFMA and fp64 VALU share one pipe on this chip (measured), so the
 //     gain over the VALU kernels is not rate but registers: with the accumulators out of the
 //     arch VGPRs a tile holds 64 channels instead of 13 and the per-tile setup is amortised 5x better.
 //   * the image pixels of a 4-source step (CT x 4 x 4 doubles) and the NEXT step's (l,m,n) come as one
 //     contiguous record, copied global -> LDS by global_load_lds_dwordx4 one step ahead (two LDS
 //     stages, one barrier per step) and read as ds_read_b128 (two channels per read) in the shadow of
-//     the MFMAs; the set-up of step it+1 (sincos, d^16) is sliced over the channel groups of step it.
+//     the MFMAs; the set-up of step it+1 (table phasors) is sliced over the channel groups of step it.
 //   * measured (tools/microbench_issue.hip): a lone wave issues an fp64 VALU op every ~5.5 cycles and an
 //     fp64 MFMA 4x4x4 every 16.4; per step 128 MFMAs + ~220 VALU ops = ~3300 cycles against 3500 measured.
 #include "af_dft_mfma.h"
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         constexpr int BPG = CPLX ? 12 : GP;       // 16-byte B reads per group of 8 channels
         constexpr int BSTRIDE = CPLX ? 48 : 16;   // double2 units between channel pairs
         double2 bg[2][BPG];
-        double anr = cur_.y0r, ani = cur_.y0i;    // phasor at the current 16-channel anchor
+        double anr = cur_.y0r, ani = cur_.y0i;    // phasor at the current anchor (re-anchoring only if MFMA_ANCHOR < CT)
         auto load_b = [&](int g, int t) {         // t-th read of group g
             if constexpr (CPLX) bg[g & 1][t] = B[(g * GP + t / 3) * BSTRIDE + (t % 3)];
             else bg[g & 1][t] = B[(g * GP + t) * BSTRIDE];

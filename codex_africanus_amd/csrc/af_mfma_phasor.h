@@ -5,7 +5,9 @@
 #include "af_common.h"
 #include "af_sincos.h"
 
-constexpr int MFMA_ANCHOR = 16;  // channels between re-anchored phasors
+constexpr int MFMA_ANCHOR = 64;  // channels between re-anchored phasors (a power of two)
+constexpr int MFMA_ANCHOR_LOG2 = MFMA_ANCHOR == 64 ? 6 : MFMA_ANCHOR == 32 ? 5 : 4;
+static_assert((1 << MFMA_ANCHOR_LOG2) == MFMA_ANCHOR, "anchor spacing 16, 32 or 64");
 
 // global -> LDS copy of `units` 16-byte units by a 256-lane block: wave `wave` copies units
 // [e0 + 64 wave, +64) of every 256-unit trip; the LDS destination of a wave instruction is
@@ -33,7 +35,7 @@ struct PhasorSetup {
     double a0, a1, a2;
     TablePhasorStage sd, s0;
     double dr, di, y0r, y0i;  // channel-step phasor d, phasor at the tile's first channel
-    double ar, ai;            // d^16
+    double ar, ai;            // d^MFMA_ANCHOR
     double kk, k2;            // 2 cos(delta), 2 cos(2 delta)
 };
 
@@ -65,7 +67,7 @@ __device__ __forceinline__ void phasor_next_segment(const PhasorSetup &P, double
 // The set-up cut into 8 slices, so that the set-up of step it+1 can be spread over the channel groups of
 // step it (its dependent chains then hide behind the MFMAs):
 //   0 header triple from LDS   1 path difference, range reductions + table reads   2 residual sines   3 residual
-//   cosines   4 table entry x residual rotation -> d, y0   5 d^16 by four squarings, 2cos(delta), 2cos(2 delta)
+//   cosines   4 table entry x residual rotation -> d, y0   5 d^MFMA_ANCHOR by squarings (dead when no tile exceeds the spacing), 2cos(delta), 2cos(2 delta)
 //   7 first 8 phasors
 // F0, FD: the tile's first-channel frequency and the channel step in 1/256 turns per metre (quarter turns x 64);
 // `table`: the block's PHASOR_TABLE-entry phasor table in LDS (table_phasor_init).
@@ -91,7 +93,7 @@ __device__ __forceinline__ void phasor_setup_slice(PhasorSetup &P, int slice, co
     case 5: {
         double ar = P.dr, ai = P.di;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < MFMA_ANCHOR_LOG2; ++t) {   // d^MFMA_ANCHOR; dead code when no tile is longer than the spacing
             const double nr = fma(ar, ar, -__dmul_rn(ai, ai)), ni = __dmul_rn(__dadd_rn(ar, ar), ai);
             ar = nr; ai = ni;
         }
