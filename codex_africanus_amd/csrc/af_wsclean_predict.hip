@@ -221,7 +221,7 @@ __global__ void wsc_pack_records(const double *__restrict__ params, const double
 template <int CT, bool GAUSS, int NG>
 __device__ __forceinline__ void component_pass(double (&acc)[CT][2], double (&R)[NG], double u, double v, double w,
                                                double F0, double FD, double NU0SQ, double C1, double C2,
-                                               unsigned lane_off, const double *rec_next)
+                                               unsigned lane_off, const double *rec_next, const double2 *ptab)
 {
     constexpr int NSLOT = HDR + CT;
     group_wait<w_wait_count(0, NG, NSLOT)>(R[0]);
@@ -242,9 +242,17 @@ __device__ __forceinline__ void component_pass(double (&acc)[CT][2], double (&R)
         rho = exp(-__dmul_rn(A, C1));
         kappa = exp(-__dmul_rn(A, C2));
     }
+    // channel-step and tile-start phasors from the block's table (af_sincos.h; F0, FD in 1/256 turns per metre)
     double dr, di, c0r, c0i;
-    sincos_quarter_turns<7>(__dmul_rn(q, FD), dr, di);
-    sincos_quarter_turns<7>(__dmul_rn(q, F0), c0r, c0i);
+    {
+        TablePhasorStage sd, s0;
+        table_phasor_reduce(sd, ptab, __dmul_rn(q, FD));
+        table_phasor_reduce(s0, ptab, __dmul_rn(q, F0));
+        table_phasor_sin(sd); table_phasor_sin(s0);
+        table_phasor_cos(sd); table_phasor_cos(s0);
+        table_phasor_finish(sd, dr, di);
+        table_phasor_finish(s0, c0r, c0i);
+    }
     const double k = __dadd_rn(dr, dr);
     double y0r = c0r, y0i = c0i;
     double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
@@ -293,13 +301,17 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void wsc_recurrence_kernel(
     constexpr int NG = w_groups(CT);
     constexpr int STRIDE = CT + 1;
     __shared__ double2 stage[64 * STRIDE];
+    __shared__ double2 ptab[PHASOR_TABLE];
+    table_phasor_init(ptab, threadIdx.x, ROWS_PER_BLOCK);
+    __syncthreads();
     const int tile = blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
     int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
     if (row >= nrow) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
     const double *tf = tilef + 8 * tile;
-    const double F0 = tf[0], FD = tf[1], NU0SQ = tf[2], C1 = tf[3], C2 = tf[4];
+    const double F0 = 64.0 * tf[0], FD = 64.0 * tf[1];   // quarter turns -> 1/256 turns per metre (exact)
+    const double NU0SQ = tf[2], C1 = tf[3], C2 = tf[4];
     const int npoint = flags[1];
 
     double acc[CT][2];
@@ -320,13 +332,13 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void wsc_recurrence_kernel(
     for (int s = 0; s < npoint; ++s) {
         const int sn = (s + 1 < nsrc) ? s + 1 : s;
         component_pass<CT, false, NG>(acc, R, u, v, w, F0, FD, NU0SQ, C1, C2, lane_off,
-                                      rec + (int64_t)sn * (NG * GROUP));
+                                      rec + (int64_t)sn * (NG * GROUP), ptab);
     }
 #pragma unroll 1
     for (int s = npoint; s < nsrc; ++s) {
         const int sn = (s + 1 < nsrc) ? s + 1 : s;
         component_pass<CT, true, NG>(acc, R, u, v, w, F0, FD, NU0SQ, C1, C2, lane_off,
-                                     rec + (int64_t)sn * (NG * GROUP));
+                                     rec + (int64_t)sn * (NG * GROUP), ptab);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
