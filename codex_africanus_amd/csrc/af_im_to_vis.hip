@@ -614,12 +614,16 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_exact_kernel(
 // padding the last tile costs more.  Real images: CT in {13, 8}; complex: CT in {11, 8}.
 int choose_ct(int64_t nchan, int nc_max, bool cplx)
 {
-    const int cands_r[2] = {13, 8}, cands_c[2] = {11, 8};
-    const int *cands = cplx ? cands_c : cands_r;
+    // candidates per correlation count: the accumulators of a tile are CT*NC complex numbers, so fewer correlations
+    // afford wider tiles (the ~50-operation set-up per (row, source, tile) is then amortised over more channels)
+    const int cands_c[2] = {11, 8};
+    const int cands_r4[2] = {13, 8}, cands_r2[4] = {26, 16, 13, 8}, cands_r1[4] = {52, 32, 13, 8};
+    const int *cands = cplx ? cands_c : nc_max == 1 ? cands_r1 : nc_max == 2 ? cands_r2 : cands_r4;
+    const int ncand = cplx ? 2 : nc_max <= 2 ? 4 : 2;
     const int per_chan = 2 + 2 * nc_max * (cplx ? 2 : 1);
     int best = cands[0];
     int64_t best_cost = -1;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ncand; ++k) {
         int ct = cands[k];
         int64_t cost = af_cdiv(nchan, ct) * (50 + (int64_t)ct * per_chan);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ct; }
@@ -715,7 +719,14 @@ int launch_chunk_nc(int nc, const Args &a)
 int launch_chunk_ct(bool cplx, int ct, int nc, const Args &a)
 {
     if (cplx) return ct == 8 ? launch_chunk_nc<8, true>(nc, a) : launch_chunk_nc<11, true>(nc, a);
-    return ct == 8 ? launch_chunk_nc<8, false>(nc, a) : launch_chunk_nc<13, false>(nc, a);
+    switch (ct) {   // the wide tiles exist for the correlation counts choose_ct offers them to
+    case 52: return launch_chunk<52, 1, false>(a);
+    case 32: return launch_chunk<32, 1, false>(a);
+    case 26: return launch_chunk<26, 2, false>(a);
+    case 16: return launch_chunk<16, 2, false>(a);
+    case 8: return launch_chunk_nc<8, false>(nc, a);
+    default: return launch_chunk_nc<13, false>(nc, a);
+    }
 }
 
 }  // namespace
@@ -725,8 +736,8 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
     if (nsrc < 0 || nchan < 0 || ncorr < 0) return 0;
     // sized for the widest padding any tile width can produce
     size_t m = 0;
-    const int cands[3] = {8, 11, 13};
-    for (int k = 0; k < 3; ++k) {
+    const int cands[7] = {8, 11, 13, 16, 26, 32, 52};
+    for (int k = 0; k < 7; ++k) {
         WsLayout L;
         if (!ws_layout(L, nsrc, nchan, ncorr, image_is_complex, cands[k])) return 0;
         if (L.total > m) m = L.total;

@@ -51,6 +51,31 @@ def test_im_to_vis_random_shapes(seed):
     assert np.abs(out - ref).max() <= tol * scale, (nrow, nsrc, nchan, ncorr, cplx, uniform, mode)
 
 
+@pytest.mark.parametrize("ncorr, nchan", [(1, 13), (1, 31), (1, 32), (1, 33), (1, 52), (1, 53), (1, 64), (1, 104),
+                                          (1, 130), (2, 15), (2, 16), (2, 17), (2, 26), (2, 27), (2, 64), (2, 78)])
+@pytest.mark.parametrize("mode", ["auto", "exact"])
+def test_im_to_vis_wide_tiles_for_few_correlations(ncorr, nchan, mode):
+    """1 and 2 correlations run channel tiles of up to 52 / 26 channels (choose_ct): every candidate width, tiles that
+    end exactly at / one channel past the band, zero pixels, both phasor modes and a non-uniform band."""
+    rng = np.random.default_rng(1000 * ncorr + nchan)
+    nrow, nsrc = 257, 19
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    img = rng.standard_normal((nsrc, nchan, ncorr))
+    img[rng.random(img.shape) < 0.1] = 0.0
+    dft.set_mode(mode)
+    try:
+        for uniform in (True, False):
+            freq = _freq(rng, nchan, uniform)
+            out = dft.im_to_vis(img, uvw, lm, freq)
+            ref = oracle.im_to_vis(img, uvw, lm, freq)
+            scale = float(np.abs(img).sum(axis=0).max())
+            tol = 1e-14 if (mode == "exact" or not uniform) else 1e-11
+            assert np.abs(out - ref).max() <= tol * scale, (uniform,)
+    finally:
+        dft.set_mode("auto")
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_vis_to_im_random_shapes(seed):
     rng = np.random.default_rng(100 + seed)
