@@ -317,15 +317,20 @@ __device__ __forceinline__ void store_tile_coop(const double (&acc)[CT][NC][2], 
 // DPP operands, and refresh every record group right after its last use.  EXTRA = vector loads
 // (besides the record refreshes) issued between the previous source's refreshes and this pass;
 // WAIT0 = group 0 has not been retired by the caller yet.
-template <int CT, int NC, bool CPLX, int NTERM, int EXTRA, bool WAIT0, int NG>
+template <int CT, int NC, bool CPLX, int NTERM, int EXTRA, bool WAIT0, int NG, bool TABLE>
 __device__ __forceinline__ void channel_pass(double (&acc)[CT][NC][2], double (&R)[NG], double q, double dr,
-                                             double di, double F0, unsigned lane_off, const double *rec_next)
+                                             double di, double F0, unsigned lane_off, const double *rec_next,
+                                             const double2 *ptab)
 {
     constexpr int W = CPLX ? 2 : 1;
     constexpr int NSLOT = 4 + CT * NC * W;
     constexpr int PER_CHAN = NC * W;
     double c0r, c0i;
-    sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
+    // TABLE: F0 in 1/256 turns per metre, phasor from the block's LDS table (af_sincos.h); else quarter turns and
+    // the polynomial pair (the four-tile kernel is at its register limit with 104 accumulators: the table's extra
+    // live values would push it to one wave per SIMD)
+    if constexpr (TABLE) table_phasor(ptab, __dmul_rn(q, F0), c0r, c0i);
+    else sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
     const double k = __dadd_rn(dr, dr);
     double y0r = c0r, y0i = c0i;
     double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
@@ -383,6 +388,9 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
     if (flags[0] != want_uniform) return;  // decided on the device by dft_prep_freq
     if (want_global >= 0 && flags[1] != want_global) return;
     __shared__ double2 stage[64 * (CT * NC + 1)];
+    __shared__ double2 ptab[PHASOR_TABLE];
+    table_phasor_init(ptab, threadIdx.x, ROWS_PER_BLOCK);
+    __syncthreads();
     constexpr int W = CPLX ? 2 : 1;
     constexpr int NG = record_groups(CT, NC, W);
     constexpr int NSLOT = 4 + CT * NC * W;
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
     const bool valid = row < nrow;
     if (!valid) row = nrow - 1;
     const double u = uvw[3 * row], v = uvw[3 * row + 1], w = uvw[3 * row + 2];
-    const double F0 = tilef[4 * tile], FD = tilef[4 * tile + 1];
+    const double F0 = 64.0 * tilef[4 * tile], FD = 64.0 * tilef[4 * tile + 1];   // quarter turns -> 1/256 turns
 
     double acc[CT][NC][2];
 #pragma unroll
@@ -426,8 +434,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
         fmac_bcast<2>(q, R[0], w);
         if constexpr (group_last_chan(0, NSLOT, PER_CHAN) < 0) group_refresh<0>(R[0], lane_off, rec_next);
         double dr, di;
-        sincos_quarter_turns<NTERM>(__dmul_rn(q, FD), dr, di);
-        channel_pass<CT, NC, CPLX, NTERM, 0, false, NG>(acc, R, q, dr, di, F0, lane_off, rec_next);
+        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
+        channel_pass<CT, NC, CPLX, NTERM, 0, false, NG, true>(acc, R, q, dr, di, F0, lane_off, rec_next, ptab);
     }
     // retire the (redundant) refreshes of the last iteration before the registers die
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,8 +527,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp4_kernel(
             const int sn = (s + 1 < nsrc_pad) ? s + 1 : s;
             const double q = xch[b & 1][j][0][lane], dr = xch[b & 1][j][1][lane], di = xch[b & 1][j][2][lane];
             // the Lg refresh above sits between the previous batch's record refreshes and pass j = 0
-            channel_pass<CT, NC, CPLX, NTERM, (j == 0 ? 1 : 0), true, NG>(acc, R, q, dr, di, F0, lane_off,
-                                                                       rec + (int64_t)sn * (NG * GROUP));
+            channel_pass<CT, NC, CPLX, NTERM, (j == 0 ? 1 : 0), true, NG, false>(acc, R, q, dr, di, F0, lane_off,
+                                                                              rec + (int64_t)sn * (NG * GROUP), nullptr);
         });
         __syncthreads();
     }

@@ -139,6 +139,15 @@ __device__ __forceinline__ void table_phasor_finish(const TablePhasorStage &s, d
     c_out = fma(s.tk.x, s.cs, -__dmul_rn(s.tk.y, s.sn));
     s_out = fma(s.tk.y, s.cs, __dmul_rn(s.tk.x, s.sn));
 }
+// the four stages in one piece
+__device__ __forceinline__ void table_phasor(const double2 *table, double x256, double &c_out, double &s_out)
+{
+    TablePhasorStage st;
+    table_phasor_reduce(st, table, x256);
+    table_phasor_sin(st);
+    table_phasor_cos(st);
+    table_phasor_finish(st, c_out, s_out);
+}
 
 
 // (cos, sin)(p) for p in RADIANS, for the kernels that must keep the reference's phase p bit for bit

@@ -191,7 +191,10 @@ __global__ __launch_bounds__(SRC_PER_BLOCK) void v2i_recurrence_kernel(
     const bool valid = src < nsrc;
     if (!valid) src = nsrc - 1;
     const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
-    const double F0 = tilef[4 * tile], FD = tilef[4 * tile + 1];
+    const double F0 = 64.0 * tilef[4 * tile], FD = 64.0 * tilef[4 * tile + 1];   // quarter turns -> 1/256 turns
+    __shared__ double2 ptab[PHASOR_TABLE];
+    table_phasor_init(ptab, threadIdx.x, SRC_PER_BLOCK);
+    __syncthreads();
     const int64_t r_begin = (int64_t)blockIdx.z * rows_per_part;
     const int64_t r_end = (r_begin + rows_per_part < nrow) ? r_begin + rows_per_part : nrow;
 
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(SRC_PER_BLOCK) void v2i_recurrence_kernel(
         fmac_bcast<2>(q, R[0], n);
         if constexpr (group_last_chan(0, NSLOT, PER_CHAN) < 0) group_refresh<0>(R[0], lane_off, rec_next);
         double c0r, c0i, dr, di;
-        sincos_quarter_turns<NTERM>(__dmul_rn(q, F0), c0r, c0i);
-        sincos_quarter_turns<NTERM>(__dmul_rn(q, FD), dr, di);
+        table_phasor(ptab, __dmul_rn(q, F0), c0r, c0i);   // F0, FD in 1/256 turns per metre (af_sincos.h)
+        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
         const double k = __dadd_rn(dr, dr);
         double y0r = c0r, y0i = c0i;
         double y1r = fma(c0r, dr, -__dmul_rn(c0i, di));
