@@ -9,6 +9,10 @@
 // One lane per visibility (row, chan), channel fastest: neighbouring channels of a row land on neighbouring
 // grid cells, so a wave's W x W gathers share cache lines; the grid (268 MB at 4096^2) lives in L2 / Infinity
 // Cache, the kernel is gather-bound.  The tap weights of a visibility are 2 W values read once per lane.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "af_common.h"
 #include "af_sincos.h"
 
@@ -161,6 +165,122 @@ __global__ __launch_bounds__(256) void degrid_kernel(const double *__restrict__ 
         are = tr; aim = ti;
     }
     double2 *o = out + idx * ncorr;
+    for (int k = 0; k < ncorr; ++k) {
+        const double2 f = coef[k];
+        o[k] = make_double2(f.x * are - f.y * aim, f.x * aim + f.y * are);
+    }
+}
+
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for8(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for8<N, I + 1>(f);
+    }
+}
+
+// value of lane (group base | K) in every lane of its 8-lane group: ds_swizzle bit-mask mode, and = 0x18, or = K
+template <int K> __device__ __forceinline__ int group8_bcast(int x)
+{
+    return __builtin_amdgcn_ds_swizzle(x, (K << 5) | 0x18);
+}
+template <int K> __device__ __forceinline__ double group8_bcast(double x)
+{
+    return __hiloint2double(group8_bcast<K>(__double2hiint(x)), group8_bcast<K>(__double2loint(x)));
+}
+
+// Cooperative variant for W <= 8 taps.  With one lane per visibility every 16-byte gather instruction touches 64
+// different cache lines, and the CU's address / tag path -- not L2 or HBM -- bounds the kernel
+// (tools/microbench_gather.hip; 49 such instructions per visibility).  Here a lane still OWNS one visibility (its
+// geometry is worked out once, by the owner), but the taps are read by eight lanes at a time: in round k the 8-lane
+// group g samples the visibility of its lane k -- lane t takes tap column t, so a tap row's 7 adjacent cells are
+// ONE instruction (1-2 lines per visibility, ~10 per instruction) and a visibility costs 7 gather instructions
+// instead of 49.  The owner's geometry and the row weights reach the group by ds_swizzle broadcasts, the columns
+// are summed across the group by a butterfly, and after 8 rounds every lane finishes its own visibility.  The sums
+// run column-first instead of row-first: the same taps and weights, different rounding order (the reference
+// compiles this loop with fastmath).  grid: ceil(nrow*nchan / 256).
+template <int WT>  // compile-time tap count (0: runtime W <= 8)
+__global__ __launch_bounds__(256) void degrid_coop_kernel(const double *__restrict__ uvw, const double2 *__restrict__ grid,
+                                                          const double *__restrict__ wavelengths,
+                                                          const int64_t *__restrict__ chanmap,
+                                                          const double *__restrict__ kernel, int Wrt, int os, int packed,
+                                                          int ncorr, const double2 *__restrict__ coef,
+                                                          double scale_factor, int phase_rotate, double ll, double mm,
+                                                          double nn, int64_t nrow, int64_t nchan, int64_t npix,
+                                                          const int *__restrict__ perm, double2 *__restrict__ out)
+{
+    const int W = WT ? WT : Wrt;
+    const int64_t vis_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = vis_raw < nrow * nchan;
+    const int64_t vis_idx = live ? vis_raw : nrow * nchan - 1;
+    const int64_t p = vis_idx / nchan, c = vis_idx - p * nchan;
+    const int64_t r = perm ? perm[p] : p;          // rows in uv-tile order
+    const double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+    const double lam = wavelengths[c];
+    const double su = u * scale_factor / lam, sv = v * scale_factor / lam;
+    const double offset_u = su + (double)(npix / 2), offset_v = sv + (double)(npix / 2);
+    const double du = rint(offset_u), dv = rint(offset_v);   // np.round: half to even
+    // owner-side geometry handed to the group: first tap cell, oversampling phases, grid band
+    const int own_fu = (int)((-offset_u + du) * os), own_fv = (int)((-offset_v + dv) * os);
+    // far outside the grid every tap is invalid anyway: clamp so that the cell index fits 32 bits
+    const double lim = (double)npix + 16.0;
+    const int own_u0 = (int)fmin(fmax(du, -lim), lim) - W / 2, own_v0 = (int)fmin(fmax(dv, -lim), lim) - W / 2;
+    const int own_band = (int)chanmap[c];
+    const int klen = os * (W + 2);
+    const int t = threadIdx.x & 7;                 // this lane's tap column (and the tap row it looks the weight up for)
+    const int inp = (int)npix;
+    double my_re = 0.0, my_im = 0.0, my_cw = 0.0;
+    static_for8<8>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        const int u0 = group8_bcast<K>(own_u0), v0 = group8_bcast<K>(own_v0);
+        const int fu = group8_bcast<K>(own_fu), fv = group8_bcast<K>(own_fv);
+        const int band = group8_bcast<K>(own_band);
+        const int gu = u0 + t;
+        const bool col_ok = t < W && gu >= 0 && gu < inp;
+        double ku = 0.0, kv_own = 0.0;
+        if (col_ok) {
+            int iu = packed ? t + (fu < 0 ? 0 : 1) + fu * (W + 2) : (t + 1) * os + fu;
+            if (iu < 0) iu += klen;
+            ku = kernel[iu];
+        }
+        if (t < W && v0 + t >= 0 && v0 + t < inp) {
+            int iv = packed ? t + (fv < 0 ? 0 : 1) + fv * (W + 2) : (t + 1) * os + fv;
+            if (iv < 0) iv += klen;
+            kv_own = kernel[iv];
+        }
+        const double2 *__restrict__ gb = grid + (int64_t)band * npix * npix + gu;
+        double cre = 0.0, cim = 0.0, skv = 0.0;   // column sums over the tap rows; sum of the valid row weights
+        static_for8<(WT ? WT : 8)>([&](auto tvc) {
+            constexpr int tv = decltype(tvc)::value;
+            const double kv = group8_bcast<tv>(kv_own);
+            const int gv = v0 + tv;
+            skv += kv;
+            if (col_ok && tv < W && gv >= 0 && gv < inp) {
+                const double2 x = gb[(int64_t)gv * npix];
+                cre = fma(x.x, kv, cre);
+                cim = fma(x.y, kv, cim);
+            }
+        });
+        double are = cre * ku, aim = cim * ku, sku = ku;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            are += __shfl_xor(are, m, 64);
+            aim += __shfl_xor(aim, m, 64);
+            sku += __shfl_xor(sku, m, 64);
+        }
+        if (t == K) { my_re = are; my_im = aim; my_cw = sku * skv; }   // sum over the valid taps of kv[tv] * ku[tu]
+    });
+    if (!live) return;
+    const double inv = 1.0 / (my_cw + 1.0e-8);
+    double are = my_re * inv, aim = my_im * inv;
+    if (phase_rotate) {  // vis *= exp(-2 pi i (u ll + v mm + w nn) / lambda)   (phase_transform_policies.py:33-35)
+        const double turns = -(u * ll + v * mm + w * nn) / lam;
+        double pc, ps;
+        sincos_quarter_turns<7>(4.0 * turns, pc, ps);
+        const double tr = are * pc - aim * ps, ti = are * ps + aim * pc;
+        are = tr; aim = ti;
+    }
+    double2 *o = out + (r * nchan + c) * ncorr;
     for (int k = 0; k < ncorr; ++k) {
         const double2 f = coef[k];
         o[k] = make_double2(f.x * are - f.y * aim, f.x * aim + f.y * are);
@@ -417,7 +537,19 @@ AF_EXPORT int af_degridder_c128(const double *uvw, const double *gridstack, cons
     const double2 *g = reinterpret_cast<const double2 *>(gridstack), *cf = reinterpret_cast<const double2 *>(corr_factors);
     double2 *o = reinterpret_cast<double2 *>(out);
     af_prof_begin(st);
-    if (kernel_width == 7)
+    static const int coop_env = getenv("AFHIP_DEGRID_COOP") ? atoi(getenv("AFHIP_DEGRID_COOP")) : 1;
+    const int64_t coop_blocks = af_cdiv(nrow * nchan, 256);
+    if (coop_env && kernel_width <= 8 && coop_blocks < (1LL << 31) && npix < (1LL << 30)) {
+        const dim3 cgrid((unsigned)coop_blocks);
+        if (kernel_width == 7)
+            hipLaunchKernelGGL((degrid_coop_kernel<7>), cgrid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel,
+                               7, (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn, nrow,
+                               nchan, npix, perm, o);
+        else
+            hipLaunchKernelGGL((degrid_coop_kernel<0>), cgrid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel,
+                               (int)kernel_width, (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll,
+                               mm, nn, nrow, nchan, npix, perm, o);
+    } else if (kernel_width == 7)
         hipLaunchKernelGGL((degrid_kernel<7>), grid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel, 7,
                            (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn, nrow, nchan,
                            npix, perm, o);
