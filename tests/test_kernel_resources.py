@@ -15,6 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "codex_africanus_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+SGPR_SPILL_OK = ("af_fused_predict.hip", "af_degridder.hip", "af_calibration.hip")
 
 
 @pytest.mark.parametrize("source, kernels, min_seen, reg_cap", [
@@ -24,6 +25,13 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # MFMA-accumulator kernels: the 64-channel tile is one wave per SIMD by design (256 AGPRs of
     # accumulators + arch VGPRs); its global -> LDS copies are asm-issued and hand-waited as well
     ("af_im_to_vis_mfma.hip", ("dft_mfma_kernel",), 3, 512),
+    ("af_vis_to_im_mfma.hip", ("v2i_mfma_kernel",), 3, 512),
+    # kernels tuned to a register budget (no counted waits, but a spill would silently cost the occupancy their
+    # design rests on): fused predict 8-wave (256 at 2 waves/SIMD), cooperative degridder, calibration consumers
+    ("af_fused_predict.hip", ("fused_predict_kernelILb0ELb0E", "fused_predict_kernelILb1ELb0E",
+                              "fused_predict_kernelILb0ELb1E", "fused_predict_kernelILb1ELb1E"), 12, 256),
+    ("af_degridder.hip", ("degrid_coop_kernel", "degrid_kernel"), 4, 256),
+    ("af_calibration.hip", ("calib_kernel",), 16, 256),
 ])
 def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels, min_seen, reg_cap):
     if not os.path.exists(HIPCC):
@@ -44,6 +52,31 @@ def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels, min_see
         sspill = int(re.search(r"SGPRs Spill: (\d+)", b).group(1))
         vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
-        assert scratch == 0 and vspill == 0 and sspill == 0, (name, scratch, vspill, sspill)
+        # SGPR spills go to VGPR lanes, not memory: they matter only for the counted-wait kernels' tight loops
+        assert scratch == 0 and vspill == 0 and (sspill == 0 or source in SGPR_SPILL_OK), (name, scratch, vspill, sspill)
         assert vgprs + agprs <= reg_cap, (name, vgprs, agprs)   # 256: two waves per SIMD
     assert seen >= min_seen, "expected the template instantiations, found %d" % seen
+
+
+def test_wave_specialised_fused_kernel_fits_three_waves_per_simd(tmp_path):
+    """The 12-wave fused predict (8 accumulating + 4 sampling waves) needs <= 168 registers and no scratch in the
+    variants the dispatcher uses it for (no Gaussian shapes)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+           "--cuda-device-only", "-c", os.path.join(CSRC, "af_fused_predict.hip"), "-o", str(tmp_path / "k.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    text = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        m = re.search(r"fused_predict_kernelILb([01])ELb0ELi(\d+)ELb1E", name)   # <FEED, GAUSS=false, NP, WS=true>
+        if not m:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        assert scratch == 0 and vgprs + agprs <= 168, (name, scratch, vgprs, agprs)
+    assert seen == 6, seen
