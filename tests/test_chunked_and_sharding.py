@@ -124,6 +124,49 @@ def test_chi2_allreduce_gloo_world2():
     assert abs(res[0][2] - res[1][2]) == 0.0     # every rank holds the same reduced vector
 
 
+def _gloo_image_worker(rank, world, port, q):
+    """Row-sharded adjoint transform: every rank images its own row block (the CPU oracle stands in for the kernel),
+    allreduce_image sums the (source, chan, corr) images -- the one data-path collective of vis_to_im."""
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        nrow, nchan, nsrc = 90, 5, 7
+        uvw = rng.standard_normal((nrow, 3)) * 500.0
+        lm = rng.standard_normal((nsrc, 2)) * 0.02
+        freq = np.linspace(1.0e9, 1.1e9, nchan)
+        vis = rng.standard_normal((nrow, nchan, 2)) + 1j * rng.standard_normal((nrow, nchan, 2))
+        flags = rng.random((nrow, nchan, 2)) < 0.1
+        (s, e) = sharding.shard_bounds(nrow, world)[rank]
+        part = torch.from_numpy(oracle.vis_to_im(vis[s:e], uvw[s:e], lm, freq, flags[s:e]))
+        total = sharding.allreduce_image(part.clone()).numpy()
+        full = oracle.vis_to_im(vis, uvw, lm, freq, flags)
+        q.put((rank, float(np.abs(total - full).max()), float(np.abs(full).max()), float(total.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vis_to_im_row_shards_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_image_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, err, scale, _ in res:
+        assert err <= 1e-12 * scale        # shard sums reassociate the row sum: rounding only
+    assert res[0][3] == res[1][3]          # every rank holds the same reduced image
+
+
 def test_allreduce_is_noop_without_process_group():
     import torch
     x = torch.arange(4, dtype=torch.float64)
