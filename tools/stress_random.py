@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Extra seeds for the random-shape parity sweeps of tests/test_gpu_fuzz.py (the committed tests run 24 seeds each):
+"""Extra seeds for the random-shape parity sweeps of tests/test_gpu_fuzz.py (the committed tests run 24 seeds each), plus
+calibration, fused-predict, beam / phase_delay and convert / chi^2 sweeps:
     python tools/stress_random.py [first_seed] [n_seeds]
 Every case is checked against the CPU oracle exactly as in the test; stops at the first failure."""
 import os
@@ -58,11 +59,61 @@ def fused_sweep(seed):
     assert np.abs(out - ref).max() < 1e-9 * FU._scale(d), (nant, nrow, nchan, nsrc)
 
 
+def beam_and_phase_sweep(seed):
+    """beam_cube_dde (arbitrary correlation dims, out-of-band channels, off-cube sources) and phase_delay"""
+    rng = np.random.default_rng(seed)
+    lw, mh, nud = int(rng.integers(2, 12)), int(rng.integers(2, 12)), int(rng.integers(2, 6))
+    corr = [(), (1,), (2,), (4,), (2, 2), (3,)][seed % 6]
+    nsrc, ntime, nant, nchan = int(rng.integers(1, 9)), int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 70))
+    beam = rng.standard_normal((lw, mh, nud) + corr) + 1j * rng.standard_normal((lw, mh, nud) + corr)
+    ext = np.array([[-0.05, 0.06], [-0.04, 0.05]])
+    fmap = np.sort(rng.uniform(1.0e9, 1.5e9, nud))
+    lm = rng.uniform(-0.08, 0.08, (nsrc, 2))
+    pa = rng.uniform(-np.pi, np.pi, (ntime, nant))
+    pe = 1e-2 * rng.standard_normal((ntime, nant, nchan, 2))
+    asc = 1.0 + 0.1 * rng.standard_normal((nant, nchan, 2))
+    freq = np.sort(rng.uniform(0.9e9, 1.6e9, nchan))
+    got = rime.beam_cube_dde(beam, ext, fmap, lm, pa, pe, asc, freq)
+    ref = oracle.beam_cube_dde(beam, ext, fmap, lm, pa, pe, asc, freq)
+    # a random (non-smooth) cube makes corr_sum cancel now and then, and the amplitude normalisation absc / |corr_sum|
+    # amplifies the last-bit differences of device and host hypot / division by that cancellation factor
+    err, scale = np.abs(got - ref), max(np.abs(ref).max(), 1.0)
+    assert got.shape == ref.shape and err.max() <= 1e-10 * scale and (err > 1e-13 * scale).mean() < 1e-3
+    uvw = rng.standard_normal((int(rng.integers(1, 200)), 3)) * 2000.0
+    ph = rime.phase_delay(lm, uvw, freq, convention=("fourier", "casa")[seed % 2])
+    assert np.abs(ph - oracle.phase_delay(lm, uvw, freq, convention=("fourier", "casa")[seed % 2])).max() < 1e-14
+
+
+def convert_and_chi2_sweep(seed):
+    import json
+    import torch
+    from codex_africanus_amd.model.coherency import convert
+    from codex_africanus_amd import sharding
+    rng = np.random.default_rng(seed)
+    cases = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "g11_convert.npz"))["cases"]))
+    isch, osch, implicit = cases[seed % len(cases)]
+    lead = tuple(int(x) for x in rng.integers(0, 9, size=int(rng.integers(0, 4))))
+    x = rng.standard_normal(lead + np.asarray(isch).shape)
+    if seed % 2:
+        x = x + 1j * rng.standard_normal(x.shape)
+    if seed % 3 == 0:
+        x = x.astype(np.complex64 if seed % 2 else np.float32)
+    got, ref = convert(x, isch, osch, implicit_stokes=implicit), oracle.convert(x, isch, osch, implicit)
+    assert got.dtype == ref.dtype and got.shape == ref.shape and np.array_equal(got, ref)
+    shape = (int(rng.integers(1, 3000)), int(rng.integers(1, 70)), int(rng.choice([1, 2, 4])))
+    m = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    d = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    w = rng.random(shape)
+    t = lambda a: torch.from_numpy(a).cuda()
+    c = sharding.chi2(t(m), t(d), t(w) if seed % 2 else None).cpu().numpy()
+    np.testing.assert_allclose(c, ((w if seed % 2 else 1.0) * np.abs(d - m) ** 2).sum(axis=(0, 2)), rtol=1e-12)
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 sweeps = [F.test_im_to_vis_random_shapes, F.test_vis_to_im_random_shapes, F.test_wsclean_predict_random_shapes,
           F.test_predict_vis_random_shapes_bit_exact, F.test_degridder_gridder_random_shapes, calibration_sweep,
-          fused_sweep]
+          fused_sweep, beam_and_phase_sweep, convert_and_chi2_sweep]
 t0 = time.time()
 for seed in range(first, first + count):
     for fn in sweeps:
