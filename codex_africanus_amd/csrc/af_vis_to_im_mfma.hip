@@ -54,39 +54,46 @@ __global__ void v2i_mfma_fill_tiles(int64_t *c0, int *ct, int64_t nfull, int tai
     if (t == nfull && tail_ct) { c0[t] = tail_c0; ct[t] = tail_ct; }
 }
 
+// Record of step `it` (4 rows) of a tile of CT channels: [(u,v,w,0) x 4 of step it + 1 | CT channels x 16 (row k, corr)
+// x (Re V, -Im V)].  One thread per complex visibility (a 16-byte load and a 16-byte store; the payload's 16
+// complex values per channel are contiguous, so stores coalesce fully and loads in 64-byte row segments), one
+// 4-byte flag word per (row, chan); the 16 header doubles of a step are written by the threads of its first channel.
 __global__ void v2i_mfma_pack(const double2 *__restrict__ vis, const unsigned char *__restrict__ vflags,
                               const double *__restrict__ uvw, const int *__restrict__ flags, int64_t nrow, int64_t nstep,
                               int64_t nchan, int64_t c0, int CT, double *__restrict__ rec, int *__restrict__ chan_any)
 {
     if (flags[3] != 1) return;  // the VALU kernels own this call: their pack pass fills the region instead
     const int64_t per = v_stage_doubles(CT);
-    const int64_t total = nstep * per;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_step = CT * 16;                 // complex values of a step's payload
+    const int64_t total = nstep * per_step;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int64_t it = i / per, idx = i - it * per;
-        double v = 0.0;
-        if (idx < 16) {  // (u,v,w) of the NEXT step's rows; non-finite rows are zeroed (see the payload)
-            const int64_t r = 4 * (it + 1) + idx / 4;
-            if (r < nrow && (idx & 3) < 3) {
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t it = i / per_step;
+        const int e = (int)(i - it * per_step), j = e >> 4, kn = e & 15;   // channel of the tile, (row k, corr)
+        const int64_t r = 4 * it + (kn >> 2), ch = c0 + j;
+        double2 out = make_double2(0.0, 0.0);
+        if (r < nrow && ch < nchan) {
+            const unsigned fl = *reinterpret_cast<const unsigned *>(vflags + (r * nchan + ch) * 4);
+            if (fl == 0) {
                 const double a = uvw[3 * r], b = uvw[3 * r + 1], c = uvw[3 * r + 2];
-                if (isfinite(a) && isfinite(b) && isfinite(c)) v = uvw[3 * r + (idx & 3)];
-            }
-        } else {
-            const int64_t e = idx - 16, j = e / 32, rr = e - j * 32;
-            const int64_t kn = rr >> 1, r = 4 * it + (kn >> 2), ch = c0 + j;
-            if (r < nrow && ch < nchan) {
-                const unsigned char *fl = vflags + (r * nchan + ch) * 4;
-                if (!(fl[0] | fl[1] | fl[2] | fl[3])) {
-                    const double a = uvw[3 * r], b = uvw[3 * r + 1], c = uvw[3 * r + 2];
-                    const double2 x = vis[(r * nchan + ch) * 4 + (kn & 3)];
-                    v = (rr & 1) ? -x.y : x.x;
-                    if (!(isfinite(a) && isfinite(b) && isfinite(c))) v = __longlong_as_double(0x7ff8000000000000LL);
-                    if ((rr & 7) == 0) chan_any[ch] = 1;  // once per unflagged (row, chan); benign race: all store 1
-                }
+                const double2 x = vis[(r * nchan + ch) * 4 + (kn & 3)];
+                out = make_double2(x.x, -x.y);
+                if (!(isfinite(a) && isfinite(b) && isfinite(c))) out = make_double2(nan, nan);
+                if ((kn & 3) == 0) chan_any[ch] = 1;  // once per unflagged (row, chan); benign race: all store 1
             }
         }
-        rec[i] = v;
+        double *step = rec + it * per;
+        *reinterpret_cast<double2 *>(step + 16 + e * 2) = out;
+        if (j == 0) {  // header: (u,v,w,0) of the NEXT step's row kn >> 2 ... written once, by the first channel's threads
+            const int64_t rn = 4 * (it + 1) + (kn >> 2);
+            double h = 0.0;
+            if (rn < nrow && (kn & 3) < 3) {
+                const double a = uvw[3 * rn], b = uvw[3 * rn + 1], c = uvw[3 * rn + 2];
+                if (isfinite(a) && isfinite(b) && isfinite(c)) h = uvw[3 * rn + (kn & 3)];
+            }
+            step[kn] = h;
+        }
     }
 }
 
@@ -229,7 +236,7 @@ int run_tiles(const double2 *vis, const unsigned char *vflags, const double *uvw
               hipStream_t st)
 {
     for (int64_t t = 0; t < ntile; ++t) {
-        int64_t blocks = af_cdiv(nstep * v_stage_doubles(CT), 256);
+        int64_t blocks = af_cdiv(nstep * CT * 16, 256);
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(v2i_mfma_pack, dim3((unsigned)blocks), dim3(256), 0, st, vis, vflags, uvw, flags, nrow, nstep,
                            nchan, c0 + t * CT, CT, rec + t * nstep * v_stage_doubles(CT), chan_any);
