@@ -78,7 +78,7 @@ def beam_and_phase_sweep(seed):
     # a random (non-smooth) cube makes corr_sum cancel now and then, and the amplitude normalisation absc / |corr_sum|
     # amplifies the last-bit differences of device and host hypot / division by that cancellation factor
     err, scale = np.abs(got - ref), max(np.abs(ref).max(), 1.0)
-    assert got.shape == ref.shape and err.max() <= 1e-10 * scale and (err > 1e-13 * scale).mean() < 1e-3
+    assert got.shape == ref.shape and err.max() <= 1e-10 * scale and (err > 1e-13 * scale).sum() <= max(2, 1e-3 * err.size)
     uvw = rng.standard_normal((int(rng.integers(1, 200)), 3)) * 2000.0
     ph = rime.phase_delay(lm, uvw, freq, convention=("fourier", "casa")[seed % 2])
     assert np.abs(ph - oracle.phase_delay(lm, uvw, freq, convention=("fourier", "casa")[seed % 2])).max() < 1e-14
