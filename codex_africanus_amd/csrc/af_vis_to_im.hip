@@ -39,15 +39,20 @@ struct VWs {
     int ct;
 };
 
-int choose_ct_v(int64_t nchan)
+int choose_ct_v(int64_t nchan, int64_t ncorr)
 {
     // 16 channels x 4 corr x 8 B = 128 accumulator VGPRs + 18 of record groups + ~58 working: two
-    // waves per SIMD (22 channels would need 258 registers and drop to one wave)
-    const int cands[2] = {16, 8};
-    int best = 16;
+    // waves per SIMD (22 channels would need 258 registers and drop to one wave).  One / two correlations
+    // afford 64 / 32 channels in the same registers: the ~50-operation set-up per (source, row, tile) is
+    // amortised over four / two times as many channels.
+    const int cands4[2] = {16, 8}, cands2[3] = {32, 16, 8}, cands1[4] = {64, 32, 16, 8};
+    const int *cands = ncorr == 1 ? cands1 : ncorr == 2 ? cands2 : cands4;
+    const int ncand = ncorr == 1 ? 4 : ncorr == 2 ? 3 : 2;
+    const int64_t per_chan = 2 + 2 * (ncorr < MAXNC ? ncorr : MAXNC);
+    int best = cands[0];
     int64_t best_cost = -1;
-    for (int k = 0; k < 2; ++k) {
-        int64_t cost = af_cdiv(nchan, cands[k]) * (50 + (int64_t)cands[k] * 10);
+    for (int k = 0; k < ncand; ++k) {
+        int64_t cost = af_cdiv(nchan, cands[k]) * (50 + (int64_t)cands[k] * per_chan);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[k]; }
     }
     return best;
@@ -386,8 +391,8 @@ AF_EXPORT size_t af_vis_to_im_workspace_bytes(int64_t nsrc, int64_t nrow, int64_
 {
     if (nsrc < 0 || nrow < 0 || nchan < 0 || ncorr < 0) return 0;
     size_t m = 0;
-    const int cands[2] = {8, 16};
-    for (int k = 0; k < 2; ++k) {
+    const int cands[4] = {8, 16, 32, 64};
+    for (int k = 0; k < 4; ++k) {
         VWs L;
         if (!vws_layout(L, nsrc, nrow, nchan, ncorr, cands[k])) return 0;
         if (L.total > m) m = L.total;
@@ -414,7 +419,7 @@ AF_EXPORT int af_vis_to_im_f64(const double *vis, const double *uvw, const doubl
         return AF_OK;
     }
     AF_REQUIRE(vis && uvw && lm && frequency && flags, "af_vis_to_im_f64: NULL array");
-    const int ct = choose_ct_v(nchan);
+    const int ct = choose_ct_v(nchan, ncorr);
     VWs L;
     vws_layout(L, nsrc, nrow, nchan, ncorr, ct);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total,
@@ -460,7 +465,9 @@ AF_EXPORT int af_vis_to_im_f64(const double *vis, const double *uvw, const doubl
     a.constant = convention == AF_CONVENTION_FOURIER ? AF_TWO_PI_OVER_C : AF_MINUS_TWO_PI_OVER_C;
     for (int chunk = 0; chunk < (int)L.nchunk; ++chunk) {
         a.chunk = chunk;
-        int rc = (ct == 8) ? v2i_launch_nc<8>(L.chunk_nc[chunk], a) : v2i_launch_nc<16>(L.chunk_nc[chunk], a);
+        int rc = ct == 64 ? v2i_launch<64, 1>(a)   // the wide tiles exist for the correlation counts choose_ct_v offers them to
+                 : ct == 32 ? (ncorr == 1 ? v2i_launch<32, 1>(a) : v2i_launch<32, 2>(a))
+                 : ct == 8 ? v2i_launch_nc<8>(L.chunk_nc[chunk], a) : v2i_launch_nc<16>(L.chunk_nc[chunk], a);
         if (rc != AF_OK) return rc;
     }
     {

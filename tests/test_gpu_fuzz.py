@@ -109,6 +109,31 @@ def test_vis_to_im_random_shapes(seed):
     assert np.abs(out - ref).max() <= tol * scale, (nrow, nsrc, nchan, ncorr, uniform, mode)
 
 
+@pytest.mark.parametrize("ncorr, nchan", [(1, 16), (1, 31), (1, 32), (1, 33), (1, 63), (1, 64), (1, 65), (1, 130),
+                                          (2, 15), (2, 16), (2, 31), (2, 32), (2, 33), (2, 64), (2, 70)])
+@pytest.mark.parametrize("mode", ["auto", "exact"])
+def test_vis_to_im_wide_tiles_for_few_correlations(ncorr, nchan, mode):
+    """1 and 2 correlations run channel tiles of up to 64 / 32 channels (choose_ct_v): every candidate width, tiles
+    ending at / one past the band, flags, both phasor modes and a non-uniform band."""
+    rng = np.random.default_rng(2000 * ncorr + nchan)
+    nrow, nsrc = 333, 21
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    vis = rng.standard_normal((nrow, nchan, ncorr)) + 1j * rng.standard_normal((nrow, nchan, ncorr))
+    flags = rng.random((nrow, nchan, ncorr)) < 0.1
+    dft.set_mode(mode)
+    try:
+        for uniform in (True, False):
+            freq = _freq(rng, nchan, uniform)
+            out = dft.vis_to_im(vis, uvw, lm, freq, flags)
+            ref = oracle.vis_to_im(vis, uvw, lm, freq, flags)
+            scale = float(np.abs(vis).sum(axis=0).max())
+            tol = 1e-14 if (mode == "exact" or not uniform) else 1e-11
+            assert np.abs(out - ref).max() <= tol * scale, (uniform,)
+    finally:
+        dft.set_mode("auto")
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_wsclean_predict_random_shapes(seed):
     rng = np.random.default_rng(200 + seed)
