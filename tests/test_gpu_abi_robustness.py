@@ -88,20 +88,27 @@ def test_concurrent_calls_from_host_threads():
 
 
 def test_entry_points_are_stream_ordered():
-    """two torch streams, two independent predicts in flight; each result is complete when ITS stream is
-    synchronised (no entry point synchronises the device or uses the NULL stream behind the caller's back)"""
+    """two torch streams, two predicts; each result is complete when ITS stream is synchronised (no entry point
+    synchronises the device or uses the NULL stream behind the caller's back).  The second stream waits for the
+    first through an event: on some boxes of the pool two compute queues that are busy at the same time are
+    time-sliced by the driver at a crawl (this test once took 13 minutes there), and concurrency is not what is
+    being tested."""
     import torch
     dev = torch.device("cuda:0")
     d = synthetic_inputs(seed=5, nrow=20000, nchan=64, nsrc=40)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     img, uvw, lm, fr = T(real_image(d)), T(d["uvw"]), T(d["lm"]), T(d["frequency"])
+    img2 = 2.0 * img
     ref = dft.im_to_vis(img, uvw, lm, fr)
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     with torch.cuda.stream(s1):
         a = dft.im_to_vis(img, uvw, lm, fr)
+        done1 = torch.cuda.Event()
+        done1.record(s1)
+    s2.wait_event(done1)
     with torch.cuda.stream(s2):
-        b = dft.im_to_vis(2.0 * img, uvw, lm, fr)
+        b = dft.im_to_vis(img2, uvw, lm, fr)
     s1.synchronize()
     assert torch.equal(a, ref)
     s2.synchronize()
