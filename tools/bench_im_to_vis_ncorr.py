@@ -1,5 +1,7 @@
+#!/usr/bin/env python
+"""im_to_vis at C2's counts with 1 / 2 / 4 correlations (VALU kernels with wide tiles for 1 and 2, MFMA kernel for 4)."""
 import sys, os, json, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from codex_africanus_amd import dft
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
