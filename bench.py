@@ -1,26 +1,33 @@
 #!/usr/bin/env python
 """
-bench.py -- headline benchmark of the RIME visibility-predict hot path on MI355X.
+bench.py -- benchmarks of the RIME visibility-predict hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
-    vis = im_to_vis(image, uvw, lm, frequency)       # direct-transform predict, BASELINE configs[1]
+    vis = predict(...)                               # the workload's transform (below)
     chi2[nu] = sum |data - vis|^2                    # per-channel chi^2 of the shard
     (N > 1) RCCL all-reduce of chi2 over xGMI         # the only cross-GPU exchange of the path
-at the shape BASELINE.json's metric is quoted on: 1e6 rows x 64 chan x 1000 point sources x
-4 corr, fp64, PER GPU (rows shard across GPUs, weak scaling: BASELINE configs[3] is 8e6 rows
-on 8 GPUs).  Metric: Mvis/s = rows x chans / second / 1e6 (whole job).
+PER GPU (rows shard across GPUs, weak scaling: BASELINE configs[3] is 8e6 rows on 8 GPUs).
+Metric: Mvis/s = rows x chans / second / 1e6 (whole job).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R --chans C --sources S]
+Workloads (--workload), one per BASELINE config a single GPU can run:
+    dft          im_to_vis, real 4-correlation image: BASELINE configs[1], the HEADLINE and the default
+                 (1e6 rows x 64 chan x 1000 point sources x 4 corr, fp64)
+    dft_complex  the same transform with complex brightness matrices (= the fused predict without DDEs)
+    fused_dde    fused predict with per-antenna beam-cube DDEs, 64 antennas: BASELINE configs[2]
+    degrid       convolutional degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7x7 taps: BASELINE configs[4]
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--rows R --chans C --sources S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  "roofline"     for the dominant kernel (dft_mfma_kernel<64>): algorithmic fp64 flops per launch /
-                 its average duration measured with HIP events on its own stream, against the
-                 fp64 peak (MFMA and VALU f64 share one 78.6 TFLOP/s pipe) -- plus, under "hbm",
-                 the algorithmic HBM bytes against the 8 TB/s peak ("Rooflines");
-  "cpu_baseline" the CPU oracle (C restatement of the numba loop, OpenMP over rows) timed on
-                 this box's host cores on a bounded row sample of the same workload.
+  "roofline"     for the workload's dominant kernel: algorithmic flops (or bytes) per launch / its average
+                 duration measured with HIP events on the stream it is launched on (the library's measurement
+                 hook af_profile_events brackets exactly that kernel), against the peak that bounds it
+                 ("Rooflines"); "traffic" = HBM bytes per launch from the PMC passes of the same
+                 command committed under profiles/ (null when no such summary exists);
+  "cpu_baseline" the CPU oracle (C restatement of the reference's numba loops) timed on this box's host
+                 cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
@@ -37,6 +44,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz, vector or matrix
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth (degridder's gather view)
+PMC_ROUND = "r02"              # profiles/<round>_<workload>_pmc_summary.json
 
 
 def parse():
@@ -49,13 +58,12 @@ def parse():
     p.add_argument("--sources", type=int, default=1000)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "fused_dde"],
-                   help="dft: im_to_vis (BASELINE configs[1], the headline); fused_dde: fused predict with "
-                        "per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2])")
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "fused_dde", "degrid"])
     p.add_argument("--pa", default="random", choices=["random", "common"],
                    help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
                         "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
                         "(a real array: coherent beam gathers)")
+    p.add_argument("--npix", type=int, default=4096, help="degrid: grid size")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend; nccl = RCCL over xGMI (default).  gloo exists to "
                         "exercise the N>1 code path on a one-GPU box (with AFHIP_BENCH_DEVICE=0)")
@@ -65,27 +73,340 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(image, uvw, lm, freq, target_core_seconds):
-    """Time the CPU oracle (kind 'port') on a bounded row sample; OpenMP over rows."""
+def _threads():
     import oracle
-    nchan, nsrc = freq.shape[0], lm.shape[0]
-    threads = oracle.num_threads(omp=True)
-    # calibrate on a few rows, single thread
+    return oracle.num_threads(omp=True)
+
+
+def _parallel_rows(fn, nrows, threads):
+    """Run fn(lo, hi) on `threads` host threads over equal row blocks (the oracle's C loops release the
+    GIL): the reference's own parallelism is exactly this, dask row chunks on a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    edges = np.linspace(0, nrows, threads + 1).astype(np.int64)
     t0 = time.perf_counter()
-    oracle.im_to_vis(image, uvw[:16], lm, freq, omp=False)
-    per_row = (time.perf_counter() - t0) / 16
-    rows = int(max(threads * 8, min(uvw.shape[0], target_core_seconds / per_row)))
-    rows -= rows % threads
-    t0 = time.perf_counter()
-    oracle.im_to_vis(image, uvw[:rows], lm, freq, omp=True)
-    dt = time.perf_counter() - t0
-    return {
-        "value": rows * nchan / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
-        "sample": "oracle im_to_vis (C restatement of africanus/dft/kernels.py:33-67, OpenMP over rows), "
-                  "%d rows x %d chan x %d src x 4 corr fp64 in %.2f s; linear in rows; "
-                  "single-thread rate %.4f Mvis/s" % (rows, nchan, nsrc, dt, nchan / per_row / 1e6),
-        "single_thread_value": nchan / per_row / 1e6,
-    }
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda k: fn(int(edges[k]), int(edges[k + 1])), range(threads)))
+    return time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------ workloads
+class Dft(object):
+    """im_to_vis (africanus/dft/kernels.py:14-69): real image (headline) or complex brightness."""
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        from codex_africanus_amd.testing import synthetic_inputs, real_image
+        self.args, self._lib, self.lib = args, _lib, lib
+        self.cplx = args.workload == "dft_complex"
+        nrow, nchan, nsrc = args.rows, args.chans, args.sources
+        self.ncorr = 4
+        d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
+        rng = np.random.default_rng(1000 + args.seed + rank)
+        uvw = np.empty((nrow, 3))
+        uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        if self.cplx:   # linear-feed coherency matrices [I+Q, U+iV, U-iV, I-Q], flat spectrum
+            image = np.ascontiguousarray(np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4)))
+        else:
+            image = real_image(d)
+        self.image, self.uvw, self.lm, self.freq = image, uvw, d["lm"], d["frequency"]
+        self.d_image, self.d_uvw, self.d_lm, self.d_freq = t(image), t(uvw), t(self.lm), t(self.freq)
+        self.ws_bytes = int(lib.af_im_to_vis_workspace_bytes(nsrc, nchan, 4, int(self.cplx)))
+        import torch
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.mode = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT,
+                     "recurrence": _lib.AF_DFT_RECURRENCE}[args.mode]
+        self.label = ("im_to_vis DFT predict, complex brightness (the fused predict without DDEs)" if self.cplx
+                      else "im_to_vis DFT predict (BASELINE configs[1])")
+
+    def predict(self, d_vis, stream, P):
+        a = self.args
+        self._lib.call("af_im_to_vis_f64", P(self.d_image), int(self.cplx), P(self.d_uvw), P(self.d_lm),
+                       P(self.d_freq), a.sources, a.rows, a.chans, 4, self._lib.CONVENTION["fourier"], self.mode,
+                       P(d_vis), P(self.d_ws), self.ws_bytes, stream)
+
+    def reference_rows(self, rows):
+        import oracle
+        return oracle.im_to_vis(self.image, self.uvw[rows], self.lm, self.freq, omp=True), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        nrow, nchan, nsrc, ncorr = a.rows, a.chans, a.sources, 4
+        # Dominant kernel = the one the library's measurement hook brackets.  4-correlation images on a
+        # one-spacing band run dft_mfma_kernel<64>: every 64-channel tile in ONE launch (C2: all 64 channels).
+        mfma = a.mode != "exact" and nchan >= 14
+        px = 16 if self.cplx else 8
+        if mfma:
+            ntile = nchan // 64 + (1 if nchan % 64 > 32 else 0)
+            dom_chans = min(nchan, ntile * 64) if ntile else nchan
+            name = ("dft_mfma_kernel<64,%s>" % str(self.cplx).lower()) if ntile else \
+                "dft_mfma_kernel<%d,%s>" % (16 if nchan <= 16 else 32, str(self.cplx).lower())
+            nstep = -(-nsrc // 4)
+            # algorithmic HBM bytes of that launch (SURVEY 8(d)): 64 B written per vis + uvw 24 B/row + its
+            # records ((64 x {1 real | 3 complex: Re, Im, -Im} + 1 header) x 16 doubles per tile and 4-source step)
+            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + max(ntile, 1) * nstep * (64 * (3 if self.cplx else 1) + 1) * 16 * 8
+        else:
+            dom_chans = nchan
+            name = "dft_exact_kernel"
+            alg_bytes = nrow * nchan * ncorr * 16 + nrow * 24 + nsrc * nchan * ncorr * px
+        # algorithmic flops per (row, chan, src): one phasor step by the three-term recurrence (2 FMA: re, im)
+        # + ncorr MACs: complex x real pixel = 2 FMA, complex x complex = 4 FMA.  FMA = 2 flop.
+        fma = 2 + ncorr * (4 if self.cplx else 2)
+        alg_flops = float(nrow) * dom_chans * nsrc * fma * 2
+        return dict(kernel=name, bound="mfma", alg_flops=alg_flops, alg_bytes=float(alg_bytes),
+                    channels_in_kernel=dom_chans,
+                    note="fp64-pipe bound (MFMA f64 and VALU f64 share one 78.6 TFLOP/s pipe on gfx950), not "
+                         "HBM-bound: nsrc phasors per 64-byte visibility; %d flop per (row, chan, src)" % (2 * fma))
+
+    def cpu_baseline(self, target_core_seconds):
+        import oracle
+        nchan, nsrc = self.freq.shape[0], self.lm.shape[0]
+        threads = _threads()
+        t0 = time.perf_counter()
+        oracle.im_to_vis(self.image, self.uvw[:16], self.lm, self.freq, omp=False)
+        per_row = (time.perf_counter() - t0) / 16
+        rows = int(max(threads * 8, min(self.uvw.shape[0], target_core_seconds / per_row)))
+        rows -= rows % threads
+        t0 = time.perf_counter()
+        oracle.im_to_vis(self.image, self.uvw[:rows], self.lm, self.freq, omp=True)
+        dt = time.perf_counter() - t0
+        return {
+            "value": rows * nchan / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "sample": "oracle im_to_vis (C restatement of africanus/dft/kernels.py:33-67, OpenMP over rows), "
+                      "%d rows x %d chan x %d src x 4 corr fp64, %s image, in %.2f s; linear in rows; "
+                      "single-thread rate %.4f Mvis/s" % (rows, nchan, nsrc, "complex" if self.cplx else "real", dt,
+                                                          nchan / per_row / 1e6),
+            "single_thread_value": nchan / per_row / 1e6,
+        }
+
+
+class FusedDde(object):
+    """BASELINE configs[2]: 64 antennas, 2016 baselines per timestep, beam cube 257 x 257 x 33
+    x 2 x 2 complex128, parallactic angles U(0, pi/6), pointing errors 1e-3 N(0,1), antenna scaling 1 +- 1e-3;
+    brightness = flat-spectrum coherency matrices of the synthetic sky.  The reference chain it replaces:
+    phase_delay -> einsum -> beam_cube_dde -> predict_vis (africanus/rime/examples/predict.py:404-525)."""
+    NANT, LW, MH, NUD = 64, 257, 257, 33
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        from codex_africanus_amd.testing import synthetic_inputs
+        self.args, self._lib = args, _lib
+        nrow, nchan, nsrc, nant = args.rows, args.chans, args.sources, self.NANT
+        d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
+        rng = np.random.default_rng(1000 + args.seed + rank)
+        uvw = np.empty((nrow, 3))
+        uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        lm, freq = d["lm"], d["frequency"]
+        a1, a2 = np.triu_indices(nant, 1)
+        nbl = a1.shape[0]
+        ntime = -(-nrow // nbl)
+        ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
+        ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
+        time_index = np.repeat(np.arange(ntime, dtype=np.int64), nbl)[:nrow]
+        g = np.linspace(-1, 1, self.LW)
+        ll, mm = np.meshgrid(g, g, indexing="ij")
+        pattern = np.exp(-(ll**2 + mm**2) / 0.5) * np.exp(1j * (0.3 * ll + 0.2 * mm))
+        gains = (1 + 0.02 * np.arange(self.NUD))[:, None] * np.array([1.0, 0.05j, -0.04j, 0.95])[None, :]
+        beam = (pattern[:, :, None, None] * gains[None, None]).reshape(self.LW, self.MH, self.NUD, 2, 2)
+        extents = np.array([[-0.06, 0.06], [-0.06, 0.06]])
+        beam_freq_map = np.linspace(freq[0], freq[-1], self.NUD)
+        pa = rng.uniform(0, np.pi / 6, (ntime, nant))
+        if args.pa == "common":
+            pa = np.linspace(0, np.pi / 6, ntime)[:, None] + 1e-3 * rng.standard_normal((ntime, nant))
+        pe = 1e-3 * rng.standard_normal((ntime, nant, nchan, 2))
+        asc = 1.0 + 1e-3 * rng.standard_normal((nant, nchan, 2))
+        X = np.ascontiguousarray(np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4))).reshape(nsrc, nchan, 2, 2)
+        n_items = ctypes.c_int64(0)
+        tip = time_index.ctypes.data_as(ctypes.c_void_p)
+        _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+        items = np.zeros((n_items.value, 4), dtype=np.int32)
+        _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
+                  ctypes.byref(n_items))
+        self.n_items, self.ntime, self.nbl = n_items.value, ntime, nbl
+        self.dv = dict(items=t(items), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
+                       fmap=t(beam_freq_map), pa=t(pa), pe=t(pe), asc=t(asc), lm=t(lm), uvw=t(uvw), freq=t(freq))
+        self.ws_bytes = int(lib.af_fused_predict_workspace_bytes(nsrc, nchan, self.LW, self.MH, self.NUD))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.h = dict(time_index=time_index, ant1=ant1, ant2=ant2, X=X, beam=beam, extents=extents,
+                      beam_freq_map=beam_freq_map, pa=pa, pe=pe, asc=asc, lm=lm, uvw=uvw, freq=freq)
+        self.ncorr = 4
+        self.label = ("fused predict with per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2]), "
+                      "parallactic angles %s" % args.pa)
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_fused_predict_c128", P(v["items"]), self.n_items, P(v["a1"]), P(v["a2"]), a.rows,
+                       P(v["lm"]), P(v["uvw"]), P(v["freq"]), P(v["X"]), a.sources, a.chans, P(v["beam"]), self.LW,
+                       self.MH, self.NUD, P(v["ext"]), P(v["fmap"]), P(v["pa"]), self.ntime, self.NANT, P(v["pe"]),
+                       P(v["asc"]), None, None, self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws),
+                       self.ws_bytes, stream)
+
+    def _chain(self, rows, dde=None, tinv=None):
+        """The reference chain on `rows` (only their timesteps' Jones terms are built)."""
+        import oracle
+        h = self.h
+        if dde is None:
+            tsel, tinv = np.unique(h["time_index"][rows], return_inverse=True)
+            dde = oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], h["lm"], h["pa"][tsel],
+                                       h["pe"][tsel], h["asc"], h["freq"])
+        phase = oracle.phase_delay(h["lm"], h["uvw"][rows], h["freq"])
+        coh = np.einsum("srf,sfij->srfij", phase, h["X"])
+        return oracle.predict_vis(tinv, h["ant1"][rows], h["ant2"][rows], dde, coh, dde, None, None, None)
+
+    def reference_rows(self, rows):
+        rows = rows[:32]
+        return self._chain(rows).reshape(len(rows), self.args.chans, 4), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        nrow, nchan, nsrc = a.rows, a.chans, a.sources
+        # SURVEY 8(d): 64 B written per vis + uvw and indices 36 B/row + the beam cube (with |.|: 24 B per complex)
+        # + parangles / pointing errors / scaling + brightness; ~150 flop per (row, chan, src): phasor 8 +
+        # E X E^H 112 + 4 complex MACs 32 (SURVEY's count, kept so that rounds compare)
+        alg_bytes = (nrow * nchan * 64 + nrow * 36 + self.LW * self.MH * self.NUD * 4 * 24
+                     + self.ntime * self.NANT * (8 + nchan * 16) + self.NANT * nchan * 16 + nsrc * nchan * 64)
+        return dict(kernel="fused_predict_kernel", bound="mfma", alg_flops=float(nrow) * nchan * nsrc * 150.0,
+                    alg_bytes=float(alg_bytes), channels_in_kernel=nchan,
+                    note="fp64 VALU bound (same 78.6 TFLOP/s fp64 pipe as the matrix path): 2x2 complex Jones "
+                         "algebra per (row, chan, src), 150 flop (SURVEY 8(d))")
+
+    def cpu_baseline(self, target_core_seconds):
+        """One timestep of the workload through the oracle chain: beam_cube_dde for the timestep's 64 antennas
+        (single thread, as the reference's numba kernel), then phase_delay -> einsum -> predict_vis on a row
+        sample spread over the host threads (dask row chunks in the reference); the row part is scaled to the
+        timestep's 2016 rows, so the Jones terms are amortised as in the full job."""
+        import oracle
+        h, a = self.h, self.args
+        threads = min(_threads(), 64)
+        rows_t = np.arange(min(self.nbl, a.rows))
+        t0 = time.perf_counter()
+        dde = oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], h["lm"], h["pa"][:1], h["pe"][:1],
+                                   h["asc"], h["freq"])
+        t_beam = time.perf_counter() - t0
+        tinv = np.zeros(len(rows_t), dtype=np.int64)
+        t0 = time.perf_counter()
+        self._chain(rows_t[:4], dde, tinv[:4])
+        per_row = (time.perf_counter() - t0) / 4
+        per_thread = int(max(2, min(32, target_core_seconds / per_row / threads)))   # coh: 4 MB per row
+        n = min(len(rows_t), per_thread * threads)
+        dt = _parallel_rows(lambda lo, hi: self._chain(rows_t[lo:hi], dde, tinv[lo:hi]) if hi > lo else None, n, threads)
+        t_step = t_beam + dt * len(rows_t) / n
+        return {
+            "value": len(rows_t) * a.chans / t_step / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "sample": "oracle chain beam_cube_dde -> phase_delay -> einsum -> predict_vis (C restatements of "
+                      "africanus/rime/fast_beam_cubes.py:57-240, phase.py:20-63, predict.py:193-252) for ONE "
+                      "timestep (%d rows x %d chan x %d src, 64 antennas): beam terms %.2f s on 1 thread + %d rows on "
+                      "%d threads in %.2f s scaled to the timestep's rows" % (len(rows_t), a.chans, a.sources,
+                                                                             t_beam, n, threads, dt),
+            "single_thread_value": a.chans / (per_row + t_beam / len(rows_t)) / 1e6,
+        }
+
+
+class Degrid(object):
+    """BASELINE configs[4]: convolutional degridding (africanus/gridding/perleypolyhedron/degridder.py:79-175) of a
+    4096^2 complex grid onto 1e6 rows x 64 chan with a 7x7-tap kernel (oversampling 63, packed gather policy),
+    XX / YY from Stokes I; uniformly random uv inside 0.45 of the grid (no track locality at all)."""
+    W, OS, CELL = 7, 63, 2.0
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        from codex_africanus_amd.gridding.perleypolyhedron import kernels
+        self.args, self._lib = args, _lib
+        nrow, nchan, npix = args.rows, args.chans, args.npix
+        freq = np.linspace(0.856e9, 1.712e9, nchan)
+        self.wl = 299792458.0 / freq
+        rng = np.random.default_rng(1000 + args.seed + rank)
+        umax = 0.45 / np.deg2rad(self.CELL / 3600.0) * self.wl.min()
+        uvw = np.zeros((nrow, 3))
+        uvw[:, :2] = rng.uniform(-1, 1, (nrow, 2)) * umax
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        self.uvw = uvw
+        g = torch.Generator(device="cpu").manual_seed(args.seed)
+        grid = torch.randn(1, npix, npix, 2, dtype=torch.float64, generator=g)
+        self.d_grid = torch.view_as_complex(grid).to(dev)
+        self.kernel = kernels.pack_kernel(kernels.kbsinc(self.W, oversample=self.OS), self.W, self.OS)
+        self.chanmap = np.zeros(nchan, dtype=np.int64)
+        self.coef = np.array([1, 1], dtype=np.complex128)      # XXYY_FROM_I
+        self.ncorr = 2
+        self.dv = dict(uvw=t(uvw), wl=t(self.wl), cm=t(self.chanmap), k=t(self.kernel), cf=t(self.coef))
+        self.ws_bytes = int(lib.af_degridder_workspace_bytes(nrow))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.centre = np.zeros(2)
+        self.label = ("convolutional degridding %d^2 grid, 7x7 taps, oversampling 63, 2 corr from Stokes I "
+                      "(BASELINE configs[4])" % npix)
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_degridder_c128", P(v["uvw"]), P(self.d_grid), P(v["wl"]), P(v["cm"]), self.CELL,
+                       self.centre.ctypes.data, self.centre.ctypes.data, P(v["k"]), self.W, self.OS, 0, P(v["cf"]),
+                       2, 1, a.rows, a.chans, a.npix, P(d_vis), P(self.d_ws), self.ws_bytes, stream)
+
+    def _oracle(self, rows, grid_host):
+        import oracle
+        return oracle.degridder(self.uvw[rows], grid_host, self.wl, self.chanmap, self.CELL, (0.0, 0.0), (0.0, 0.0),
+                                self.kernel, self.W, self.OS, "None", "None", "XXYY_FROM_I",
+                                "conv_1d_axisymmetric_packed_gather")
+
+    def reference_rows(self, rows):
+        return self._oracle(rows, self.d_grid.cpu().numpy()), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        nvis = float(a.rows) * a.chans
+        # algorithmic HBM bytes: the visibilities written (ncorr x 16 B each), uvw, and the grid read ONCE (it
+        # is re-read ~12x through L2 / Infinity Cache by the 49-tap gathers: "gather" below)
+        alg_bytes = nvis * self.ncorr * 16 + a.rows * 24 + float(a.npix) ** 2 * 16
+        taps = nvis * self.W * self.W
+        return dict(kernel="degrid_coop_kernel<7>", bound="hbm", alg_bytes=alg_bytes, alg_flops=taps * 8.0,
+                    channels_in_kernel=a.chans,
+                    gather={"achieved": taps * 16 / kernel_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                            "frac": taps * 16 / kernel_s / 1e9 / L2_PEAK_GBS,
+                            "note": "16-byte grid cells gathered per tap (49 per visibility), served by L2 / "
+                                    "Infinity Cache: the resource that actually bounds the kernel"},
+                    note="HBM view: 32 B written per visibility + the grid once; the kernel is bound by the "
+                         "gather path (784 B of grid cells per visibility through L2), see 'gather'")
+
+    def cpu_baseline(self, target_core_seconds):
+        threads = _threads()
+        gh = self.d_grid.cpu().numpy()
+        t0 = time.perf_counter()
+        self._oracle(np.arange(64), gh)
+        per_row = (time.perf_counter() - t0) / 64
+        n = int(max(threads * 16, min(self.args.rows, target_core_seconds / per_row)))
+        n -= n % threads
+        rows = np.arange(n)
+        dt = _parallel_rows(lambda lo, hi: self._oracle(rows[lo:hi], gh), n, threads)
+        return {
+            "value": n * self.args.chans / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "sample": "oracle degridder (C restatement of africanus/gridding/perleypolyhedron/degridder.py:15-175, "
+                      "packed gather policy), %d rows x %d chan on %d threads in %.2f s; linear in rows; "
+                      "single-thread rate %.3f Mvis/s" % (n, self.args.chans, threads, dt,
+                                                          self.args.chans / per_row / 1e6),
+            "single_thread_value": self.args.chans / per_row / 1e6,
+        }
+
+
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "fused_dde": FusedDde, "degrid": Degrid}
+
+
+def pmc_traffic(workload, is_default_shape):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of THIS command; KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 streaming reads -- an upper bound where reads are narrower)."""
+    if not is_default_shape:
+        return None, None
+    for name in ("%s_%s_pmc_summary.json" % (PMC_ROUND, workload), "r01_pmc_summary.json" if workload == "dft" else None,
+                 "r01_fused_pmc_summary.json" if workload == "fused_dde" else None):
+        if not name:
+            continue
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            c = json.load(open(path))
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/" + name
+    return None, None
 
 
 def main():
@@ -116,84 +437,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     from codex_africanus_amd import _lib
-    from codex_africanus_amd.testing import synthetic_inputs, real_image
     lib = _lib.load()
 
-    nrow, nchan, nsrc, ncorr = args.rows, args.chans, args.sources, 4
-    # every rank draws the same sky and its own uvw shard (seed + rank): rows are independent
-    d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
-    rng = np.random.default_rng(1000 + args.seed + rank)
-    uvw = np.empty((nrow, 3))
-    uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
-    uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
-    uvw[:, 2] = rng.uniform(-400, 400, nrow)
-    image = real_image(d)
-    lm, freq = d["lm"], d["frequency"]
-
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_image, d_uvw, d_lm, d_freq = t(image), t(uvw), t(lm), t(freq)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    wl = WORKLOADS[args.workload](args, rank, dev, lib, _lib, t)
+    nrow, nchan, nsrc, ncorr = args.rows, args.chans, args.sources, wl.ncorr
     d_vis = torch.empty((nrow, nchan, ncorr), dtype=torch.complex128, device=dev)
     d_chi2 = torch.zeros(nchan, dtype=torch.float64, device=dev)
-    ws_bytes = int(lib.af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, 0))
-    d_ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
-    mode = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE}[args.mode]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    P = lambda x: ctypes.c_void_p(x.data_ptr())
-
-    if args.workload == "dft":
-        def predict():
-            _lib.call("af_im_to_vis_f64", P(d_image), 0, P(d_uvw), P(d_lm), P(d_freq), nsrc, nrow, nchan, ncorr,
-                      _lib.CONVENTION["fourier"], mode, P(d_vis), P(d_ws), ws_bytes, stream)
-    else:
-        # BASELINE configs[2]: 64 antennas, 2016 baselines per timestep, beam cube
-        # 257 x 257 x 33 x 2 x 2 complex128, parallactic angles U(0, pi/6), pointing errors 1e-3 N(0,1),
-        # antenna scaling 1 +- 1e-3; brightness = flat-spectrum coherency matrices of the synthetic sky
-        nant = 64
-        a1, a2 = np.triu_indices(nant, 1)
-        nbl = a1.shape[0]
-        ntime = -(-nrow // nbl)
-        ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
-        ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
-        time_index = np.repeat(np.arange(ntime, dtype=np.int64), nbl)[:nrow]
-        g = np.linspace(-1, 1, 257)
-        ll, mm = np.meshgrid(g, g, indexing="ij")
-        pattern = np.exp(-(ll**2 + mm**2) / 0.5) * np.exp(1j * (0.3 * ll + 0.2 * mm))
-        gains = (1 + 0.02 * np.arange(33))[:, None] * np.array([1.0, 0.05j, -0.04j, 0.95])[None, :]
-        beam = (pattern[:, :, None, None] * gains[None, None]).reshape(257, 257, 33, 2, 2)
-        extents = np.array([[-0.06, 0.06], [-0.06, 0.06]])
-        beam_freq_map = np.linspace(freq[0], freq[-1], 33)
-        pa = rng.uniform(0, np.pi / 6, (ntime, nant))
-        if args.pa == "common":
-            pa = np.linspace(0, np.pi / 6, ntime)[:, None] + 1e-3 * rng.standard_normal((ntime, nant))
-        pe = 1e-3 * rng.standard_normal((ntime, nant, nchan, 2))
-        asc = 1.0 + 1e-3 * rng.standard_normal((nant, nchan, 2))
-        X = np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4)).reshape(nsrc, nchan, 2, 2)
-        n_items = ctypes.c_int64(0)
-        tip = time_index.ctypes.data_as(ctypes.c_void_p)
-        _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
-        items = np.zeros((n_items.value, 4), dtype=np.int32)
-        _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
-                  ctypes.byref(n_items))
-        fd = dict(items=t(items), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
-                  fmap=t(beam_freq_map), pa=t(pa), pe=t(pe), asc=t(asc))
-        fws_bytes = int(lib.af_fused_predict_workspace_bytes(nsrc, nchan, 257, 257, 33))
-        d_fws = torch.empty(max(fws_bytes, 256), dtype=torch.uint8, device=dev)
-        fused_host = dict(time_index=time_index, ant1=ant1, ant2=ant2, X=X, beam=beam, extents=extents,
-                          beam_freq_map=beam_freq_map, pa=pa, pe=pe, asc=asc)
-
-        def predict():
-            _lib.call("af_fused_predict_c128", P(fd["items"]), n_items.value, P(fd["a1"]), P(fd["a2"]), nrow,
-                      P(d_lm), P(d_uvw), P(d_freq), P(fd["X"]), nsrc, nchan, P(fd["beam"]), 257, 257, 33,
-                      P(fd["ext"]), P(fd["fmap"]), P(fd["pa"]), ntime, nant, P(fd["pe"]), P(fd["asc"]), None, None,
-                      _lib.CONVENTION["fourier"], P(d_vis), P(d_fws), fws_bytes, stream)
 
     # "observed" data for the chi^2: the model itself plus a fixed perturbation (one extra predict)
-    predict()
+    wl.predict(d_vis, stream, P)
     d_data = d_vis.clone()
     d_data += 0.01
 
     def step():
-        predict()
+        wl.predict(d_vis, stream, P)
         _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
         if world > 1:
             dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
@@ -241,69 +501,30 @@ def main():
     # parity of the benchmarked output against the CPU oracle on a row sample (checker only)
     max_err = None
     if rank == 0 and args.check_rows > 0:
-        import oracle
         rows = np.linspace(0, nrow - 1, min(args.check_rows, nrow)).astype(np.int64)
+        ref, rows = wl.reference_rows(rows)
         got = d_vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
-        if args.workload == "dft":
-            ref = oracle.im_to_vis(image, uvw[rows], lm, freq, omp=True)
-        else:
-            # the reference chain on the sampled rows (only their timesteps' Jones terms are built)
-            h = fused_host
-            rows = rows[:32]
-            got = got[:32].reshape(32, nchan, 2, 2)
-            tsel, tinv = np.unique(h["time_index"][rows], return_inverse=True)
-            dde = oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], lm, h["pa"][tsel],
-                                       h["pe"][tsel], h["asc"], freq)
-            phase = oracle.phase_delay(lm, uvw[rows], freq)
-            coh = np.einsum("srf,sfij->srfij", phase, h["X"])
-            ref = oracle.predict_vis(tinv, h["ant1"][rows], h["ant2"][rows], dde, coh, dde, None, None, None)
-        max_err = float(np.abs(got - ref).max())
+        max_err = float(np.abs(got - ref.reshape(got.shape)).max())
 
     if rank == 0:
         total_vis = world * nrow * nchan
         ms_per_step = elapsed / args.steps * 1e3
-        # Dominant kernel = the one the library's measurement hook brackets.  Real 4-correlation images
-        # on a one-spacing band run dft_mfma_kernel<64>: every 64-channel tile in ONE launch (C2: all
-        # 64 channels).  --mode exact runs dft_exact_kernel over all channels.
-        mfma = args.mode != "exact" and ncorr == 4 and nchan >= 14
-        if mfma:
-            ntile = nchan // 64 + (1 if nchan % 64 > 32 else 0)
-            dom_chans = min(nchan, ntile * 64) if ntile else nchan
-            kernel_name = "dft_mfma_kernel<64>" if ntile else "dft_mfma_kernel<%d>" % (16 if nchan <= 16 else 32)
-            nstep = -(-nsrc // 4)
-            # algorithmic HBM bytes of that launch: 64 B written per vis + uvw 24 B/row +
-            # its records ((64 + 1) x 16 doubles per tile and 4-source step); it reads nothing else from HBM
-            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + max(ntile, 1) * nstep * 65 * 16 * 8
-        else:
-            ct = 13
-            ntile = -(-nchan // ct)
-            dom_chans = nchan
-            kernel_name = "dft_exact_kernel<13,4,false>"
-            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + ntile * nsrc * 512
-        # algorithmic flops: per (row, chan, src) one complex phasor step (recurrence, 2 FMA) +
-        # ncorr complex-by-real MACs (2 FMA each) = 10 FMA = 20 flop; the MACs are fp64 MFMA
-        # (v_mfma_f64_4x4x4_4b), the recurrence fp64 VALU -- one shared fp64 pipe on this chip
-        alg_flops = float(nrow) * dom_chans * nsrc * (2 + 2 * ncorr) * 2
-        workload = "im_to_vis DFT predict (BASELINE configs[1])"
-        if args.workload == "fused_dde":
-            # + indices 12 B/row, beam cube + |beam| + parangles/pointing/scaling; ~150 flop
-            # per (row, chan, src): phasor 8 + E X E^H 112 + 4 complex MACs 32
-            alg_bytes = (nrow * nchan * 64 + nrow * 36 + 257 * 257 * 33 * 4 * 24 + ntime * nant * (8 + nchan * 16)
-                         + nant * nchan * 16 + nsrc * nchan * 64)
-            alg_flops = float(nrow) * nchan * nsrc * 150.0
-            kernel_name = "fused_predict_kernel"
-            workload = ("fused predict with per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2]), "
-                        "parallactic angles %s" % args.pa)
-        achieved = alg_bytes / kernel_s / 1e9
-        # HBM bytes per launch from the PMC passes of THIS command committed under profiles/
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; KB units; FETCH_SIZE doubled
-        # as MI355X_MICROARCH.md prescribes for gfx950 streaming reads -- an upper bound here).
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and (nrow, nchan, nsrc, args.mode, args.workload) == (1000000, 64, 1000, "auto", "dft"):
-            c = json.load(open(pmc))
-            traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/r01_pmc_summary.json"
+        r = wl.roofline(kernel_s)
+        default_shape = (nrow, nchan, nsrc, args.mode, args.pa, args.npix) == (1000000, 64, 1000, "auto", "random", 4096)
+        traffic, traffic_src = pmc_traffic(args.workload, default_shape)
+        hbm_ach = r["alg_bytes"] / kernel_s / 1e9
+        fp_ach = r["alg_flops"] / kernel_s / 1e12
+        hbm = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
+               "algorithmic_bytes": r["alg_bytes"]}
+        fp64 = {"achieved": fp_ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp_ach / FP64_PEAK_TFLOPS,
+                "algorithmic_flops": r["alg_flops"]}
+        top = fp64 if r["bound"] == "mfma" else hbm
+        roof = {"kernel": r["kernel"], "bound": r["bound"], "achieved": top["achieved"], "peak": top["peak"],
+                "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": kernel_s * 1e3, "channels_in_kernel": r["channels_in_kernel"], "note": r["note"],
+                "hbm": hbm, "fp64": fp64}
+        if "gather" in r:
+            roof["gather"] = r["gather"]
         out = {
             "metric": "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err",
             "value": total_vis / (elapsed / args.steps) / 1e6,
@@ -313,7 +534,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload + " + per-channel chi^2" + (
+                "workload": wl.label + " + per-channel chi^2" + (
                     "" if world == 1 else " + RCCL all-reduce" if args.backend == "nccl" else " + gloo all-reduce"),
                 "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": ncorr,
                 "rows_total": world * nrow, "phasor_mode": args.mode,
@@ -321,29 +542,10 @@ def main():
                             % (world, "none" if world == 1 else args.backend),
             },
             "fp64_max_abs_err": max_err,
-            "roofline": {
-                "kernel": kernel_name,
-                # both workloads are bound by the fp64 pipe ("mfma": the dense fp64 matrix peak equals the vector
-                # peak on this chip): im_to_vis issues fp64 MFMA + VALU, fused_dde fp64 VALU (Jones algebra);
-                # the HBM view of the same launch is in "hbm"
-                "bound": "mfma",
-                "achieved": alg_flops / kernel_s / 1e12,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": alg_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": kernel_s * 1e3, "algorithmic_flops": alg_flops,
-                "channels_in_kernel": dom_chans if args.workload == "dft" else nchan,
-                "note": "fp64-pipe bound (MFMA f64 and VALU f64 share it; 78.6 TFLOP/s spec for either), not "
-                        "HBM-bound: nsrc=1000 phasors per 64-byte visibility",
-                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "algorithmic_bytes": alg_bytes},
-                "fp64": {"achieved": alg_flops / kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": alg_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS},
-            },
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload == "dft":
-            out["cpu_baseline"] = cpu_baseline(image, uvw, lm, freq, args.cpu_seconds)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

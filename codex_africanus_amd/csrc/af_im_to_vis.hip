@@ -113,8 +113,15 @@ __global__ void dft_prep_src(const double *__restrict__ lm, int64_t nsrc, int cl
 // Per channel tile: quarter-turn rates F0_4 = 4*sign*nu[c0]/c and FD_4 = 4*sign*dnu/c,
 // dnu from the tile's own end points; uniform iff every channel of every tile sits within
 // 2 ulp of the tile's arithmetic progression.  One thread per tile; flags[0] &= uniform.
+//
+// flags[1] carries two promises.  (a) every tile has tile 0's channel spacing, so the channel-step phasor of a
+// (row, source) can be shared by all tiles (dpp4 kernel).  (b) when the MFMA-accumulator kernels own the band
+// (mfma_ct = their tile width, else 0): every MFMA tile is ONE arithmetic progression -- dft_mfma_kernel
+// evaluates a whole tile as nu[c0] + j * dnu, so a jump between two of THESE tiles that falls inside an MFMA
+// tile (concatenated spectral windows with equal channel widths) must clear the flag as well; a jump on an
+// MFMA tile boundary is harmless, every MFMA tile takes its own first frequency.
 __global__ void dft_prep_freq(const double *__restrict__ freq, int64_t nchan, int64_t ntile, int CT, int sign,
-                              double *__restrict__ tilef, double *__restrict__ freq_pad,
+                              int mfma_ct, double *__restrict__ tilef, double *__restrict__ freq_pad,
                               int *__restrict__ flags)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,6 +150,12 @@ __global__ void dft_prep_freq(const double *__restrict__ freq, int64_t nchan, in
     const double df0 = (n0 > 1) ? (freq[n0 - 1] - freq[0]) / (double)(n0 - 1) : 0.0;
     if (nc > 1 && !(fabs(df - df0) <= 4.0 * 2.220446049250313e-16 * fmax(fabs(df), fabs(df0)) * (double)CT))
         atomicAnd(&flags[1], 0);
+    if (mfma_ct > 0 && t > 0 && (c0 % mfma_ct) != 0) {
+        // the step INTO this tile continues the progression (differences of ~1e9 Hz values: 4 ulp of nu)
+        const double step = f0 - freq[c0 - 1];
+        const double tol = 4.0 * 2.220446049250313e-16 * fmax(fabs(f0), fabs(freq[c0 - 1]));
+        if (!(fabs(step - df0) <= tol)) atomicAnd(&flags[1], 0);
+    }
 }
 
 // Build the records of one correlation chunk: for every (tile, source) a block of
@@ -800,7 +813,7 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
                        reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad));
     AF_LAUNCH_CHECK();
     hipLaunchKernelGGL(dft_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan,
-                       L.ntile, ct, convention, reinterpret_cast<double *>(ws + L.tilef),
+                       L.ntile, ct, convention, mfma ? 64 : 0, reinterpret_cast<double *>(ws + L.tilef),
                        reinterpret_cast<double *>(ws + L.freq), reinterpret_cast<int *>(ws + L.flags));
     AF_LAUNCH_CHECK();
     if (mode == AF_DFT_RECURRENCE)  // caller asserts uniform spacing

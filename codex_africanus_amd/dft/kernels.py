@@ -1,5 +1,7 @@
 """im_to_vis with the signature of africanus/dft/kernels.py:14-16."""
+import contextlib
 import os
+import threading
 
 import numpy as np
 
@@ -8,24 +10,46 @@ from .._device import Call, np_dtype_of
 
 _MODES = {"auto": _lib.AF_DFT_AUTO, "exact": _lib.AF_DFT_EXACT, "recurrence": _lib.AF_DFT_RECURRENCE,
           "valu": _lib.AF_DFT_AUTO | _lib.AF_DFT_VALU_ONLY}
-_mode = os.environ.get("AFHIP_DFT_MODE", "auto")
-if _mode not in _MODES:
+_default_mode = os.environ.get("AFHIP_DFT_MODE", "auto")
+if _default_mode not in _MODES:
     raise ValueError("AFHIP_DFT_MODE must be one of %s" % sorted(_MODES))
 
 
+class _ThreadMode(threading.local):
+    """The phasor mode is per THREAD: the transforms are called concurrently from dask worker threads (the
+    reference kernels are nogil and stateless, africanus/util/numba.py:9-12), so one caller's set_mode must not
+    change what another thread's call in flight computes.  A thread that never called set_mode sees the
+    process default (AFHIP_DFT_MODE, else 'auto')."""
+    value = None
+
+
+_tls = _ThreadMode()
+
+
 def set_mode(mode):
-    """Phasor evaluation: 'auto' (channel recurrence when ``frequency`` is uniformly
+    """Phasor evaluation for the CALLING THREAD: 'auto' (channel recurrence when ``frequency`` is uniformly
     spaced, decided on the device; otherwise the exact path), 'exact' (reference operation
     order + full-accuracy sincos per (row, source, chan)), 'recurrence' (force), 'valu' ('auto' with
-    im_to_vis kept on the VALU recurrence kernels instead of the MFMA-accumulator ones)."""
-    global _mode
-    if mode not in _MODES:
+    im_to_vis kept on the VALU recurrence kernels instead of the MFMA-accumulator ones).  ``None`` returns the
+    thread to the process default."""
+    if mode is not None and mode not in _MODES:
         raise ValueError("mode must be one of %s" % sorted(_MODES))
-    _mode = mode
+    _tls.value = mode
 
 
 def get_mode():
-    return _mode
+    return _tls.value if _tls.value is not None else _default_mode
+
+
+@contextlib.contextmanager
+def mode(name):
+    """``with dft.mode('exact'): ...`` -- set_mode for the duration of a block, this thread only."""
+    previous = _tls.value
+    set_mode(name)
+    try:
+        yield
+    finally:
+        _tls.value = previous
 
 
 def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
@@ -65,7 +89,7 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
         ws_bytes = _lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, int(is_cplx))
         p_ws = c.scratch(ws_bytes)
         _lib.call("af_im_to_vis_f64", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
-                  _lib.CONVENTION[convention], _MODES[_mode], p_out, p_ws, max(int(ws_bytes), 256), c.stream)
+                  _lib.CONVENTION[convention], _MODES[get_mode()], p_out, p_ws, max(int(ws_bytes), 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
 
 
@@ -108,6 +132,6 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
         ws_bytes = int(_lib.load().af_vis_to_im_workspace_bytes(nsrc, nrow, nchan, ncorr))
         p_ws = c.scratch(ws_bytes)
         _lib.call("af_vis_to_im_f64", p_vis, p_uvw, p_lm, p_fr, p_fl, nsrc, nrow, nchan, ncorr,
-                  _lib.CONVENTION[convention], _MODES[_mode] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws,
+                  _lib.CONVENTION[convention], _MODES[get_mode()] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws,
                   max(ws_bytes, 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.float64 else out_dtype)

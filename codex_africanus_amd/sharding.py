@@ -82,7 +82,22 @@ def chi2(model, data, weight=None):
     from . import _lib
     if not (model.is_cuda and data.is_cuda):
         raise ValueError("chi2 expects ROCm tensors")
-    model, data = model.contiguous(), data.contiguous()
+    if tuple(model.shape) != tuple(data.shape) or model.dim() < 2:
+        raise ValueError("chi2: model %s and data %s must share one (row, chan, ...) shape"
+                         % (tuple(model.shape), tuple(data.shape)))
+    # af_chi2_c128 reads 16-byte complex values: complex64 operands (im_to_vis of all-float32 inputs) are
+    # widened here, anything that is not complex is refused rather than reinterpreted
+    for name, x in (("model", model), ("data", data)):
+        if x.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("chi2: %s must be complex64 or complex128, got %s" % (name, x.dtype))
+    model = model.to(torch.complex128).contiguous()
+    data = data.to(torch.complex128).contiguous()
+    if weight is not None:
+        if weight.is_complex() or tuple(weight.shape) != tuple(model.shape):
+            raise ValueError("chi2: weight must be real with the shape of the visibilities %s, got %s %s"
+                             % (tuple(model.shape), weight.dtype, tuple(weight.shape)))
+        if weight.device != model.device:
+            raise ValueError("chi2: weight lives on %s, the visibilities on %s" % (weight.device, model.device))
     nrow, nchan = int(model.shape[0]), int(model.shape[1])
     ncorr = int(np.prod(model.shape[2:])) if model.dim() > 2 else 1
     out = torch.empty(nchan, dtype=torch.float64, device=model.device)

@@ -1,0 +1,127 @@
+"""
+BASELINE configs at FULL size on one MI355X, through the C ABI, on exactly the inputs `bench.py --workload ...`
+builds (the tests instantiate bench.py's workload objects): rows sampled against the CPU oracle plus the
+size-independent properties the domain offers -- linearity, row-shard invariance (a shard's rows equal the same
+rows of the full call bit for bit: what the multi-GPU sharding relies on), finite checksums.
+
+  configs[1]  im_to_vis 1e6 x 64 x 1000 x 4: tests/test_gpu_parity.py::test_im_to_vis_full_size_c2_properties
+  configs[1'] the same with complex brightness (= fused predict without DDEs)           -- here
+  configs[2]  fused predict with beam-cube DDEs, 64 antennas, 257 x 257 x 33 cube       -- here
+  configs[4]  degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7 x 7 taps               -- here
+(configs[3] is configs[1] row-sharded over 8 GPUs: world-2 gloo tests in tests/test_chunked_and_sharding.py.)
+"""
+import argparse
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(name, **over):
+    import torch
+    import bench
+    from codex_africanus_amd import _lib
+    args = argparse.Namespace(gpus=1, steps=1, warmup=0, rows=1000000, chans=64, sources=1000, seed=0, mode="auto",
+                              workload=name, pa="random", npix=4096, backend="nccl", no_cpu_baseline=True,
+                              cpu_seconds=1.0, check_rows=0)
+    for k, v in over.items():
+        setattr(args, k, v)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    wl = bench.WORKLOADS[name](args, 0, dev, _lib.load(), _lib, t)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    vis = torch.empty((args.rows, args.chans, wl.ncorr), dtype=torch.complex128, device=dev)
+    wl.predict(vis, stream, P)
+    torch.cuda.synchronize()
+    return wl, vis, args
+
+
+def _sample(vis, rows):
+    import torch
+    return vis[torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(vis.device)].cpu().numpy()
+
+
+def test_fused_dde_full_size_c3():
+    """BASELINE configs[2]: 1e6 rows x 64 chan x 1000 src, 64 antennas, 257 x 257 x 33 x 2 x 2 cube.  Rows of the
+    first, a middle and the last (short) timestep against the reference chain phase_delay -> einsum ->
+    beam_cube_dde -> predict_vis (oracle), north-star tolerance 1e-8 absolute; a timestep-aligned and an
+    unaligned row shard equal the full call bit for bit; x2 brightness is exact."""
+    import torch
+    from codex_africanus_amd import rime
+    wl, vis, args = _workload("fused_dde")
+    h = wl.h
+    nrow, nbl = args.rows, wl.nbl
+    assert tuple(vis.shape) == (nrow, 64, 4)
+    rows = np.concatenate([np.arange(0, nbl, 211), 250 * nbl + np.arange(5, nbl, 199),
+                           np.arange((wl.ntime - 1) * nbl, nrow, 7)[:12]])
+    ref, rows = wl.reference_rows(rows)           # the oracle chain on (up to) 32 of them
+    got = _sample(vis, rows)
+    err = np.abs(got - ref.reshape(got.shape)).max()
+    assert err < 1e-8, err
+    assert err < 1e-9 * np.abs(h["X"]).sum(axis=0).max()      # and the relative bound of tests/test_gpu_fused.py
+    # row shards through the reference-shaped entry point (device tensors): 37 timesteps from timestep 100, and
+    # a shard that starts and ends inside timesteps
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dv = wl.dv
+    for a, b in ((100 * nbl, 137 * nbl), (123457, 234567)):
+        t0, t1 = int(h["time_index"][a]), int(h["time_index"][b - 1]) + 1
+        part = rime.fused_predict_vis(T(h["time_index"][a:b]), dv["a1"][a:b], dv["a2"][a:b], dv["lm"], dv["uvw"][a:b],
+                                      dv["freq"], dv["X"], dv["beam"], dv["ext"], dv["fmap"], dv["pa"][t0:t1],
+                                      dv["pe"][t0:t1], dv["asc"])
+        assert torch.equal(part.reshape(b - a, 64, 4), vis[a:b])
+    del part
+    # linearity in the brightness: a power of two commutes with every rounding
+    a, b = 500 * nbl, 520 * nbl
+    t0, t1 = 500, 520
+    twice = rime.fused_predict_vis(T(h["time_index"][a:b]), dv["a1"][a:b], dv["a2"][a:b], dv["lm"], dv["uvw"][a:b],
+                                   dv["freq"], dv["X"] * 2.0, dv["beam"], dv["ext"], dv["fmap"], dv["pa"][t0:t1],
+                                   dv["pe"][t0:t1], dv["asc"])
+    assert torch.equal(twice.reshape(b - a, 64, 4), vis[a:b] * 2.0)
+    power = (vis.real ** 2 + vis.imag ** 2).sum(dim=(0, 2))
+    assert bool(torch.isfinite(power).all()) and bool((power > 0).all())
+
+
+def test_degrid_full_size_c5():
+    """BASELINE configs[4]: 4096^2 grid, 1e6 rows x 64 chan, 7 x 7 taps.  Sampled rows against the oracle degridder
+    (to rounding: the sums run column-first), x2 grid exact, a row shard equals the full call bit for bit (the
+    uv-tile ordering of the rows is transparent), XX == YY for Stokes I."""
+    import torch
+    from codex_africanus_amd.gridding.perleypolyhedron.degridder import degridder
+    wl, vis, args = _workload("degrid")
+    nrow = args.rows
+    assert tuple(vis.shape) == (nrow, 64, 2)
+    rows = np.linspace(0, nrow - 1, 300).astype(np.int64)
+    ref, _ = wl.reference_rows(rows)
+    got = _sample(vis, rows)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert torch.equal(vis[:, :, 0], vis[:, :, 1])
+    dv = wl.dv
+    pol = ("None", "None", "XXYY_FROM_I", "conv_1d_axisymmetric_packed_gather")
+    a, b = 123457, 654321
+    part = degridder(dv["uvw"][a:b], wl.d_grid, dv["wl"], dv["cm"], wl.CELL, (0.0, 0.0), (0.0, 0.0), dv["k"], wl.W,
+                     wl.OS, *pol)
+    assert torch.equal(part, vis[a:b])
+    twice = degridder(dv["uvw"][a:b], wl.d_grid * 2.0, dv["wl"], dv["cm"], wl.CELL, (0.0, 0.0), (0.0, 0.0), dv["k"],
+                      wl.W, wl.OS, *pol)
+    # the normalisation divides by (sum of weights + 1e-8): a factor 2 of the grid still commutes with it exactly
+    assert torch.equal(twice, part * 2.0)
+    assert bool(torch.isfinite(vis.real).all()) and bool(torch.isfinite(vis.imag).all())
+
+
+def test_im_to_vis_complex_full_size():
+    """configs[1] with complex brightness matrices (what the fused predict without DDEs runs): sampled rows vs the
+    oracle < 1e-8, shard invariance, exact linearity."""
+    import torch
+    from codex_africanus_amd import dft
+    wl, vis, args = _workload("dft_complex")
+    nrow = args.rows
+    rows = np.linspace(0, nrow - 1, 48).astype(np.int64)
+    ref, _ = wl.reference_rows(rows)
+    assert np.abs(_sample(vis, rows) - ref).max() < 1e-8
+    a, b = 123457, 654321
+    part = dft.im_to_vis(wl.d_image, wl.d_uvw[a:b], wl.d_lm, wl.d_freq)
+    assert torch.equal(part, vis[a:b])
+    assert torch.equal(dft.im_to_vis(wl.d_image * 4.0, wl.d_uvw[a:b], wl.d_lm, wl.d_freq), part * 4.0)

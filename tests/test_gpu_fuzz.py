@@ -206,6 +206,32 @@ def test_piecewise_uniform_bands_take_the_per_tile_kernels():
     assert np.abs(got - ref).max() <= 1e-11 * np.abs(vis).sum(axis=0).max()
 
 
+@pytest.mark.parametrize("sub,nsub", [(8, 2), (16, 2), (13, 2), (26, 2), (11, 2), (8, 3), (13, 5), (64, 2), (32, 3)])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_equal_width_subbands_with_a_gap(sub, nsub, cplx):
+    """concatenated spectral windows: SAME channel width, a gap between the windows.  Every VALU tile is
+    uniform and all tiles share one spacing, but an MFMA tile (64 channels, evaluated as nu[c0] + j dnu) that
+    straddles a gap is not an arithmetic progression: the device-side flags must keep such bands off
+    dft_mfma_kernel (af_im_to_vis.hip dft_prep_freq).  Gaps on the VALU tile boundaries 8 / 11 / 13 /
+    16, inside a tile, and on a 64-channel MFMA tile boundary (harmless: every MFMA tile has its own start)."""
+    rng = np.random.default_rng(1000 * sub + nsub)
+    nrow, nsrc = 130, 19
+    uvw = rng.standard_normal((nrow, 3)) * 3000.0
+    lm = rng.standard_normal((nsrc, 2)) * 0.03
+    freq = np.concatenate([1.0e9 + 0.2e9 * k + 1e6 * np.arange(sub) for k in range(nsub)])
+    img = rng.standard_normal((nsrc, freq.size, 4))
+    if cplx:
+        img = img + 1j * rng.standard_normal(img.shape)
+    dft.set_mode("auto")
+    out = dft.im_to_vis(img, uvw, lm, freq)
+    ref = oracle.im_to_vis(img, uvw, lm, freq)
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(img).sum(axis=0).max()
+    # the adjoint keeps its own per-MFMA-tile test (flags[3]); same bands
+    got = dft.vis_to_im(ref, uvw, lm, freq, np.zeros(ref.shape, dtype=bool))
+    want = oracle.vis_to_im(ref, uvw, lm, freq, np.zeros(ref.shape, dtype=bool))
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(ref).sum(axis=0).max()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_degridder_gridder_random_shapes(seed):
     """kernel widths 1..11, oversampling 1..63, odd grid sizes, rows below and above the uv-tile-order threshold, band
