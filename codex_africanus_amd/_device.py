@@ -13,10 +13,16 @@ PyTorch is only plumbing here (device memory and streams); no torch op does arit
 of the path.
 """
 import ctypes
+import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, placement
+
+
+# measurement hook (tools/bench_small_calls.py): AFHIP_POOL=0 restores round 1's host path -- hipMalloc / hipFree
+# per array per call and the NULL stream -- for before / after comparisons
+_USE_POOL = os.environ.get("AFHIP_POOL", "1") != "0"
 
 
 def _is_torch(x):
@@ -49,17 +55,19 @@ def np_dtype_of(x):
 
 
 class _OwnedBuffer(object):
-    """Device memory owned by libafhip (host mode)."""
+    """Device memory of one host-mode call, drawn from libafhip's per-device scratch pool (af_pool_malloc): in
+    steady state no hipMalloc / hipFree happens on this path.  Returned to the pool only after the call's stream
+    has been synchronised (Call.__exit__), so a block is idle when another thread picks it up."""
 
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
         p = ctypes.c_void_p()
-        _lib.call("af_malloc", ctypes.byref(p), max(self.nbytes, 1))
+        _lib.call("af_pool_malloc" if _USE_POOL else "af_malloc", ctypes.byref(p), max(self.nbytes, 1))
         self.ptr = p.value
 
     def free(self):
         if self.ptr:
-            _lib.call("af_free", self.ptr)
+            _lib.call("af_pool_free" if _USE_POOL else "af_free", self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -74,38 +82,23 @@ class _PinnedPool(object):
 
     A device -> host copy into pageable memory runs at 10-15 GB/s (the runtime stages it through its own pinned
     bounce buffers); into page-locked memory it runs at PCIe rate.  The result array is a view of a pinned
-    buffer; when the array (and every view of it) is garbage collected the buffer goes back to the pool, so a
-    loop that drops its previous result re-uses the same pages.  Buffers above `LIMIT` pooled bytes are freed.
+    buffer from libafhip's host pool (af_pool_malloc_host: size-bucketed, least-recently-freed eviction, capped by
+    AFHIP_PINNED_LIMIT); when the array (and every view of it) is garbage collected the buffer goes back to the
+    pool, so a loop that drops its previous result re-uses the same pages, ragged chunk sizes included.
     """
-    LIMIT = 16 << 30
     MIN_BYTES = 1 << 20          # small results: plain numpy arrays, not worth pinning
 
-    def __init__(self):
-        import threading
-        self._lock = threading.Lock()
-        self._free = {}          # nbytes -> [ptr, ...]
-        self._pooled = 0
-
     def take(self, nbytes):
-        with self._lock:
-            lst = self._free.get(nbytes)
-            if lst:
-                self._pooled -= nbytes
-                return lst.pop()
         p = ctypes.c_void_p()
         lib = _lib.load()
-        if lib.af_malloc_host(ctypes.byref(p), ctypes.c_size_t(nbytes)) != 0 or not p.value:
+        if lib.af_pool_malloc_host(ctypes.byref(p), ctypes.c_size_t(nbytes)) != 0 or not p.value:
             return None            # no page-locked memory to be had: the caller falls back to pageable
         return p.value
 
-    def give(self, ptr, nbytes):
-        with self._lock:
-            if self._pooled + nbytes <= self.LIMIT:
-                self._free.setdefault(nbytes, []).append(ptr)
-                self._pooled += nbytes
-                return
+    @staticmethod
+    def give(ptr):
         try:
-            _lib.load().af_free_host(ctypes.c_void_p(ptr))
+            _lib.load().af_pool_free_host(ctypes.c_void_p(ptr))
         except Exception:
             pass
 
@@ -119,7 +112,7 @@ class _PinnedPool(object):
         if ptr is None:
             return None
         raw = (ctypes.c_char * nbytes).from_address(ptr)
-        weakref.finalize(raw, self.give, ptr, nbytes)   # raw is the base of every view handed out
+        weakref.finalize(raw, self.give, ptr)   # raw is the base of every view handed out
         return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
 
@@ -153,10 +146,19 @@ class Call(object):
             self.stream = ctypes.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
         else:
             _lib.load()
-            self.stream = None  # default stream of the thread's current device
+            # host mode: the block's device (placement: row-block index or calling thread), then this thread's
+            # own stream on it -- concurrent calls from dask worker threads do not meet on the NULL stream
+            placement.activate()
+            self.stream = _lib.thread_stream() if _USE_POOL else None
         return self
 
     def __exit__(self, *exc):
+        if self._owned and exc and exc[0] is not None:
+            # error path: work may still be in flight on buffers about to return to the pool
+            try:
+                _lib.call("af_stream_synchronize", self.stream)
+            except Exception:
+                pass
         for b in self._owned:
             b.free()
         self._owned = []

@@ -36,6 +36,15 @@ _SIGNATURES = {
     "af_free": (_int, [_vp]),
     "af_malloc_host": (_int, [ctypes.POINTER(_vp), _sz]),
     "af_free_host": (_int, [_vp]),
+    "af_pool_malloc": (_int, [ctypes.POINTER(_vp), _sz]),
+    "af_pool_free": (_int, [_vp]),
+    "af_pool_malloc_host": (_int, [ctypes.POINTER(_vp), _sz]),
+    "af_pool_free_host": (_int, [_vp]),
+    "af_pool_trim": (_int, [_int, _sz]),
+    "af_pool_stats": (_int, [_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_i64),
+                             ctypes.POINTER(_i64)]),
+    "af_thread_stream": (_int, [ctypes.POINTER(_vp)]),
+    "af_shutdown": (_int, []),
     "af_memcpy_h2d": (_int, [_vp, _vp, _sz, _vp]),
     "af_memcpy_d2h": (_int, [_vp, _vp, _sz, _vp]),
     "af_memcpy_d2d": (_int, [_vp, _vp, _sz, _vp]),
@@ -208,3 +217,25 @@ def device_info(device=None):
     call("af_device_info", device, name, 256, arch, 256, ctypes.byref(cus), ctypes.byref(mem))
     return dict(name=name.value.decode(), arch=arch.value.decode(), compute_units=cus.value,
                 total_mem=mem.value)
+
+
+def thread_stream():
+    """The calling thread's own stream on its current device (af_thread_stream), as a c_void_p."""
+    st = _vp()
+    call("af_thread_stream", ctypes.byref(st))
+    return st
+
+
+def pool_stats(device=None):
+    """Scratch-pool counters of `device` (None = current, -1 = the page-locked host list)."""
+    device = get_device() if device is None else device
+    cached, used, hits, misses = _sz(0), _sz(0), _i64(0), _i64(0)
+    call("af_pool_stats", int(device), ctypes.byref(cached), ctypes.byref(used), ctypes.byref(hits),
+         ctypes.byref(misses))
+    return dict(cached_bytes=cached.value, in_use_bytes=used.value, hits=hits.value, misses=misses.value)
+
+
+def shutdown():
+    """Release every cached pool block and the per-thread streams (af_shutdown)."""
+    if _lib is not None:
+        call("af_shutdown")

@@ -13,6 +13,7 @@ except ImportError as e:  # pragma: no cover - depends on the environment
     _dask_error = e
 
 from .kernels import im_to_vis as _np_im_to_vis, vis_to_im as _np_vis_to_im
+from .. import placement
 
 
 def _first(x):
@@ -21,9 +22,12 @@ def _first(x):
     return x
 
 
-def _im_to_vis_block(image, uvw, lm, frequency, convention, dtype_):
-    return _np_im_to_vis(_first(image), _first(uvw), _first(lm), frequency,
-                         convention=convention, dtype=dtype_)
+def _im_to_vis_block(image, uvw, lm, frequency, block_id=None, convention="fourier", dtype_=None):
+    # block_id: the row block's number (a one-element array riding along the "row" axis): row block k runs on
+    # GPU k % n_devices (codex_africanus_amd/placement.py)
+    with placement.block(block_id):
+        return _np_im_to_vis(_first(image), _first(uvw), _first(lm), frequency,
+                             convention=convention, dtype=dtype_)
 
 
 def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=np.complex128):
@@ -37,14 +41,17 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=np.complex1
         raise ValueError("Image chunks and lm chunks must match on first axis")
     if image.chunks[1] != frequency.chunks[0]:
         raise ValueError("Image chunks must match frequency chunks on second axis")
+    # blocks are matched by position (align_arrays=False): the checks above already made the chunkings agree
     return da.blockwise(_im_to_vis_block, ("row", "chan", "corr"), image, ("src", "chan", "corr"),
                         uvw, ("row", "uvwc"), lm, ("src", "lmc"), frequency, ("chan",),
-                        convention=convention, dtype_=dtype, dtype=dtype)
+                        da.arange(len(uvw.chunks[0]), chunks=1, dtype=np.int64), ("row",),
+                        align_arrays=False, convention=convention, dtype_=dtype, dtype=dtype)
 
 
-def _vis_to_im_block(vis, uvw, lm, frequency, flags, convention, dtype_):
-    return _np_vis_to_im(vis, _first(uvw), _first(lm), frequency, flags, convention=convention,
-                         dtype=dtype_)[None, ...]
+def _vis_to_im_block(vis, uvw, lm, frequency, flags, block_id=None, convention="fourier", dtype_=None):
+    with placement.block(block_id):
+        return _np_vis_to_im(vis, _first(uvw), _first(lm), frequency, flags, convention=convention,
+                             dtype=dtype_)[None, ...]
 
 
 def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=np.float64):
@@ -60,6 +67,8 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=np.flo
         raise ValueError("Vis chunks must match flags chunks on all axes")
     ims = da.blockwise(_vis_to_im_block, ("row", "src", "chan", "corr"), vis, ("row", "chan", "corr"),
                        uvw, ("row", "uvwc"), lm, ("src", "lmc"), frequency, ("chan",),
-                       flags, ("row", "chan", "corr"), adjust_chunks={"row": 1},
+                       flags, ("row", "chan", "corr"),
+                       da.arange(len(uvw.chunks[0]), chunks=1, dtype=np.int64), ("row",),
+                       align_arrays=False, adjust_chunks={"row": 1},
                        convention=convention, dtype_=dtype, dtype=dtype)
     return ims.sum(axis=0)

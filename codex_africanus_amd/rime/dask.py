@@ -22,6 +22,7 @@ from .predict import predict_vis as _np_predict_vis, predict_checks
 from .fast_beam_cubes import beam_cube_dde as _np_beam_cube_dde
 from .wsclean_predict import wsclean_predict as _np_wsclean_predict
 from .feeds import feed_rotation as _np_feed_rotation
+from .. import placement
 
 
 def _need_dask():
@@ -34,6 +35,13 @@ def _first(x):
     while isinstance(x, list):
         x = x[0]
     return x
+
+
+def _row_block_ids(nblocks):
+    """One element per row block, holding the block's number: rides along the "row" axis of a blockwise call
+    (matched by position, ``align_arrays=False``) so that the block function knows which row block it is and
+    ``placement`` can map row block k to GPU k % n_devices (north star: dask row chunks -> GPUs of one node)."""
+    return da.arange(nblocks, chunks=1, dtype=np.int64)
 
 
 # ---------------------------------------------------------------------------- phase_delay
@@ -98,21 +106,23 @@ def beam_cube_dde(beam, beam_lm_extents, beam_freq_map, lm, parallactic_angles, 
 
 
 # ---------------------------------------------------------------------------- predict_vis
-def _coh_block(time_index, antenna1, antenna2, dde1, coh, dde2, base_vis):
+def _coh_block(time_index, antenna1, antenna2, dde1, coh, dde2, base_vis, block_id=None):
     # dde blocks lose the single-chunk 'ant' axis into a list; a chained running sum arrives
     # with the length-1 source axis the previous link added
     if base_vis is not None:
         base_vis = base_vis[0]
-    vis = _np_predict_vis(time_index, antenna1, antenna2,
-                          None if dde1 is None else _first(dde1), coh,
-                          None if dde2 is None else _first(dde2), None, base_vis, None)
+    with placement.block(block_id):
+        vis = _np_predict_vis(time_index, antenna1, antenna2,
+                              None if dde1 is None else _first(dde1), coh,
+                              None if dde2 is None else _first(dde2), None, base_vis, None)
     return vis[None, ...]
 
 
-def _die_block(time_index, antenna1, antenna2, die1, base_vis, die2):
-    return _np_predict_vis(time_index, antenna1, antenna2, None, None, None,
-                           None if die1 is None else _first(die1), base_vis,
-                           None if die2 is None else _first(die2))
+def _die_block(time_index, antenna1, antenna2, die1, base_vis, die2, block_id=None):
+    with placement.block(block_id):
+        return _np_predict_vis(time_index, antenna1, antenna2, None, None, None,
+                               None if die1 is None else _first(die1), base_vis,
+                               None if die2 is None else _first(die2))
 
 
 def _check_jones_chunks(name, arr, ant_axis, time_axis, time_index, pair):
@@ -139,6 +149,7 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
     present = [a for a in (dde1_jones, source_coh, dde2_jones, die1_jones, die2_jones) if a is not None]
     out_dtype = np.result_type(*[a.dtype for a in present]) if present else base_vis.dtype
     row_chunks = time_index.chunks[0]
+    block_ids = _row_block_ids(len(row_chunks))
 
     summed = None
     if have_ddes or have_coh:
@@ -155,8 +166,8 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
                 _coh_block, coh_ix, time_index, ("row",), antenna1, ("row",), antenna2, ("row",),
                 d1, None if d1 is None else jones_ix, co, None if co is None else coh_ix,
                 d2, None if d2 is None else jones_ix,
-                bvis, None if bvis is None else coh_ix,
-                align_arrays=False, adjust_chunks={"row": row_chunks},
+                bvis, None if bvis is None else coh_ix, block_ids, ("row",),
+                align_arrays=False, adjust_chunks={"row": row_chunks, "src": 1},
                 meta=np.empty((0,) * len(coh_ix), dtype=out_dtype), dtype=out_dtype)
 
         if streams is True:
@@ -177,7 +188,7 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
     g_ix, v_ix = ("row", "ant", "chan") + cd, ("row", "chan") + cd
     return da.blockwise(
         _die_block, v_ix, time_index, ("row",), antenna1, ("row",), antenna2, ("row",),
-        die1_jones, None if die1_jones is None else g_ix, base_vis, v_ix,
-        die2_jones, None if die2_jones is None else g_ix,
+        die1_jones, None if die1_jones is None else g_ix, base_vis, None if base_vis is None else v_ix,
+        die2_jones, None if die2_jones is None else g_ix, block_ids, ("row",),
         align_arrays=False, adjust_chunks={"row": row_chunks},
         meta=np.empty((0,) * len(v_ix), dtype=out_dtype), dtype=out_dtype)

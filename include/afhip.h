@@ -70,6 +70,28 @@ int af_malloc(void **dptr, size_t bytes);
 int af_free(void *dptr);
 int af_malloc_host(void **hptr, size_t bytes); /* pinned host memory */
 int af_free_host(void *hptr);
+/* Per-device scratch pool (SURVEY 8(b) "Ownership": the reference allocates with np.zeros / np.empty per call,
+ * africanus/rime/predict.py:271, africanus/dft/kernels.py:45; on the device the equivalent hipMalloc / hipFree
+ * pair per array per call synchronises the device).  af_pool_malloc returns a block of >= `bytes` on the calling
+ * thread's current device, re-using a cached block when one fits; af_pool_free hands it back to the cache (work
+ * that uses the block must be complete, or every later user must run on the same stream).  _host: page-locked
+ * host memory.  Cached bytes are capped per device (env AFHIP_POOL_LIMIT, default 32 GiB; AFHIP_PINNED_LIMIT,
+ * default 8 GiB, for the host list), least recently freed blocks go first.  af_pool_trim(device, keep) releases
+ * cached blocks of `device` (-1 = host list) down to `keep` bytes; af_pool_stats reports cached / handed-out
+ * bytes and cache hits / misses. */
+int af_pool_malloc(void **dptr, size_t bytes);
+int af_pool_free(void *dptr);
+int af_pool_malloc_host(void **hptr, size_t bytes);
+int af_pool_free_host(void *hptr);
+int af_pool_trim(int device, size_t keep_bytes);
+int af_pool_stats(int device, size_t *cached_bytes, size_t *in_use_bytes, int64_t *hits, int64_t *misses);
+/* The calling thread's own (non-blocking) stream on its current device, created at first use: host threads
+ * (dask workers; the reference kernels are nogil, africanus/util/numba.py:9-12) drive the device concurrently
+ * without meeting on the NULL stream.  Owned by the library; do not destroy. */
+int af_thread_stream(void **stream);
+/* Releases every cached pool block and destroys the per-thread streams; no other call may be in flight.
+ * Idempotent, and the library stays usable afterwards. */
+int af_shutdown(void);
 int af_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int af_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int af_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);

@@ -1,0 +1,110 @@
+"""
+Driven by tests/test_gpu_dask_conda.py in an interpreter that has dask (python >= 3.8, numpy >= 1.20; no pytest, no
+torch needed): the build's dask front-ends (codex_africanus_amd/rime/dask.py, dft/dask.py; reference
+africanus/rime/dask_predict.py:443-593, africanus/dft/dask.py:26-90) on the HIP library, computed with dask's THREADED
+scheduler, against G12 (the reference's own dask results) and the unchunked goldens.  Prints DASK_CASES_OK.
+"""
+import os
+import sys
+
+import numpy as np
+import dask
+import dask.array as da
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from codex_africanus_amd.rime import dask as rdask            # noqa: E402
+from codex_africanus_amd.dft import dask as ddask              # noqa: E402
+from codex_africanus_amd import placement, _lib                # noqa: E402
+
+CHUNKS = {"source": (2, 3, 4, 2, 2, 2, 2, 2, 2), "time": (2, 1, 1), "row": (4, 4, 2), "ant": (4,), "chan": (3, 2)}
+CORR = {"c1": (1,), "c2": (2,), "c22": (2, 2)}
+DDE = {"ddecoh": (True, True, True), "dde": (True, False, True), "coh": (False, True, False)}
+DIE = {"diebv": (True, True, True), "die": (True, False, True), "bv": (False, True, False)}
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+def raises(exc, match, fn):
+    try:
+        fn()
+    except exc as e:
+        assert match in str(e), (match, str(e))
+        return
+    raise AssertionError("no %s raised" % exc.__name__)
+
+
+def main():
+    g2, g3, g6, g12 = load("g2_predict_vis.npz"), load("g3_im_to_vis.npz"), load("g6_vis_to_im.npz"), load("g12_dask.npz")
+    s, t, r, a, c = (CHUNKS[k] for k in ("source", "time", "row", "ant", "chan"))
+    idx = [da.from_array(g2[k], chunks=r) for k in ("time_idx", "ant1", "ant2")]
+    ncase = 0
+    with dask.config.set(scheduler="threads", num_workers=6):
+        for ck, cs in CORR.items():
+            get = lambda k: g2["%s_%s" % (ck, k)]
+            dde = lambda x: da.from_array(x, chunks=(s, t, a, c) + cs)
+            die = lambda x: da.from_array(x, chunks=(t, a, c) + cs)
+            for dk, (a1j, blj, a2j) in DDE.items():
+                for gk, (g1j, bvis, g2j) in DIE.items():
+                    args = (dde(get("a1")) if a1j else None,
+                            da.from_array(get("bl"), chunks=(s, r, c) + cs) if blj else None,
+                            dde(get("a2")) if a2j else None, die(get("g1")) if g1j else None,
+                            da.from_array(get("bv"), chunks=(r, c) + cs) if bvis else None,
+                            die(get("g2")) if g2j else None)
+                    st = rdask.predict_vis(*idx, *args, streams=True)
+                    fan = rdask.predict_vis(*idx, *args, streams=False)
+                    assert st.chunks[0] == r and fan.chunks[0] == r and st.dtype == np.complex128
+                    st, fan = dask.compute(st, fan)
+                    key = "%s_%s_%s" % (ck, dk, gk)
+                    # serial chain: bit for bit the reference's dask result
+                    assert np.array_equal(st, g12[key + "_streams1"]), key
+                    assert np.abs(fan - g12[key + "_streams0"]).max() < 1e-12, key
+                    assert np.abs(fan - g2[key + "_vis"]).max() < 1e-12, key
+                    ncase += 2
+        # dies only: base_vis is None
+        g = rdask.predict_vis(*idx, None, None, None, da.from_array(g2["c22_g1"], chunks=(t, a, c, 2, 2)), None,
+                              da.from_array(g2["c22_g2"], chunks=(t, a, c, 2, 2))).compute()
+        from codex_africanus_amd import rime
+        assert np.array_equal(g, rime.predict_vis(g2["time_idx"], g2["ant1"], g2["ant2"], None, None, None,
+                                                  g2["c22_g1"], None, g2["c22_g2"]))
+        # chunk errors of the reference (africanus/rime/dask_predict.py:478-524)
+        raises(ValueError, "Subdivision of antenna dimension",
+               lambda: rdask.predict_vis(*idx, da.from_array(g2["c22_a1"], chunks=(s, t, (2, 2), c, 2, 2)), None,
+                                         da.from_array(g2["c22_a2"], chunks=(s, t, (2, 2), c, 2, 2))))
+        raises(ValueError, "does not equal number of time chunks",
+               lambda: rdask.predict_vis(*idx, da.from_array(g2["c22_a1"], chunks=(s, (2, 2), a, c, 2, 2)), None,
+                                         da.from_array(g2["c22_a2"], chunks=(s, (2, 2), a, c, 2, 2))))
+        # dft
+        vis = ddask.im_to_vis(da.from_array(g3["img_r4"], chunks=(13, 3, 4)), da.from_array(g3["uvw"], chunks=(10, 3)),
+                              da.from_array(g3["lm"], chunks=(13, 2)), da.from_array(g3["frequency"], chunks=3))
+        assert vis.chunks == ((10,) * 5, (3, 3), (4,))
+        vis = vis.compute()
+        assert np.abs(vis - g12["im_to_vis_r4_rows10_chans3"]).max() <= 1e-11 * np.abs(g3["img_r4"]).sum(axis=0).max()
+        raises(ValueError, "lm chunks must match",
+               lambda: ddask.im_to_vis(da.from_array(g3["img_r4"], chunks=(13, 3, 4)), da.from_array(g3["uvw"], chunks=(10, 3)),
+                                       da.from_array(g3["lm"], chunks=(5, 2)), da.from_array(g3["frequency"], chunks=3)))
+        rr, cc = (100, 100, 100), (35, 35)
+        im = ddask.vis_to_im(da.from_array(g6["vis70"], chunks=(rr, cc, 4)), da.from_array(g6["uvw300"], chunks=(rr, 3)),
+                             da.from_array(g6["lm"], chunks=(11, 2)), da.from_array(g6["frequency70"], chunks=cc),
+                             da.from_array(g6["flags70"], chunks=(rr, cc, 4))).compute()
+        assert np.abs(im - g12["vis_to_im_70_rows100_chans35"]).max() <= 1e-11 * np.abs(g6["vis70"]).sum(axis=0).max()
+        raises(ValueError, "Vis chunks must match flags",
+               lambda: ddask.vis_to_im(da.from_array(g6["vis70"], chunks=(rr, cc, 4)), da.from_array(g6["uvw300"], chunks=(rr, 3)),
+                                       da.from_array(g6["lm"], chunks=(11, 2)), da.from_array(g6["frequency70"], chunks=cc),
+                                       da.from_array(g6["flags70"], chunks=(rr, (70,), 4))))
+        # phase_delay
+        g1 = load("g1_phase_delay.npz")
+        ph = rdask.phase_delay(da.from_array(g1["lm"], chunks=(3, 2)), da.from_array(g1["uvw"], chunks=(10, 3)),
+                               da.from_array(g1["frequency"], chunks=2)).compute()
+        assert np.array_equal(ph, rime.phase_delay(g1["lm"], g1["uvw"], g1["frequency"]))
+    stats = _lib.pool_stats(0)
+    print("predict_vis cases: %d; placement devices %s policy %s; pool hits %d misses %d"
+          % (ncase, placement.devices(), placement.get_policy(), stats["hits"], stats["misses"]))
+    _lib.shutdown()
+    print("DASK_CASES_OK")
+
+
+if __name__ == "__main__":
+    main()

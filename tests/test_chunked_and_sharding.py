@@ -171,3 +171,83 @@ def test_allreduce_is_noop_without_process_group():
     import torch
     x = torch.arange(4, dtype=torch.float64)
     assert sharding.allreduce_chi2(x.clone()).equal(x)
+
+
+# ------------------------------------------------------------------------------ block -> GPU placement
+def test_placement_row_blocks_round_robin_over_devices():
+    """row block k -> devices[k % n] (north star: dask row chunks map to the GPUs of one node); arithmetic only"""
+    from codex_africanus_amd import placement
+    devs = tuple(range(8))
+    assert [placement.device_for_block(k, devs) for k in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    assert [placement.device_for_block(k, (3, 5)) for k in range(5)] == [3, 5, 3, 5, 3]
+    # 8e6 rows in 1e6-row chunks (BASELINE configs[3]): one chunk per GPU, none shared, none idle
+    assert sorted(placement.device_for_block(k, devs) for k in range(8)) == list(devs)
+    assert placement.parse_device_list(None, 4) == (0, 1, 2, 3)
+    assert placement.parse_device_list("2,0", 4) == (2, 0)
+    for bad in ("4", "0,0", "-1", ","):
+        with pytest.raises(ValueError):
+            placement.parse_device_list(bad, 4)
+
+
+def test_placement_block_context_and_policies():
+    from codex_africanus_amd import placement
+    devs = (0, 1, 2, 3)
+    assert placement.choose(devs=devs, policy="none") is None
+    with placement.block(np.array([6])):                 # the one-element array dask hands a block function
+        assert placement.choose(devs=devs, policy="block") == 2
+        with placement.block(1):
+            assert placement.choose(devs=devs, policy="block") == 1
+        assert placement.choose(devs=devs, policy="block") == 2
+        # policy 'thread' ignores block indices
+        assert placement.choose(devs=devs, policy="thread") == placement.device_for_thread(devs)
+    # without a block index the calling thread's device is used
+    assert placement.choose(devs=devs, policy="block") == placement.device_for_thread(devs)
+
+
+def test_placement_threads_cover_all_devices():
+    """N >= n_devices worker threads drive every device: threads are numbered in order of first use"""
+    import threading
+    from codex_africanus_amd import placement
+    devs = tuple(range(4))
+    seen, lock, gate = [], threading.Lock(), threading.Barrier(8)
+
+    def worker():
+        gate.wait()
+        d = placement.device_for_thread(devs)
+        assert placement.device_for_thread(devs) == d            # sticky
+        with lock:
+            seen.append(d)
+    ts = [threading.Thread(target=worker) for _ in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert sorted(set(seen)) == list(devs) and all(seen.count(d) == 2 for d in devs)
+
+
+def _placement_rank(rank, world, port, q):
+    """world-2 check: each rank owns its shard's row blocks; block -> device is the same arithmetic on both"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from codex_africanus_amd import placement, sharding
+    import torch
+    bounds = sharding.shard_bounds(8000, world)
+    lo, hi = bounds[rank]
+    blocks = list(range(lo // 1000, hi // 1000))                 # 1000-row dask chunks of this rank's shard
+    mine = torch.tensor([placement.device_for_block(k, tuple(range(8))) for k in blocks])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    q.put((rank, torch.cat(gathered).tolist()))
+    dist.destroy_process_group()
+
+
+def test_placement_world2_gloo():
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_placement_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert res[0] == res[1] == list(range(8))            # 8 row chunks over 2 ranks -> 8 distinct devices, in order

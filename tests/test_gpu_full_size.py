@@ -74,8 +74,8 @@ def test_fused_dde_full_size_c3():
         assert torch.equal(part.reshape(b - a, 64, 4), vis[a:b])
     del part
     # linearity in the brightness: a power of two commutes with every rounding
-    a, b = 500 * nbl, 520 * nbl
-    t0, t1 = 500, 520
+    a, b = 400 * nbl, 420 * nbl
+    t0, t1 = 400, 420
     twice = rime.fused_predict_vis(T(h["time_index"][a:b]), dv["a1"][a:b], dv["a2"][a:b], dv["lm"], dv["uvw"][a:b],
                                    dv["freq"], dv["X"] * 2.0, dv["beam"], dv["ext"], dv["fmap"], dv["pa"][t0:t1],
                                    dv["pe"][t0:t1], dv["asc"])
