@@ -41,8 +41,11 @@ constexpr int THREADS = 512;
 constexpr int RPT = 4;  // rows per lane
 
 struct FusedWs {
-    size_t lmn, f4, freq_data, gauss, babs, total;
+    size_t lmn, f4, freq_data, gauss, planes, total;
 };
+
+// channels whose pre-interpolated beam planes are resident at a time (one launch of the main kernel per group)
+constexpr int64_t PLANE_GROUP = 64;
 
 FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud)
 {
@@ -53,7 +56,9 @@ FusedWs fused_ws(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, 
     w.f4 = take((size_t)nchan * sizeof(double));
     w.freq_data = take((size_t)nchan * 3 * sizeof(double));
     w.gauss = take((size_t)nsrc * 4 * sizeof(double));  // (el*gs, em*gs, er, is_extended) per source
-    w.babs = take((size_t)beam_lw * beam_mh * beam_nud * 16 * sizeof(double));  // 128-B voxel records
+    (void)beam_nud;
+    const int64_t group = nchan < PLANE_GROUP ? nchan : PLANE_GROUP;
+    w.planes = take((size_t)group * beam_lw * beam_mh * 16 * sizeof(double));  // 128-B cell records per channel
     w.total = o;
     return w;
 }
@@ -98,31 +103,44 @@ __global__ void fused_prep_gauss(const double *__restrict__ shape_params, int64_
     gp[4 * s + 0] = el; gp[4 * s + 1] = em; gp[4 * s + 2] = er; gp[4 * s + 3] = ext;
 }
 
-// One 128-byte record per voxel, once per call: for each of the 4 correlations (re, im, |.|, 0).
-// Sampling a voxel then touches exactly one cache line, and a lane that owns one correlation
-// reads its own 32 bytes (hypot per sample would otherwise dominate the beam stage).
-constexpr int VREC = 16;  // doubles per voxel record
-__global__ void beam_pack_kernel(const double2 *__restrict__ beam, int64_t nvox, double *__restrict__ rec)
+// Per-channel beam planes.  The trilinear sample of the reference (rime/fast_beam_cubes.py:170-225) is a sum over
+// 8 voxels with weights w_lm * nud (lower frequency plane) and w_lm * (1 - nud) (upper plane), where the plane pair
+// and nud depend on the CHANNEL only (freq_grid_interp, :10-54).  Interpolating along frequency first, once per
+// (cell, channel), leaves a bilinear sample of 4 cells per Jones term: half the gathers, half the L2 -> L1 line
+// traffic and half the weights of the 8-voxel form, for one extra pass over 2 planes per channel (microseconds).
+// One 128-byte record per (channel, l, m): for each of the 4 correlations (re, im, |.|, 0) with
+//   re, im = nud * v_lower + (1 - nud) * v_upper,   |.| = nud * |v_lower| + (1 - nud) * |v_upper|
+// (the reference sums |v| of every voxel, :170-225: np.abs is taken before the interpolation, as here).
+constexpr int VREC = 16;  // doubles per cell record
+__global__ void beam_plane_kernel(const double2 *__restrict__ beam, int64_t ncell, int64_t beam_nud,
+                                  const double *__restrict__ freq_data, int64_t f0, double *__restrict__ planes)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (voxel, corr)
+    const int64_t f = f0 + blockIdx.y;
+    const double nud = freq_data[3 * f + 1], inv = __dsub_rn(1.0, nud);
+    const int64_t gc0 = (int64_t)freq_data[3 * f + 2];
+    double *__restrict__ rec = planes + (int64_t)blockIdx.y * ncell * VREC;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (cell, corr)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < nvox * 4; i += stride) {
-        double2 b = beam[i];
-        rec[i * 4 + 0] = b.x;
-        rec[i * 4 + 1] = b.y;
-        rec[i * 4 + 2] = hypot(b.x, b.y);
-        rec[i * 4 + 3] = 0.0;
+    for (; i < ncell * 4; i += stride) {
+        const int64_t cell = i >> 2, corr = i & 3;
+        const double2 lo = beam[(cell * beam_nud + gc0) * 4 + corr], hi = beam[(cell * beam_nud + gc0 + 1) * 4 + corr];
+        double4 r;
+        r.x = fma(nud, lo.x, __dmul_rn(inv, hi.x));
+        r.y = fma(nud, lo.y, __dmul_rn(inv, hi.y));
+        r.z = fma(nud, hypot(lo.x, lo.y), __dmul_rn(inv, hypot(hi.x, hi.y)));
+        r.w = 0.0;
+        *reinterpret_cast<double4 *>(rec + i * 4) = r;
     }
 }
 
-// One correlation of beam_sample_corr (af_beam_device.h) from the packed records: weighted sums of
-// the 8 voxels in the reference's order (FMA-contracted: the fused path is checked to 1e-9, not bit
+// One correlation of beam_sample_corr (af_beam_device.h) from the channel's plane records: bilinear sums over
+// the 4 cells (FMA-contracted and frequency-first: the fused path is checked to 1e-9, not bit
 // for bit), then the amplitude-preserving normalisation corr_sum * absc_sum / |corr_sum|.
-__device__ __forceinline__ double2 beam_reduce1(const double2 (&v)[8], const double (&ab)[8], const double (&wt)[8])
+__device__ __forceinline__ double2 beam_reduce1(const double2 (&v)[4], const double (&ab)[4], const double (&wt)[4])
 {
     double cre = 0.0, cim = 0.0, absc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
         cre = fma(wt[k], v[k].x, cre);
         cim = fma(wt[k], v[k].y, cim);
         absc = fma(wt[k], ab[k], absc);
@@ -137,10 +155,9 @@ __device__ __forceinline__ double2 beam_reduce1(const double2 (&v)[8], const dou
     return make_double2(__dmul_rn(cre, sc), __dmul_rn(cim, sc));
 }
 
-// Geometry of one beam sample for the packed records: beam_voxels (af_beam_device.h; reference
-// rime/fast_beam_cubes.py:130-225, same operations in the same order) with 32-bit BYTE offsets into the record
-// array: off[0..3] are the (l, m) corners on the lower frequency plane, the upper plane is +VREC*8 bytes (an
-// immediate offset of the load), so a sample costs four address computations instead of eight 64-bit ones.
+// Geometry of one beam sample on a channel plane: the (l, m) part of beam_voxels (af_beam_device.h; reference
+// rime/fast_beam_cubes.py:130-169, same operations in the same order) with 32-bit BYTE offsets of the four corner
+// cells into the plane's records and the four bilinear weights.
 struct FusedGrid {
     double lower_l, lower_m, lscale, mscale, lmaxf, mmaxf;
     int lmaxi, mmaxi;
@@ -148,13 +165,12 @@ struct FusedGrid {
 };
 struct FusedVoxels {
     unsigned off[4];
-    double wt[8];
+    double wt[4];
 };
 __device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, double m, double sin_pa, double cos_pa,
                                              double pe_l, double pe_m, double as_l, double as_m, double freq_scale,
-                                             double nud, int gc0, FusedVoxels &vx)
+                                             FusedVoxels &vx)
 {
-    const double inv_nud = __dsub_rn(1.0, nud);
     const double sl = __dmul_rn(l, freq_scale), sm = __dmul_rn(m, freq_scale);
     const double tl = __dadd_rn(sl, pe_l), tm = __dadd_rn(sm, pe_m);
     double vl = __dsub_rn(__dmul_rn(tl, cos_pa), __dmul_rn(tm, sin_pa));
@@ -171,12 +187,9 @@ __device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, doubl
     const int gl0 = (int)fl, gm0 = (int)fm;
     const double ld = __dsub_rn(vl, fl), md = __dsub_rn(vm, fm);
     const double omld = __dsub_rn(1.0, ld), ommd = __dsub_rn(1.0, md);
-    const double w00 = __dmul_rn(omld, ommd), w10 = __dmul_rn(ld, ommd), w01 = __dmul_rn(omld, md), w11 = __dmul_rn(ld, md);
-    vx.wt[0] = __dmul_rn(w00, nud); vx.wt[1] = __dmul_rn(w10, nud);
-    vx.wt[2] = __dmul_rn(w01, nud); vx.wt[3] = __dmul_rn(w11, nud);
-    vx.wt[4] = __dmul_rn(w00, inv_nud); vx.wt[5] = __dmul_rn(w10, inv_nud);
-    vx.wt[6] = __dmul_rn(w01, inv_nud); vx.wt[7] = __dmul_rn(w11, inv_nud);
-    const unsigned base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m + (unsigned)gc0 * (VREC * 8u);
+    vx.wt[0] = __dmul_rn(omld, ommd); vx.wt[1] = __dmul_rn(ld, ommd);
+    vx.wt[2] = __dmul_rn(omld, md); vx.wt[3] = __dmul_rn(ld, md);
+    const unsigned base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m;
     const unsigned dl = gl0 < g.lmaxi ? g.stride_l : 0u, dm = gm0 < g.mmaxi ? g.stride_m : 0u;  // upper neighbour clamped
     vx.off[0] = base; vx.off[1] = base + dl; vx.off[2] = base + dm; vx.off[3] = base + dl + dm;
 }
@@ -190,10 +203,12 @@ template <int QL> __device__ __forceinline__ double quad_bcast(double x)
 {
     return __hiloint2double(quad_bcast<QL>(__double2hiint(x)), quad_bcast<QL>(__double2loint(x)));
 }
-__device__ __forceinline__ double quad_swap1(double x)
+// the value of the even (ODD = 0) / odd (ODD = 1) lane of this lane's PAIR: quad_perm [0,0,2,2] / [1,1,3,3]
+template <int ODD> __device__ __forceinline__ double pair_bcast(double x)
 {
-    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xf, 0xf, true),
-                            __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xf, 0xf, true));
+    constexpr int PERM = ODD ? 0xF5 : 0xA0;
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), PERM, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(x), PERM, 0xf, 0xf, true));
 }
 
 struct C2 {
@@ -231,16 +246,35 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
     acc.im = fma(a.im, b.re, acc.im);
 }
 
-// exp(2 pi i x / 256) for x = q * f4 * 64 (f4 in quarter turns per metre): table phasor of af_sincos.h in one piece
-constexpr int PH_TABLE = PHASOR_TABLE;
-__device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, double x256)
+// exp(2 pi i x / PH_TABLE) for x = q * f4 * PH_TABLE / 4 (f4 in quarter turns per metre): the table phasor of
+// af_sincos.h with a four times finer table (16 KB of LDS): exp(2 pi i k / 1024) from the table times a residual
+// rotation |theta| <= pi / 1024 = 3.1e-3 by sin = theta - theta^3 / 6 (next term 2.3e-15) and cos = 1 - theta^2 / 2 +
+// theta^4 / 24 (next term 1.2e-18): 12 fp64 operations per phasor instead of 14 (stage 2 is fp64-issue bound, every
+// operation per (row, source) counts), errors far below the rounding of the phase argument itself (~1e-11).
+constexpr int PH_TABLE = 1024;
+__device__ __forceinline__ void fine_table_init(double2 *table, int tid, int nthreads)
 {
-    TablePhasorStage st;
-    table_phasor_reduce(st, table, x256);
-    table_phasor_sin(st);
-    table_phasor_cos(st);
+    for (int i = tid; i < PH_TABLE; i += nthreads) {
+        double c, sn;
+        sincos_quarter_turns<7>((double)i * (4.0 / PH_TABLE), c, sn);
+        table[i] = make_double2(c, sn);
+    }
+}
+__device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, double x)
+{
+    constexpr double T = 6.283185307179586476925 / PH_TABLE;
+    constexpr double S1 = T, S3 = -T * T * T / 6.0;
+    constexpr double C2c = -T * T / 2.0, C4 = T * T * T * T / 24.0;
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double a = __dadd_rn(x, MAGIC);
+    const double2 tk = table[__double2loint(a) & (PH_TABLE - 1)];
+    const double z = __dsub_rn(x, __dsub_rn(a, MAGIC));  // [-0.5, 0.5]
+    const double z2 = __dmul_rn(z, z);
+    const double sn = __dmul_rn(z, fma(z2, S3, S1));
+    const double cs = fma(z2, fma(z2, C4, C2c), 1.0);
     C2 y;
-    table_phasor_finish(st, y.re, y.im);
+    y.re = fma(tk.x, cs, -__dmul_rn(tk.y, sn));
+    y.im = fma(tk.y, cs, __dmul_rn(tk.x, sn));
     return y;
 }
 
@@ -252,7 +286,9 @@ __device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, do
 // 512..767 only sample the beam (stage 1), one batch ahead, into the other half of a double-buffered Jones region;
 // one barrier per batch.  Each SIMD then holds two accumulating waves (fp64 issue bound) and one sampling wave
 // (L1-fill bound), whose stalls the other two fill.
-template <bool FEED, bool GAUSS, int NP, bool WS>
+// ST > 0: the batch size `st` is the compile-time constant ST (and NP > 0): stage 2's source loop is unrolled and every
+// Jones read is one per-row base address (set once per batch) plus an immediate offset.
+template <bool FEED, bool GAUSS, int NP, bool WS, int ST>
 __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
@@ -261,23 +297,25 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     const double *__restrict__ freq_data, const double *__restrict__ parangles,
     const double *__restrict__ point_errors, const double *__restrict__ antenna_scaling,
     const double2 *__restrict__ feed_rot, const double *__restrict__ gauss, const double *__restrict__ freq, int nsrc,
-    int64_t nchan, int64_t ntime, int nant, int st, double2 *__restrict__ out, int only_stage)
+    int64_t nchan, int64_t ntime, int nant, int st_arg, double2 *__restrict__ out, int only_stage, int64_t f0)
 {
     extern __shared__ double2 lds[];
     const int np = NP > 0 ? NP : nant;
+    const int st = ST > 0 ? ST : st_arg;
     constexpr int NBUF = WS ? 2 : 1;              // Jones buffers: E then G, each [st][4][np]
     constexpr int NTHREADS = WS ? THREADS + THREADS / 2 : THREADS;
     constexpr int PLANES = WS ? THREADS / 2 : THREADS;   // lanes that sample the beam
     const int tid = threadIdx.x;
     const bool consumer = !WS || tid < THREADS;
     const int ptid = WS ? tid - THREADS : tid;    // lane number among the sampling lanes
-    const int64_t f = blockIdx.y;
+    const int64_t f = f0 + blockIdx.y;            // planes hold channels f0 .. f0 + gridDim.y - 1
     const int t = items[4 * blockIdx.x + 0];
     const int64_t r0 = items[4 * blockIdx.x + 1];
     const int rc = items[4 * blockIdx.x + 2];
 
     // ---- stage-2 state: this lane's rows -----------------------------------------------------
-    double u[RPT], v[RPT], w[RPT];
+    const double FT = f4[f] * (PH_TABLE / 4.0), NU = freq[f];   // 1/PH_TABLE turns per metre (exact scaling of f4)
+    double u[RPT], v[RPT], w[RPT], us[RPT], vs[RPT], ws[RPT];
     int a1[RPT], a2[RPT];
     bool live[RPT];
     C2 acc[RPT][4];
@@ -288,17 +326,19 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
         const int64_t r = r0 + (live[k] ? rl : 0);
         u[k] = uvw[3 * r]; v[k] = uvw[3 * r + 1]; w[k] = uvw[3 * r + 2];
         a1[k] = ant1[r]; a2[k] = ant2[r];
+        // this channel's table units per metre folded into the row's coordinates (one operation less per
+        // (row, source); the Gaussian shape keeps the plain coordinates)
+        us[k] = __dmul_rn(u[k], FT); vs[k] = __dmul_rn(v[k], FT); ws[k] = __dmul_rn(w[k], FT);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
     }
-    const double F256 = f4[f] * 64.0, NU = freq[f];   // 1/256 turns per metre (exact scaling of f4)
 
     // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
     // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m); ldsR[a] = the antenna's 2x2 feed rotation (optional)
     double *ldsA = reinterpret_cast<double *>(lds + (size_t)NBUF * 2 * st * 4 * np);
     double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
     double2 *ldsT = ldsR + (size_t)4 * nant;      // phasor table
-    table_phasor_init(ldsT, tid, NTHREADS);
+    fine_table_init(ldsT, tid, NTHREADS);
     constexpr bool have_feed = FEED;
     if (have_feed)
         for (int i = tid; i < 4 * nant; i += NTHREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
@@ -316,14 +356,16 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
         const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
         grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
         grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
-        grid.stride_m = (unsigned)beam_nud * (VREC * 8u);
+        grid.stride_m = VREC * 8u;
         grid.stride_l = (unsigned)beam_mh * grid.stride_m;
     }
-    const double fscale = freq_data[3 * f + 0], fnud = freq_data[3 * f + 1];
-    const int fgc0 = (int)freq_data[3 * f + 2];
+    const double fscale = freq_data[3 * f + 0];
     const int ntask = st * np;             // Jones slots per batch (antennas >= nant of a padded stride are skipped)
     const int e_corr = tid & 3;            // this lane's correlation in stage 1
-    const char *vrec_c = reinterpret_cast<const char *>(vrec) + e_corr * 32;   // this lane's 32 bytes of a record
+    // this channel's plane (block-uniform base: the gathers below are scalar base + 32-bit lane offset), and this
+    // lane's 32 bytes of a record
+    const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
+    const unsigned corr_off = e_corr * 32u;
     __syncthreads();
 
     auto stage1 = [&](int s0, double2 *ldsE, double2 *ldsG) {
@@ -359,13 +401,13 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
             {
                 const int a = (own.info >> 11) & 1023;
                 fused_voxels(grid, own.lm.x, own.lm.y, ldsA[6 * a + 0], ldsA[6 * a + 1], ldsA[6 * a + 2], ldsA[6 * a + 3],
-                             ldsA[6 * a + 4], ldsA[6 * a + 5], fscale, fnud, fgc0, gx);
+                             ldsA[6 * a + 4], ldsA[6 * a + 5], fscale, gx);
             }
             // One sampling round in two halves: gathers issued, then consumed.
             struct Round {
                 int info;
-                double2 b0, b1, v[8];
-                double ab[8], wt[8];
+                double2 b0, b1, v[4];
+                double ab[4], wt[4];
             };
             auto issue = [&](auto lane_c, Round &R) {
                 constexpr int QL = decltype(lane_c)::value;
@@ -379,12 +421,12 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                 R.b1 = bp[2 + (e_corr & 1)];
                 unsigned off[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) off[k] = (unsigned)quad_bcast<QL>((int)gx.off[k]);
+                for (int k = 0; k < 4; ++k) off[k] = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) R.wt[k] = quad_bcast<QL>(gx.wt[k]);
+                for (int k = 0; k < 4; ++k) R.wt[k] = quad_bcast<QL>(gx.wt[k]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double *r = reinterpret_cast<const double *>(vrec_c + (size_t)off[k & 3]) + (k >> 2) * VREC;
+                for (int k = 0; k < 4; ++k) {
+                    const double *r = reinterpret_cast<const double *>(plane + (size_t)off[k]);
                     R.v[k] = *reinterpret_cast<const double2 *>(r);
                     R.ab[k] = r[2];
                 }
@@ -396,12 +438,10 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                 const double2 b0 = R.b0, b1 = R.b1;
                 double2 e = beam_reduce1(R.v, R.ab, R.wt);
                 if (!have) e = make_double2(0.0, 0.0);
-                // the row-mate's E (components 2i and 2i+1 live in adjacent lanes): quad exchange
-                C2 Eme, Emate;
-                Eme.re = e.x; Eme.im = e.y;
-                Emate.re = quad_swap1(e.x);
-                Emate.im = quad_swap1(e.y);
-                C2 E0 = (e_corr & 1) ? Emate : Eme, E1 = (e_corr & 1) ? Eme : Emate;  // E[2i], E[2i+1]
+                // E[2i] and E[2i+1] of this lane's row i of the Jones matrix live in the even / odd lane of its pair
+                C2 E0, E1;
+                E0.re = pair_bcast<0>(e.x); E0.im = pair_bcast<0>(e.y);
+                E1.re = pair_bcast<1>(e.x); E1.im = pair_bcast<1>(e.y);
                 if constexpr (have_feed) {
                     // E <- E . R(t, antenna)  (einsum "stafij,tajk->stafik", rime/examples/predict.py:472):
                     // this lane's component (i, j = e_corr & 1) is E[i,0] R[0,j] + E[i,1] R[1,j]
@@ -411,11 +451,8 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                     C2 Er = cmul(E0, R0);
                     cmac(Er, E1, R1);
                     e = make_double2(Er.re, Er.im);
-                    Eme = Er;
-                    Emate.re = quad_swap1(Er.re);
-                    Emate.im = quad_swap1(Er.im);
-                    E0 = (e_corr & 1) ? Emate : Eme;
-                    E1 = (e_corr & 1) ? Eme : Emate;
+                    E0.re = pair_bcast<0>(Er.re); E0.im = pair_bcast<0>(Er.im);
+                    E1.re = pair_bcast<1>(Er.re); E1.im = pair_bcast<1>(Er.im);
                 }
                 C2 B0, B1, G;
                 B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
@@ -443,15 +480,22 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     auto stage2 = [&](int s0, const double2 *ldsE, const double2 *ldsG) {
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
-        for (int sl = 0; sl < nb && only_stage != 1; ++sl) {
-            const double l = lmn[4 * (s0 + sl)], m = lmn[4 * (s0 + sl) + 1], n = lmn[4 * (s0 + sl) + 2];
+        // per-row base addresses of the batch's Jones terms: the reads below are base + a constant
+        const double2 *rowG[RPT], *rowE[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { rowG[k] = ldsG + a1[k]; rowE[k] = ldsE + a2[k]; }
+        auto one_source = [&](int sl) {
+            // ST > 0 always walks whole batches: a source beyond the last one has E = G = 0 in LDS (stage 1 writes
+            // zeros for it) and adds exactly nothing; only its coordinates must come from a valid address
+            const int sg = (ST > 0 && s0 + sl >= nsrc) ? nsrc - 1 : s0 + sl;
+            const double l = lmn[4 * sg], m = lmn[4 * sg + 1], n = lmn[4 * sg + 2];
             // Gaussian shape factors exp(-(u1^2 + v1^2) (nu gs)^2) of this lane's rows (gaussian_shape.py:52-60);
             // computed ahead of the row loop so that exp's temporaries do not overlap the Jones algebra
             double shape[RPT];
             bool extended = false;
             if constexpr (GAUSS) {
-                const double gel = gauss[4 * (s0 + sl)], gem = gauss[4 * (s0 + sl) + 1], ger = gauss[4 * (s0 + sl) + 2];
-                extended = gauss[4 * (s0 + sl) + 3] != 0.0;  // block-uniform
+                const double gel = gauss[4 * sg], gem = gauss[4 * sg + 1], ger = gauss[4 * sg + 2];
+                extended = gauss[4 * sg + 3] != 0.0;  // block-uniform
                 if (extended) {
 #pragma unroll
                     for (int k = 0; k < RPT; ++k) {
@@ -460,18 +504,17 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                     }
                 }
             }
-            const double2 *pE = ldsE + (size_t)sl * 4 * np, *pG = ldsG + (size_t)sl * 4 * np;
+            const int so = sl * 4 * np;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const double q = fma(n, w[k], fma(m, v[k], __dmul_rn(l, u[k])));
-                C2 y = table_phasor(ldsT, __dmul_rn(q, F256));
+                C2 y = table_phasor(ldsT, fma(n, ws[k], fma(m, vs[k], __dmul_rn(l, us[k]))));
                 if constexpr (GAUSS) {
                     if (extended) { y.re *= shape[k]; y.im *= shape[k]; }
                 }
                 C2 Gp[4], Eq[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    double2 g = pG[c * np + a1[k]], e = pE[c * np + a2[k]];
+                    double2 g = rowG[k][so + c * np], e = rowE[k][so + c * np];
                     Gp[c].re = g.x; Gp[c].im = g.y;
                     Eq[c].re = e.x; Eq[c].im = e.y;
                 }
@@ -485,6 +528,19 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                 cmac(acc[k][2], y, M2);
                 cmac(acc[k][3], y, M3);
             }
+        };
+        if (only_stage == 1) return;
+        if constexpr (ST > 0) {
+#pragma unroll
+            for (int sl = 0; sl < ST; ++sl) {
+                one_source(sl);
+                // keep the sources apart: interleaved, their live Jones terms exceed the 168 registers of
+                // three waves per SIMD
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 1
+            for (int sl = 0; sl < nb; ++sl) one_source(sl);
         }
     };
     const size_t buf_elems = (size_t)2 * st * 4 * np;   // one buffer: E then G
@@ -604,7 +660,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_fused_predict_c128: workspace must be 256-byte aligned");
     char *ws = static_cast<char *>(workspace);
     double *lmn = reinterpret_cast<double *>(ws + W.lmn), *f4 = reinterpret_cast<double *>(ws + W.f4);
-    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *babs = reinterpret_cast<double *>(ws + W.babs);
+    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *planes = reinterpret_cast<double *>(ws + W.planes);
 
     hipLaunchKernelGGL(fused_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st_, lm, nsrc, lmn);
     AF_LAUNCH_CHECK();
@@ -621,16 +677,9 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
                            gp);
         AF_LAUNCH_CHECK();
     }
-    {
-        const int64_t nvox = beam_lw * beam_mh * beam_nud;
-        AF_REQUIRE(nvox < (1LL << 25), "af_fused_predict_c128: beam cube too large (32-bit byte offsets into the 128-byte "
-                                       "voxel records: fewer than 2^25 voxels)");
-        int64_t blocks = af_cdiv(nvox * 4, 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(beam_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st_,
-                           reinterpret_cast<const double2 *>(beam), nvox, babs);
-        AF_LAUNCH_CHECK();
-    }
+    const int64_t ncell = beam_lw * beam_mh;
+    AF_REQUIRE(ncell < (1LL << 25), "af_fused_predict_c128: beam cube too large (32-bit byte offsets into the 128-byte "
+                                    "cell records of a channel plane: fewer than 2^25 cells per plane)");
     // sources per batch: as many as fit 128 KB of LDS (E and G: 128 bytes per (source, antenna))
     // (E and G: 128 bytes per (source, antenna); 112 bytes of constants per antenna; 160 KiB per workgroup)
     // antenna stride of the Jones arrays: a compile-time constant for the common array sizes
@@ -645,6 +694,13 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     const int nbuf = ws_mode ? 2 : 1;
     int st = (int)((160 * 1024 - fixed) / (128 * nbuf * np));
     if (st > 1024 / np) st = (int)(1024 / np);
+    {   // whole super-rounds of the sampling lanes: st * np a multiple of their number (a partly filled super-round
+        // costs as much as a full one: 9 sources x 64 antennas on 256 lanes ran 3 super-rounds for 2.25 of work)
+        const int64_t lanes = ws_mode ? THREADS / 2 : THREADS;
+        int64_t m = 1;
+        while ((m * np) % lanes != 0 && m < lanes) ++m;
+        if (st >= m) st -= st % (int)m;
+    }
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
     const size_t lds_bytes = (size_t)nbuf * 2 * st * 4 * np * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
@@ -655,28 +711,40 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // measurement hook (tools/profile_fused.sh): AFHIP_FUSED_STAGE=1 / 2 runs only the beam stage / only the
     // accumulation stage (results are then meaningless); unset = the real kernel
     static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
+    // channels in groups of PLANE_GROUP: interpolate the group's beam planes, then one launch for its channels (the
+    // planes of a group are rewritten by the next group's pass on the same stream, after this group's kernel)
     auto launch = [&](auto kernel, int nthreads) -> int {
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
-        af_prof_begin(st_);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nchan), dim3(nthreads), lds_bytes, st_, items, antenna1,
-                           antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), babs, beam_lw, beam_mh,
-                           beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
-                           reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc, nchan, ntime,
-                           (int)nant, st, reinterpret_cast<double2 *>(out), only_stage);
-        AF_LAUNCH_CHECK();
+        for (int64_t f0 = 0; f0 < nchan; f0 += PLANE_GROUP) {
+            const int64_t nf = nchan - f0 < PLANE_GROUP ? nchan - f0 : PLANE_GROUP;
+            int64_t blocks = af_cdiv(ncell * 4, 256);
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(beam_plane_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, st_,
+                               reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes);
+            AF_LAUNCH_CHECK();
+            if (f0 == 0) af_prof_begin(st_);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nf), dim3(nthreads), lds_bytes, st_, items, antenna1,
+                               antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw,
+                               beam_mh, beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors,
+                               antenna_scaling, reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc,
+                               nchan, ntime, (int)nant, st, reinterpret_cast<double2 *>(out), only_stage, f0);
+            if (f0 == 0) af_prof_end(st_);
+            AF_LAUNCH_CHECK();
+        }
         return AF_OK;
     };
-#define AF_FUSED_PICK(NPC)                                                                                               \
-    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true>, THREADS + THREADS / 2)                          \
-                     : launch(fused_predict_kernel<false, false, NPC, true>, THREADS + THREADS / 2))                        \
-             : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false>, THREADS)                               \
-                              : launch(fused_predict_kernel<true, false, NPC, false>, THREADS))                             \
-                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, false>, THREADS)                              \
-                              : launch(fused_predict_kernel<false, false, NPC, false>, THREADS))))
-    rc = NPv == 64 ? AF_FUSED_PICK(64) : NPv == 128 ? AF_FUSED_PICK(128) : AF_FUSED_PICK(0);
+#define AF_FUSED_PICK(NPC, STC)                                                                                          \
+    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true, STC>, THREADS + THREADS / 2)                     \
+                     : launch(fused_predict_kernel<false, false, NPC, true, STC>, THREADS + THREADS / 2))                   \
+             : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false, 0>, THREADS)                            \
+                              : launch(fused_predict_kernel<true, false, NPC, false, 0>, THREADS))                          \
+                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, false, 0>, THREADS)                           \
+                              : launch(fused_predict_kernel<false, false, NPC, false, 0>, THREADS))))
+    // the 64-antenna-stride, wave-specialised, 8-sources-per-batch case (BASELINE configs[2]) has its source loop unrolled
+    static const int unroll_env = getenv("AFHIP_FUSED_UNROLL") ? atoi(getenv("AFHIP_FUSED_UNROLL")) : 1;   // A/B hook
+    if (NPv == 64 && ws_mode && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8);
+    else rc = NPv == 64 ? AF_FUSED_PICK(64, 0) : NPv == 128 ? AF_FUSED_PICK(128, 0) : AF_FUSED_PICK(0, 0);
 #undef AF_FUSED_PICK
-    if (rc != AF_OK) return rc;
-    af_prof_end(st_);
-    return AF_OK;
+    return rc;
 }
