@@ -471,6 +471,358 @@ __global__ __launch_bounds__(256) void grid_wave7_kernel(const double *__restric
         if (wsum[b] != 0.0) unsafeAtomicAdd(&wt[b], wsum[b]);
 }
 
+
+// ---- gridder, tile-binned: visibilities sorted by uv tile, accumulated in LDS, one flush per tile chunk ----------
+// Global fp64 atomics run at ~1.3 TB/s on this chip whatever their locality (MI355X_MICROARCH.md, "Global float
+// atomics": they execute at the memory side): 49 taps x 16 B x 6.4e7 visibilities = 50 GB of adds at configs[4] is
+// ~40 ms on any global-atomic design.  Here the W x W scatter of a visibility goes into an LDS image of its uv tile
+// instead, and only the finished tile image is added to the grid, once per chunk of visibilities:
+//   1. grid_tile_count:   every visibility (row, chan) -> bin = (band, 32 x 32-cell tile of its nearest cell); counts
+//   2. grid_tile_scan:    bin starts, and the prefix of the bins' chunk counts (a chunk = up to TILE_CHUNK visibilities
+//                         of one bin = one workgroup: a crowded tile is shared by several workgroups)
+//   3. grid_tile_scatter: the visibility indices of every bin, contiguous (counting sort; order inside a bin arbitrary)
+//   4. grid_tile_kernel:  workgroup = ONE WAVE = one chunk.  Its LDS holds a private image of the 32 x 32 tile plus a
+//                         halo of W/2 cells (23 KB at W = 7: six waves per CU); passes of 64 visibilities: every lane
+//                         sets up ONE visibility (Stokes value, tap weights, origin) in LDS from operands fetched a pass
+//                         ahead, then the wave walks the 64 with lanes = (tap row, tap column, re / im): a tap row is 2W
+//                         contiguous doubles, 64 / 2W rows per instruction (W = 7: two read-add-write steps per
+//                         visibility, row pitch chosen so that the rows of one instruction do not share banks) --
+//                         plain LDS accesses, no atomics: measured, ds_add_f64 retires about one lane per clock per CU
+//                         (13.9 ms for this pass with a shared 64 x 64 image and LDS atomics);
+//                         finally the image is added to the grid (contiguous row segments: the fast atomic shape).
+// No host synchronisation: the number of chunks is bounded by nvis / TILE_CHUNK + nbins, surplus workgroups exit.
+// The order of the adds inside a tile follows the (arbitrary) order of the counting sort: reproducible to rounding.
+constexpr int TILE = 16;
+constexpr int TILE_CHUNK = 8192;
+constexpr int TILE_THREADS = 64;       // one wave per workgroup: the LDS image is private to it
+
+struct GridGeom {
+    double scale_factor;
+    int64_t npix, nchan;
+    int ntx;        // tiles per axis
+    int nbins;      // nband * ntx * ntx
+};
+
+// nearest cell of a visibility and whether it takes part at all (finite coordinates): THE definition used by the
+// count, scatter and accumulate passes alike
+__device__ __forceinline__ bool grid_vis_cell(const double *__restrict__ uvw, const double *__restrict__ wavelengths,
+                                              const GridGeom &g, int64_t r, int64_t c, double &offset_u, double &offset_v,
+                                              int64_t &disc_u, int64_t &disc_v)
+{
+    const double lam = wavelengths[c];
+    offset_u = uvw[3 * r] * g.scale_factor / lam + (double)(g.npix / 2);
+    offset_v = uvw[3 * r + 1] * g.scale_factor / lam + (double)(g.npix / 2);
+    if (!(isfinite(offset_u) && isfinite(offset_v) && fabs(offset_u) < 1e9 && fabs(offset_v) < 1e9)) return false;
+    disc_u = (int64_t)rint(offset_u);
+    disc_v = (int64_t)rint(offset_v);
+    return true;
+}
+
+__device__ __forceinline__ int grid_tile_of(int64_t disc, int ntx)
+{
+    int64_t t = disc >= 0 ? disc / TILE : -1;
+    return (int)(t < 0 ? 0 : (t >= ntx ? ntx - 1 : t));
+}
+
+// key of visibility i, or -1 (dropped)
+__device__ __forceinline__ int grid_vis_key(const double *__restrict__ uvw, const double *__restrict__ wavelengths,
+                                            const int64_t *__restrict__ chanmap, const GridGeom &g, int64_t i)
+{
+    const int64_t r = i / g.nchan, c = i - r * g.nchan;
+    double ou, ov;
+    int64_t du, dv;
+    if (!grid_vis_cell(uvw, wavelengths, g, r, c, ou, ov, du, dv)) return -1;
+    return ((int)chanmap[c] * g.ntx + grid_tile_of(dv, g.ntx)) * g.ntx + grid_tile_of(du, g.ntx);
+}
+
+// Adjacent lanes are adjacent channels of a row: runs of equal keys.  One atomic per run (its first lane), the other
+// lanes take their slot from the run's base: returns this lane's slot in its bin, or -1.
+__device__ __forceinline__ int grid_run_atomic(int *__restrict__ counter, int key, bool want_slot)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool leader = lane == 0 || prev != key;
+    const unsigned long long leaders = __ballot(leader);
+    const unsigned long long above = lane == 63 ? 0ULL : (leaders >> (lane + 1));
+    const int run = above ? __ffsll((long long)above) : 64 - lane;   // lanes up to the next leader
+    int base = 0;
+    if (leader && key >= 0) base = atomicAdd(&counter[key], run);
+    if (!want_slot) return 0;
+    // the run's first lane: highest leader bit at or below this lane
+    const unsigned long long below = leaders & (~0ULL >> (63 - lane));
+    const int first = 63 - __clzll((long long)below);
+    base = __shfl(base, first, 64);
+    return key >= 0 ? base + (lane - first) : -1;
+}
+
+__global__ __launch_bounds__(256) void grid_tile_count(const double *__restrict__ uvw, const double *__restrict__ wavelengths,
+                                                       const int64_t *__restrict__ chanmap, GridGeom g, int64_t nvis,
+                                                       int *__restrict__ count)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < nvis; i0 += stride) {   // whole waves stay together
+        const int64_t i = i0 + threadIdx.x;
+        const int key = i < nvis ? grid_vis_key(uvw, wavelengths, chanmap, g, i) : -1;
+        grid_run_atomic(count, key, false);
+    }
+}
+
+// one block: start[b] = exclusive prefix of count (start[nbins] = total), cursor = start, cstart[b] = exclusive prefix of
+// the bins' chunk counts (cstart[nbins] = number of chunks)
+__global__ __launch_bounds__(1024) void grid_tile_scan(const int *__restrict__ count, int nbins, int *__restrict__ start,
+                                                       int *__restrict__ cursor, int *__restrict__ cstart)
+{
+    __shared__ int part[1024], cpart[1024];
+    const int t = threadIdx.x;
+    const int per = (nbins + 1023) / 1024;
+    const int lo = t * per, hi = (lo + per < nbins) ? lo + per : nbins;
+    int s = 0, cs = 0;
+    for (int b = lo; b < hi; ++b) { s += count[b]; cs += (count[b] + TILE_CHUNK - 1) / TILE_CHUNK; }
+    part[t] = s; cpart[t] = cs;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a = t >= off ? part[t - off] : 0, ca = t >= off ? cpart[t - off] : 0;
+        __syncthreads();
+        part[t] += a; cpart[t] += ca;
+        __syncthreads();
+    }
+    int base = part[t] - s, cbase = cpart[t] - cs;
+    for (int b = lo; b < hi; ++b) {
+        start[b] = base; cursor[b] = base; cstart[b] = cbase;
+        base += count[b]; cbase += (count[b] + TILE_CHUNK - 1) / TILE_CHUNK;
+    }
+    if (t == 1023) { start[nbins] = part[1023]; cstart[nbins] = cpart[1023]; }
+}
+
+__global__ __launch_bounds__(256) void grid_tile_scatter(const double *__restrict__ uvw, const double *__restrict__ wavelengths,
+                                                         const int64_t *__restrict__ chanmap, GridGeom g, int64_t nvis,
+                                                         int *__restrict__ cursor, unsigned *__restrict__ idx)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < nvis; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        const int key = i < nvis ? grid_vis_key(uvw, wavelengths, chanmap, g, i) : -1;
+        const int slot = grid_run_atomic(cursor, key, true);
+        if (slot >= 0) idx[slot] = (unsigned)i;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(TILE_THREADS) void grid_tile_kernel(
+    const double *__restrict__ uvw, const double2 *__restrict__ vis, const double *__restrict__ wavelengths,
+    const double *__restrict__ kernel, int os, int packed, int ncorr, const double2 *__restrict__ coef, GridGeom g,
+    int phase_rotate, double ll, double mm, double nn, const int *__restrict__ start, const int *__restrict__ cstart,
+    const unsigned *__restrict__ idx, double *__restrict__ grid, double *__restrict__ wt)
+{
+    constexpr int H = W / 2;
+    constexpr int REG = TILE + 2 * H;                       // cells per side of the LDS image
+    // doubles per image row: >= 2 REG and = 16 mod 32, so that consecutive tap rows start 32 banks apart
+    constexpr int PITCH = ((2 * REG - 16 + 31) / 32) * 32 + 16;
+    constexpr int ROWLEN = 2 * W;                           // doubles of one tap row
+    constexpr int RPI = 64 / ROWLEN < W ? 64 / ROWLEN : W;  // tap rows per instruction
+    constexpr int NINSTR = (W + RPI - 1) / RPI;
+    constexpr int DUMMY = REG * PITCH;                      // one spare cell per lane: the target of idle lanes
+    __shared__ double tile[REG * PITCH + 64];               // this WAVE's private image of its tile (+ halo)
+    extern __shared__ double ktab[];                        // the convolution kernel: os * (W + 2) taps
+    const int lane = threadIdx.x;
+
+    // which (bin, chunk) am I: largest bin with cstart[bin] <= blockIdx.x
+    const int nchunks = cstart[g.nbins];
+    if ((int)blockIdx.x >= nchunks) return;
+    int lo = 0, hi = g.nbins;                               // invariant: cstart[lo] <= w < cstart[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cstart[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int bin = lo, chunk = (int)blockIdx.x - cstart[bin];
+    const int first = start[bin] + chunk * TILE_CHUNK;
+    const int last = (first + TILE_CHUNK < start[bin + 1]) ? first + TILE_CHUNK : start[bin + 1];
+    const int tx = bin % g.ntx, ty = (bin / g.ntx) % g.ntx, band = bin / (g.ntx * g.ntx);
+    const int64_t reg_u0 = (int64_t)tx * TILE - H, reg_v0 = (int64_t)ty * TILE - H;   // grid cell of image (0, 0)
+    double *gb = grid + (int64_t)band * g.npix * g.npix * 2;
+
+    const int klen = os * (W + 2);
+    for (int e = lane; e < REG * PITCH + 64; e += 64) tile[e] = 0.0;
+    for (int e = lane; e < klen; e += 64) ktab[e] = kernel[e];
+
+    // this lane's role in the wave's walk: (tap row of the instruction, tap column, re / im).  Everything that
+    // depends on the lane only is folded into constants, so that a visibility costs the lane one multiply-add per
+    // address: byte address = on1 * (image offset of the visibility) + off8, with on1 = 0 and off8 = the lane's spare
+    // cell for the lanes that have no tap in instruction k (they add garbage to a cell nobody reads).
+    const int seg = lane / ROWLEN, pos = lane - seg * ROWLEN, tu = pos >> 1, part = pos & 1;
+    const int kstep = packed ? 1 : os;                      // kernel index step between consecutive taps
+    unsigned on1[NINSTR], off8[NINSTR], kv8[NINSTR];
+#pragma unroll
+    for (int k = 0; k < NINSTR; ++k) {
+        const int tv = k * RPI + seg;
+        const bool on = seg < RPI && tv < W;
+        on1[k] = on ? 1u : 0u;
+        off8[k] = 8u * (unsigned)(on ? tv * PITCH + tu * 2 + part : DUMMY + lane);
+        kv8[k] = 8u * (unsigned)((on ? tv : 0) * kstep);
+    }
+    const unsigned ku8 = 8u * (unsigned)((seg < RPI ? tu : 0) * kstep);
+    const double is_im = part ? 1.0 : 0.0, is_re = part ? 0.0 : 1.0;
+    const char *tile_b = reinterpret_cast<const char *>(tile);
+    const char *ktab_b = reinterpret_cast<const char *>(ktab);
+    double cw_sum = 0.0;
+    // raw operands of a visibility, fetched one pass ahead of their use (and its index two passes ahead): the
+    // dependent global loads index -> (uvw, vis) never sit between two accumulation loops
+    struct Raw { double u, v, w, lam; double2 x[4]; bool have; };
+    auto fetch = [&](int j, unsigned i32) {
+        Raw R;
+        R.have = j < last;
+        const int64_t i = R.have ? (int64_t)i32 : 0;
+        const int64_t r = i / g.nchan, c = i - r * g.nchan;
+        R.u = uvw[3 * r]; R.v = uvw[3 * r + 1]; R.w = uvw[3 * r + 2];
+        R.lam = wavelengths[c];
+        const double2 *x = vis + (r * g.nchan + c) * ncorr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.x[k] = k < ncorr ? x[k] : make_double2(0.0, 0.0);
+        return R;
+    };
+    unsigned i_next = first + lane < last ? idx[first + lane] : 0u;
+    Raw nxt = fetch(first + lane, i_next);
+    i_next = first + 64 + lane < last ? idx[first + 64 + lane] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int base = first; base < last; base += 64) {
+        // ---- every lane sets up one visibility (operands fetched during the previous pass), in registers
+        const Raw cur = nxt;
+        nxt = fetch(base + 64 + lane, i_next);
+        i_next = base + 128 + lane < last ? idx[base + 128 + lane] : 0u;
+        int img = -1, iu = 0, iv = 0;           // image offset of the footprint's first cell (-1: not for the walk)
+        double sre = 0.0, sim = 0.0;
+        if (cur.have) {
+            const double offset_u = cur.u * g.scale_factor / cur.lam + (double)(g.npix / 2);
+            const double offset_v = cur.v * g.scale_factor / cur.lam + (double)(g.npix / 2);
+            const int64_t disc_u = (int64_t)rint(offset_u), disc_v = (int64_t)rint(offset_v);   // binned: finite
+            double pc = 1.0, ps = 0.0;
+            if (phase_rotate) sincos_quarter_turns<7>(4.0 * ((cur.u * ll + cur.v * mm + cur.w * nn) / cur.lam), pc, ps);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < ncorr) {
+                    const double xr = cur.x[k].x * pc - cur.x[k].y * ps, xi = cur.x[k].x * ps + cur.x[k].y * pc;
+                    sre += coef[k].x * xr - coef[k].y * xi;
+                    sim += coef[k].x * xi + coef[k].y * xr;
+                }
+            }
+            const int frac_u = (int)((-offset_u + (double)disc_u) * os), frac_v = (int)((-offset_v + (double)disc_v) * os);
+            // kernel index of tap t = first index + t * kstep (convolution_policies.py:228-247 packed: the wrap of
+            // negative indices is the same for every tap of a visibility; :303-310 unpacked: never negative)
+            iu = packed ? (frac_u < 0 ? 0 : 1) + frac_u * (W + 2) : os + frac_u;
+            iv = packed ? (frac_v < 0 ? 0 : 1) + frac_v * (W + 2) : os + frac_v;
+            if (iu < 0) iu += klen;
+            if (iv < 0) iv += klen;
+            double su = 0.0, sv = 0.0;
+#pragma unroll
+            for (int t = 0; t < W; ++t) { su += ktab[iu + t * kstep]; sv += ktab[iv + t * kstep]; }
+            cw_sum += su * sv;      // all W x W taps, on or off the grid, as the reference counts them
+            const int u0 = (int)(disc_u - H - reg_u0), v0 = (int)(disc_v - H - reg_v0);   // footprint origin in the image
+            if (u0 >= 0 && u0 + W <= REG && v0 >= 0 && v0 + W <= REG) {
+                img = v0 * PITCH + u0 * 2;      // whole footprint inside the image: every centre inside the tile
+            } else {
+                // centre beyond the grid (clamped into an edge tile): its few in-grid taps go straight to the grid
+                for (int tv = 0; tv < W; ++tv)
+                    for (int t = 0; t < W; ++t) {
+                        const int64_t cu = disc_u - H + t, cv = disc_v - H + tv;
+                        if (cu >= 0 && cu < g.npix && cv >= 0 && cv < g.npix) {
+                            const double wgt = ktab[iv + tv * kstep] * ktab[iu + t * kstep];
+                            unsafeAtomicAdd(gb + (cv * g.npix + cu) * 2, wgt * sre);
+                            unsafeAtomicAdd(gb + (cv * g.npix + cu) * 2 + 1, wgt * sim);
+                        }
+                    }
+            }
+        }
+        // ---- walk the visibilities that have their footprint in the image: lane j's registers hold visibility j,
+        // read by v_readlane; the tap weights come from the kernel table in LDS; the image update is a plain
+        // read-add-write (the image is private to the wave, the lanes of an instruction hit distinct cells, the LDS
+        // executes a wave's accesses in order).  The operands of the next visibility are staged between the image reads
+        // and the image writes of the current one, so a visibility costs one LDS round trip.
+        unsigned long long todo = __ballot(img >= 0);
+        const int kidx = iu | (iv << 16);                    // both below 2^15 (checked on the host)
+        struct Stage { unsigned a[NINSTR]; double x[NINSTR]; };
+        auto stage = [&](int i) {
+            Stage S;
+            const unsigned img_i = 8u * (unsigned)__builtin_amdgcn_readlane(img, i);
+            const int kidx_i = __builtin_amdgcn_readlane(kidx, i);
+            const unsigned iu_i = 8u * (unsigned)(kidx_i & 0xffff), iv_i = 8u * (unsigned)(kidx_i >> 16);
+            const double re_i = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sre), i),
+                                                 __builtin_amdgcn_readlane(__double2loint(sre), i));
+            const double im_i = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sim), i),
+                                                 __builtin_amdgcn_readlane(__double2loint(sim), i));
+            const double ku = *reinterpret_cast<const double *>(ktab_b + (iu_i + ku8));
+            double kv[NINSTR];
+#pragma unroll
+            for (int k = 0; k < NINSTR; ++k) kv[k] = *reinterpret_cast<const double *>(ktab_b + (iv_i + kv8[k]));
+            const double val = fma(is_im, im_i, is_re * re_i) * ku;
+#pragma unroll
+            for (int k = 0; k < NINSTR; ++k) {
+                S.a[k] = on1[k] * img_i + off8[k];          // v_mad_u32_u24: img_i < 2^24
+                S.x[k] = val * kv[k];
+            }
+            return S;
+        };
+        if (todo) {
+            int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            Stage S = stage(i);
+            while (true) {
+                double c[NINSTR];
+#pragma unroll
+                for (int k = 0; k < NINSTR; ++k) c[k] = *reinterpret_cast<const double *>(tile_b + S.a[k]);
+                const bool more = todo != 0;
+                i = more ? __ffsll((long long)todo) - 1 : i;
+                todo &= todo - 1;
+                Stage N = stage(i);                           // its table reads queue behind the image reads ...
+#pragma unroll
+                for (int k = 0; k < NINSTR; ++k) asm volatile("" : "+v"(N.x[k]));   // ... and are issued before the writes
+#pragma unroll
+                for (int k = 0; k < NINSTR; ++k)
+                    *reinterpret_cast<double *>(const_cast<char *>(tile_b) + S.a[k]) = c[k] + S.x[k];
+                if (!more) break;
+                S = N;
+            }
+        }
+    }
+    // ---- weight sum of the chunk's visibilities
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cw_sum += __shfl_xor(cw_sum, o, 64);
+    if (lane == 0 && cw_sum != 0.0) unsafeAtomicAdd(&wt[band], cw_sum);
+    // ---- flush: image rows are contiguous on the grid; image cells beyond the grid's edge are dropped here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < REG * REG * 2; e += 64) {
+        const int gv = e / (2 * REG), rem = e - gv * (2 * REG);
+        const double x = tile[gv * PITCH + rem];
+        const int64_t cell_v = reg_v0 + gv, cell_u = reg_u0 + (rem >> 1);
+        if (x != 0.0 && cell_v >= 0 && cell_v < g.npix && cell_u >= 0 && cell_u < g.npix)
+            unsafeAtomicAdd(gb + (cell_v * g.npix + cell_u) * 2 + (rem & 1), x);
+    }
+}
+
+struct GridTileWs { size_t count, start, cursor, cstart, idx, total; };
+GridTileWs grid_tile_ws(int64_t nvis, int64_t nbins)
+{
+    GridTileWs w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    w.count = take((size_t)(nbins + 1) * sizeof(int));
+    w.start = take((size_t)(nbins + 1) * sizeof(int));
+    w.cursor = take((size_t)(nbins + 1) * sizeof(int));
+    w.cstart = take((size_t)(nbins + 1) * sizeof(int));
+    w.idx = take((size_t)nvis * sizeof(unsigned));
+    w.total = o;
+    return w;
+}
+
+// the tile path serves kernel widths 3 / 5 / 7 / 9 with problem sizes whose indices fit 32 bits
+bool grid_tile_ok(int64_t nrow, int64_t nchan, int64_t nband, int64_t npix, int64_t W, int conv_policy)
+{
+    if (conv_policy == 2 || !(W == 3 || W == 5 || W == 7 || W == 9)) return false;
+    const int64_t ntx = af_cdiv(npix, TILE);
+    return nrow * nchan < (1LL << 31) && nband * ntx * ntx < (1LL << 22) && nrow * nchan >= 4096;
+}
+
 // gridder.py:114-116: every band divided by its weight sum + 1e-8
 __global__ void grid_normalize_kernel(double2 *__restrict__ grid, const double *__restrict__ wt, int64_t npix2, int64_t total)
 {
@@ -562,10 +914,14 @@ AF_EXPORT int af_degridder_c128(const double *uvw, const double *gridstack, cons
     return AF_OK;
 }
 
-AF_EXPORT size_t af_gridder_workspace_bytes(int64_t nrow, int64_t nband)
+AF_EXPORT size_t af_gridder_workspace_bytes(int64_t nrow, int64_t nchan, int64_t nband, int64_t npix)
 {
-    if (nrow < 0 || nband < 0) return 0;
-    return af_degridder_workspace_bytes(nrow) + af_align_up((size_t)(nband > 0 ? nband : 1) * sizeof(double), 256);
+    if (nrow < 0 || nchan < 0 || nband < 0 || npix < 0) return 0;
+    size_t b = af_degridder_workspace_bytes(nrow) + af_align_up((size_t)(nband > 0 ? nband : 1) * sizeof(double), 256);
+    const int64_t ntx = af_cdiv(npix > 0 ? npix : 1, TILE);
+    if (nrow * nchan < (1LL << 31) && nband * ntx * ntx < (1LL << 22))   // the tile path's index arrays
+        b += grid_tile_ws(nrow * nchan, nband * ntx * ntx).total;
+    return b;
 }
 
 AF_EXPORT int af_gridder_c128(const double *uvw, const double *vis, const double *wavelengths, const int64_t *chanmap,
@@ -589,7 +945,7 @@ AF_EXPORT int af_gridder_c128(const double *uvw, const double *vis, const double
     AF_REQUIRE(uvw && vis && wavelengths && chanmap && corr_factors && image_centre_host && phase_centre_host &&
                    (convolution_kernel || conv_policy == 2),
                "af_gridder_c128: NULL array");
-    const size_t need = af_gridder_workspace_bytes(nrow, nband);
+    const size_t need = af_gridder_workspace_bytes(nrow, nchan, nband, npix);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= need, "af_gridder_c128: workspace too small (%zu < %zu)",
                workspace_bytes, need);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_gridder_c128: workspace must be 256-byte aligned");
@@ -602,35 +958,80 @@ AF_EXPORT int af_gridder_c128(const double *uvw, const double *vis, const double
     char *ws = static_cast<char *>(workspace);
     double *wt = reinterpret_cast<double *>(ws + af_degridder_workspace_bytes(nrow));
     AF_HIP(hipMemsetAsync(wt, 0, (size_t)nband * sizeof(double), st));
-    const int *perm = nullptr;
-    if (nrow >= 4096 && nrow < (1LL << 31)) {
-        int *hist = reinterpret_cast<int *>(ws);
-        int *pm = reinterpret_cast<int *>(ws + af_align_up(NBIN * sizeof(int), 256));
-        unsigned short *key = reinterpret_cast<unsigned short *>(ws + af_align_up(NBIN * sizeof(int), 256) +
-                                                                 af_align_up((size_t)nrow * sizeof(int), 256));
-        AF_HIP(hipMemsetAsync(hist, 0, NBIN * sizeof(int), st));
-        hipLaunchKernelGGL(degrid_bin_kernel_dev, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow,
-                           wavelengths, nchan, scale_factor, npix, key, hist);
-        AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(degrid_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
-        AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(degrid_scatter_kernel, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, key, nrow, hist, pm);
-        AF_LAUNCH_CHECK();
-        perm = pm;
-    }
-    const dim3 grid((unsigned)af_cdiv(nrow * nchan, 256)), block(256);
     const double2 *vs = reinterpret_cast<const double2 *>(vis), *cf = reinterpret_cast<const double2 *>(corr_factors);
-    af_prof_begin(st);
-    if (kernel_width == 7 && conv_policy != 2)
-        hipLaunchKernelGGL(grid_wave7_kernel, grid, block, 0, st, uvw, vs, wavelengths, chanmap, convolution_kernel,
-                           (int)kernel_oversampling, conv_policy == 1, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn,
-                           nrow, nchan, npix, (int)nband, perm, gridstack, wt);
-    else
-        hipLaunchKernelGGL((grid_kernel<0>), grid, block, 0, st, uvw, vs, wavelengths, chanmap, convolution_kernel,
-                           (int)kernel_width, (int)kernel_oversampling, conv_policy, ncorr, cf, scale_factor, phase_rotate,
-                           ll, mm, nn, nrow, nchan, npix, (int)nband, perm, gridstack, wt);
-    af_prof_end(st);
-    AF_LAUNCH_CHECK();
+    static const int tile_env = getenv("AFHIP_GRID_TILES") ? atoi(getenv("AFHIP_GRID_TILES")) : 1;   // A/B hook
+    if (tile_env && grid_tile_ok(nrow, nchan, nband, npix, kernel_width, conv_policy)) {
+        // ---- tile-binned LDS accumulation
+        GridGeom g;
+        g.scale_factor = scale_factor; g.npix = npix; g.nchan = nchan;
+        g.ntx = (int)af_cdiv(npix, TILE); g.nbins = (int)(nband * g.ntx * g.ntx);
+        const int64_t nvis = nrow * nchan;
+        const GridTileWs T = grid_tile_ws(nvis, g.nbins);
+        char *tw = ws + af_degridder_workspace_bytes(nrow) + af_align_up((size_t)nband * sizeof(double), 256);
+        int *count = reinterpret_cast<int *>(tw + T.count), *start = reinterpret_cast<int *>(tw + T.start);
+        int *cursor = reinterpret_cast<int *>(tw + T.cursor), *cstart = reinterpret_cast<int *>(tw + T.cstart);
+        unsigned *idx = reinterpret_cast<unsigned *>(tw + T.idx);
+        AF_HIP(hipMemsetAsync(count, 0, (size_t)(g.nbins + 1) * sizeof(int), st));
+        int64_t blocks = af_cdiv(nvis, 256);
+        if (blocks > 16384) blocks = 16384;
+        af_prof_begin(st);
+        hipLaunchKernelGGL(grid_tile_count, dim3((unsigned)blocks), dim3(256), 0, st, uvw, wavelengths, chanmap, g, nvis, count);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_tile_scan, dim3(1), dim3(1024), 0, st, count, g.nbins, start, cursor, cstart);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(grid_tile_scatter, dim3((unsigned)blocks), dim3(256), 0, st, uvw, wavelengths, chanmap, g, nvis,
+                           cursor, idx);
+        AF_LAUNCH_CHECK();
+        const int64_t max_chunks = nvis / TILE_CHUNK + g.nbins;
+        const size_t ktab_bytes = (size_t)kernel_oversampling * (kernel_width + 2) * sizeof(double);
+        AF_REQUIRE(ktab_bytes <= 32 * 1024, "af_gridder_c128: convolution kernel table too large for LDS");
+        auto run = [&](auto kernel) -> int {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)max_chunks), dim3(TILE_THREADS), ktab_bytes, st, uvw, vs, wavelengths,
+                               convolution_kernel, (int)kernel_oversampling, (int)(conv_policy == 1), ncorr, cf, g,
+                               phase_rotate, ll, mm, nn, start, cstart, idx, gridstack, wt);
+            AF_LAUNCH_CHECK();
+            return AF_OK;
+        };
+        int rc;
+        switch (kernel_width) {
+        case 3: rc = run(grid_tile_kernel<3>); break;
+        case 5: rc = run(grid_tile_kernel<5>); break;
+        case 7: rc = run(grid_tile_kernel<7>); break;
+        default: rc = run(grid_tile_kernel<9>); break;
+        }
+        if (rc != AF_OK) return rc;
+        af_prof_end(st);
+    } else {
+        // ---- global fp64 atomics (other kernel widths, nearest-neighbour policy, small calls), rows in uv-tile order
+        const int *perm = nullptr;
+        if (nrow >= 4096 && nrow < (1LL << 31)) {
+            int *hist = reinterpret_cast<int *>(ws);
+            int *pm = reinterpret_cast<int *>(ws + af_align_up(NBIN * sizeof(int), 256));
+            unsigned short *key = reinterpret_cast<unsigned short *>(ws + af_align_up(NBIN * sizeof(int), 256) +
+                                                                     af_align_up((size_t)nrow * sizeof(int), 256));
+            AF_HIP(hipMemsetAsync(hist, 0, NBIN * sizeof(int), st));
+            hipLaunchKernelGGL(degrid_bin_kernel_dev, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow,
+                               wavelengths, nchan, scale_factor, npix, key, hist);
+            AF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(degrid_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
+            AF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(degrid_scatter_kernel, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, key, nrow, hist, pm);
+            AF_LAUNCH_CHECK();
+            perm = pm;
+        }
+        const dim3 grid((unsigned)af_cdiv(nrow * nchan, 256)), block(256);
+        af_prof_begin(st);
+        if (kernel_width == 7 && conv_policy != 2)
+            hipLaunchKernelGGL(grid_wave7_kernel, grid, block, 0, st, uvw, vs, wavelengths, chanmap, convolution_kernel,
+                               (int)kernel_oversampling, conv_policy == 1, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn,
+                               nrow, nchan, npix, (int)nband, perm, gridstack, wt);
+        else
+            hipLaunchKernelGGL((grid_kernel<0>), grid, block, 0, st, uvw, vs, wavelengths, chanmap, convolution_kernel,
+                               (int)kernel_width, (int)kernel_oversampling, conv_policy, ncorr, cf, scale_factor, phase_rotate,
+                               ll, mm, nn, nrow, nchan, npix, (int)nband, perm, gridstack, wt);
+        af_prof_end(st);
+        AF_LAUNCH_CHECK();
+    }
     if (do_normalize) {
         const int64_t total = nband * npix * npix;
         AF_REQUIRE(af_cdiv(total, 256) < (1LL << 31), "af_gridder_c128: grid too large for one launch");

@@ -65,7 +65,7 @@ def gridder(uvw, vis, wavelengths, chanmap, npix, cell, image_centre, phase_cent
         p_uvw, p_wl, p_k = c.inp(uvw, np.float64), c.inp(wavelengths, np.float64), c.inp(convolution_kernel, np.float64)
         p_v, p_cm, p_cf = c.inp(vis, np.complex128), c.inp(chanmap, np.int64), c.inp(coef, np.complex128)
         p_out, h = c.out((nband, npix, npix), np.complex128)
-        ws_bytes = int(_lib.load().af_gridder_workspace_bytes(nrow, nband))
+        ws_bytes = int(_lib.load().af_gridder_workspace_bytes(nrow, nchan, nband, npix))
         p_ws = c.scratch(ws_bytes)
         _lib.call("af_gridder_c128", p_uvw, p_v, p_wl, p_cm, npix, float(cell), ic.ctypes.data, pc.ctypes.data, p_k, W, OS,
                   int(phase_transform_policy == "phase_rotate"), p_cf, ncorr, _CONV[convolution_policy],

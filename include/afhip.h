@@ -377,8 +377,8 @@ int af_compute_and_corrupt_vis_c128(const int64_t *time_bin_indices, const int64
  * applies the facet phase rotation with sign +1 first; do_normalize divides every band by its summed tap weights
  * + 1e-8.  vis (nrow,nchan,ncorr) complex128 (not modified); gridstack (nband,npix,npix) complex128, zeroed by the
  * call; the adds are hardware fp64 atomics, so results are reproducible to rounding only.
- * workspace: af_gridder_workspace_bytes(nrow, nband). */
-size_t af_gridder_workspace_bytes(int64_t nrow, int64_t nband);
+ * workspace: af_gridder_workspace_bytes(nrow, nchan, nband, npix). */
+size_t af_gridder_workspace_bytes(int64_t nrow, int64_t nchan, int64_t nband, int64_t npix);
 int af_gridder_c128(const double *uvw, const double *vis, const double *wavelengths, const int64_t *chanmap,
                     int64_t npix, double cell, const double *image_centre_host, const double *phase_centre_host,
                     const double *convolution_kernel, int64_t kernel_width, int64_t kernel_oversampling,

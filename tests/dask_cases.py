@@ -7,12 +7,17 @@ scheduler, against G12 (the reference's own dask results) and the unchunked gold
 import os
 import sys
 
-import numpy as np
-import dask
-import dask.array as da
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+# libafhip (and the HIP runtime under it) first: conda's scipy, which dask imports, ships an older libstdc++ than
+# the ROCm runtime needs, and whichever libstdc++ is loaded first serves the whole process
+from codex_africanus_amd import _lib as _lib_first             # noqa: E402
+_lib_first.load()
+
+import numpy as np                                              # noqa: E402
+import dask                                                     # noqa: E402
+import dask.array as da                                         # noqa: E402
+
 from codex_africanus_amd.rime import dask as rdask            # noqa: E402
 from codex_africanus_amd.dft import dask as ddask              # noqa: E402
 from codex_africanus_amd import placement, _lib                # noqa: E402
