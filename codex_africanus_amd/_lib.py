@@ -101,6 +101,13 @@ _SIGNATURES = {
     "af_spectral_model_f64": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "af_compute_and_corrupt_vis_c128": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                                _int, _int, _vp, _vp, _sz, _vp]),
+    "af_im_to_vis_model_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int]),
+    "af_im_to_vis_model_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _i64, _i64,
+                                      _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "af_fused_predict_model_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64]),
+    "af_fused_predict_model_c128": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                           _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                           _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_gridder_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "af_gridder_c128": (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _i64, _i64, _int, _vp, _int, _int,
                                _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),

@@ -58,6 +58,25 @@ def _prepare(jones, arrays, vis_like, vis_type):
     return mode, ncorr
 
 
+def _check_bins(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, nrow):
+    """What the kernels rely on: one count per bin start, as many gain time slots as bins, antenna numbers inside the
+    gain array.  Shapes always; values only for host-resident (numpy) arrays -- a device tensor is trusted rather than
+    synchronised on.  The reference indexes out of bounds in these cases (numba has no bounds check)."""
+    if tuple(time_bin_indices.shape) != tuple(time_bin_counts.shape) or len(time_bin_indices.shape) != 1:
+        raise ValueError("time_bin_indices and time_bin_counts must be 1-D and equally long")
+    if int(jones.shape[0]) < int(time_bin_indices.shape[0]):
+        raise ValueError("jones holds %d time slots for %d time bins" % (int(jones.shape[0]), int(time_bin_indices.shape[0])))
+    if tuple(antenna1.shape) != (nrow,) or tuple(antenna2.shape) != (nrow,):
+        raise ValueError("antenna1 and antenna2 must have one entry per row")
+    nant = int(jones.shape[1])
+    if nrow and isinstance(antenna1, np.ndarray) and isinstance(antenna2, np.ndarray):
+        lo, hi = min(int(antenna1.min()), int(antenna2.min())), max(int(antenna1.max()), int(antenna2.max()))
+        if lo < 0 or hi >= nant:
+            raise ValueError("antenna indices span [%d, %d], jones holds %d antennas" % (lo, hi, nant))
+    if isinstance(time_bin_counts, np.ndarray) and time_bin_counts.size and int(time_bin_counts.min()) < 0:
+        raise ValueError("time_bin_counts must not be negative")
+
+
 def _result_dtype(*arrays):
     return np.result_type(np.complex64, *[np_dtype_of(a) for a in arrays])
 
@@ -75,6 +94,7 @@ def corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, mo
     ntime, nant = int(jones.shape[0]), int(jones.shape[1])
     out_shape = tuple(int(s) for s in model.shape[:2]) + tuple(int(s) for s in model.shape[3:])
     out_dtype = np_dtype_of(model)
+    _check_bins(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, nrow)
     with Call(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model) as c:
         p_tbi, p_tbc = c.inp(time_bin_indices, np.int64), c.inp(time_bin_counts, np.int64)
         p_a1, p_a2 = c.inp(antenna1, np.int64), c.inp(antenna2, np.int64)
@@ -102,6 +122,7 @@ def compute_and_corrupt_vis(time_bin_indices, time_bin_counts, antenna1, antenna
         raise ValueError("model (time, chan, dir, corr...), lm (time, dir, 2) and freq (chan,) disagree")
     out_shape = (nrow, nchan) + tuple(int(s) for s in model.shape[3:])
     out_dtype = np_dtype_of(jones)
+    _check_bins(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, nrow)
     with Call(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, model, uvw, freq, lm) as c:
         p_tbi, p_tbc = c.inp(time_bin_indices, np.int64), c.inp(time_bin_counts, np.int64)
         p_a1, p_a2 = c.inp(antenna1, np.int64), c.inp(antenna2, np.int64)
@@ -127,6 +148,7 @@ def residual_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, v
         raise ValueError("vis, flag (row, chan, corr...) and model (row, chan, dir, corr...) disagree")
     ntime, nant = int(jones.shape[0]), int(jones.shape[1])
     out_dtype = np_dtype_of(vis)
+    _check_bins(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, nrow)
     with Call(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag, model) as c:
         p_tbi, p_tbc = c.inp(time_bin_indices, np.int64), c.inp(time_bin_counts, np.int64)
         p_a1, p_a2 = c.inp(antenna1, np.int64), c.inp(antenna2, np.int64)
@@ -154,6 +176,7 @@ def correct_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vi
         raise ValueError("vis and flag must have the same shape")
     ntime, nant = int(jones.shape[0]), int(jones.shape[1])
     out_dtype = np_dtype_of(vis)
+    _check_bins(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, nrow)
     with Call(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vis, flag) as c:
         p_tbi, p_tbc = c.inp(time_bin_indices, np.int64), c.inp(time_bin_counts, np.int64)
         p_a1, p_a2 = c.inp(antenna1, np.int64), c.inp(antenna2, np.int64)

@@ -135,3 +135,77 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
                   _lib.CONVENTION[convention], _MODES[get_mode()] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws,
                   max(ws_bytes, 256), c.stream)
         return c.result(h, cast=None if out_dtype == np.float64 else out_dtype)
+
+
+# ---------------------------------------------------------------------------------------- predict from the sky model
+_STOKES = ("I", "Q", "U", "V")
+_SPECTRAL_BASES = {0: 0, 1: 1, 2: 2, "std": 0, "log": 1, "log10": 2}
+
+
+def model_tables(stokes, spi, corr_schema, base, stokes_schema=None, implicit_stokes=False):
+    """Host-side resolution shared by the model-level entry points: validates (stokes, spi) like ``spectral_model``
+    (africanus/model/spectral/spec_model.py:102-236), resolves ``corr_schema`` like ``convert``
+    (africanus/model/coherency/conversion.py:143-204) and returns (base int32 array, ctypes tables src1 / src2 / op,
+    npol, ncorr, correlation shape, image_is_complex)."""
+    import ctypes
+    from ..model.coherency.conversion import convert_setup
+    if len(stokes.shape) != 2 or len(spi.shape) != 3:
+        raise ValueError("stokes must be (source, pol) and spi (source, spi-comps, pol)")
+    npol = int(stokes.shape[1])
+    if int(spi.shape[2]) != npol:
+        raise ValueError("Correlations on stokes and spi don't agree")
+    if stokes_schema is None:
+        stokes_schema = list(_STOKES[:npol])
+    bl = list(base) if isinstance(base, (list, tuple)) else [base] * npol
+    bl = bl + [bl[-1]] * (npol - len(bl))
+    try:
+        b = np.array([_SPECTRAL_BASES[x] for x in bl[:npol]], dtype=np.int32)
+    except (KeyError, TypeError):
+        raise ValueError("Invalid base")
+    probe = np.empty((1, npol), dtype=np.float64)       # the spectra are float64: the dtype convert() would see
+    mapping, in_shape, out_shape, out_dtype = convert_setup(probe, stokes_schema, corr_schema, implicit_stokes)
+    ncorr = int(np.prod(out_shape, dtype=np.int64))
+    src1, src2, ops = (ctypes.c_int * ncorr)(), (ctypes.c_int * ncorr)(), (ctypes.c_int * ncorr)()
+    for s1, s2, op, pos in mapping:
+        src1[pos], src2[pos], ops[pos] = s1, s2, op
+    return b, (src1, src2, ops), npol, ncorr, tuple(out_shape), np.dtype(out_dtype).kind == "c"
+
+
+def im_to_vis_from_model(stokes, spi, ref_freq, uvw, lm, frequency, corr_schema=(("XX", "XY"), ("YX", "YY")), base=0,
+                         convention="fourier", dtype=None, stokes_schema=None):
+    """
+    ``im_to_vis(convert(spectral_model(stokes, spi, ref_freq, frequency, base), stokes_schema, corr_schema), uvw, lm,
+    frequency)`` -- the model steps of africanus/rime/examples/predict.py:494-498 in front of the direct transform
+    (africanus/dft/kernels.py:14-69) -- in ONE device call: the spectra and the correlations are evaluated on the
+    device into the call's workspace, the caller never forms (or uploads) a (source, chan, corr) image.
+
+    ``stokes`` (source, pol), ``spi`` (source, spi-comps, pol), ``ref_freq`` (source,), ``stokes_schema`` default
+    ``["I", "Q", "U", "V"][:pol]``, ``corr_schema`` e.g. ``[["XX", "XY"], ["YX", "YY"]]``, ``["XX", "YY"]``,
+    ``["RR", "LL"]``; returns (row, chan) + the shape of ``corr_schema``.  Same values, bit for bit, as the chain of the
+    three stand-alone functions (same kernels); the same exceptions as ``spectral_model`` / ``convert`` / ``im_to_vis``.
+    """
+    if convention not in _lib.CONVENTION:
+        raise ValueError("convention not in ('fourier', 'casa')")
+    b, (src1, src2, ops), npol, ncorr, corr_shape, cplx = model_tables(stokes, spi, corr_schema, base, stokes_schema)
+    if len(uvw.shape) != 2 or uvw.shape[1] != 3:
+        raise ValueError("uvw must have shape (row, 3)")
+    if len(lm.shape) != 2 or lm.shape[1] != 2:
+        raise ValueError("lm must have shape (source, 2)")
+    nsrc, nspi, nchan, nrow = int(stokes.shape[0]), int(spi.shape[1]), int(frequency.shape[0]), int(uvw.shape[0])
+    if int(lm.shape[0]) != nsrc or int(spi.shape[0]) != nsrc or tuple(ref_freq.shape) != (nsrc,):
+        raise ValueError("stokes, spi, ref_freq and lm disagree on the number of sources")
+    if dtype is None:
+        out_dtype = np.result_type(np.complex64, *[np_dtype_of(a) for a in (stokes, spi, ref_freq, uvw, lm, frequency)])
+    else:
+        out_dtype = np.dtype(dtype)
+    with Call(stokes, spi, ref_freq, uvw, lm, frequency) as c:
+        p_st, p_sp, p_rf = c.inp(stokes, np.float64), c.inp(spi, np.float64), c.inp(ref_freq, np.float64)
+        p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)
+        p_b = c.inp(b, np.int32)
+        p_out, h = c.out((nrow, nchan) + corr_shape, np.complex128)
+        ws_bytes = int(_lib.load().af_im_to_vis_model_workspace_bytes(nsrc, nchan, npol, ncorr, int(cplx)))
+        p_ws = c.scratch(ws_bytes)
+        _lib.call("af_im_to_vis_model_f64", p_st, p_sp, p_rf, p_b, nspi, npol, src1, src2, ops, ncorr, int(cplx), p_uvw,
+                  p_lm, p_fr, nsrc, nrow, nchan, _lib.CONVENTION[convention], _MODES[get_mode()], p_out, p_ws,
+                  max(ws_bytes, 256), c.stream)
+        return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)

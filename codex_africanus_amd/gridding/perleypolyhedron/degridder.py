@@ -50,6 +50,8 @@ def degridder(uvw, gridstack, wavelengths, chanmap, cell, image_centre, phase_ce
     if len(uvw.shape) != 2 or uvw.shape[1] != 3:
         raise ValueError("UVW array must be array of tripples")
     cm = chanmap.detach().cpu().numpy() if _is_torch(chanmap) else np.asarray(chanmap)
+    if cm.size and int(cm.min()) < 0:
+        raise ValueError("chanmap holds negative band numbers")
     if cm.size and int(gridstack.shape[0]) < int(cm.max()) + 1:
         raise ValueError("Not enough channel bands in grid stack to match mfs band mapping")
     W, OS = int(convolution_kernel_width), int(convolution_kernel_oversampling)

@@ -56,7 +56,12 @@ def gridder(uvw, vis, wavelengths, chanmap, npix, cell, image_centre, phase_cent
         raise ValueError("stokes_conversion_policy '%s' needs %d correlations" % (stokes_conversion_policy, coef.shape[0]))
     W, OS = int(convolution_kernel_width), int(convolution_kernel_oversampling)
     cm = chanmap.detach().cpu().numpy() if _is_torch(chanmap) else np.asarray(chanmap)
+    if cm.size and int(cm.min()) < 0:
+        raise ValueError("chanmap holds negative band numbers")
     nband = int(cm.max()) + 1 if cm.size else 0
+    if convolution_policy != "conv_nn_scatter" and \
+            int(np.prod(tuple(convolution_kernel.shape), dtype=np.int64)) != OS * (W + 2):
+        raise ValueError("convolution_kernel must hold oversampling * (width + 2) taps")
     nrow, npix = int(uvw.shape[0]), int(npix)
     ic = np.ascontiguousarray(image_centre, dtype=np.float64).reshape(2)
     pc = np.ascontiguousarray(phase_centre, dtype=np.float64).reshape(2)

@@ -24,11 +24,12 @@ def _host(a):
     return a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
 
 
-def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
+def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
                       beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
                       point_errors=None, antenna_scaling=None,
                       die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
-                      feed_rotation=None, gauss_shape=None):
+                      feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
+                      corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0):
     """
     ``V_pq = G_p ( B_pq + sum_s E_ps (K_pqs X_s) E_qs^H ) G_q^H`` from source-level inputs.
 
@@ -41,7 +42,11 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     ``E <- E R`` (the ``einsum("stafij,tajk->stafik")`` of africanus/rime/examples/predict.py:472; needs the
     beam arguments) and ``gauss_shape`` (source, 3) = (major, minor, orientation) in radians, the Gaussian
     shape function of africanus/model/shape/gaussian_shape.py multiplied onto the phase term (rows of zeros
-    are point sources).  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    are point sources).  Instead of ``brightness`` the SKY MODEL may be given: ``stokes`` (source, 4), ``spi``
+    (source, spi-comps, 4), ``ref_freq`` (source,), ``corr_schema`` (2 x 2 nested: linear or circular feeds) and
+    ``spectral_base``; ``brightness = convert(spectral_model(stokes, spi, ref_freq, frequency, spectral_base),
+    ["I","Q","U","V"], corr_schema)`` (africanus/rime/examples/predict.py:494-498) is then evaluated on the device inside
+    the call and no (source, chan, 2, 2) array exists on the caller's side.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
     ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
     per-antenna Jones terms on the device.  float64 / complex128 only.
     """
@@ -59,7 +64,29 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     nsrc, nrow, nchan = int(lm.shape[0]), int(uvw.shape[0]), int(frequency.shape[0])
     if tuple(lm.shape) != (nsrc, 2) or tuple(uvw.shape) != (nrow, 3):
         raise ValueError("lm must be (source, 2) and uvw (row, 3)")
-    bshape = tuple(int(s) for s in brightness.shape)
+    model = stokes is not None or spi is not None or ref_freq is not None
+    if model:
+        if brightness is not None or stokes is None or spi is None or ref_freq is None:
+            raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
+        from ..dft.kernels import model_tables
+        m_base, m_tabs, m_npol, m_ncorr, m_shape, _ = model_tables(stokes, spi, corr_schema, spectral_base)
+        if m_shape != (2, 2):
+            raise ValueError("corr_schema must be a 2 x 2 schema, e.g. [['XX', 'XY'], ['YX', 'YY']]")
+        if int(stokes.shape[0]) != nsrc or int(spi.shape[0]) != nsrc or tuple(ref_freq.shape) != (nsrc,):
+            raise ValueError("stokes, spi, ref_freq and lm disagree on the number of sources")
+        if gauss_shape is not None and beam is None:
+            raise ValueError("gauss_shape without a beam is not fused yet")
+        if beam is None:
+            # no DDEs: the model-level direct transform, phase_delay's clamped n
+            vis = _model_dft(stokes, spi, ref_freq, uvw, lm, frequency, m_base, m_tabs, m_npol, convention)
+            if die1_jones is None and base_vis is None:
+                return vis
+            return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+        brightness = None
+        flat_spectrum = False
+    elif brightness is None:
+        raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
+    bshape = tuple(int(s) for s in brightness.shape) if brightness is not None else (nsrc, nchan, 2, 2)
     if bshape == (nsrc, 2, 2):
         flat_spectrum = True
     elif bshape == (nsrc, nchan, 2, 2):
@@ -72,8 +99,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
 
     if gauss_shape is not None and tuple(gauss_shape.shape) != (nsrc, 3):
         raise ValueError("gauss_shape must have shape (source, 3)")
-    with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, feed_rotation, gauss_shape,
-              *beam_args) as c:
+    with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, feed_rotation, gauss_shape, stokes, spi,
+              ref_freq, *beam_args) as c:
         if flat_spectrum:
             if _is_torch(brightness):
                 brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
@@ -81,6 +108,9 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 brightness = np.broadcast_to(np.asarray(brightness)[:, None], (nsrc, nchan, 2, 2))
         p_lm, p_uvw, p_fr = c.inp(lm, np.float64), c.inp(uvw, np.float64), c.inp(frequency, np.float64)
         p_b = c.inp(brightness, np.complex128)
+        if model:
+            p_st, p_sp, p_rf = c.inp(stokes, np.float64), c.inp(spi, np.float64), c.inp(ref_freq, np.float64)
+            p_mb = c.inp(m_base, np.int32)
         p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
         conv = _lib.CONVENTION[convention]
         if not have_beam and gauss_shape is not None:
@@ -126,13 +156,39 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
             p_fr_rot = c.inp(feed_rotation, np.complex128)
             p_gs = c.inp(gauss_shape, np.float64)
-            ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
-            p_ws = c.scratch(ws_bytes)
-            _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, p_b,
-                      nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
-                      p_as, p_fr_rot, p_gs, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+            if model:
+                ws_bytes = int(_lib.load().af_fused_predict_model_workspace_bytes(nsrc, nchan, m_npol, beam_lw, beam_mh,
+                                                                                  beam_nud))
+                p_ws = c.scratch(ws_bytes)
+                _lib.call("af_fused_predict_model_c128", p_st, p_sp, p_rf, p_mb, int(spi.shape[1]), m_npol, m_tabs[0],
+                          m_tabs[1], m_tabs[2], p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, nsrc, nchan,
+                          p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_fr_rot, p_gs,
+                          conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+            else:
+                ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
+                p_ws = c.scratch(ws_bytes)
+                _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, p_b,
+                          nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
+                          p_as, p_fr_rot, p_gs, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
         vis = c.result(h)
     if die1_jones is None and base_vis is None:
         return vis
     # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
     return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+
+
+def _model_dft(stokes, spi, ref_freq, uvw, lm, frequency, base, tabs, npol, convention):
+    """Model-level direct transform with phase_delay's clamped n (the no-DDE route of fused_predict_vis): the four
+    complex correlations, (row, chan, 2, 2)."""
+    nsrc, nspi, nchan, nrow = int(stokes.shape[0]), int(spi.shape[1]), int(frequency.shape[0]), int(uvw.shape[0])
+    with Call(stokes, spi, ref_freq, uvw, lm, frequency) as c:
+        p_st, p_sp, p_rf = c.inp(stokes, np.float64), c.inp(spi, np.float64), c.inp(ref_freq, np.float64)
+        p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)
+        p_b = c.inp(base, np.int32)
+        p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
+        ws_bytes = int(_lib.load().af_im_to_vis_model_workspace_bytes(nsrc, nchan, npol, 4, 1))
+        p_ws = c.scratch(ws_bytes)
+        _lib.call("af_im_to_vis_model_f64", p_st, p_sp, p_rf, p_b, nspi, npol, tabs[0], tabs[1], tabs[2], 4, 1, p_uvw,
+                  p_lm, p_fr, nsrc, nrow, nchan, _lib.CONVENTION[convention], _lib.AF_DFT_AUTO | _lib.AF_DFT_CLAMP_N,
+                  p_out, p_ws, max(ws_bytes, 256), c.stream)
+        return c.result(h)

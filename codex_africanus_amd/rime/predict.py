@@ -100,6 +100,24 @@ def _index_array(c, a):
     return c.inp(a, np.int64), 8
 
 
+def _check_indices(time_index, antenna1, antenna2, ntime, nant, have_jones):
+    """Index ranges the kernel relies on when per-antenna terms are gathered.  The reference reads out of bounds (or
+    raises an IndexError under numba's boundscheck); on the device a bad index is an out-of-bounds read that can kill
+    the context, so host-resident (numpy) index arrays are checked here -- O(row), negligible next to the upload.
+    Device-resident index tensors are trusted (checking would cost a device -> host synchronisation per call)."""
+    if not have_jones or any(not isinstance(a, np.ndarray) for a in (time_index, antenna1, antenna2)):
+        return
+    if time_index.size == 0:
+        return
+    span = int(time_index.max()) - int(time_index.min())
+    if span >= ntime:
+        raise ValueError("time_index spans %d timesteps, the Jones terms hold %d" % (span + 1, ntime))
+    lo = min(int(antenna1.min()), int(antenna2.min()))
+    hi = max(int(antenna1.max()), int(antenna2.max()))
+    if lo < 0 or hi >= nant:
+        raise ValueError("antenna indices span [%d, %d], the Jones terms hold %d antennas" % (lo, hi, nant))
+
+
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None, dde2_jones=None,
                 die1_jones=None, base_vis=None, die2_jones=None):
     """
@@ -174,6 +192,7 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
     _expect("die1_jones", die1_jones, (ntime, nant, nchan) + corrs)
     _expect("die2_jones", die2_jones, (ntime, nant, nchan) + corrs)
     _expect("base_vis", base_vis, (nrow, nchan) + corrs)
+    _check_indices(time_index, antenna1, antenna2, ntime, nant, have_ddes or have_dies)
 
     with Call(time_index, antenna1, antenna2, *arrays) as c:
         p_ti, ib = _index_array(c, time_index)

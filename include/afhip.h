@@ -359,6 +359,34 @@ int af_spectral_model_f64(const double *stokes, const double *spi, const double 
                           const int *base, int64_t nsrc, int64_t nspi, int64_t npol, int64_t nchan, double *out,
                           void *stream);
 
+/* Predict from the sky model: the reference's predict script forms the brightness with
+ *   stokes = spectral_model(stokes, spi, ref_freq, frequency, base); brightness = convert(stokes, [I,Q,U,V], corr_schema)
+ * (africanus/rime/examples/predict.py:494-498) in front of the predict.  These entry points take (stokes, spi,
+ * ref_freq) -- stokes (nsrc,npol), spi (nsrc,nspi,npol), ref_freq (nsrc), base (npol) int32 DEVICE as in
+ * af_spectral_model_f64; src1/src2/op (ncorr) HOST tables as in af_coherency_convert (the resolved corr_schema) -- and
+ * run both steps on the device into the call's workspace: no (source, chan, corr) array on the caller's side.
+ * image_is_complex = 0 when every correlation is a real product of the (real) Stokes spectra (e.g. XX, YY from I, Q):
+ * the transform then runs its real-image kernels.  The rest as af_im_to_vis_f64 / af_fused_predict_c128 (whose
+ * brightness is always the four complex correlations, ncorr = 4). */
+size_t af_im_to_vis_model_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t npol, int64_t ncorr, int image_is_complex);
+int af_im_to_vis_model_f64(const double *stokes, const double *spi, const double *ref_freq, const int *base,
+                           int64_t nspi, int64_t npol, const int *src1_host, const int *src2_host, const int *op_host,
+                           int64_t ncorr, int image_is_complex, const double *uvw, const double *lm,
+                           const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int convention, int mode,
+                           double *out, void *workspace, size_t workspace_bytes, void *stream);
+size_t af_fused_predict_model_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t npol, int64_t beam_lw,
+                                              int64_t beam_mh, int64_t beam_nud);
+int af_fused_predict_model_c128(const double *stokes, const double *spi, const double *ref_freq, const int *base,
+                                int64_t nspi, int64_t npol, const int *src1_host, const int *src2_host,
+                                const int *op_host, const int32_t *items, int64_t nitems, const int32_t *antenna1,
+                                const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                                const double *frequency, int64_t nsrc, int64_t nchan, const double *beam, int64_t beam_lw,
+                                int64_t beam_mh, int64_t beam_nud, const double *beam_lm_extents,
+                                const double *beam_freq_map, const double *parallactic_angles, int64_t ntime,
+                                int64_t nant, const double *point_errors, const double *antenna_scaling,
+                                const double *feed_rotation, const double *gauss_shape, int convention, double *out,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* Replaces africanus.calibration.utils.compute_and_corrupt_vis (calibration/utils/compute_and_corrupt_vis.py:73-152):
  * corrupt_vis with the model coherencies formed on the fly from a time-variable point-source model,
  *   source_vis = model[t,nu,dir] * exp(-2 pi i nu/c (u l + v m + w (n - 1))) / n,  n = sqrt(1 - l^2 - m^2),
