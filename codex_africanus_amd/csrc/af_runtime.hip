@@ -362,8 +362,11 @@ AF_EXPORT int af_thread_stream(void **stream)
 // Releases every cached block (all devices and the page-locked list) and destroys the per-thread streams.
 // Blocks still handed out stay valid and are released by their af_pool_free.  No other libafhip call may be in
 // flight on another thread.  Idempotent; the library is usable again afterwards.
+void af_wgrid_shutdown();   // af_wgridder.hip: cached FFT plans
+
 AF_EXPORT int af_shutdown(void)
 {
+    af_wgrid_shutdown();
     Pool &P = pool();
     std::vector<std::pair<int, hipStream_t>> streams;
     {

@@ -387,6 +387,27 @@ int af_fused_predict_model_c128(const double *stokes, const double *spi, const d
                                 const double *feed_rotation, const double *gauss_shape, int convention, double *out,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* wgridder-style degridding, image -> visibilities at a requested accuracy (BASELINE configs[4]):
+ * the entry under africanus.gridding.wgridder.model (africanus/gridding/wgridder/im2vis.py:14-61), whose arithmetic is the
+ * un-vendored ducc0.wgridder.dirty2ms -- parity is pinned only by the reference's accuracy contract
+ * (africanus/gridding/wgridder/tests/test_wgridder.py:18-113): relative l2 error against the direct transform
+ *   vis[r,nu] = sum_xy image[x,y] / n * exp(-2 pi i nu/c (u x + v y - w (n - 1)))   <= epsilon.
+ * One imaging band per call: freq (nchan_band) are columns chan0.. of the (nrow, nchan_total) arrays vis (complex128,
+ * the band's columns are overwritten), wgt (float64 or NULL) and mask (bytes or NULL: 0 = skip, result 0).
+ * image (nx, ny) float64; corr_u (nx) / corr_v (ny): 1 / Fourier transform of the kernel along the padded axes
+ * (af_wgrid_padded); quad_t / quad_w (48): Gauss-Legendre nodes / weights on (0, 1); kernel_width W and beta: the
+ * exponential-of-semicircle kernel exp(beta (sqrt(1 - (2t/W)^2) - 1)); [wl_min, wl_max]: range of w nu / c over the
+ * band (HOST scalars, they size the w-plane loop); max_abs_nm1: largest |n - 1| of the image.  All device work is
+ * enqueued on `stream`; uses hipFFT (plans cached per device and size, released by af_shutdown). */
+int64_t af_wgrid_padded(int64_t n);
+size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny);
+int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
+                        int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx, double celly,
+                        const double *corr_u, const double *corr_v, const double *quad_t, const double *quad_w,
+                        int kernel_width, double beta, double wl_min, double wl_max, double max_abs_nm1,
+                        int do_wstacking, const double *wgt, const unsigned char *mask, double *vis, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* Replaces africanus.calibration.utils.compute_and_corrupt_vis (calibration/utils/compute_and_corrupt_vis.py:73-152):
  * corrupt_vis with the model coherencies formed on the fly from a time-variable point-source model,
  *   source_vis = model[t,nu,dir] * exp(-2 pi i nu/c (u l + v m + w (n - 1))) / n,  n = sqrt(1 - l^2 - m^2),

@@ -104,11 +104,53 @@ def main():
         ph = rdask.phase_delay(da.from_array(g1["lm"], chunks=(3, 2)), da.from_array(g1["uvw"], chunks=(10, 3)),
                                da.from_array(g1["frequency"], chunks=2)).compute()
         assert np.array_equal(ph, rime.phase_delay(g1["lm"], g1["uvw"], g1["frequency"]))
+    producers_and_calibration()
     stats = _lib.pool_stats(0)
     print("predict_vis cases: %d; placement devices %s policy %s; pool hits %d misses %d"
           % (ncase, placement.devices(), placement.get_policy(), stats["hits"], stats["misses"]))
     _lib.shutdown()
     print("DASK_CASES_OK")
+
+
+def producers_and_calibration():
+    """dask front-ends of the producers / calibration consumers (africanus/rime/dask.py:144-163, model/shape/dask.py,
+    model/spectral/dask.py, calibration/utils/dask.py, rime/dask_predict.py:609-658) against the array-level calls"""
+    from codex_africanus_amd.rime import feed_rotation, wsclean_predict
+    from codex_africanus_amd.model.shape import gaussian
+    from codex_africanus_amd.model.shape import dask as sdask
+    from codex_africanus_amd.model.spectral import spectral_model
+    from codex_africanus_amd.model.spectral import dask as pdask
+    from codex_africanus_amd.calibration import utils as cu
+    from codex_africanus_amd.calibration.utils import dask as cdask
+    g8, g9, g7 = load("g8_producers.npz"), load("g9_calibration.npz"), load("g7_wsclean.npz")
+    with dask.config.set(scheduler="threads", num_workers=4):
+        out = rdask.feed_rotation(da.from_array(g8["pa"], chunks=(2, 3)), "circular").compute()
+        assert np.array_equal(out, feed_rotation(g8["pa"], "circular"))
+        out = sdask.gaussian(da.from_array(g8["uvw"], chunks=(13, 3)), da.from_array(g8["freq"], chunks=5),
+                             da.from_array(g8["shape_params"], chunks=(9, 3))).compute()
+        assert np.array_equal(out, gaussian(g8["uvw"], g8["freq"], g8["shape_params"]))
+        out = pdask.spectral_model(da.from_array(g8["stokes"], chunks=(4, 4)), da.from_array(g8["spi"], chunks=(4, 3, 4)),
+                                   da.from_array(g8["spec_ref_freq"], chunks=4), da.from_array(g8["freq"], chunks=7),
+                                   base=[0, 1, 2]).compute()
+        assert np.array_equal(out, spectral_model(g8["stokes"], g8["spi"], g8["spec_ref_freq"], g8["freq"], base=[0, 1, 2]))
+        # calibration: 5 time bins of 6 rows, chunked 2 + 2 + 1 bins (chunkify_rows), chunk-local bin starts
+        row_chunks, tbi, tbc = cu.chunkify_rows(g9["time"], 2)
+        tchunks = (2, 2, 1)
+        d = lambda x, c: da.from_array(x, chunks=c)
+        jones, model = g9["full_jones"], g9["full_model"]
+        dj = d(jones, (tchunks,) + jones.shape[1:])
+        dm = d(model, (row_chunks,) + model.shape[1:])
+        idx = [d(tbi, (tchunks,)), d(tbc, (tchunks,)), d(g9["ant1"], (row_chunks,)), d(g9["ant2"], (row_chunks,))]
+        vis = cdask.corrupt_vis(*idx, dj, dm).compute()
+        assert np.array_equal(vis, g9["full_vis"])
+        dv, df = d(g9["full_data"], (row_chunks,) + vis.shape[1:]), d(g9["full_flag"], (row_chunks,) + vis.shape[1:])
+        res = cdask.residual_vis(*idx, dj, dv, df, dm).compute()
+        assert np.array_equal(res, g9["full_residual"])
+        j1 = np.ascontiguousarray(jones[:, :, :, :1])
+        cor = cdask.correct_vis(*idx, d(j1, (tchunks,) + j1.shape[1:]), dv, df).compute()
+        assert np.array_equal(cor, g9["full_corrected"])
+        raises(ValueError, "Cannot chunk jones over antenna",
+               lambda: cdask.corrupt_vis(*idx, d(jones, (tchunks, 2) + jones.shape[2:]), dm))
 
 
 if __name__ == "__main__":

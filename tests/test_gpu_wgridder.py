@@ -1,0 +1,108 @@
+"""
+wgridder-style degridding (BASELINE configs[4]; africanus/gridding/wgridder/im2vis.py:63-99).  The reference's
+arithmetic is ducc0 (absent: parity unpinned); what its tests pin is the accuracy contract
+(africanus/gridding/wgridder/tests/test_wgridder.py:18-113): relative l2 error <= epsilon against the direct transform.
+Same recipe here (their shapes, field of view and uvw scaling), for the image -> visibility direction, with the direct
+transform evaluated by the CPU oracle's im_to_vis on the image's pixels as point sources.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd.gridding.wgridder import model
+
+pytestmark = pytest.mark.gpu
+LIGHTSPEED = 2.99792458e8
+
+
+def _l2error(a, b):
+    return np.sqrt(np.sum(np.abs(a - b) ** 2) / np.maximum(np.sum(np.abs(a) ** 2), np.sum(np.abs(b) ** 2)))
+
+
+def _explicit_degridder(uvw, freq, image, cell, celly, apply_w=True):
+    """vis[r, c] = sum_xy image[x, y] / n exp(-2 pi i f/c (u x + v y - w (n - 1))): the adjoint of explicit_gridder
+    (test_wgridder.py:18-46), through the oracle's direct transform (sources = pixels, w negated)."""
+    nx, ny = image.shape
+    x, y = np.meshgrid(*[-ss / 2 + np.arange(ss) for ss in (nx, ny)], indexing="ij")
+    x, y = x * cell, y * celly
+    lm = np.stack([x.ravel(), y.ravel()], axis=1)
+    if apply_w:
+        n = np.sqrt(1.0 - x ** 2 - y ** 2)
+        img = (image / n).ravel()
+        uvw2 = uvw * np.array([1.0, 1.0, -1.0])
+        src = np.broadcast_to(img[:, None, None], (img.size, freq.size, 1)).copy()
+        return oracle.im_to_vis(src, uvw2, lm, freq, omp=True)[:, :, 0]
+    ph = (uvw[:, None, 0, None] * lm[None, None, :, 0] + uvw[:, None, 1, None] * lm[None, None, :, 1]) \
+        * (freq / LIGHTSPEED)[None, :, None]
+    return (np.exp(-2j * np.pi * ph) * image.ravel()[None, None, :]).sum(axis=2)
+
+
+def _case(nx, ny, fov, nrow, nchan, nband, seed=420):
+    rng = np.random.default_rng(seed)
+    cell = fov * np.pi / 180 / nx
+    f0 = 1e9
+    freq = f0 + np.arange(nchan) * (f0 / nchan)
+    uvw = (rng.random((nrow, 3)) - 0.5) / (cell * freq[-1] / LIGHTSPEED)
+    step = nchan // nband
+    freq_bin_idx = np.arange(0, nchan, step)
+    freq_bin_counts = np.append(freq_bin_idx, nchan)[1:] - np.append(freq_bin_idx, nchan)[:-1]
+    image = rng.standard_normal((freq_bin_idx.size, nx, ny))
+    return cell, freq, uvw, freq_bin_idx, freq_bin_counts, image
+
+
+@pytest.mark.parametrize("ny", (18, 64))
+@pytest.mark.parametrize("nchan, nband", [(1, 1), (7, 1), (7, 3)])
+@pytest.mark.parametrize("epsilon", (1e-3, 1e-4, 1e-6))
+def test_model_meets_the_accuracy_contract(ny, nchan, nband, epsilon):
+    """test_wgridder.py:49-113 transposed to the degridder: 16 x ny pixels, 5 degree field, 1000 rows"""
+    nx, fov, nrow = 16, 5.0, 1000
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, fov, nrow, nchan, nband)
+    vis = model(uvw, freq, image, fbi, fbc, cell, epsilon=epsilon)
+    assert vis.shape == (nrow, nchan) and vis.dtype == np.complex128
+    ref = np.zeros((nrow, nchan), dtype=np.complex128)
+    for b in range(fbi.size):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref[:, ind] = _explicit_degridder(uvw, freq[ind], image[b], cell, cell)
+    assert _l2error(vis, ref) <= epsilon
+
+
+def test_model_weights_flags_wide_field_and_no_wstacking():
+    nx, ny, nrow, nchan = 24, 20, 700, 4
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 25.0, nrow, nchan, 2, seed=7)      # 25 degrees: a strong w term
+    celly = cell * 1.3
+    rng = np.random.default_rng(3)
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.2).astype(np.uint8)                # != 0: process
+    ref = np.zeros((nrow, nchan), dtype=np.complex128)
+    for b in range(2):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref[:, ind] = _explicit_degridder(uvw, freq[ind], image[b], cell, celly)
+    vis = model(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, celly=celly, epsilon=1e-7)
+    assert np.all(vis[flag == 0] == 0)
+    assert _l2error(vis, ref * wgt * (flag != 0)) <= 1e-7
+    # without w-stacking: w and n are ignored (ducc0's do_wstacking=False)
+    flat = model(uvw, freq, image, fbi, fbc, cell, celly=celly, epsilon=1e-6, do_wstacking=False)
+    ref0 = np.zeros_like(ref)
+    for b in range(2):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref0[:, ind] = _explicit_degridder(uvw, freq[ind], image[b], cell, celly, apply_w=False)
+    assert _l2error(flat, ref0) <= 1e-6
+    assert _l2error(flat, ref) > 1e-3          # and the w term matters at this field of view
+    # float32 images give complex64 (result_type(image, complex64))
+    assert model(uvw, freq, image.astype(np.float32), fbi, fbc, cell, epsilon=1e-4).dtype == np.complex64
+    # row chunks carry bin starts that do not begin at zero (im2vis.py:33)
+    again = model(uvw, freq, image, fbi + 5, fbc, cell, weights=wgt, flag=flag, celly=celly, epsilon=1e-7)
+    np.testing.assert_array_equal(again, vis)
+
+
+def test_model_device_resident_matches_host():
+    import torch
+    cell, freq, uvw, fbi, fbc, image = _case(20, 32, 3.5, 777, 4, 2, seed=11)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    host = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+    dev = model(t(uvw), t(freq), t(image), fbi, fbc, cell, epsilon=1e-5)
+    np.testing.assert_array_equal(dev.cpu().numpy(), host)
+    with pytest.raises(ValueError, match="horizon"):
+        model(uvw, freq, image, fbi, fbc, 0.2)
+    with pytest.raises(ValueError, match="one entry per band"):
+        model(uvw, freq, image, fbi[:1], fbc, cell)
