@@ -15,7 +15,8 @@
 //     exp(+2 pi i w_k (n - 1)), is zero-padded to twice its size and Fourier transformed (hipFFT) into a uv grid;
 //     every visibility within W/2 planes of k then takes its W x W cells of that grid, weighted by psi(du) psi(dv)
 //     psi(dw), and adds them to its sum.  Plane spacing dw = 1 / (2 sigma max|n - 1|).
-// The planes are processed one at a time (one grid resident); all work is enqueued on the caller's stream.
+// The planes are built in batches of as many grids as the workspace holds; per batch ONE pass over the visibilities
+// takes every visibility through its own planes.  All work is enqueued on the caller's stream.
 #include <hipfft/hipfft.h>
 
 #include <cmath>
@@ -84,49 +85,124 @@ __global__ void wg_fill_plane(const double *__restrict__ image, const double *__
     grid[px * nv + py] = make_double2(v * c, v * s);
 }
 
-// vis[r, chan0 + c] (+)= psi_w * sum over W x W cells of plane k; one lane per visibility
-__global__ void wg_degrid_plane(const double *__restrict__ uvw, const double *__restrict__ freq, int64_t nrow, int64_t nchan_b,
-                                int64_t chan0, int64_t nchan_total, const double2 *__restrict__ grid, int64_t nu, int64_t nv,
-                                double cellx, double celly, int W, double beta, double w0, double dw, int k, int do_w,
-                                const unsigned char *__restrict__ mask, double2 *__restrict__ vis)
+// ---- rows in uv-tile order (as in af_degridder.hip): rows arrive time-major, i.e. in no useful uv order; visiting them
+// tile by tile of their mid-band position on the padded grid (64 x 64 tiles, Morton ordered; counting sort) keeps the
+// gathers of concurrently running waves inside one cache-sized neighbourhood of every plane
+constexpr int WG_NBIN = 4096;
+__device__ __forceinline__ unsigned wg_morton6(unsigned x, unsigned y)
+{
+    unsigned k = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) k |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+    return k;
+}
+__global__ void wg_bin_rows(const double *__restrict__ uvw, int64_t nrow, const double *__restrict__ freq, int64_t nchan_b,
+                            double su, double sv, unsigned short *__restrict__ key, int *__restrict__ hist)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const double fl = freq[nchan_b / 2] / AF_LIGHTSPEED;
+    // fraction of the padded grid, origin in the middle, wrapped
+    double x = uvw[3 * r] * fl * su + 0.5, y = uvw[3 * r + 1] * fl * sv + 0.5;
+    x = (x - floor(x)) * 64.0; y = (y - floor(y)) * 64.0;
+    x = x < 0.0 ? 0.0 : (x > 63.0 ? 63.0 : x);
+    y = y < 0.0 ? 0.0 : (y > 63.0 ? 63.0 : y);
+    const unsigned k = wg_morton6((unsigned)x & 63u, (unsigned)y & 63u);
+    key[r] = (unsigned short)k;
+    atomicAdd(&hist[k], 1);
+}
+__global__ __launch_bounds__(1024) void wg_scan_bins(int *__restrict__ hist)   // in place: counts -> starts
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    int v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = hist[4 * t + i]; s += v[i]; }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int base = part[t] - s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hist[4 * t + i] = base; base += v[i]; }
+}
+__global__ void wg_scatter_rows(const unsigned short *__restrict__ key, int64_t nrow, int *__restrict__ start,
+                                int *__restrict__ perm)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    perm[atomicAdd(&start[key[r]], 1)] = (int)r;
+}
+
+// vis[r, chan0 + c] += sum over the resident planes [pk0, pk1) within the visibility's W-plane support of psi_w times
+// the W x W cells of that plane's grid; one lane per visibility, every tap weight in registers
+template <int W>
+__global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict__ uvw, const double *__restrict__ freq,
+                                                        int64_t nrow, int64_t nchan_b, int64_t chan0, int64_t nchan_total,
+                                                        const double2 *__restrict__ grids, int64_t nu, int64_t nv,
+                                                        double cellx, double celly, double beta, double w0, double dw,
+                                                        int pk0, int pk1, int do_w, const unsigned char *__restrict__ mask,
+                                                        const int *__restrict__ perm, double2 *__restrict__ vis)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrow * nchan_b) return;
-    const int64_t r = i / nchan_b, c = i - r * nchan_b;
+    const int64_t p = i / nchan_b, c = i - p * nchan_b;
+    const int64_t r = perm ? perm[p] : p;                   // rows in uv-tile order
     const int64_t o = r * nchan_total + chan0 + c;
     if (mask && !mask[o]) return;
     const double fl = freq[c] / AF_LIGHTSPEED;
-    const double inv_half_w = 2.0 / (double)W;
-    double kw = 1.0;
+    constexpr double inv_half_w = 2.0 / (double)W;
+    double gw = 0.0;
+    int k0 = 0, k1 = 1;                                 // this visibility's planes [k0, k1), clipped to the batch
     if (do_w) {
-        const double gw = (uvw[3 * r + 2] * fl - w0) / dw - (double)k;
-        if (!(fabs(gw) < 0.5 * W)) return;
-        kw = es_kernel(gw, inv_half_w, beta);
+        gw = (uvw[3 * r + 2] * fl - w0) / dw;
+        if (!isfinite(gw)) return;
+        k0 = (int)ceil(gw - 0.5 * W);
+        k1 = k0 + W;
+        k0 = k0 < pk0 ? pk0 : k0;
+        k1 = k1 > pk1 ? pk1 : k1;
+        if (k0 >= k1) return;
     }
     const double gu = uvw[3 * r] * fl * cellx * (double)nu, gv = uvw[3 * r + 1] * fl * celly * (double)nv;
     if (!(isfinite(gu) && isfinite(gv))) return;
     const int64_t iu0 = (int64_t)ceil(gu - 0.5 * W), iv0 = (int64_t)ceil(gv - 0.5 * W);
-    double ku[WG_MAXW], kv[WG_MAXW];
+    double ku[W], kv[W];
+    int pu[W], pv[W];
+#pragma unroll
     for (int t = 0; t < W; ++t) {
         ku[t] = es_kernel((double)(iu0 + t) - gu, inv_half_w, beta);
         kv[t] = es_kernel((double)(iv0 + t) - gv, inv_half_w, beta);
+        pu[t] = (int)(((iu0 + t) % nu + nu) % nu);
+        pv[t] = (int)(((iv0 + t) % nv + nv) % nv);
     }
     double are = 0.0, aim = 0.0;
-    for (int a = 0; a < W; ++a) {
-        const int64_t pu = ((iu0 + a) % nu + nu) % nu;
-        double rre = 0.0, rim = 0.0;
-        for (int b = 0; b < W; ++b) {
-            const int64_t pv = ((iv0 + b) % nv + nv) % nv;
-            const double2 g = grid[pu * nv + pv];
-            rre = fma(kv[b], g.x, rre);
-            rim = fma(kv[b], g.y, rim);
+    for (int k = k0; k < k1; ++k) {
+        const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+        const double2 *__restrict__ grid = grids + (int64_t)(k - pk0) * nu * nv;
+        double pre = 0.0, pim = 0.0;
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+            const double2 *__restrict__ row = grid + (int64_t)pu[a] * nv;
+            double rre = 0.0, rim = 0.0;
+#pragma unroll
+            for (int b = 0; b < W; ++b) {
+                const double2 g = row[pv[b]];
+                rre = fma(kv[b], g.x, rre);
+                rim = fma(kv[b], g.y, rim);
+            }
+            pre = fma(ku[a], rre, pre);
+            pim = fma(ku[a], rim, pim);
         }
-        are = fma(ku[a], rre, are);
-        aim = fma(ku[a], rim, aim);
+        are = fma(kw, pre, are);
+        aim = fma(kw, pim, aim);
     }
     double2 acc = vis[o];
-    acc.x = fma(kw, are, acc.x);
-    acc.y = fma(kw, aim, acc.y);
+    acc.x += are;
+    acc.y += aim;
     vis[o] = acc;
 }
 
@@ -142,13 +218,16 @@ __global__ void wg_finish(double2 *__restrict__ vis, const double *__restrict__ 
     vis[o] = v;
 }
 
-struct WgWs { size_t grid, A, nm1, total; };
-WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv)
+struct WgWs { size_t hist, perm, key, grid, A, nm1, total; };
+WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow)
 {
     WgWs w;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
-    w.grid = take((size_t)(nu * nv) * 2 * sizeof(double));
+    w.hist = take(WG_NBIN * sizeof(int));
+    w.perm = take((size_t)nrow * sizeof(int));
+    w.key = take((size_t)nrow * sizeof(unsigned short));
+    w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
     w.total = o;
@@ -177,10 +256,23 @@ int plan_for(int nu, int nv, hipfftHandle *out)
 // padded grid size of an image axis: twice the pixels, rounded up to a multiple of 16 (FFT-friendly, even)
 AF_EXPORT int64_t af_wgrid_padded(int64_t n) { return n <= 0 ? 0 : ((2 * n + 15) / 16) * 16; }
 
-AF_EXPORT size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny)
+// `planes` = number of w-plane grids the workspace holds at a time (>= 1; the call works through the planes in batches of
+// that many: one pass over the visibilities per batch)
+AF_EXPORT size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow)
 {
-    if (nx < 0 || ny < 0) return 0;
-    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny)).total;
+    if (nx < 0 || ny < 0 || planes < 0 || nrow < 0) return 0;
+    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny), planes, nrow).total;
+}
+
+// number of w-planes a call will work through: the wrapper sizes its workspace with it
+AF_EXPORT int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking)
+{
+    if (!do_wstacking) return 1;
+    if (!(std::isfinite(wl_min) && std::isfinite(wl_max) && wl_max >= wl_min && max_abs_nm1 >= 0.0)) return -1;
+    const double dw = 1.0 / (2.0 * 2.0 * (max_abs_nm1 > 1e-12 ? max_abs_nm1 : 1e-12));
+    const double span = (wl_max - wl_min) / (dw > 1e12 ? 1e12 : dw);
+    if (!(span < 1e6)) return -1;
+    return (int64_t)ceil(span) + kernel_width + 1;
 }
 
 // One imaging band.  uvw (nrow,3) [m]; freq (nchan_band) [Hz]: the band's channels, which are columns chan0 .. of the
@@ -196,16 +288,19 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
 {
     AF_REQUIRE(nrow >= 0 && nchan_band >= 0 && nx >= 1 && ny >= 1 && chan0 >= 0 && chan0 + nchan_band <= nchan_total,
                "af_wgrid_im2vis_f64: bad extents");
-    AF_REQUIRE(kernel_width >= 2 && kernel_width <= WG_MAXW, "af_wgrid_im2vis_f64: kernel width %d not in 2..%d", kernel_width,
+    AF_REQUIRE(kernel_width >= 4 && kernel_width <= WG_MAXW, "af_wgrid_im2vis_f64: kernel width %d not in 4..%d", kernel_width,
                WG_MAXW);
     hipStream_t st = af_stream(stream);
     if (nrow == 0 || nchan_band == 0) return AF_OK;
     AF_REQUIRE(uvw && freq && image && corr_u && corr_v && quad_t && quad_w && vis, "af_wgrid_im2vis_f64: NULL array");
     const int64_t nu = af_wgrid_padded(nx), nv = af_wgrid_padded(ny);
     AF_REQUIRE(nu < (1LL << 15) && nv < (1LL << 15), "af_wgrid_im2vis_f64: image too large");
-    const WgWs L = wg_ws(nx, ny, nu, nv);
-    AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total, "af_wgrid_im2vis_f64: workspace too small (%zu < %zu)",
-               workspace_bytes, L.total);
+    // as many resident planes as the workspace holds
+    const size_t one = wg_ws(nx, ny, nu, nv, 1, nrow).total, per_plane = (size_t)(nu * nv) * 16;
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= one, "af_wgrid_im2vis_f64: workspace too small (%zu < %zu)",
+               workspace_bytes, one);
+    const int64_t resident = 1 + (int64_t)((workspace_bytes - one) / per_plane);
+    const WgWs L = wg_ws(nx, ny, nu, nv, resident, nrow);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_wgrid_im2vis_f64: workspace must be 256-byte aligned");
     char *ws = static_cast<char *>(workspace);
     double2 *grid = reinterpret_cast<double2 *>(ws + L.grid);
@@ -230,25 +325,58 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
     AF_LAUNCH_CHECK();
     // the band's columns start from zero
     AF_HIP(hipMemset2DAsync(vis + 2 * chan0, (size_t)nchan_total * 16, 0, (size_t)nchan_band * 16, (size_t)nrow, st));
+    const int *perm = nullptr;
+    if (nrow >= 4096 && nrow < (1LL << 31)) {
+        int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
+        unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
+        AF_HIP(hipMemsetAsync(hist, 0, WG_NBIN * sizeof(int), st));
+        hipLaunchKernelGGL(wg_bin_rows, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow, freq, nchan_band,
+                           cellx, celly, key, hist);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_scan_bins, dim3(1), dim3(1024), 0, st, hist);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_scatter_rows, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, key, nrow, hist, pm);
+        AF_LAUNCH_CHECK();
+        perm = pm;
+    }
     hipfftHandle plan;
     int rc = plan_for((int)nu, (int)nv, &plan);
     if (rc != AF_OK) return rc;
     af_prof_begin(st);
-    for (int k = 0; k < nplanes; ++k) {
-        AF_HIP(hipMemsetAsync(grid, 0, (size_t)(nu * nv) * 16, st));
-        hipLaunchKernelGGL(wg_fill_plane, dim3(nb_img), dim3(256), 0, st, image, A, nm1, nx, ny, nu, nv, w0 + k * dw, grid);
-        AF_LAUNCH_CHECK();
-        {
+    for (int pk0 = 0; pk0 < nplanes; pk0 += (int)resident) {
+        const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
+        for (int k = pk0; k < pk1; ++k) {
+            double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
+            AF_HIP(hipMemsetAsync(gk, 0, (size_t)(nu * nv) * 16, st));
+            hipLaunchKernelGGL(wg_fill_plane, dim3(nb_img), dim3(256), 0, st, image, A, nm1, nx, ny, nu, nv, w0 + k * dw, gk);
+            AF_LAUNCH_CHECK();
             std::lock_guard<std::mutex> g(g_plan_mu);   // a plan carries its stream: set and enqueue together
             hipfftResult fr = hipfftSetStream(plan, st);
             if (fr == HIPFFT_SUCCESS)
-                fr = hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(grid),
-                                   reinterpret_cast<hipfftDoubleComplex *>(grid), HIPFFT_FORWARD);
+                fr = hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(gk),
+                                   reinterpret_cast<hipfftDoubleComplex *>(gk), HIPFFT_FORWARD);
             AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT failed (%d)", (int)fr);
         }
-        hipLaunchKernelGGL(wg_degrid_plane, dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0, nchan_total,
-                           grid, nu, nv, cellx, celly, kernel_width, beta, w0, dw, k, do_wstacking, mask,
-                           reinterpret_cast<double2 *>(vis));
+#define AF_WG_LAUNCH(WC)                                                                                               \
+    hipLaunchKernelGGL((wg_degrid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,       \
+                       nchan_total, grid, nu, nv, cellx, celly, beta, w0, dw, pk0, pk1, do_wstacking, mask, perm,        \
+                       reinterpret_cast<double2 *>(vis))
+        switch (kernel_width) {
+        case 4: AF_WG_LAUNCH(4); break;
+        case 5: AF_WG_LAUNCH(5); break;
+        case 6: AF_WG_LAUNCH(6); break;
+        case 7: AF_WG_LAUNCH(7); break;
+        case 8: AF_WG_LAUNCH(8); break;
+        case 9: AF_WG_LAUNCH(9); break;
+        case 10: AF_WG_LAUNCH(10); break;
+        case 11: AF_WG_LAUNCH(11); break;
+        case 12: AF_WG_LAUNCH(12); break;
+        case 13: AF_WG_LAUNCH(13); break;
+        case 14: AF_WG_LAUNCH(14); break;
+        case 15: AF_WG_LAUNCH(15); break;
+        default: AF_WG_LAUNCH(16); break;
+        }
+#undef AF_WG_LAUNCH
         AF_LAUNCH_CHECK();
     }
     af_prof_end(st);

@@ -8,6 +8,7 @@ from ..._device import Call, _is_torch, np_dtype_of
 
 LIGHTSPEED = 2.99792458e8
 _NQUAD = 48
+PLANE_BUDGET = 48 << 30      # bytes of w-plane grids kept resident per call (288 GB of HBM per GPU)
 
 
 def kernel_parameters(epsilon):
@@ -99,15 +100,25 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
         p_out, h = c.out((nrow, nchan), np.complex128)
         if nrow * nchan:
             _lib.call("af_memset", p_out, 0, nrow * nchan * 16, c.stream)     # channels outside every band stay 0
-        ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny))
-        p_ws = c.scratch(ws_bytes)
         import ctypes
+        # per band: the range of w nu / c; the workspace holds as many w-plane grids as the largest band needs, within
+        # PLANE_BUDGET bytes (beyond it the planes are worked through in batches)
+        bands = []
         for b in range(nband):
             c0, nc = int(fbi[b]), int(fbc[b])
             if nc == 0 or nrow == 0:
                 continue
             f = fhost[c0:c0 + nc] / LIGHTSPEED
             cands = (wmin * f.min(), wmin * f.max(), wmax * f.min(), wmax * f.max())
+            npl = int(lib.af_wgrid_planes(float(min(cands)), float(max(cands)), float(max_nm1), W, int(bool(do_wstacking))))
+            if npl < 1:
+                raise ValueError("w range of band %d is not finite or needs more than 1e6 w-planes" % b)
+            bands.append((b, c0, nc, cands, npl))
+        want = max([x[4] for x in bands] + [1])
+        resident = max(1, min(want, PLANE_BUDGET // (nu * nv * 16)))
+        ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny, resident, nrow))
+        p_ws = c.scratch(ws_bytes)
+        for b, c0, nc, cands, npl in bands:
             _lib.call("af_wgrid_im2vis_f64", p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,
                       ctypes.c_void_p(p_img.value + 8 * b * nx * ny), nx, ny, float(cell), float(celly), p_cu, p_cv, p_qt,
                       p_qw, W, beta, float(min(cands)), float(max(cands)), float(max_nm1), int(bool(do_wstacking)), p_wgt,

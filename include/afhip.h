@@ -400,7 +400,9 @@ int af_fused_predict_model_c128(const double *stokes, const double *spi, const d
  * band (HOST scalars, they size the w-plane loop); max_abs_nm1: largest |n - 1| of the image.  All device work is
  * enqueued on `stream`; uses hipFFT (plans cached per device and size, released by af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);
-size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny);
+/* planes: w-plane grids resident at a time (>= 1; af_wgrid_planes() of them = a single pass over the visibilities) */
+size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow);
+int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking);
 int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
                         int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx, double celly,
                         const double *corr_u, const double *corr_v, const double *quad_t, const double *quad_w,
