@@ -218,14 +218,27 @@ class FusedDde(object):
         pe = 1e-3 * rng.standard_normal((ntime, nant, nchan, 2))
         asc = 1.0 + 1e-3 * rng.standard_normal((nant, nchan, 2))
         X = np.ascontiguousarray(np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4))).reshape(nsrc, nchan, 2, 2)
-        n_items = ctypes.c_int64(0)
+        # the plan (host side, once per row layout): 2 x 2 blocks of baselines that share their antennas' Jones terms
+        # (AFHIP_FUSED_GROUPS=0: plain row ranges, for A/B runs)
+        n_items, n_groups = ctypes.c_int64(0), ctypes.c_int64(0)
         tip = time_index.ctypes.data_as(ctypes.c_void_p)
-        _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
-        items = np.zeros((n_items.value, 4), dtype=np.int32)
-        _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
-                  ctypes.byref(n_items))
+        pa1, pa2 = ant1.ctypes.data_as(ctypes.c_void_p), ant2.ctypes.data_as(ctypes.c_void_p)
+        if os.environ.get("AFHIP_FUSED_GROUPS", "1") != "0":
+            _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, None, 0, ctypes.byref(n_items), None, 0,
+                      ctypes.byref(n_groups))
+            items = np.zeros((n_items.value, 4), dtype=np.int32)
+            groups = np.zeros((n_groups.value, 8), dtype=np.int32)
+            _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, items.ctypes.data_as(ctypes.c_void_p),
+                      n_items.value, ctypes.byref(n_items), groups.ctypes.data_as(ctypes.c_void_p), n_groups.value,
+                      ctypes.byref(n_groups))
+        else:
+            groups = None
+            _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+            items = np.zeros((n_items.value, 4), dtype=np.int32)
+            _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
+                      ctypes.byref(n_items))
         self.n_items, self.ntime, self.nbl = n_items.value, ntime, nbl
-        self.dv = dict(items=t(items), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
+        self.dv = dict(items=t(items), groups=None if groups is None else t(groups), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
                        fmap=t(beam_freq_map), pa=t(pa), pe=t(pe), asc=t(asc), lm=t(lm), uvw=t(uvw), freq=t(freq))
         self.ws_bytes = int(lib.af_fused_predict_workspace_bytes(nsrc, nchan, self.LW, self.MH, self.NUD))
         self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
@@ -237,7 +250,8 @@ class FusedDde(object):
 
     def predict(self, d_vis, stream, P):
         a, v = self.args, self.dv
-        self._lib.call("af_fused_predict_c128", P(v["items"]), self.n_items, P(v["a1"]), P(v["a2"]), a.rows,
+        self._lib.call("af_fused_predict_c128", P(v["items"]), self.n_items, P(v["a1"]), P(v["a2"]),
+                       None if v["groups"] is None else P(v["groups"]), a.rows,
                        P(v["lm"]), P(v["uvw"]), P(v["freq"]), P(v["X"]), a.sources, a.chans, P(v["beam"]), self.LW,
                        self.MH, self.NUD, P(v["ext"]), P(v["fmap"]), P(v["pa"]), self.ntime, self.NANT, P(v["pe"]),
                        P(v["asc"]), None, None, self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws),

@@ -82,7 +82,9 @@ _SIGNATURES = {
                                     _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "af_fused_plan_rows": (_int, [_vp, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
     "af_fused_predict_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
-    "af_fused_predict_c128": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+    "af_fused_plan_groups": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64), _vp, _i64,
+                                    ctypes.POINTER(_i64)]),
+    "af_fused_predict_c128": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                      _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_chi2_c128": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "af_feed_rotation_f64": (_int, [_vp, _i64, _int, _vp, _vp]),
@@ -105,7 +107,7 @@ _SIGNATURES = {
     "af_im_to_vis_model_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _i64, _i64,
                                       _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "af_fused_predict_model_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64]),
-    "af_fused_predict_model_c128": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+    "af_fused_predict_model_c128": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp,
                                            _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
                                            _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_wgrid_padded": (_i64, [_i64]),

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "af_common.h"
 #include "af_beam_device.h"
@@ -39,6 +40,7 @@ namespace {
 
 constexpr int THREADS = 512;
 constexpr int RPT = 4;  // rows per lane
+constexpr int PLANE_PAD = 4;   // double2 elements of padding per (source, component) plane of the Jones arrays in LDS
 
 struct FusedWs {
     size_t lmn, f4, freq_data, gauss, planes, total;
@@ -288,9 +290,15 @@ __device__ __forceinline__ C2 table_phasor(const double2 *__restrict__ table, do
 // (L1-fill bound), whose stalls the other two fill.
 // ST > 0: the batch size `st` is the compile-time constant ST (and NP > 0): stage 2's source loop is unrolled and every
 // Jones read is one per-row base address (set once per batch) plus an immediate offset.
-template <bool FEED, bool GAUSS, int NP, bool WS, int ST>
+// GR (grouped rows): items list GROUPS of up to four rows (p_i, q_j), i, j in {0, 1} -- 2 x 2 blocks of baselines that
+// share their antennas (af_fused_plan_groups) -- instead of row ranges.  A lane owns one group: the Jones terms of p0, p1
+// (G) and q0, q1 (E) serve four rows, 5 LDS reads per (row, source) instead of 8 (G p0, E q0 | E q1 | G p1 | E q0 again:
+// with no more live registers than the row-by-row form), and the planes hold even and odd antennas in separate halves so
+// that the lanes' q0 = 0, 2, 4, ... (and q1 = 1, 3, ...) are contiguous 16-byte elements: conflict-free reads.
+template <bool FEED, bool GAUSS, int NP, bool WS, int ST, bool GR>
 __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_predict_kernel(
     const int32_t *__restrict__ items, const int32_t *__restrict__ ant1, const int32_t *__restrict__ ant2,
+    const int32_t *__restrict__ groups,
     const double *__restrict__ uvw, const double *__restrict__ lmn, const double *__restrict__ f4,
     const double2 *__restrict__ brightness, const double *__restrict__ vrec,
     int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
@@ -301,7 +309,15 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
 {
     extern __shared__ double2 lds[];
     const int np = NP > 0 ? NP : nant;
+    // double2 elements between the component planes of a source's Jones terms: the antenna stride plus 4 (64 bytes),
+    // so that the four lanes of a quad, which write the four components of ONE term, hit four different bank groups
+    // (at a plane stride of np * 16 bytes = a multiple of the 256-byte bank width they all hit the same one: measured,
+    // a quarter of the kernel's LDS cycles were conflicts, 27 % of those from these writes)
+    const int npp = np + PLANE_PAD;
     const int st = ST > 0 ? ST : st_arg;
+    // element of antenna a inside a plane: GR splits the plane into an even-antenna and an odd-antenna half
+    const int half = npp >> 1;
+    auto slot_of = [&](int a) { return GR ? (a & 1) * half + (a >> 1) : a; };
     constexpr int NBUF = WS ? 2 : 1;              // Jones buffers: E then G, each [st][4][np]
     constexpr int NTHREADS = WS ? THREADS + THREADS / 2 : THREADS;
     constexpr int PLANES = WS ? THREADS / 2 : THREADS;   // lanes that sample the beam
@@ -317,25 +333,43 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     const double FT = f4[f] * (PH_TABLE / 4.0), NU = freq[f];   // 1/PH_TABLE turns per metre (exact scaling of f4)
     double u[RPT], v[RPT], w[RPT], us[RPT], vs[RPT], ws[RPT];
     int a1[RPT], a2[RPT];
-    bool live[RPT];
     C2 acc[RPT][4];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int rl = tid + k * THREADS;
-        live[k] = consumer && rl < rc;
-        const int64_t r = r0 + (live[k] ? rl : 0);
+        int64_t r;
+        if constexpr (GR) {
+            // item = (time, first group, group count): lane tid owns group r0 + tid; slot k = (i, j) = (k >> 1, k & 1)
+            const bool have = consumer && tid < rc;
+            const int32_t *g = groups + (r0 + (have ? tid : 0)) * 8;
+            const int gr = g[4 + k];
+            r = (have && gr >= 0) ? gr : 0;
+            a1[k] = g[k >> 1];          // p_i
+            a2[k] = g[2 + (k & 1)];     // q_j
+        } else {
+            r = r0 + ((consumer && rl < rc) ? rl : 0);
+        }
         u[k] = uvw[3 * r]; v[k] = uvw[3 * r + 1]; w[k] = uvw[3 * r + 2];
-        a1[k] = ant1[r]; a2[k] = ant2[r];
+        if constexpr (!GR) { a1[k] = ant1[r]; a2[k] = ant2[r]; }
         // this channel's table units per metre folded into the row's coordinates (one operation less per
         // (row, source); the Gaussian shape keeps the plain coordinates)
         us[k] = __dmul_rn(u[k], FT); vs[k] = __dmul_rn(v[k], FT); ws[k] = __dmul_rn(w[k], FT);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
     }
+    // element offsets (double2 units, from the start of the dynamic LDS) of this lane's Jones terms in the CURRENT
+    // buffer: E planes of antenna2 / q, G planes of antenna1 / p.  Kept up to date in place from batch to batch (the
+    // buffers alternate), so that the loop carries one register per operand and every read is offset + constant.
+    int eoff[RPT], goff[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        eoff[k] = slot_of(a2[k]);
+        goff[k] = st * 4 * npp + slot_of(a1[k]);
+    }
 
     // ---- stage-1 state: per-antenna constants of this (timestep, channel) in LDS ------------------
     // ldsA[a] = (sin pa, cos pa, pe_l, pe_m, as_l, as_m); ldsR[a] = the antenna's 2x2 feed rotation (optional)
-    double *ldsA = reinterpret_cast<double *>(lds + (size_t)NBUF * 2 * st * 4 * np);
+    double *ldsA = reinterpret_cast<double *>(lds + (size_t)NBUF * 2 * st * 4 * npp);
     double2 *ldsR = reinterpret_cast<double2 *>(ldsA + (size_t)6 * nant);
     double2 *ldsT = ldsR + (size_t)4 * nant;      // phasor table
     fine_table_init(ldsT, tid, NTHREADS);
@@ -459,8 +493,8 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                 G = cmul(E0, B0);
                 cmac(G, E1, B1);
                 if (have_task) {
-                    ldsE[((size_t)e_sl * 4 + e_corr) * np + e_ant] = e;
-                    ldsG[((size_t)e_sl * 4 + e_corr) * np + e_ant] = have ? make_double2(G.re, G.im)
+                    ldsE[((size_t)e_sl * 4 + e_corr) * npp + slot_of(e_ant)] = e;
+                    ldsG[((size_t)e_sl * 4 + e_corr) * npp + slot_of(e_ant)] = have ? make_double2(G.re, G.im)
                                                                           : make_double2(0.0, 0.0);
                 }
             };
@@ -477,13 +511,9 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
             issue(I3{}, R); finish(R);
         }
     };
-    auto stage2 = [&](int s0, const double2 *ldsE, const double2 *ldsG) {
+    auto stage2 = [&](int s0) {
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
-        // per-row base addresses of the batch's Jones terms: the reads below are base + a constant
-        const double2 *rowG[RPT], *rowE[RPT];
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) { rowG[k] = ldsG + a1[k]; rowE[k] = ldsE + a2[k]; }
         auto one_source = [&](int sl) {
             // ST > 0 always walks whole batches: a source beyond the last one has E = G = 0 in LDS (stage 1 writes
             // zeros for it) and adds exactly nothing; only its coordinates must come from a valid address
@@ -504,30 +534,45 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                     }
                 }
             }
-            const int so = sl * 4 * np;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                C2 y = table_phasor(ldsT, fma(n, ws[k], fma(m, vs[k], __dmul_rn(l, us[k]))));
-                if constexpr (GAUSS) {
-                    if (extended) { y.re *= shape[k]; y.im *= shape[k]; }
-                }
-                C2 Gp[4], Eq[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double2 g = rowG[k][so + c * np], e = rowE[k][so + c * np];
-                    Gp[c].re = g.x; Gp[c].im = g.y;
-                    Eq[c].re = e.x; Eq[c].im = e.y;
-                }
-                // M = G_p . E_q^H :  M[i][j] = sum_k G[i][k] conj(E[j][k])
-                C2 M0 = cmulc(Gp[0], Eq[0]); cmacc(M0, Gp[1], Eq[1]);
-                C2 M1 = cmulc(Gp[0], Eq[2]); cmacc(M1, Gp[1], Eq[3]);
-                C2 M2 = cmulc(Gp[2], Eq[0]); cmacc(M2, Gp[3], Eq[1]);
-                C2 M3 = cmulc(Gp[2], Eq[2]); cmacc(M3, Gp[3], Eq[3]);
-                cmac(acc[k][0], y, M0);
-                cmac(acc[k][1], y, M1);
-                cmac(acc[k][2], y, M2);
-                cmac(acc[k][3], y, M3);
+            const int so = sl * 4 * npp;
+            // Jones operands of the row being worked on (re-used across the slots of a group)
+            C2 Gp0, Gp1, Gp2, Gp3, Eq0, Eq1, Eq2, Eq3;
+#define AF_LOAD_G(off) do { const double2 *b_ = lds + ((off) + so);                                                   \
+        double2 x0 = b_[0], x1 = b_[npp], x2 = b_[2 * npp], x3 = b_[3 * npp];                                    \
+        Gp0.re = x0.x; Gp0.im = x0.y; Gp1.re = x1.x; Gp1.im = x1.y; Gp2.re = x2.x; Gp2.im = x2.y;                 \
+        Gp3.re = x3.x; Gp3.im = x3.y; } while (0)
+#define AF_LOAD_E(off) do { const double2 *b_ = lds + ((off) + so);                                                   \
+        double2 x0 = b_[0], x1 = b_[npp], x2 = b_[2 * npp], x3 = b_[3 * npp];                                    \
+        Eq0.re = x0.x; Eq0.im = x0.y; Eq1.re = x1.x; Eq1.im = x1.y; Eq2.re = x2.x; Eq2.im = x2.y;                 \
+        Eq3.re = x3.x; Eq3.im = x3.y; } while (0)
+            // acc[k] += y M,  M = G_p . E_q^H :  M[i][j] = sum_k G[i][k] conj(E[j][k]).  The phasor first, then the
+            // operand loads LOADS (none when the previous slot's operands serve), then the algebra: the operands are not
+            // live while the phasor's temporaries are
+#define AF_ROW(k, LOADS) do {                                                                                   \
+        C2 y = table_phasor(ldsT, fma(n, ws[k], fma(m, vs[k], __dmul_rn(l, us[k]))));                            \
+        if constexpr (GAUSS) { if (extended) { y.re *= shape[k]; y.im *= shape[k]; } }                           \
+        LOADS;                                                                                                   \
+        C2 M0 = cmulc(Gp0, Eq0); cmacc(M0, Gp1, Eq1);                                                            \
+        C2 M1 = cmulc(Gp0, Eq2); cmacc(M1, Gp1, Eq3);                                                            \
+        C2 M2 = cmulc(Gp2, Eq0); cmacc(M2, Gp3, Eq1);                                                            \
+        C2 M3 = cmulc(Gp2, Eq2); cmacc(M3, Gp3, Eq3);                                                            \
+        cmac(acc[k][0], y, M0); cmac(acc[k][1], y, M1); cmac(acc[k][2], y, M2); cmac(acc[k][3], y, M3);          \
+    } while (0)
+            if constexpr (GR) {
+                // slots k = 2 i + j: (p0,q0) (p0,q1) (p1,q1) (p1,q0); every operand change is one 4-read load
+                AF_ROW(0, AF_LOAD_G(goff[0]); AF_LOAD_E(eoff[0]));
+                AF_ROW(1, AF_LOAD_E(eoff[1]));
+                AF_ROW(3, AF_LOAD_G(goff[2]));
+                AF_ROW(2, AF_LOAD_E(eoff[0]));
+            } else {
+                AF_ROW(0, AF_LOAD_G(goff[0]); AF_LOAD_E(eoff[0]));
+                AF_ROW(1, AF_LOAD_G(goff[1]); AF_LOAD_E(eoff[1]));
+                AF_ROW(2, AF_LOAD_G(goff[2]); AF_LOAD_E(eoff[2]));
+                AF_ROW(3, AF_LOAD_G(goff[3]); AF_LOAD_E(eoff[3]));
             }
+#undef AF_LOAD_G
+#undef AF_LOAD_E
+#undef AF_ROW
         };
         if (only_stage == 1) return;
         if constexpr (ST > 0) {
@@ -543,12 +588,12 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
             for (int sl = 0; sl < nb; ++sl) one_source(sl);
         }
     };
-    const size_t buf_elems = (size_t)2 * st * 4 * np;   // one buffer: E then G
+    const size_t buf_elems = (size_t)2 * st * 4 * npp;   // one buffer: E then G
     if constexpr (!WS) {
         for (int s0 = 0; s0 < nsrc; s0 += st) {
-            stage1(s0, lds, lds + (size_t)st * 4 * np);
+            stage1(s0, lds, lds + (size_t)st * 4 * npp);
             __syncthreads();
-            stage2(s0, lds, lds + (size_t)st * 4 * np);
+            stage2(s0);
             __syncthreads();
         }
     } else {
@@ -562,22 +607,32 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
             int b = 0;
             for (int s0 = 0; s0 < nsrc; s0 += st, ++b) {
                 double2 *E = lds + (size_t)(b & 1) * buf_elems;
-                stage1(s0, E, E + (size_t)st * 4 * np);
+                stage1(s0, E, E + (size_t)st * 4 * npp);
                 __syncthreads();
             }
             return;
         }
         int b = 0;
         for (int s0 = 0; s0 < nsrc; s0 += st, ++b) {
-            const double2 *E = lds + (size_t)(b & 1) * buf_elems;
             __syncthreads();
-            stage2(s0, E, E + (size_t)st * 4 * np);
+            stage2(s0);
+            // on to the other buffer, in place
+            const int step = (b & 1) ? -(int)buf_elems : (int)buf_elems;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) { eoff[k] += step; goff[k] += step; }
         }
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        if (live[k]) {
-            double2 *o = out + ((r0 + tid + k * THREADS) * nchan + f) * 4;
+        // where slot k goes (not kept in registers through the main loop)
+        int64_t orow = -1;
+        if constexpr (GR) {
+            if (tid < rc) orow = groups[(r0 + tid) * 8 + 4 + k];
+        } else {
+            if (tid + k * THREADS < rc) orow = r0 + tid + k * THREADS;
+        }
+        if (orow >= 0) {
+            double2 *o = out + (orow * nchan + f) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = make_double2(acc[k][c].re, acc[k][c].im);
         }
@@ -619,6 +674,107 @@ AF_EXPORT int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, i
     return AF_OK;
 }
 
+// Host-side planner of the grouped form (host pointers): every run of consecutive rows with equal time_index is cut
+// into GROUPS of up to four rows (p_i, q_j), i, j in {0, 1}: rows whose antennas fall into the same pair of antenna
+// pairs (antenna1 >> 1, antenna2 >> 1) share a group (slot 2 (antenna1 & 1) + (antenna2 & 1)); groups left with a
+// single row are then merged two by two (their rows become slots (0,0) and (1,1) of a group with unrelated p's and
+// q's), so that a 64-antenna timestep (2016 baselines) is 512 groups = one workgroup.  Any row order, repeated
+// baselines and autocorrelations are fine: a row that finds its slot taken opens another group.
+//   groups (ngroups, 8) int32: p0, p1, q0, q1, row(0,0), row(0,1), row(1,0), row(1,1)  (row = -1: empty slot)
+//   items  (nitems, 4)  int32: time_index - min(time_index), first group, group count (<= 512), 1
+// Two-call protocol: with items_host == NULL or groups_host == NULL only the counts are returned.
+AF_EXPORT int af_fused_plan_groups(const int64_t *time_index_host, const int32_t *antenna1_host,
+                                   const int32_t *antenna2_host, int64_t nrow, int64_t nant, int32_t *items_host,
+                                   int64_t max_items, int64_t *nitems, int32_t *groups_host, int64_t max_groups,
+                                   int64_t *ngroups)
+{
+    AF_REQUIRE(nitems != nullptr && ngroups != nullptr, "af_fused_plan_groups: count pointer is NULL");
+    *nitems = 0;
+    *ngroups = 0;
+    if (nrow == 0) return AF_OK;
+    AF_REQUIRE(time_index_host && antenna1_host && antenna2_host, "af_fused_plan_groups: NULL array");
+    AF_REQUIRE(nant >= 1 && nant <= 664 && nrow < (1LL << 31), "af_fused_plan_groups: bad extents");
+    const bool write = items_host != nullptr && groups_host != nullptr;
+    int64_t tmin = time_index_host[0];
+    for (int64_t r = 1; r < nrow; ++r) tmin = time_index_host[r] < tmin ? time_index_host[r] : tmin;
+    const int64_t hb = (nant + 1) / 2;
+    std::vector<int32_t> stamp((size_t)(hb * hb), -1), last((size_t)(hb * hb), 0);
+    struct Grp { int32_t p[2], q[2], row[4]; };
+    std::vector<Grp> run;
+    int64_t ni = 0, ng = 0, run_id = 0;
+    const int32_t top = (int32_t)nant - 1;
+    for (int64_t start = 0; start < nrow;) {
+        int64_t end = start + 1;
+        while (end < nrow && time_index_host[end] == time_index_host[start]) ++end;
+        run.clear();
+        for (int64_t r = start; r < end; ++r) {
+            const int32_t a1 = antenna1_host[r], a2 = antenna2_host[r];
+            AF_REQUIRE(a1 >= 0 && a1 < nant && a2 >= 0 && a2 < nant, "af_fused_plan_groups: antenna index out of range");
+            const size_t key = (size_t)(a1 >> 1) * hb + (a2 >> 1);
+            const int slot = 2 * (a1 & 1) + (a2 & 1);
+            int g = -1;
+            if (stamp[key] == (int32_t)run_id && run[(size_t)last[key]].row[slot] < 0) g = last[key];
+            if (g < 0) {
+                Grp G;
+                G.p[0] = a1 & ~1; G.p[1] = (a1 | 1) > top ? top : (a1 | 1);
+                G.q[0] = a2 & ~1; G.q[1] = (a2 | 1) > top ? top : (a2 | 1);
+                G.row[0] = G.row[1] = G.row[2] = G.row[3] = -1;
+                run.push_back(G);
+                g = (int)run.size() - 1;
+                stamp[key] = (int32_t)run_id;
+                last[key] = g;
+            }
+            run[(size_t)g].row[slot] = (int32_t)r;
+        }
+        ++run_id;
+        // merge the single-row groups two by two
+        std::vector<Grp> out;
+        out.reserve(run.size());
+        int pending = -1;
+        for (size_t g = 0; g < run.size(); ++g) {
+            int cnt = 0, slot = 0;
+            for (int k = 0; k < 4; ++k)
+                if (run[g].row[k] >= 0) { ++cnt; slot = k; }
+            if (cnt != 1) { out.push_back(run[g]); continue; }
+            Grp S;     // the single row as slot (0,0) of a group of its own antennas
+            S.p[0] = S.p[1] = run[g].p[slot >> 1]; S.q[0] = S.q[1] = run[g].q[slot & 1];
+            S.row[0] = run[g].row[slot]; S.row[1] = S.row[2] = S.row[3] = -1;
+            if (pending < 0) {
+                out.push_back(S);
+                pending = (int)out.size() - 1;
+            } else {   // second single: slot (1,1) of the pending group
+                out[(size_t)pending].p[1] = S.p[0];
+                out[(size_t)pending].q[1] = S.q[0];
+                out[(size_t)pending].row[3] = S.row[0];
+                pending = -1;
+            }
+        }
+        for (size_t g0 = 0; g0 < out.size(); g0 += THREADS) {
+            const size_t cnt = out.size() - g0 < (size_t)THREADS ? out.size() - g0 : (size_t)THREADS;
+            if (write) {
+                AF_REQUIRE(ni < max_items && ng + (int64_t)cnt <= max_groups, "af_fused_plan_groups: output arrays too small");
+                AF_REQUIRE(time_index_host[start] - tmin < (1LL << 31), "af_fused_plan_groups: index does not fit int32");
+                items_host[4 * ni + 0] = (int32_t)(time_index_host[start] - tmin);
+                items_host[4 * ni + 1] = (int32_t)ng;
+                items_host[4 * ni + 2] = (int32_t)cnt;
+                items_host[4 * ni + 3] = 1;
+                for (size_t k = 0; k < cnt; ++k) {
+                    const Grp &G = out[g0 + k];
+                    int32_t *o = groups_host + 8 * (ng + (int64_t)k);
+                    o[0] = G.p[0]; o[1] = G.p[1]; o[2] = G.q[0]; o[3] = G.q[1];
+                    o[4] = G.row[0]; o[5] = G.row[1]; o[6] = G.row[2]; o[7] = G.row[3];
+                }
+            }
+            ++ni;
+            ng += (int64_t)cnt;
+        }
+        start = end;
+    }
+    *nitems = ni;
+    *ngroups = ng;
+    return AF_OK;
+}
+
 AF_EXPORT size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
                                                   int64_t beam_nud)
 {
@@ -627,7 +783,8 @@ AF_EXPORT size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, i
 }
 
 AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *antenna1,
-                                    const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                                    const int32_t *antenna2, const int32_t *groups, int64_t nrow, const double *lm,
+                                    const double *uvw,
                                     const double *frequency, const double *brightness, int64_t nsrc, int64_t nchan,
                                     const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
                                     const double *beam_lm_extents, const double *beam_freq_map,
@@ -651,7 +808,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         AF_HIP(hipMemsetAsync(out, 0, sizeof(double) * 2 * 4 * (size_t)(nrow * nchan), st_));
         return AF_OK;
     }
-    AF_REQUIRE(items && antenna1 && antenna2 && lm && uvw && frequency && brightness && beam && beam_lm_extents &&
+    AF_REQUIRE(items && (groups || (antenna1 && antenna2)) && lm && uvw && frequency && brightness && beam && beam_lm_extents &&
                    beam_freq_map && parallactic_angles && point_errors && antenna_scaling,
                "af_fused_predict_c128: NULL array");
     const FusedWs W = fused_ws(nsrc, nchan, beam_lw, beam_mh, beam_nud);
@@ -690,9 +847,10 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // and no Gaussian shapes are folded in (that variant needs more than the 168 registers of 3 waves per SIMD);
     // AFHIP_FUSED_WS=0 selects the 8-wave kernel
     static const int ws_env = getenv("AFHIP_FUSED_WS") ? atoi(getenv("AFHIP_FUSED_WS")) : 1;
-    const bool ws_mode = ws_env != 0 && gauss_shape == nullptr && (160 * 1024 - fixed) / (256 * np) >= 2;
+    const int64_t npp = np + PLANE_PAD;   // padded plane stride of the Jones arrays (see the kernel)
+    const bool ws_mode = ws_env != 0 && gauss_shape == nullptr && (160 * 1024 - fixed) / (256 * npp) >= 2;
     const int nbuf = ws_mode ? 2 : 1;
-    int st = (int)((160 * 1024 - fixed) / (128 * nbuf * np));
+    int st = (int)((160 * 1024 - fixed) / (128 * nbuf * npp));
     if (st > 1024 / np) st = (int)(1024 / np);
     {   // whole super-rounds of the sampling lanes: st * np a multiple of their number (a partly filled super-round
         // costs as much as a full one: 9 sources x 64 antennas on 256 lanes ran 3 super-rounds for 2.25 of work)
@@ -703,7 +861,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     }
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    const size_t lds_bytes = (size_t)nbuf * 2 * st * 4 * np * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
+    const size_t lds_bytes = (size_t)nbuf * 2 * st * 4 * npp * sizeof(double2) + (size_t)nant * 6 * sizeof(double) +
                              (size_t)nant * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
     AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_c128: %zu bytes of LDS needed (nant = %lld)", lds_bytes,
                (long long)nant);
@@ -725,7 +883,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
             AF_LAUNCH_CHECK();
             if (f0 == 0) af_prof_begin(st_);
             hipLaunchKernelGGL(kernel, dim3((unsigned)nitems, (unsigned)nf), dim3(nthreads), lds_bytes, st_, items, antenna1,
-                               antenna2, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw,
+                               antenna2, groups, uvw, lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw,
                                beam_mh, beam_nud, beam_lm_extents, freq_data, parallactic_angles, point_errors,
                                antenna_scaling, reinterpret_cast<const double2 *>(feed_rotation), gp, frequency, (int)nsrc,
                                nchan, ntime, (int)nant, st, reinterpret_cast<double2 *>(out), only_stage, f0);
@@ -734,17 +892,23 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         }
         return AF_OK;
     };
-#define AF_FUSED_PICK(NPC, STC)                                                                                          \
-    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true, STC>, THREADS + THREADS / 2)                     \
-                     : launch(fused_predict_kernel<false, false, NPC, true, STC>, THREADS + THREADS / 2))                   \
-             : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false, 0>, THREADS)                            \
-                              : launch(fused_predict_kernel<true, false, NPC, false, 0>, THREADS))                          \
-                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, false, 0>, THREADS)                           \
-                              : launch(fused_predict_kernel<false, false, NPC, false, 0>, THREADS))))
-    // the 64-antenna-stride, wave-specialised, 8-sources-per-batch case (BASELINE configs[2]) has its source loop unrolled
+#define AF_FUSED_PICK(NPC, STC, GRC)                                                                                     \
+    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true, STC, GRC>, THREADS + THREADS / 2)                \
+                     : launch(fused_predict_kernel<false, false, NPC, true, STC, GRC>, THREADS + THREADS / 2))              \
+             : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false, 0, false>, THREADS)                     \
+                              : launch(fused_predict_kernel<true, false, NPC, false, 0, false>, THREADS))                   \
+                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, false, 0, false>, THREADS)                    \
+                              : launch(fused_predict_kernel<false, false, NPC, false, 0, false>, THREADS))))
+    // the grouped form (items of af_fused_plan_groups) exists for the wave-specialised kernels; the 64-antenna-stride,
+    // 8-sources-per-batch case (BASELINE configs[2]) has its source loop unrolled
     static const int unroll_env = getenv("AFHIP_FUSED_UNROLL") ? atoi(getenv("AFHIP_FUSED_UNROLL")) : 1;   // A/B hook
-    if (NPv == 64 && ws_mode && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8);
-    else rc = NPv == 64 ? AF_FUSED_PICK(64, 0) : NPv == 128 ? AF_FUSED_PICK(128, 0) : AF_FUSED_PICK(0, 0);
+    AF_REQUIRE(groups == nullptr || ws_mode, "af_fused_predict_c128: grouped items need the wave-specialised kernel "
+                                             "(no Gaussian shapes, AFHIP_FUSED_WS != 0): plan with af_fused_plan_rows");
+    if (groups != nullptr) {
+        if (NPv == 64 && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8, true);
+        else rc = NPv == 64 ? AF_FUSED_PICK(64, 0, true) : NPv == 128 ? AF_FUSED_PICK(128, 0, true) : AF_FUSED_PICK(0, 0, true);
+    } else if (NPv == 64 && ws_mode && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8, false);
+    else rc = NPv == 64 ? AF_FUSED_PICK(64, 0, false) : NPv == 128 ? AF_FUSED_PICK(128, 0, false) : AF_FUSED_PICK(0, 0, false);
 #undef AF_FUSED_PICK
     return rc;
 }

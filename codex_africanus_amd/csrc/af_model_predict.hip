@@ -79,7 +79,8 @@ AF_EXPORT size_t af_fused_predict_model_workspace_bytes(int64_t nsrc, int64_t nc
 AF_EXPORT int af_fused_predict_model_c128(const double *stokes, const double *spi, const double *ref_freq, const int *base,
                                           int64_t nspi, int64_t npol, const int *src1_host, const int *src2_host,
                                           const int *op_host, const int32_t *items, int64_t nitems, const int32_t *antenna1,
-                                          const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                                          const int32_t *antenna2, const int32_t *groups, int64_t nrow, const double *lm,
+                                          const double *uvw,
                                           const double *frequency, int64_t nsrc, int64_t nchan, const double *beam,
                                           int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *beam_lm_extents,
                                           const double *beam_freq_map, const double *parallactic_angles, int64_t ntime,
@@ -101,7 +102,7 @@ AF_EXPORT int af_fused_predict_model_c128(const double *stokes, const double *sp
                              1, reinterpret_cast<double *>(ws + W.spec), brightness, stream);
         if (rc != AF_OK) return rc;
     }
-    return af_fused_predict_c128(items, nitems, antenna1, antenna2, nrow, lm, uvw, frequency, brightness, nsrc, nchan, beam,
+    return af_fused_predict_c128(items, nitems, antenna1, antenna2, groups, nrow, lm, uvw, frequency, brightness, nsrc, nchan, beam,
                                  beam_lw, beam_mh, beam_nud, beam_lm_extents, beam_freq_map, parallactic_angles, ntime, nant,
                                  point_errors, antenna_scaling, feed_rotation, gauss_shape, convention, out, ws + W.rest, rest,
                                  stream);

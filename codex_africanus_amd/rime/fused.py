@@ -12,6 +12,7 @@ The reference's own counterpart is the experimental fused RIME
 (africanus/experimental/rime/fused/core.py:88-120).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -142,10 +143,29 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("antenna index out of range")
             n_items = ctypes.c_int64(0)
             tip = ti.ctypes.data_as(ctypes.c_void_p)
-            _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
-            items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
-            _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p),
-                      n_items.value, ctypes.byref(n_items))
+            # the wave-specialised kernel (no Gaussian shapes) takes the grouped plan: 2 x 2 blocks of baselines that
+            # share their antennas' Jones terms; otherwise plain row ranges
+            # (that kernel double-buffers the Jones terms in LDS: up to ~230 antennas)
+            grouped = gauss_shape is None and nant <= 230 and os.environ.get("AFHIP_FUSED_WS", "1") != "0" and \
+                os.environ.get("AFHIP_FUSED_GROUPS", "1") != "0"
+            p_groups = None
+            if grouped:
+                a1i, a2i = np.ascontiguousarray(a1h, dtype=np.int32), np.ascontiguousarray(a2h, dtype=np.int32)
+                n_groups = ctypes.c_int64(0)
+                pa1, pa2 = a1i.ctypes.data_as(ctypes.c_void_p), a2i.ctypes.data_as(ctypes.c_void_p)
+                _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, None, 0, ctypes.byref(n_items), None, 0,
+                          ctypes.byref(n_groups))
+                items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
+                groups = np.zeros((max(n_groups.value, 1), 8), dtype=np.int32)
+                _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, items.ctypes.data_as(ctypes.c_void_p),
+                          n_items.value, ctypes.byref(n_items), groups.ctypes.data_as(ctypes.c_void_p), n_groups.value,
+                          ctypes.byref(n_groups))
+                p_groups = c.inp(groups, np.int32)
+            else:
+                _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+                items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
+                _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p),
+                          n_items.value, ctypes.byref(n_items))
             p_items = c.inp(items, np.int32)
             p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
             p_beam, p_ext, p_map = c.inp(beam, np.complex128), c.inp(beam_lm_extents, np.float64), \
@@ -161,13 +181,13 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                                                                                   beam_nud))
                 p_ws = c.scratch(ws_bytes)
                 _lib.call("af_fused_predict_model_c128", p_st, p_sp, p_rf, p_mb, int(spi.shape[1]), m_npol, m_tabs[0],
-                          m_tabs[1], m_tabs[2], p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, nsrc, nchan,
+                          m_tabs[1], m_tabs[2], p_items, n_items.value, p_a1, p_a2, p_groups, nrow, p_lm, p_uvw, p_fr, nsrc, nchan,
                           p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_fr_rot, p_gs,
                           conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
             else:
                 ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
                 p_ws = c.scratch(ws_bytes)
-                _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, nrow, p_lm, p_uvw, p_fr, p_b,
+                _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, p_groups, nrow, p_lm, p_uvw, p_fr, p_b,
                           nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
                           p_as, p_fr_rot, p_gs, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
         vis = c.result(h)

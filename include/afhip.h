@@ -246,8 +246,18 @@ int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *it
                        int64_t max_items, int64_t *nitems);
 size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
                                         int64_t beam_nud);
+/* Grouped form of the plan (HOST pointers): runs of equal time_index cut into groups of up to four rows that share
+ * their antennas, rows (p_i, q_j), i, j in {0, 1}: groups (ngroups,8) int32 = p0, p1, q0, q1, row(0,0), row(0,1),
+ * row(1,0), row(1,1) (-1 = empty); items (nitems,4) = (time index, first group, group count <= 512, 1).  With NULL
+ * output arrays only the counts are returned.  A lane of the kernel then owns one group and reads the Jones terms of
+ * its two + two antennas once for four baselines.  Pass the DEVICE copies as `items` and `groups` of
+ * af_fused_predict_c128 (antenna1 / antenna2 may then be NULL); `groups` NULL = the row-range items of
+ * af_fused_plan_rows.  Grouped items need the wave-specialised kernel (no gauss_shape). */
+int af_fused_plan_groups(const int64_t *time_index_host, const int32_t *antenna1_host, const int32_t *antenna2_host,
+                         int64_t nrow, int64_t nant, int32_t *items_host, int64_t max_items, int64_t *nitems,
+                         int32_t *groups_host, int64_t max_groups, int64_t *ngroups);
 int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *antenna1,
-                          const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                          const int32_t *antenna2, const int32_t *groups, int64_t nrow, const double *lm, const double *uvw,
                           const double *frequency, const double *brightness, int64_t nsrc,
                           int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh,
                           int64_t beam_nud, const double *beam_lm_extents, const double *beam_freq_map,
@@ -379,7 +389,8 @@ size_t af_fused_predict_model_workspace_bytes(int64_t nsrc, int64_t nchan, int64
 int af_fused_predict_model_c128(const double *stokes, const double *spi, const double *ref_freq, const int *base,
                                 int64_t nspi, int64_t npol, const int *src1_host, const int *src2_host,
                                 const int *op_host, const int32_t *items, int64_t nitems, const int32_t *antenna1,
-                                const int32_t *antenna2, int64_t nrow, const double *lm, const double *uvw,
+                                const int32_t *antenna2, const int32_t *groups, int64_t nrow, const double *lm,
+                                const double *uvw,
                                 const double *frequency, int64_t nsrc, int64_t nchan, const double *beam, int64_t beam_lw,
                                 int64_t beam_mh, int64_t beam_nud, const double *beam_lm_extents,
                                 const double *beam_freq_map, const double *parallactic_angles, int64_t ntime,

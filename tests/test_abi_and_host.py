@@ -159,3 +159,45 @@ def test_convert_setup_resolution():
     assert m == [(2, 3, C.HALF_SUB, 0)]
     m = C.convert_setup(np.zeros((3, 1)), ["I"], ["XX", "XY"], True)[0]
     assert m == [(0, -1, C.ADD, 0), (-1, -1, C.ADDJ, 1)]
+
+
+@pytest.mark.parametrize("nant, nrow", [(64, 40000), (7, 300), (5, 37), (130, 9000), (2, 9), (1, 4)])
+def test_fused_group_plan_covers_every_row_once(nant, nrow):
+    """af_fused_plan_groups (host side, no GPU work): every row lands in exactly one slot of one group, slot (i, j)'s row
+    has antenna1 = p_i and antenna2 = q_j, items hold at most 512 groups; a 64-antenna timestep (2016 baselines) is
+    exactly 512 groups = one workgroup of the fused kernel."""
+    import ctypes
+    from codex_africanus_amd import _lib
+    from codex_africanus_amd.testing import synthetic_inputs
+    d = synthetic_inputs(seed=1, nrow=nrow, nchan=2, nsrc=2, nant=max(nant, 2))
+    a1, a2 = d["ant1"] % nant, d["ant2"] % nant                 # nant = 1: autocorrelations only
+    rng = np.random.default_rng(nant)
+    if nant == 7:                                                # repeated baselines and a shuffled order inside timesteps
+        a1, a2 = np.concatenate([a1, a1[:50]]), np.concatenate([a2, a2[:50]])
+        d["time_index"] = np.concatenate([d["time_index"], np.full(50, d["time_index"][-1])])
+        nrow += 50
+    ti = np.ascontiguousarray(d["time_index"], np.int64) + 3    # plans are relative to the smallest time index
+    a1, a2 = np.ascontiguousarray(a1, np.int32), np.ascontiguousarray(a2, np.int32)
+    P = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    ni, ng = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.call("af_fused_plan_groups", P(ti), P(a1), P(a2), nrow, nant, None, 0, ctypes.byref(ni), None, 0, ctypes.byref(ng))
+    items, groups = np.zeros((ni.value, 4), np.int32), np.zeros((ng.value, 8), np.int32)
+    _lib.call("af_fused_plan_groups", P(ti), P(a1), P(a2), nrow, nant, P(items), ni.value, ctypes.byref(ni), P(groups),
+              ng.value, ctypes.byref(ng))
+    rows = groups[:, 4:].ravel()
+    assert np.array_equal(np.sort(rows[rows >= 0]), np.arange(nrow))
+    for k, (i, j) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        m = groups[:, 4 + k] >= 0
+        assert np.array_equal(a1[groups[m, 4 + k]], groups[m, i]) and np.array_equal(a2[groups[m, 4 + k]], groups[m, 2 + j])
+    assert groups[:, :4].min() >= 0 and groups[:, :4].max() < nant
+    assert items[:, 2].max() <= 512 and items[:, 2].sum() == len(groups) and np.all(items[:, 3] == 1)
+    assert np.array_equal(items[:, 1], np.concatenate([[0], np.cumsum(items[:, 2])[:-1]]))
+    # every group's rows share one time index, which is the item's (relative to the minimum)
+    for t, g0, cnt, _ in items:
+        r = groups[g0:g0 + cnt, 4:].ravel()
+        assert np.all(ti[r[r >= 0]] - ti.min() == t)
+    if nant == 64:
+        assert items[0, 2] == 512
+    with pytest.raises(ValueError, match="antenna index out of range"):
+        _lib.call("af_fused_plan_groups", P(ti), P(a1 + nant), P(a2), nrow, nant, None, 0, ctypes.byref(ni), None, 0,
+                  ctypes.byref(ng))

@@ -151,3 +151,31 @@ def test_fused_with_feed_rotation_and_gaussian_sources(feed_type):
     with pytest.raises(ValueError, match="feed_rotation multiplies the beam term"):
         rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
                                feed_rotation=frot)
+
+
+def test_fused_grouped_plan_equals_row_plan_bit_for_bit(monkeypatch):
+    """the 2 x 2-baseline-block plan (af_fused_plan_groups: a lane owns up to four rows that share their antennas' Jones
+    terms) and the plain row-range plan run the same operations per (row, source) in the same order"""
+    for nant, nrow in ((64, 4100), (9, 700), (70, 2600)):
+        d = _problem(31, nrow, 5, 19, nant)
+        d["time_index"] = d["time_index"] + 2
+        args = (d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"], d["beam"], d["extents"],
+                d["beam_freq_map"], d["pa"], d["pe"], d["as"])
+        monkeypatch.setenv("AFHIP_FUSED_GROUPS", "1")
+        grouped = rime.fused_predict_vis(*args)
+        monkeypatch.setenv("AFHIP_FUSED_GROUPS", "0")
+        by_rows = rime.fused_predict_vis(*args)
+        np.testing.assert_array_equal(grouped, by_rows)
+        assert np.abs(grouped - _oracle_chain(d, True)).max() < 1e-9 * _scale(d)
+    # rows of a timestep in a shuffled order, repeated baselines, autocorrelations
+    d = _problem(32, 600, 4, 11, 8)
+    rng = np.random.default_rng(5)
+    perm = np.concatenate([rng.permutation(np.flatnonzero(d["time_index"] == t)) for t in np.unique(d["time_index"])])
+    for k in ("ant1", "ant2", "uvw", "time_index"):
+        d[k] = d[k][perm]
+    d["ant2"][::7] = d["ant1"][::7]
+    d["ant1"][5], d["ant2"][5] = d["ant1"][4], d["ant2"][4]
+    monkeypatch.setenv("AFHIP_FUSED_GROUPS", "1")
+    out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                                 d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"])
+    assert np.abs(out - _oracle_chain(d, True)).max() < 1e-9 * _scale(d)

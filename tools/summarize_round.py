@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof_round (tools/profile_round.sh) into profiles/<round>_*:
+  <round>_<workload>_bench_line.json      the un-profiled JSON line of bench.py --workload <workload>
+  <round>_<workload>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of the same command (3 timed steps)
+  <round>_<workload>_pmc_summary.json     per-launch means of the PMC passes for the workload's dominant kernel
+  <round>_<workload>_pmc_<pass>.csv       the counter rows of that kernel, per dispatch
+  <round>_aux_<tool>.json / _kernel_stats.csv   the auxiliary benches
+    python tools/summarize_round.py r02"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
+DST = os.path.join(ROOT, "profiles")
+DOMINANT = {"dft": "dft_mfma_kernel", "dft_complex": "dft_mfma_kernel", "fused_dde": "fused_predict_kernel",
+            "degrid": "degrid_coop_kernel"}
+
+
+def find(base, suffix):
+    hits = sorted(glob.glob(os.path.join(base, "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    for w, dom in DOMINANT.items():
+        base = os.path.join(SRC, w)
+        if not os.path.isdir(base):
+            continue
+        summary = {"workload": w, "kernel_substring": dom}
+        bl = os.path.join(base, "bench_line.json")
+        if os.path.exists(bl):
+            lines = [x for x in open(bl).read().splitlines() if x.startswith("{")]
+            if lines:
+                open(os.path.join(DST, "%s_%s_bench_line.json" % (tag, w)), "w").write(lines[-1] + "\n")
+                d = json.loads(lines[-1])
+                summary["bench_kernel_ms_hip_events"] = d["roofline"]["kernel_ms"]
+                summary["bench_value_Mvis_s"] = d["value"]
+        stats = find(os.path.join(base, "stats"), "kernel_stats.csv")
+        if stats:
+            shutil.copy(stats, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, w)))
+            for row in csv.DictReader(open(stats)):
+                if dom in row["Name"]:
+                    summary["kernel"] = row["Name"]
+                    summary["calls_kernel_trace_stats"] = int(row["Calls"])
+                    summary["avg_ns_kernel_trace_stats"] = float(row["AverageNs"])
+                    break
+        for sub in ("fetch", "write", "sq", "sq2"):
+            cc = find(os.path.join(base, sub), "counter_collection.csv")
+            if not cc:
+                continue
+            rows = [r for r in csv.DictReader(open(cc)) if dom in r["Kernel_Name"]]
+            if not rows:
+                continue
+            with open(os.path.join(DST, "%s_%s_pmc_%s.csv" % (tag, w, sub)), "w", newline="") as f:
+                wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                wr.writeheader()
+                wr.writerows(rows)
+            per = {}
+            for r in rows:
+                per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for k, v in per.items():
+                summary[k] = sum(v) / len(v)
+            kt = find(os.path.join(base, sub), "kernel_trace.csv")
+            if kt:
+                dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))
+                       if dom in r["Kernel_Name"]]
+                if dur:
+                    summary["avg_ns_under_pmc_%s" % sub] = sum(dur) / len(dur)
+        if "SQ_LDS_BANK_CONFLICT" in summary and summary.get("SQ_LDS_IDX_ACTIVE"):
+            summary["lds_conflict_ratio"] = summary["SQ_LDS_BANK_CONFLICT"] / summary["SQ_LDS_IDX_ACTIVE"]
+        if "GRBM_GUI_ACTIVE" in summary and "avg_ns_under_pmc_sq" in summary:
+            summary["clock_GHz"] = summary["GRBM_GUI_ACTIVE"] / 8.0 / summary["avg_ns_under_pmc_sq"]
+        json.dump(summary, open(os.path.join(DST, "%s_%s_pmc_summary.json" % (tag, w)), "w"), indent=1)
+        print(json.dumps(summary, indent=1))
+    for d in sorted(glob.glob(os.path.join(SRC, "aux", "*"))):
+        t = os.path.basename(d)
+        res = os.path.join(d, "result.json")
+        if os.path.exists(res) and os.path.getsize(res):
+            shutil.copy(res, os.path.join(DST, "%s_aux_%s.json" % (tag, t)))
+        stats = find(os.path.join(d, "stats"), "kernel_stats.csv")
+        if stats:
+            # keep the library's own kernels (and the FFT) only
+            rows = [r for r in csv.DictReader(open(stats)) if "anonymous namespace" in r["Name"] or "fft" in r["Name"]
+                    or "transpose" in r["Name"]]
+            if rows:
+                with open(os.path.join(DST, "%s_aux_%s_kernel_stats.csv" % (tag, t)), "w", newline="") as f:
+                    wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                    wr.writeheader()
+                    wr.writerows(rows)
+
+
+if __name__ == "__main__":
+    main()
