@@ -71,7 +71,8 @@ def test_wave_specialised_fused_kernel_fits_three_waves_per_simd(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        m = re.search(r"fused_predict_kernelILb([01])ELb0ELi(\d+)ELb1ELi(\d+)E", name)   # <FEED, GAUSS=false, NP, WS=true, ST>
+        # <FEED, GAUSS=false, NP, WS=true, ST, GR>
+        m = re.search(r"fused_predict_kernelILb([01])ELb0ELi(\d+)ELb1ELi(\d+)ELb([01])E", name)
         if not m:
             continue
         seen += 1
@@ -79,4 +80,4 @@ def test_wave_specialised_fused_kernel_fits_three_waves_per_simd(tmp_path):
         vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         assert scratch == 0 and vgprs + agprs <= 168, (name, scratch, vgprs, agprs)
-    assert seen == 8, seen      # NP in {64, 128, run-time} x FEED, plus the unrolled ST = 8 pair at NP = 64
+    assert seen == 16, seen     # (NP in {64, 128, run-time} + the unrolled ST = 8 at NP = 64) x FEED x grouped / row plan
