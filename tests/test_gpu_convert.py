@@ -82,18 +82,3 @@ def test_convert_non_finite(g11):
             assert got.dtype == ref.dtype
             for part in (np.real, np.imag):
                 assert np.array_equal(part(got), part(ref), equal_nan=True), (isch, osch, kind, got, ref)
-
-
-def test_convert_dask(g11):
-    """model/coherency/tests/test_convert.py:143-160: chunked == unchunked"""
-    da = pytest.importorskip("dask.array")
-    from codex_africanus_amd.model.coherency.dask import convert as da_convert
-    for chunks in (((10, 5, 3), (2, 3), (3,)), ((6, 8), (3, 3), (4, 4)), ((5, 5, 5),)):
-        vis_shape = tuple(sum(c) for c in chunks)
-        for isch, osch, implicit in json.loads(str(g11["cases"]))[:11]:
-            ishape = np.asarray(isch).shape
-            n = int(np.prod(vis_shape + ishape))
-            vis = np.arange(1.0, n + 1.0).reshape(vis_shape + ishape)
-            dvis = da.from_array(vis, chunks=chunks + tuple((s,) for s in ishape))
-            got = da_convert(dvis, isch, osch).compute(scheduler="threads")
-            assert np.array_equal(got, convert(vis, isch, osch))

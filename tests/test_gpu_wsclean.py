@@ -135,11 +135,4 @@ def test_chunked_and_dask_wsclean_predict(g7):
     out = chunked.wsclean_predict(*a, chunks={"source": 10, "row": 50, "chan": (40, 30)})
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 1e-11 * scale
-    da = pytest.importorskip("dask.array")
-    from codex_africanus_amd.rime import dask as rdask
-    s, r, c = 10, 50, (40, 30)
-    d = [da.from_array(a[0], chunks=(r, 3)), da.from_array(a[1], chunks=(s, 2)), da.from_array(a[2], chunks=s),
-         da.from_array(a[3], chunks=s), da.from_array(a[4], chunks=(s, a[4].shape[1])), da.from_array(a[5], chunks=s),
-         da.from_array(a[6], chunks=s), da.from_array(a[7], chunks=(s, 3)), da.from_array(a[8], chunks=(c,))]
-    out = rdask.wsclean_predict(*d).compute(scheduler="sync")
-    assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-11 * scale
+    # the dask front-end of the same chunking: tests/dask_cases.py (run by tests/test_gpu_dask_conda.py)
