@@ -330,8 +330,9 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     const int rc = items[4 * blockIdx.x + 2];
 
     // ---- stage-2 state: this lane's rows -----------------------------------------------------
-    const double FT = f4[f] * (PH_TABLE / 4.0), NU = freq[f];   // 1/PH_TABLE turns per metre (exact scaling of f4)
-    double u[RPT], v[RPT], w[RPT], us[RPT], vs[RPT], ws[RPT];
+    const double FT = f4[f] * (PH_TABLE / 4.0);   // 1/PH_TABLE turns per metre (exact scaling of f4)
+    const double GK = freq[f] / FT;               // Gaussian shapes: (u nu) = us * GK
+    double us[RPT], vs[RPT], ws[RPT];
     int a1[RPT], a2[RPT];
     C2 acc[RPT][4];
 #pragma unroll
@@ -349,11 +350,11 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
         } else {
             r = r0 + ((consumer && rl < rc) ? rl : 0);
         }
-        u[k] = uvw[3 * r]; v[k] = uvw[3 * r + 1]; w[k] = uvw[3 * r + 2];
+        const double u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
         if constexpr (!GR) { a1[k] = ant1[r]; a2[k] = ant2[r]; }
         // this channel's table units per metre folded into the row's coordinates (one operation less per
-        // (row, source); the Gaussian shape keeps the plain coordinates)
-        us[k] = __dmul_rn(u[k], FT); vs[k] = __dmul_rn(v[k], FT); ws[k] = __dmul_rn(w[k], FT);
+        // (row, source); the Gaussian shape rescales them)
+        us[k] = __dmul_rn(u, FT); vs[k] = __dmul_rn(v, FT); ws[k] = __dmul_rn(w, FT);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c].re = acc[k][c].im = 0.0;
     }
@@ -529,7 +530,8 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                 if (extended) {
 #pragma unroll
                     for (int k = 0; k < RPT; ++k) {
-                        const double u1 = (u[k] * gem - v[k] * gel) * ger * NU, v1 = (u[k] * gel + v[k] * gem) * NU;
+                        // u nu = us * (nu / FT): the rows keep only their scaled coordinates (registers)
+                        const double u1 = (us[k] * gem - vs[k] * gel) * ger * GK, v1 = (us[k] * gel + vs[k] * gem) * GK;
                         shape[k] = exp(-(u1 * u1 + v1 * v1));
                     }
                 }
@@ -848,7 +850,7 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // AFHIP_FUSED_WS=0 selects the 8-wave kernel
     static const int ws_env = getenv("AFHIP_FUSED_WS") ? atoi(getenv("AFHIP_FUSED_WS")) : 1;
     const int64_t npp = np + PLANE_PAD;   // padded plane stride of the Jones arrays (see the kernel)
-    const bool ws_mode = ws_env != 0 && gauss_shape == nullptr && (160 * 1024 - fixed) / (256 * npp) >= 2;
+    const bool ws_mode = ws_env != 0 && (160 * 1024 - fixed) / (256 * npp) >= 2;
     const int nbuf = ws_mode ? 2 : 1;
     int st = (int)((160 * 1024 - fixed) / (128 * nbuf * npp));
     if (st > 1024 / np) st = (int)(1024 / np);
@@ -893,8 +895,10 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         return AF_OK;
     };
 #define AF_FUSED_PICK(NPC, STC, GRC)                                                                                     \
-    (ws_mode ? (feed ? launch(fused_predict_kernel<true, false, NPC, true, STC, GRC>, THREADS + THREADS / 2)                \
-                     : launch(fused_predict_kernel<false, false, NPC, true, STC, GRC>, THREADS + THREADS / 2))              \
+    (ws_mode ? (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, true, 0, false>, THREADS + THREADS / 2)        \
+                              : launch(fused_predict_kernel<true, false, NPC, true, STC, GRC>, THREADS + THREADS / 2))      \
+                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, true, 0, false>, THREADS + THREADS / 2)       \
+                              : launch(fused_predict_kernel<false, false, NPC, true, STC, GRC>, THREADS + THREADS / 2)))    \
              : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false, 0, false>, THREADS)                     \
                               : launch(fused_predict_kernel<true, false, NPC, false, 0, false>, THREADS))                   \
                      : (gauss ? launch(fused_predict_kernel<false, true, NPC, false, 0, false>, THREADS)                    \
@@ -902,12 +906,17 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // the grouped form (items of af_fused_plan_groups) exists for the wave-specialised kernels; the 64-antenna-stride,
     // 8-sources-per-batch case (BASELINE configs[2]) has its source loop unrolled
     static const int unroll_env = getenv("AFHIP_FUSED_UNROLL") ? atoi(getenv("AFHIP_FUSED_UNROLL")) : 1;   // A/B hook
+    AF_REQUIRE(groups == nullptr || !gauss, "af_fused_predict_c128: Gaussian shapes take the row-range plan "
+                                            "(af_fused_plan_rows): the grouped kernel with them exceeds 168 registers");
     AF_REQUIRE(groups == nullptr || ws_mode, "af_fused_predict_c128: grouped items need the wave-specialised kernel "
-                                             "(no Gaussian shapes, AFHIP_FUSED_WS != 0): plan with af_fused_plan_rows");
+                                             "(AFHIP_FUSED_WS != 0, at most ~230 antennas): plan with af_fused_plan_rows");
+    // (the unrolled source loop is for the variants without Gaussian shapes: eight inlined exp() bodies do not fit the
+    // registers of three waves per SIMD)
+    const bool unroll = NPv == 64 && ws_mode && st == 8 && unroll_env && !gauss;
     if (groups != nullptr) {
-        if (NPv == 64 && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8, true);
+        if (unroll) rc = AF_FUSED_PICK(64, 8, true);
         else rc = NPv == 64 ? AF_FUSED_PICK(64, 0, true) : NPv == 128 ? AF_FUSED_PICK(128, 0, true) : AF_FUSED_PICK(0, 0, true);
-    } else if (NPv == 64 && ws_mode && st == 8 && unroll_env) rc = AF_FUSED_PICK(64, 8, false);
+    } else if (unroll) rc = AF_FUSED_PICK(64, 8, false);
     else rc = NPv == 64 ? AF_FUSED_PICK(64, 0, false) : NPv == 128 ? AF_FUSED_PICK(128, 0, false) : AF_FUSED_PICK(0, 0, false);
 #undef AF_FUSED_PICK
     return rc;

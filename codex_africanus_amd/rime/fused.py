@@ -143,7 +143,7 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("antenna index out of range")
             n_items = ctypes.c_int64(0)
             tip = ti.ctypes.data_as(ctypes.c_void_p)
-            # the wave-specialised kernel (no Gaussian shapes) takes the grouped plan: 2 x 2 blocks of baselines that
+            # the wave-specialised kernel without Gaussian shapes takes the grouped plan: 2 x 2 blocks of baselines that
             # share their antennas' Jones terms; otherwise plain row ranges
             # (that kernel double-buffers the Jones terms in LDS: up to ~230 antennas)
             grouped = gauss_shape is None and nant <= 230 and os.environ.get("AFHIP_FUSED_WS", "1") != "0" and \

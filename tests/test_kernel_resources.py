@@ -60,7 +60,8 @@ def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels, min_see
 
 def test_wave_specialised_fused_kernel_fits_three_waves_per_simd(tmp_path):
     """The 12-wave fused predict (8 accumulating + 4 sampling waves) needs <= 168 registers and no scratch in the
-    variants the dispatcher uses it for (no Gaussian shapes)."""
+    variants without Gaussian shapes; the Gaussian ones (rolled source loop) may keep a few spilled values outside
+    the hot loop."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
