@@ -25,12 +25,75 @@ def _host(a):
     return a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a)
 
 
+class FusedPlan(object):
+    """Row layout of a fused predict with DDEs: how the rows of every timestep are dealt to the lanes of a workgroup.
+    Built by :func:`fused_plan`; holds host copies of the plan arrays and uploads them once per device."""
+
+    def __init__(self, nrow, nant, nsteps, items, groups, antenna1, antenna2):
+        self.nrow, self.nant, self.nsteps = nrow, nant, nsteps
+        self.items, self.groups = items, groups
+        self.antenna1, self.antenna2 = antenna1, antenna2
+        self.n_items = int(items.shape[0]) if nrow else 0
+        self._dev = {}
+
+    def device(self, arr, call):
+        """`arr` (one of this plan's arrays) for the call: the numpy array in host mode, a cached tensor in device mode"""
+        if not call.device_mode:
+            return arr
+        import torch
+        key = (id(arr), str(call.torch_device))
+        t = self._dev.get(key)
+        if t is None:
+            t = self._dev[key] = torch.from_numpy(arr).to(call.torch_device)
+        return t
+
+
+def fused_plan(time_index, antenna1, antenna2, nant, grouped=True):
+    """
+    Plan of a row layout for :func:`fused_predict_vis` with DDEs (host side, O(row)): runs of consecutive rows with
+    equal ``time_index`` become workgroup items.  ``grouped`` (default): rows are dealt in 2 x 2 blocks of baselines that
+    share their antennas' Jones terms (``af_fused_plan_groups``: 5 instead of 8 LDS reads per (row, source); up to ~230
+    antennas, no Gaussian shapes); otherwise plain row ranges (``af_fused_plan_rows``).  ``nant`` = the antenna extent
+    of the per-antenna arrays (parallactic_angles.shape[1]).
+    """
+    ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
+    a1h = np.ascontiguousarray(_host(antenna1), dtype=np.int32)
+    a2h = np.ascontiguousarray(_host(antenna2), dtype=np.int32)
+    nrow, nant = int(ti.shape[0]), int(nant)
+    if a1h.shape != (nrow,) or a2h.shape != (nrow,):
+        raise ValueError("time_index, antenna1 and antenna2 must have shape (row,)")
+    if nrow and (min(a1h.min(), a2h.min()) < 0 or max(a1h.max(), a2h.max()) >= nant):
+        raise ValueError("antenna index out of range")
+    nsteps = int(ti.max()) - int(ti.min()) + 1 if nrow else 0
+    grouped = grouped and nant <= 230 and os.environ.get("AFHIP_FUSED_WS", "1") != "0" and \
+        os.environ.get("AFHIP_FUSED_GROUPS", "1") != "0"
+    n_items = ctypes.c_int64(0)
+    tip = ti.ctypes.data_as(ctypes.c_void_p)
+    groups = None
+    if grouped:
+        n_groups = ctypes.c_int64(0)
+        pa1, pa2 = a1h.ctypes.data_as(ctypes.c_void_p), a2h.ctypes.data_as(ctypes.c_void_p)
+        _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, None, 0, ctypes.byref(n_items), None, 0,
+                  ctypes.byref(n_groups))
+        items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
+        groups = np.zeros((max(n_groups.value, 1), 8), dtype=np.int32)
+        _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, items.ctypes.data_as(ctypes.c_void_p),
+                  n_items.value, ctypes.byref(n_items), groups.ctypes.data_as(ctypes.c_void_p), n_groups.value,
+                  ctypes.byref(n_groups))
+    else:
+        _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
+        items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
+        _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
+                  ctypes.byref(n_items))
+    return FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h)
+
+
 def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
                       beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
                       point_errors=None, antenna_scaling=None,
                       die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
                       feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
-                      corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0):
+                      corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, plan=None):
     """
     ``V_pq = G_p ( B_pq + sum_s E_ps (K_pqs X_s) E_qs^H ) G_q^H`` from source-level inputs.
 
@@ -47,7 +110,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     (source, spi-comps, 4), ``ref_freq`` (source,), ``corr_schema`` (2 x 2 nested: linear or circular feeds) and
     ``spectral_base``; ``brightness = convert(spectral_model(stokes, spi, ref_freq, frequency, spectral_base),
     ["I","Q","U","V"], corr_schema)`` (africanus/rime/examples/predict.py:494-498) is then evaluated on the device inside
-    the call and no (source, chan, 2, 2) array exists on the caller's side.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    the call and no (source, chan, 2, 2) array exists on the caller's side.  ``plan``: a :func:`fused_plan` of the
+    row layout (time_index, antenna1, antenna2) -- made once and re-used for every call on that layout (every channel
+    block, every imaging cycle); without it the plan is rebuilt per call, which costs a device -> host copy of the three
+    index arrays and O(row) host work.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
     ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
     per-antenna Jones terms on the device.  float64 / complex128 only.
     """
@@ -134,39 +200,17 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("point_errors must have shape (time, ant, chan, 2)")
             if tuple(antenna_scaling.shape) != (nant, nchan, 2):
                 raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
-            # plan: runs of equal time_index (host side, O(nrow))
-            ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
-            if nrow and (int(ti.max()) - int(ti.min()) >= ntime):
-                raise ValueError("time_index spans more timesteps than parallactic_angles has")
-            a1h, a2h = _host(antenna1), _host(antenna2)
-            if nrow and (min(a1h.min(), a2h.min()) < 0 or max(a1h.max(), a2h.max()) >= nant):
-                raise ValueError("antenna index out of range")
-            n_items = ctypes.c_int64(0)
-            tip = ti.ctypes.data_as(ctypes.c_void_p)
-            # the wave-specialised kernel without Gaussian shapes takes the grouped plan: 2 x 2 blocks of baselines that
-            # share their antennas' Jones terms; otherwise plain row ranges
-            # (that kernel double-buffers the Jones terms in LDS: up to ~230 antennas)
-            grouped = gauss_shape is None and nant <= 230 and os.environ.get("AFHIP_FUSED_WS", "1") != "0" and \
-                os.environ.get("AFHIP_FUSED_GROUPS", "1") != "0"
-            p_groups = None
-            if grouped:
-                a1i, a2i = np.ascontiguousarray(a1h, dtype=np.int32), np.ascontiguousarray(a2h, dtype=np.int32)
-                n_groups = ctypes.c_int64(0)
-                pa1, pa2 = a1i.ctypes.data_as(ctypes.c_void_p), a2i.ctypes.data_as(ctypes.c_void_p)
-                _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, None, 0, ctypes.byref(n_items), None, 0,
-                          ctypes.byref(n_groups))
-                items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
-                groups = np.zeros((max(n_groups.value, 1), 8), dtype=np.int32)
-                _lib.call("af_fused_plan_groups", tip, pa1, pa2, nrow, nant, items.ctypes.data_as(ctypes.c_void_p),
-                          n_items.value, ctypes.byref(n_items), groups.ctypes.data_as(ctypes.c_void_p), n_groups.value,
-                          ctypes.byref(n_groups))
-                p_groups = c.inp(groups, np.int32)
-            else:
-                _lib.call("af_fused_plan_rows", tip, nrow, None, 0, ctypes.byref(n_items))
-                items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
-                _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p),
-                          n_items.value, ctypes.byref(n_items))
-            p_items = c.inp(items, np.int32)
+            if plan is None:
+                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=gauss_shape is None)
+            if plan.nrow != nrow or plan.nant != nant or plan.nsteps > ntime:
+                raise ValueError("plan was made for %d rows, %d antennas, %d timesteps; the call has %d, %d, %d"
+                                 % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
+            if plan.groups is not None and gauss_shape is not None:
+                raise ValueError("Gaussian shapes need a plan made with grouped=False")
+            n_items = ctypes.c_int64(plan.n_items)
+            p_items = c.inp(plan.device(plan.items, c), np.int32)
+            p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
+            a1h, a2h = plan.antenna1, plan.antenna2
             p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
             p_beam, p_ext, p_map = c.inp(beam, np.complex128), c.inp(beam_lm_extents, np.float64), \
                 c.inp(beam_freq_map, np.float64)

@@ -179,3 +179,28 @@ def test_fused_grouped_plan_equals_row_plan_bit_for_bit(monkeypatch):
     out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
                                  d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"])
     assert np.abs(out - _oracle_chain(d, True)).max() < 1e-9 * _scale(d)
+
+
+def test_fused_plan_is_reusable_and_checked():
+    """a plan of the row layout made once serves every call on that layout (device-resident inputs need no device ->
+    host copy of the index arrays then); a plan of another layout is refused"""
+    import torch
+    d = _problem(41, 1300, 6, 13, 12)
+    args = (d["lm"], d["uvw"], d["frequency"], d["X"], d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"])
+    ref = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], *args)
+    plan = rime.fused_plan(d["time_index"], d["ant1"], d["ant2"], 12)
+    assert plan.groups is not None and plan.nrow == 1300
+    out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], *args, plan=plan)
+    np.testing.assert_array_equal(out, ref)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    targs = [t(a) for a in args]
+    for _ in range(2):          # second call: the plan's device copies are cached
+        dev = rime.fused_predict_vis(t(d["time_index"]), t(d["ant1"]), t(d["ant2"]), *targs, plan=plan)
+        np.testing.assert_array_equal(dev.cpu().numpy(), ref)
+    rows = rime.fused_plan(d["time_index"], d["ant1"], d["ant2"], 12, grouped=False)
+    assert rows.groups is None
+    np.testing.assert_array_equal(rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], *args, plan=rows), ref)
+    with pytest.raises(ValueError, match="plan was made for"):
+        rime.fused_predict_vis(d["time_index"][:-1], d["ant1"][:-1], d["ant2"][:-1], d["lm"], d["uvw"][:-1], *args[2:], plan=plan)
+    with pytest.raises(ValueError, match="antenna index out of range"):
+        rime.fused_plan(d["time_index"], d["ant1"] + 20, d["ant2"], 12)

@@ -27,6 +27,8 @@ for t in bench_gridder bench_degridder bench_wgridder bench_vis_to_im bench_wscl
     mkdir -p "$OUT/aux/$t"
     python3 tools/$t.py > "$OUT/aux/$t/result.json" 2> "$OUT/aux/$t/stderr.log"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/aux/$t/stats" -o stats -- python3 tools/$t.py > "$OUT/aux/$t/stats.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/aux/$t/fetch" -o fetch -- python3 tools/$t.py > "$OUT/aux/$t/fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/aux/$t/write" -o write -- python3 tools/$t.py > "$OUT/aux/$t/write.log" 2>&1
 done
 find "$OUT" -name "*kernel_stats.csv" | wc -l
 for f in "$OUT"/*/bench_line.json; do tail -c 300 "$f"; echo; done

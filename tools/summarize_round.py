@@ -82,6 +82,33 @@ def main():
         res = os.path.join(d, "result.json")
         if os.path.exists(res) and os.path.getsize(res):
             shutil.copy(res, os.path.join(DST, "%s_aux_%s.json" % (tag, t)))
+        # HBM traffic per dispatch of the library's kernels: FETCH_SIZE / WRITE_SIZE (KB) from their own passes, the
+        # durations of the same dispatches from those passes' kernel traces; per kernel name: the LARGEST dispatch (the
+        # bench-sized one, not the small verification calls)
+        per_kernel = {}
+        for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            cc = find(os.path.join(d, sub), "counter_collection.csv")
+            kt = find(os.path.join(d, sub), "kernel_trace.csv")
+            if not cc or not kt:
+                continue
+            dur = {r["Dispatch_Id"]: float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))}
+            for r in csv.DictReader(open(cc)):
+                if "anonymous namespace" not in r["Kernel_Name"] or r["Counter_Name"] != key:
+                    continue
+                name = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+                e = per_kernel.setdefault(name, {})
+                ns = dur.get(r["Dispatch_Id"], 0.0)
+                if ns >= e.get(key + "_ns", -1.0):
+                    e[key + "_ns"] = ns
+                    e[key + "_KB"] = float(r["Counter_Value"])
+        if per_kernel:
+            for name, e in per_kernel.items():
+                if "FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e:
+                    ns = max(e["FETCH_SIZE_ns"], e["WRITE_SIZE_ns"])
+                    e["hbm_GB_2fetch_plus_write"] = (2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024.0 / 1e9
+                    e["hbm_GBs"] = e["hbm_GB_2fetch_plus_write"] / (ns * 1e-9) if ns else None
+                    e["ms"] = ns / 1e6
+            json.dump(per_kernel, open(os.path.join(DST, "%s_aux_%s_pmc_hbm.json" % (tag, t)), "w"), indent=1, sort_keys=True)
         stats = find(os.path.join(d, "stats"), "kernel_stats.csv")
         if stats:
             # keep the library's own kernels (and the FFT) only
