@@ -17,7 +17,13 @@
 //     psi(dw), and adds them to its sum.  Plane spacing dw = 1 / (2 sigma max|n - 1|).
 // The planes are built in batches of as many grids as the workspace holds; per batch ONE pass over the visibilities
 // takes every visibility through its own planes.  All work is enqueued on the caller's stream.
+// Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: 45 ms, profiles/r02_aux_bench_wgridder_*):
+//   * planes: pruned 2-D transform (wg_fill_rows -> hipFFT rows -> wg_transpose_rows -> hipFFT rows), v-major;
+//   * visibilities: counting sort by (32 x 32 tile, w-plane) on the device, chunks of <= 256 of one tile, the tile's
+//     cells of every plane staged through LDS (wg_degrid_tiles); small calls gather from memory (wg_degrid_planes).
 #include <hipfft/hipfft.h>
+
+#include <stdlib.h>
 
 #include <cmath>
 #include <map>
@@ -30,9 +36,15 @@ namespace {
 constexpr int WG_MAXW = 16;
 constexpr int WG_QUAD = 48;   // Gauss-Legendre nodes handed over by the host for the kernel's Fourier transform
 
+// `batch` contiguous rows of length n, in place (kind is 1: kept for other layouts)
 struct PlanKey {
-    int dev, nu, nv;
-    bool operator<(const PlanKey &o) const { return dev != o.dev ? dev < o.dev : (nu != o.nu ? nu < o.nu : nv < o.nv); }
+    int dev, kind, n, batch;
+    bool operator<(const PlanKey &o) const
+    {
+        if (dev != o.dev) return dev < o.dev;
+        if (kind != o.kind) return kind < o.kind;
+        return n != o.n ? n < o.n : batch < o.batch;
+    }
 };
 std::mutex g_plan_mu;
 std::map<PlanKey, hipfftHandle> g_plans;
@@ -46,10 +58,19 @@ __device__ __forceinline__ double es_kernel(double t, double inv_half_w, double 
 
 // A[x, y] = cu[x] cv[y] / (n psihat_w(dw (n - 1))) and nm1[x, y] = n - 1 (0 and A = cu cv without w-stacking);
 // psihat_w(xi) = (W/2) sum_q wq psi(tq) cos(pi W xi tq) over the Gauss-Legendre nodes tq in (0, 1) (even integrand)
-__global__ void wg_geometry(int64_t nx, int64_t ny, double cellx, double celly, const double *__restrict__ cu,
-                            const double *__restrict__ cv, const double *__restrict__ qt, const double *__restrict__ qw,
-                            int W, double beta, double dw, int do_w, double *__restrict__ A, double *__restrict__ nm1)
+__global__ __launch_bounds__(256) void wg_geometry(int64_t nx, int64_t ny, double cellx, double celly,
+                                                   const double *__restrict__ cu, const double *__restrict__ cv,
+                                                   const double *__restrict__ qt, const double *__restrict__ qw, int W,
+                                                   double beta, double dw, int do_w, double *__restrict__ A,
+                                                   double *__restrict__ nm1)
 {
+    __shared__ double node[WG_QUAD], wpsi[WG_QUAD];
+    if (threadIdx.x < WG_QUAD) {
+        const double t = qt[threadIdx.x];
+        node[threadIdx.x] = (double)W * t;                  // cos(pi W xi t) as cospi(xi * node)
+        wpsi[threadIdx.x] = qw[threadIdx.x] * exp(beta * (sqrt(1.0 - t * t) - 1.0));
+    }
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx * ny) return;
     const int64_t ix = i / ny, iy = i - ix * ny;
@@ -62,8 +83,8 @@ __global__ void wg_geometry(int64_t nx, int64_t ny, double cellx, double celly, 
         m = -eps / (sqrt(1.0 - eps) + 1.0);             // n - 1, test_wgridder.py:27
         const double xi = dw * m;
         double ph = 0.0;
-        for (int q = 0; q < WG_QUAD; ++q)
-            ph += qw[q] * exp(beta * (sqrt(1.0 - qt[q] * qt[q]) - 1.0)) * cos(3.141592653589793 * W * xi * qt[q]);
+#pragma unroll 8
+        for (int q = 0; q < WG_QUAD; ++q) ph += wpsi[q] * cospi(xi * node[q]);
         ph *= (double)W;                                // (W/2) * 2 (the even integrand's two halves)
         a /= (m + 1.0) * ph;
     }
@@ -71,18 +92,51 @@ __global__ void wg_geometry(int64_t nx, int64_t ny, double cellx, double celly, 
     nm1[i] = m;
 }
 
-// padded grid of plane k: image A exp(+2 pi i w_k (n - 1)) at the wrapped position of every pixel
-__global__ void wg_fill_plane(const double *__restrict__ image, const double *__restrict__ A, const double *__restrict__ nm1,
-                              int64_t nx, int64_t ny, int64_t nu, int64_t nv, double wk, double2 *__restrict__ grid)
+// The padded plane of w-plane k is the 2-D transform of the image times A exp(+2 pi i w_k (n - 1)), zero padded from
+// (nx, ny) to (nu, nv).  Only nx of its nu rows are not zero, so the transform along v is taken for those rows only, in a
+// compact staging array S (nx, nv); S is then transposed into the plane -- stored v-major, G[pv * nu + pu], rows of the
+// image at their wrapped positions pu = (ix - nx/2) mod nu, zeros between -- where the transform along u is a batch of
+// contiguous rows again.  No memset, no transposes inside the FFT library: per plane 0.5 GB written + 2 x 0.5 GB (FFT)
+// + 0.5 GB read / 1 GB written (transpose) + 2 x 1 GB (FFT), against 9 GB for a 2-D plan over the zeroed plane.
+__global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ image, const double *__restrict__ A,
+                                                    const double *__restrict__ nm1, int64_t nx, int64_t ny, int64_t nv,
+                                                    double wk, double2 *__restrict__ S)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx * ny) return;
-    const int64_t ix = i / ny, iy = i - ix * ny;
-    const int64_t px = (ix - nx / 2 + nu) % nu, py = (iy - ny / 2 + nv) % nv;
-    const double v = image[i] * A[i];
-    double s, c;
-    sincospi(2.0 * wk * nm1[i], &s, &c);
-    grid[px * nv + py] = make_double2(v * c, v * s);
+    if (i >= nx * nv) return;
+    const int64_t ix = i / nv, pv = i - ix * nv;
+    int64_t iy = pv + ny / 2;                               // pv = (iy - ny/2) mod nv
+    iy = iy >= nv ? iy - nv : iy;
+    double2 out = make_double2(0.0, 0.0);
+    if (iy < ny) {
+        const int64_t j = ix * ny + iy;
+        const double v = image[j] * A[j];
+        double sn, cs;
+        sincospi(2.0 * wk * nm1[j], &sn, &cs);
+        out = make_double2(v * cs, v * sn);
+    }
+    S[i] = out;
+}
+// G[pv * nu + pu] = S[ix(pu) * nv + pv] (0 where pu is not a row of the image); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void wg_transpose_rows(const double2 *__restrict__ S, int64_t nx, int64_t nu, int64_t nv,
+                                                         double2 *__restrict__ G)
+{
+    __shared__ double2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
+    const int64_t pu0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t pu = pu0 + ty + 8 * j, pv = pv0 + tx;
+        int64_t ix = pu + nx / 2;                           // pu = (ix - nx/2) mod nu
+        ix = ix >= nu ? ix - nu : ix;
+        tile[ty + 8 * j][tx] = (pu < nu && pv < nv && ix < nx) ? S[ix * nv + pv] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t pv = pv0 + ty + 8 * j, pu = pu0 + tx;
+        if (pv < nv && pu < nu) G[pv * nu + pu] = tile[tx][ty + 8 * j];
+    }
 }
 
 // ---- rows in uv-tile order (as in af_degridder.hip): rows arrive time-major, i.e. in no useful uv order; visiting them
@@ -138,8 +192,290 @@ __global__ void wg_scatter_rows(const unsigned short *__restrict__ key, int64_t 
     perm[atomicAdd(&start[key[r]], 1)] = (int)r;
 }
 
-// vis[r, chan0 + c] += sum over the resident planes [pk0, pk1) within the visibility's W-plane support of psi_w times
-// the W x W cells of that plane's grid; one lane per visibility, every tap weight in registers
+// ---- visibilities in (uv tile, w-plane) order, tiles staged through LDS.  Measured (rocprofv3 FETCH_SIZE,
+// profiles/r02_aux_bench_wgridder_pmc_hbm.json): with only the ROWS in tile order the gather pass moved 890 GB through
+// the memory system for 350 GB of cells (a row's channels lie on a ray across many tiles, every lane fetches its own
+// 128-byte lines of W x W cells x W planes) at the 6.5 TB/s the memory system gives.  Here the VISIBILITIES (row, chan)
+// are counting-sorted on the device by the 32 x 32-cell tile of their first cell, and within a tile by w-plane
+// (count -> scan -> scatter, one atomic per run of equal keys among adjacent lanes); the sorted list is cut into chunks
+// of <= 256 visibilities of ONE tile, and a workgroup takes a chunk through the planes its visibilities need: the
+// tile's (32 + W - 1)^2 cells of a plane are loaded once, coalesced, into LDS and every lane takes its W x W cells from
+// there.  Memory traffic per chunk: (planes spanned) x 23 KB instead of 256 x W x W x W gathered lines.
+constexpr int WG_TILE = 32;
+constexpr int WG_KB = 32;            // w-plane buckets of the sort key (locality only: the kernel finds its own plane range)
+constexpr int WG_CHUNK = 256;
+struct WgSort {
+    const double *uvw, *freq;
+    const unsigned char *mask;
+    int64_t nvis, nchan_b, chan0, nchan_total, nu, nv;
+    double cellx, celly, w0, dw;
+    int W, do_w, nplanes, kb, nty;
+};
+// (in everything below "u" is the SLOW axis of the stored planes and "v" the fast one: the planes are v-major, so the
+// host hands uvw's v as this code's u -- component 1 -- and u as its v)
+constexpr int WG_CU = 1, WG_CV = 0;
+// first cell of a visibility's support along one axis, wrapped onto the grid: the sort key and the tile kernel must
+// agree on it to the last bit, so both call this
+__device__ __forceinline__ int wg_first_cell(double g, int W, int n)
+{
+    const double t = ceil(g - 0.5 * W);                     // |t| < 1e15: exact in double
+    const double m = t - (double)n * floor(t / (double)n);
+    int p = (int)m;
+    p = p < 0 ? p + n : p;                                  // (rounding of t / n at multiples of n)
+    return p >= n ? p - n : p;
+}
+__device__ __forceinline__ int wg_vis_key(const WgSort &q, int64_t i)
+{
+    const unsigned r = (unsigned)i / (unsigned)q.nchan_b, c = (unsigned)i - r * (unsigned)q.nchan_b;   // nvis < 2^31
+    if (q.mask && !q.mask[(int64_t)r * q.nchan_total + q.chan0 + c]) return -1;
+    const double fl = q.freq[c] / AF_LIGHTSPEED;
+    const double *__restrict__ p = q.uvw + 3 * (int64_t)r;
+    const double gu = p[WG_CU] * fl * q.cellx * (double)q.nu, gv = p[WG_CV] * fl * q.celly * (double)q.nv;
+    if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return -1;
+    int kb = 0;
+    if (q.do_w) {
+        const double gw = (p[2] * fl - q.w0) / q.dw;
+        if (!isfinite(gw)) return -1;
+        double k0 = ceil(gw - 0.5 * q.W);
+        k0 = k0 < 0.0 ? 0.0 : (k0 > (double)(q.nplanes - 1) ? (double)(q.nplanes - 1) : k0);
+        kb = (int)(k0 * (double)q.kb / (double)q.nplanes);
+        kb = kb >= q.kb ? q.kb - 1 : kb;
+    }
+    const int pu = wg_first_cell(gu, q.W, (int)q.nu), pv = wg_first_cell(gv, q.W, (int)q.nv);
+    return ((pu / WG_TILE) * q.nty + pv / WG_TILE) * q.kb + kb;
+}
+// one atomic per run of equal keys among adjacent lanes; returns this lane's slot (or -1)
+__device__ __forceinline__ int wg_run_atomic(int *__restrict__ counter, int key, bool want_slot)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool leader = lane == 0 || prev != key;
+    const unsigned long long leaders = __ballot(leader);
+    const unsigned long long above = lane == 63 ? 0ULL : (leaders >> (lane + 1));
+    const int run = above ? __ffsll((long long)above) : 64 - lane;
+    int base = 0;
+    if (leader && key >= 0) base = atomicAdd(&counter[key], run);
+    if (!want_slot) return 0;
+    const unsigned long long below = leaders & (~0ULL >> (63 - lane));
+    const int first = 63 - __clzll((long long)below);
+    base = __shfl(base, first, 64);
+    return key >= 0 ? base + (lane - first) : -1;
+}
+__global__ __launch_bounds__(256) void wg_vis_count(WgSort q, int *__restrict__ count)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < q.nvis; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        wg_run_atomic(count, i < q.nvis ? wg_vis_key(q, i) : -1, false);
+    }
+}
+// count -> start (exclusive prefix; start[nbins] = total), cursor = start; three launches: sums of 1024-bin blocks, their
+// prefix (one block), then every block scans its bins from its base
+__global__ __launch_bounds__(256) void wg_scan_sums(const int *__restrict__ count, int nbins, int *__restrict__ sums)
+{
+    __shared__ int part[4];
+    const int b0 = blockIdx.x * 1024;
+    int s = 0;
+    for (int j = threadIdx.x; j < 1024; j += 256) s += b0 + j < nbins ? count[b0 + j] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void wg_scan_top(int *__restrict__ sums, int nblk, int *__restrict__ total)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblk + 1023) / 1024;
+    const int lo = t * per < nblk ? t * per : nblk, hi = lo + per < nblk ? lo + per : nblk;
+    int s = 0;
+    for (int b = lo; b < hi; ++b) s += sums[b];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    int base = part[t] - s;
+    for (int b = lo; b < hi; ++b) { const int c = sums[b]; sums[b] = base; base += c; }
+    if (t == 1023) *total = part[1023];
+}
+__global__ __launch_bounds__(256) void wg_scan_bins_from(const int *__restrict__ count, int nbins, const int *__restrict__ sums,
+                                                         int *__restrict__ start, int *__restrict__ cursor)
+{
+    __shared__ int part[4];
+    const int b0 = blockIdx.x * 1024 + threadIdx.x * 4;      // four consecutive bins per lane
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = b0 + j < nbins ? count[b0 + j] : 0; s += v[j]; }
+    int incl = s;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int a = __shfl_up(incl, off, 64);
+        incl += lane >= off ? a : 0;
+    }
+    if (lane == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = sums[blockIdx.x] + incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += part[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b0 + j < nbins) { start[b0 + j] = base; cursor[b0 + j] = base; }
+        base += v[j];
+    }
+}
+__global__ __launch_bounds__(256) void wg_vis_scatter(WgSort q, int *__restrict__ cursor, unsigned *__restrict__ idx)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < q.nvis; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        const int slot = wg_run_atomic(cursor, i < q.nvis ? wg_vis_key(q, i) : -1, true);
+        if (slot >= 0) idx[slot] = (unsigned)i;
+    }
+}
+// chunk table: (tile, first sorted index) of every <= 256 visibilities of one tile; *nchunks counts them
+__global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int2 *__restrict__ chunks,
+                              int *__restrict__ nchunks)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const int lo = start[t * kb], hi = start[(t + 1) * kb];
+    const int n = (hi - lo + WG_CHUNK - 1) / WG_CHUNK;
+    if (n == 0) return;
+    const int base = atomicAdd(nchunks, n);
+    for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * WG_CHUNK);
+}
+
+// one workgroup per chunk: vis[...] += sum over the resident planes [pk0, pk1) the chunk's visibilities touch
+template <int W>
+__global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
+                                                       int64_t nchan_b, int64_t chan0, int64_t nchan_total,
+                                                       const double2 *__restrict__ grids, int64_t nu, int64_t nv,
+                                                       double cellx, double celly, double beta, double w0, double dw,
+                                                       int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
+                                                       const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
+                                                       const int *__restrict__ nchunks, double2 *__restrict__ vis)
+{
+    constexpr int R = WG_TILE + W - 1;
+    constexpr int NL = (R * R + 255) / 256;
+    __shared__ double2 reg[R * R];
+    __shared__ int kred[8];
+    if ((int)blockIdx.x >= *nchunks) return;
+    const int2 ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nty = (int)((nv + WG_TILE - 1) / WG_TILE);
+    const int tu = ch.x / nty, tv = ch.x - tu * nty;
+    int n = start[(ch.x + 1) * kb] - ch.y;
+    n = n > WG_CHUNK ? WG_CHUNK : n;
+
+    // this lane's visibility
+    constexpr double inv_half_w = 2.0 / (double)W;
+    double ku[W], kv[W], gw = 0.0;
+    int k0 = 0x7fffffff, k1 = -0x7fffffff, lofs = 0;
+    int64_t o = 0;
+    if (tid < n) {
+        const unsigned i = idx[ch.y + tid];
+        const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
+        o = (int64_t)r * nchan_total + chan0 + c;
+        const double fl = freq[c] / AF_LIGHTSPEED;
+        k0 = 0; k1 = 1;
+        if (do_w) {
+            gw = (uvw[3 * (int64_t)r + 2] * fl - w0) / dw;
+            k0 = (int)ceil(gw - 0.5 * W);
+            k1 = k0 + W;
+        }
+        k0 = k0 < pk0 ? pk0 : k0;
+        k1 = k1 > pk1 ? pk1 : k1;
+        const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
+        const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
+        const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;   // first tap's offset
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            ku[t] = es_kernel(fu + (double)t, inv_half_w, beta);
+            kv[t] = es_kernel(fv + (double)t, inv_half_w, beta);
+        }
+        const int lu = wg_first_cell(gu, W, (int)nu) - tu * WG_TILE, lv = wg_first_cell(gv, W, (int)nv) - tv * WG_TILE;
+        lofs = lu * R + lv;
+        if (k0 >= k1) { k0 = 0x7fffffff; k1 = -0x7fffffff; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < W; ++t) { ku[t] = 0.0; kv[t] = 0.0; }
+    }
+    // plane range of the chunk
+    int kmin = k0, kmax = k1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if ((tid & 63) == 0) { kred[tid >> 6] = kmin; kred[4 + (tid >> 6)] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        kmin = kred[w] < kmin ? kred[w] : kmin;
+        kmax = kred[4 + w] > kmax ? kred[4 + w] : kmax;
+    }
+    if (kmin >= kmax) return;
+
+    // this lane's cells of the tile region: element e = tid + 256 q -> (row e / R, column e % R), wrapped on the grid
+    int64_t gofs[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        const int e = tid + 256 * q, a = e / R, b = e - a * R;
+        gofs[q] = e < R * R ? (int64_t)((tu * WG_TILE + a) % nu) * nv + (tv * WG_TILE + b) % nv : -1;
+    }
+    const int64_t plane = nu * nv;
+    double2 pre[NL];
+    const double2 *__restrict__ g = grids + (int64_t)(kmin - pk0) * plane;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) pre[q] = gofs[q] >= 0 ? g[gofs[q]] : make_double2(0.0, 0.0);
+    double are = 0.0, aim = 0.0;
+    for (int k = kmin; k < kmax; ++k) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q)
+            if (tid + 256 * q < R * R) reg[tid + 256 * q] = pre[q];
+        __syncthreads();
+        if (k + 1 < kmax) {                                  // next plane's cells travel while this one is summed
+            g += plane;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) pre[q] = gofs[q] >= 0 ? g[gofs[q]] : make_double2(0.0, 0.0);
+        }
+        if (k >= k0 && k < k1) {
+            const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+            const double2 *__restrict__ cell = reg + lofs;
+            double pre_ = 0.0, pim_ = 0.0;
+#pragma unroll
+            for (int a = 0; a < W; ++a) {
+                double rre = 0.0, rim = 0.0;
+#pragma unroll
+                for (int b = 0; b < W; ++b) {
+                    const double2 v = cell[a * R + b];
+                    rre = fma(kv[b], v.x, rre);
+                    rim = fma(kv[b], v.y, rim);
+                }
+                pre_ = fma(ku[a], rre, pre_);
+                pim_ = fma(ku[a], rim, pim_);
+            }
+            are = fma(kw, pre_, are);
+            aim = fma(kw, pim_, aim);
+        }
+        __syncthreads();
+    }
+    if (k0 < k1) {
+        double2 acc = vis[o];
+        acc.x += are;
+        acc.y += aim;
+        vis[o] = acc;
+    }
+}
+
+// (small calls) vis[r, chan0 + c] += sum over the resident planes [pk0, pk1) within the visibility's W-plane support of
+// psi_w times the W x W cells of that plane's grid; one lane per visibility gathering from memory
 template <int W>
 __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict__ uvw, const double *__restrict__ freq,
                                                         int64_t nrow, int64_t nchan_b, int64_t chan0, int64_t nchan_total,
@@ -167,7 +503,7 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
         k1 = k1 > pk1 ? pk1 : k1;
         if (k0 >= k1) return;
     }
-    const double gu = uvw[3 * r] * fl * cellx * (double)nu, gv = uvw[3 * r + 1] * fl * celly * (double)nv;
+    const double gu = uvw[3 * r + WG_CU] * fl * cellx * (double)nu, gv = uvw[3 * r + WG_CV] * fl * celly * (double)nv;
     if (!(isfinite(gu) && isfinite(gv))) return;
     const int64_t iu0 = (int64_t)ceil(gu - 0.5 * W), iv0 = (int64_t)ceil(gv - 0.5 * W);
     double ku[W], kv[W];
@@ -218,8 +554,9 @@ __global__ void wg_finish(double2 *__restrict__ vis, const double *__restrict__ 
     vis[o] = v;
 }
 
-struct WgWs { size_t hist, perm, key, grid, A, nm1, total; };
-WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow)
+struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, chunks, stage, grid, A, nm1, total; int nbins, ntiles, kb; };
+int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
+WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow, int64_t nvis_max)
 {
     WgWs w;
     size_t o = 0;
@@ -227,6 +564,17 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.hist = take(WG_NBIN * sizeof(int));
     w.perm = take((size_t)nrow * sizeof(int));
     w.key = take((size_t)nrow * sizeof(unsigned short));
+    // (the sort's tables are laid out for the largest bucket count: the layout must not depend on the call's w range)
+    w.ntiles = (int)(((nu + WG_TILE - 1) / WG_TILE) * ((nv + WG_TILE - 1) / WG_TILE));
+    w.kb = WG_KB;
+    w.nbins = w.ntiles * WG_KB;
+    w.sums = take((size_t)(w.nbins / 1024 + 2) * sizeof(int));
+    w.vcount = take((size_t)(w.nbins + 2) * sizeof(int));       // [nbins + 1] = the chunk counter
+    w.vstart = take((size_t)(w.nbins + 1) * sizeof(int));
+    w.vcursor = take((size_t)(w.nbins + 1) * sizeof(int));
+    w.vidx = take((size_t)nvis_max * sizeof(unsigned));
+    w.chunks = take((size_t)(w.ntiles + nvis_max / WG_CHUNK + 1) * sizeof(int2));
+    w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
@@ -234,20 +582,35 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     return w;
 }
 
-int plan_for(int nu, int nv, hipfftHandle *out)
+int plan_for(int kind, int n, int batch, hipfftHandle *out)
 {
     int dev = 0;
     AF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(g_plan_mu);
-    const PlanKey key{dev, nu, nv};
+    const PlanKey key{dev, kind, n, batch};
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
         hipfftHandle p;
-        const hipfftResult r = hipfftPlan2d(&p, nu, nv, HIPFFT_Z2Z);
-        AF_REQUIRE(r == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipfftPlan2d(%d, %d) failed (%d)", nu, nv, (int)r);
+        hipfftResult r;
+        int len[1] = {n};
+        r = hipfftPlanMany(&p, 1, len, len, 1, n, len, 1, n, HIPFFT_Z2Z, batch);
+        AF_REQUIRE(r == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT plan (kind %d, %d x %d) failed (%d)", kind, n, batch, (int)r);
         it = g_plans.emplace(key, p).first;
     }
     *out = it->second;
+    return AF_OK;
+}
+
+int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st)
+{
+    hipfftHandle plan;
+    const int rc = plan_for(1, n, batch, &plan);
+    if (rc != AF_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_plan_mu);              // a plan carries its stream: set and enqueue together
+    hipfftResult fr = hipfftSetStream(plan, st);
+    hipfftDoubleComplex *d = reinterpret_cast<hipfftDoubleComplex *>(at);
+    if (fr == HIPFFT_SUCCESS) fr = hipfftExecZ2Z(plan, d, d, HIPFFT_FORWARD);
+    AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT failed (%d)", (int)fr);
     return AF_OK;
 }
 
@@ -258,10 +621,11 @@ AF_EXPORT int64_t af_wgrid_padded(int64_t n) { return n <= 0 ? 0 : ((2 * n + 15)
 
 // `planes` = number of w-plane grids the workspace holds at a time (>= 1; the call works through the planes in batches of
 // that many: one pass over the visibilities per batch)
-AF_EXPORT size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow)
+// nchan_max: the largest number of channels of a band the workspace will be used for
+AF_EXPORT size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max)
 {
-    if (nx < 0 || ny < 0 || planes < 0 || nrow < 0) return 0;
-    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny), planes, nrow).total;
+    if (nx < 0 || ny < 0 || planes < 0 || nrow < 0 || nchan_max < 0) return 0;
+    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny), planes, nrow, nrow * nchan_max).total;
 }
 
 // number of w-planes a call will work through: the wrapper sizes its workspace with it
@@ -296,14 +660,15 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
     const int64_t nu = af_wgrid_padded(nx), nv = af_wgrid_padded(ny);
     AF_REQUIRE(nu < (1LL << 15) && nv < (1LL << 15), "af_wgrid_im2vis_f64: image too large");
     // as many resident planes as the workspace holds
-    const size_t one = wg_ws(nx, ny, nu, nv, 1, nrow).total, per_plane = (size_t)(nu * nv) * 16;
+    const int64_t nvis = nrow * nchan_band;
+    const size_t one = wg_ws(nx, ny, nu, nv, 1, nrow, nvis).total, per_plane = (size_t)(nu * nv) * 16;
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= one, "af_wgrid_im2vis_f64: workspace too small (%zu < %zu)",
                workspace_bytes, one);
     const int64_t resident = 1 + (int64_t)((workspace_bytes - one) / per_plane);
-    const WgWs L = wg_ws(nx, ny, nu, nv, resident, nrow);
+    const WgWs L = wg_ws(nx, ny, nu, nv, resident, nrow, nvis);
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_wgrid_im2vis_f64: workspace must be 256-byte aligned");
     char *ws = static_cast<char *>(workspace);
-    double2 *grid = reinterpret_cast<double2 *>(ws + L.grid);
+    double2 *grid = reinterpret_cast<double2 *>(ws + L.grid), *S = reinterpret_cast<double2 *>(ws + L.stage);
     double *A = reinterpret_cast<double *>(ws + L.A), *nm1 = reinterpret_cast<double *>(ws + L.nm1);
 
     // plane geometry: spacing from the largest |n - 1| of the image at an oversampling of 2 along w
@@ -326,7 +691,10 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
     // the band's columns start from zero
     AF_HIP(hipMemset2DAsync(vis + 2 * chan0, (size_t)nchan_total * 16, 0, (size_t)nchan_band * 16, (size_t)nrow, st));
     const int *perm = nullptr;
-    if (nrow >= 4096 && nrow < (1LL << 31)) {
+    // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
+    static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
+    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
+    if (!tiled && nrow >= 4096 && nrow < (1LL << 31)) {
         int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
         unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
         AF_HIP(hipMemsetAsync(hist, 0, WG_NBIN * sizeof(int), st));
@@ -339,28 +707,61 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
         AF_LAUNCH_CHECK();
         perm = pm;
     }
-    hipfftHandle plan;
-    int rc = plan_for((int)nu, (int)nv, &plan);
-    if (rc != AF_OK) return rc;
+    const int kb = wg_kb(nplanes), nbins = L.ntiles * kb;
+    int *vcount = reinterpret_cast<int *>(ws + L.vcount), *vstart = reinterpret_cast<int *>(ws + L.vstart);
+    const unsigned *vidx = reinterpret_cast<unsigned *>(ws + L.vidx);
+    const int2 *chunks = reinterpret_cast<int2 *>(ws + L.chunks);
+    const int *nchunks = vcount + nbins + 1;
+    const unsigned max_chunks = (unsigned)(L.ntiles + nvis / WG_CHUNK + 1);
+    if (tiled) {
+        int *vcursor = reinterpret_cast<int *>(ws + L.vcursor);
+        WgSort q{uvw, freq, mask, nvis, nchan_band, chan0, nchan_total, nv, nu, celly, cellx, w0, dw,
+                 kernel_width, do_wstacking, nplanes, kb, (int)((nu + WG_TILE - 1) / WG_TILE)};
+        AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
+        int64_t blocks = af_cdiv(nvis, 256);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wg_vis_count, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount);
+        AF_LAUNCH_CHECK();
+        const int nblk = (int)af_cdiv(nbins, 1024);
+        int *sums = reinterpret_cast<int *>(ws + L.sums);
+        hipLaunchKernelGGL(wg_scan_sums, dim3((unsigned)nblk), dim3(256), 0, st, vcount, nbins, sums);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_scan_top, dim3(1), dim3(1024), 0, st, sums, nblk, vstart + nbins);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)nblk), dim3(256), 0, st, vcount, nbins, sums, vstart, vcursor);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, st, q, vcursor,
+                           reinterpret_cast<unsigned *>(ws + L.vidx));
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(L.ntiles, 256)), dim3(256), 0, st, vstart, L.ntiles, kb,
+                           reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
+        AF_LAUNCH_CHECK();
+    }
     af_prof_begin(st);
     for (int pk0 = 0; pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
         for (int k = pk0; k < pk1; ++k) {
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
-            AF_HIP(hipMemsetAsync(gk, 0, (size_t)(nu * nv) * 16, st));
-            hipLaunchKernelGGL(wg_fill_plane, dim3(nb_img), dim3(256), 0, st, image, A, nm1, nx, ny, nu, nv, w0 + k * dw, gk);
+            hipLaunchKernelGGL(wg_fill_rows, dim3((unsigned)af_cdiv(nx * nv, 256)), dim3(256), 0, st, image, A, nm1, nx, ny,
+                               nv, w0 + k * dw, S);
             AF_LAUNCH_CHECK();
-            std::lock_guard<std::mutex> g(g_plan_mu);   // a plan carries its stream: set and enqueue together
-            hipfftResult fr = hipfftSetStream(plan, st);
-            if (fr == HIPFFT_SUCCESS)
-                fr = hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(gk),
-                                   reinterpret_cast<hipfftDoubleComplex *>(gk), HIPFFT_FORWARD);
-            AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT failed (%d)", (int)fr);
+            int rc = wg_fft_rows((int)nv, (int)nx, S, st);                      // along v, the image's rows only
+            if (rc != AF_OK) return rc;
+            hipLaunchKernelGGL(wg_transpose_rows, dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0,
+                               st, S, nx, nu, nv, gk);
+            AF_LAUNCH_CHECK();
+            rc = wg_fft_rows((int)nu, (int)nv, gk, st);                          // along u, every column
+            if (rc != AF_OK) return rc;
         }
 #define AF_WG_LAUNCH(WC)                                                                                               \
-    hipLaunchKernelGGL((wg_degrid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,       \
-                       nchan_total, grid, nu, nv, cellx, celly, beta, w0, dw, pk0, pk1, do_wstacking, mask, perm,        \
-                       reinterpret_cast<double2 *>(vis))
+    if (tiled)                                                                                                         \
+        hipLaunchKernelGGL((wg_degrid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,      \
+                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
+                           kb, chunks, nchunks, reinterpret_cast<double2 *>(vis));                                       \
+    else                                                                                                               \
+        hipLaunchKernelGGL((wg_degrid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,   \
+                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, perm,    \
+                           reinterpret_cast<double2 *>(vis))
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
         case 5: AF_WG_LAUNCH(5); break;

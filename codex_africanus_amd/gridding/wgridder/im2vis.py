@@ -116,7 +116,7 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
             bands.append((b, c0, nc, cands, npl))
         want = max([x[4] for x in bands] + [1])
         resident = max(1, min(want, PLANE_BUDGET // (nu * nv * 16)))
-        ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny, resident, nrow))
+        ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny, resident, nrow, max([x[2] for x in bands] + [1])))
         p_ws = c.scratch(ws_bytes)
         for b, c0, nc, cands, npl in bands:
             _lib.call("af_wgrid_im2vis_f64", p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,

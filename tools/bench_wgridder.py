@@ -25,13 +25,19 @@ nz = rng.integers(0, npix, (5000, 2))
 image[0, nz[:, 0], nz[:, 1]] = rng.lognormal(0, 1, 5000)
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 args = (T(uvw), T(freq), T(image), np.array([0]), np.array([nchan]), cell)
-vis = model(*args, epsilon=eps); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(3):
+for _ in range(2):
     vis = model(*args, epsilon=eps)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 3
+torch.cuda.synchronize()
+# per-call HIP-event times; the median is reported (on some boxes of the pool one call in a few stalls for ~0.5 s on the
+# host side of an allocation, which a mean over a handful of calls would report as the kernel's time)
+times = []
+for _ in range(7):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    vis = model(*args, epsilon=eps)
+    e1.record(); torch.cuda.synchronize()
+    times.append(e0.elapsed_time(e1))
+ms = float(np.median(times))
 rows = np.linspace(0, nrow - 1, 64).astype(int)
 ix, iy = np.nonzero(image[0])
 x, y = (ix - npix / 2) * cell, (iy - npix / 2) * cell
@@ -42,6 +48,6 @@ got = vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
 l2 = float(np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)))
 wl = np.abs(uvw[:, 2]).max() * freq.max() / 299792458.0
 emax = 2 * (npix / 2 * cell) ** 2
-print(json.dumps(dict(ms=ms, Mvis_per_s=nrow * nchan / ms / 1e3, epsilon=eps, taps=kernel_parameters(eps)[0],
+print(json.dumps(dict(ms=ms, ms_calls=[round(t, 2) for t in times], Mvis_per_s=nrow * nchan / ms / 1e3, epsilon=eps, taps=kernel_parameters(eps)[0],
                       l2_error_vs_direct_transform=l2, npix=npix, rows=nrow, chans=nchan,
                       w_planes=int(np.ceil(2 * wl * 4 * emax / (np.sqrt(1 - emax) + 1))) + kernel_parameters(eps)[0] + 1)))
