@@ -652,6 +652,8 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
 {
     AF_REQUIRE(nrow >= 0 && nchan_band >= 0 && nx >= 1 && ny >= 1 && chan0 >= 0 && chan0 + nchan_band <= nchan_total,
                "af_wgrid_im2vis_f64: bad extents");
+    AF_REQUIRE(nx % 2 == 0 && ny % 2 == 0, "af_wgrid_im2vis_f64: image dimensions must be even (%lld x %lld)", (long long)nx,
+               (long long)ny);
     AF_REQUIRE(kernel_width >= 4 && kernel_width <= WG_MAXW, "af_wgrid_im2vis_f64: kernel width %d not in 4..%d", kernel_width,
                WG_MAXW);
     hipStream_t st = af_stream(stream);

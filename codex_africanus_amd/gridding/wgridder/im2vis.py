@@ -74,6 +74,9 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
             raise ValueError("%s must have shape (row, chan)" % name)
     out_dtype = np.result_type(np_dtype_of(image), np.complex64)
     W, beta = kernel_parameters(float(epsilon))
+    if nx % 2 or ny % 2:
+        # ducc0 requires even image sizes (the phase centre is the pixel nx/2, ny/2); so does this entry
+        raise ValueError("image dimensions must be even (got %d x %d)" % (nx, ny))
     lib = _lib.load()
     nu, nv = int(lib.af_wgrid_padded(nx)), int(lib.af_wgrid_padded(ny))
     corr_u, corr_v = kernel_correction(nx, nu, W, beta), kernel_correction(ny, nv, W, beta)

@@ -106,3 +106,51 @@ def test_model_device_resident_matches_host():
         model(uvw, freq, image, fbi, fbc, 0.2)
     with pytest.raises(ValueError, match="one entry per band"):
         model(uvw, freq, image, fbi[:1], fbc, cell)
+    with pytest.raises(ValueError, match="must be even"):      # as ducc0
+        model(uvw, freq, image[:, :19], fbi, fbc, cell)
+
+
+def _wide_case(nx, ny, nrow, nchan, seed):
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 25.0, nrow, nchan, 1, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.15).astype(np.uint8)
+    uvw[5] = 0.0                                            # a row in the middle of every axis
+    uvw[6, :2] *= -1.0
+    return cell, freq, uvw, fbi, fbc, image, wgt, flag
+
+
+@pytest.mark.parametrize("nx, ny, epsilon", [(64, 48, 1e-7), (34, 70, 1e-4), (48, 48, 1e-10)])
+def test_sorted_tile_path_meets_the_contract_and_matches_the_gather_path(nx, ny, epsilon):
+    """Calls of >= 65536 visibilities sort them by (uv tile, w-plane) and stage the tiles through LDS; smaller calls
+    gather from memory.  Same planes, same taps: the two agree far inside epsilon, and both meet the contract.  Odd
+    sizes, non-square pixels, flags and weights, tiles that wrap around the grid's edges."""
+    nrow, nchan = 3000, 24                                  # 72000 visibilities
+    cell, freq, uvw, fbi, fbc, image, wgt, flag = _wide_case(nx, ny, nrow, nchan, seed=nx)
+    celly = cell * 0.8
+    vis = model(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, celly=celly, epsilon=epsilon)
+    ref = _explicit_degridder(uvw, freq, image[0], cell, celly) * wgt * (flag != 0)
+    assert np.all(vis[flag == 0] == 0)
+    assert _l2error(vis, ref) <= epsilon
+    # the gather path on the same planes: the w range of a call fixes the planes, so keep the two extreme rows in
+    # every piece
+    lo, hi = np.argmin(uvw[:, 2]), np.argmax(uvw[:, 2])
+    for a in range(0, nrow, 1000):
+        rows = np.unique(np.concatenate([np.arange(a, a + 1000), [lo, hi]]))
+        part = model(uvw[rows], freq, image, fbi, fbc, cell, weights=wgt[rows], flag=flag[rows], celly=celly,
+                     epsilon=epsilon)
+        assert np.abs(part - vis[rows]).max() <= 1e-12 * np.abs(vis).max()
+
+
+def test_sorted_tile_path_in_plane_batches(monkeypatch):
+    """A workspace that holds fewer planes than the call needs: the planes are worked through in batches, one pass of
+    the sorted visibilities per batch.  Same result as with every plane resident, to rounding."""
+    from codex_africanus_amd.gridding.wgridder import im2vis
+    cell, freq, uvw, fbi, fbc, image, wgt, flag = _wide_case(40, 40, 3000, 24, seed=5)
+    full = model(uvw, freq, image, fbi, fbc, cell, flag=flag, epsilon=1e-6)
+    nu = 2 * 40 + (-2 * 40) % 16
+    monkeypatch.setattr(im2vis, "PLANE_BUDGET", 3 * nu * nu * 16)
+    batched = model(uvw, freq, image, fbi, fbc, cell, flag=flag, epsilon=1e-6)
+    assert np.abs(batched - full).max() <= 1e-13 * np.abs(full).max()
+    flat = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-6, do_wstacking=False)
+    assert _l2error(flat, _explicit_degridder(uvw, freq, image[0], cell, cell, apply_w=False)) <= 1e-6
