@@ -133,18 +133,21 @@ class Dft(object):
         a = self.args
         nrow, nchan, nsrc, ncorr = a.rows, a.chans, a.sources, 4
         # Dominant kernel = the one the library's measurement hook brackets.  4-correlation images on a
-        # one-spacing band run dft_mfma_kernel<64>: every 64-channel tile in ONE launch (C2: all 64 channels).
+        # one-spacing band run dft_mfma_kernel<CT>: every CT-channel tile in ONE launch (C2: all 64 channels); CT = 32
+        # for real images (two waves per SIMD), 64 for complex ones (af_im_to_vis_mfma.hip main_ct).
         mfma = a.mode != "exact" and nchan >= 14
         px = 16 if self.cplx else 8
         if mfma:
-            ntile = nchan // 64 + (1 if nchan % 64 > 32 else 0)
-            dom_chans = min(nchan, ntile * 64) if ntile else nchan
-            name = ("dft_mfma_kernel<64,%s>" % str(self.cplx).lower()) if ntile else \
-                "dft_mfma_kernel<%d,%s>" % (16 if nchan <= 16 else 32, str(self.cplx).lower())
+            ct = 64 if self.cplx else 32
+            ntile = nchan // ct + (1 if nchan % ct > ct // 2 else 0)
+            dom_chans = min(nchan, ntile * ct) if ntile else nchan
+            if not ntile:
+                ct = 16 if nchan <= 16 else 32
+            name = "dft_mfma_kernel<%d,%s>" % (ct, str(self.cplx).lower())
             nstep = -(-nsrc // 4)
             # algorithmic HBM bytes of that launch: 64 B written per vis + uvw 24 B/row + its
-            # records ((64 x {1 real | 3 complex: Re, Im, -Im} + 1 header) x 16 doubles per tile and 4-source step)
-            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + max(ntile, 1) * nstep * (64 * (3 if self.cplx else 1) + 1) * 16 * 8
+            # records ((CT x {1 real | 3 complex: Re, Im, -Im} + 1 header) x 16 doubles per tile and 4-source step)
+            alg_bytes = nrow * dom_chans * ncorr * 16 + nrow * 24 + max(ntile, 1) * nstep * (ct * (3 if self.cplx else 1) + 1) * 16 * 8
         else:
             dom_chans = nchan
             name = "dft_exact_kernel"

@@ -21,6 +21,8 @@
 //     the MFMAs; the set-up of step it+1 (table phasors) is sliced over the channel groups of step it.
 //   * measured (tools/microbench_issue.hip): a lone wave issues an fp64 VALU op every ~5.5 cycles and an
 //     fp64 MFMA 4x4x4 every 16.4; per step 128 MFMAs + ~220 VALU ops = ~3300 cycles against 3500 measured.
+#include <stdlib.h>
+
 #include "af_dft_mfma.h"
 #include "af_mfma_phasor.h"
 
@@ -237,23 +239,38 @@ __global__ void mfma_fix_columns(const int *__restrict__ flags, const int *__res
 }
 
 struct Plan {
-    int64_t nfull;       // tiles of 64 channels (a last partial tile wider than 32 channels counts)
+    int ct;              // width of the main tiles: 64 or 32 channels (main_ct)
+    int64_t nfull;       // main tiles (a last partial tile wider than half a tile counts)
     int tail_ct;         // 0, 16 or 32: width of the last tile when narrower
     int64_t tail_c0;
     size_t f0_off, rec_off, tail_rec_off, total;
 };
 
+// Tile width of the band's main launch.  Real images: 32 channels -- 128 AGPRs + 128 VGPRs, so TWO waves share a SIMD
+// and one wave's MFMAs run in the other's issue gaps (a lone wave issues an fp64 VALU op every ~5.5 cycles, not 4):
+// 20.7 ms against 21.6 ms with 64-channel tiles at 1e6 x 64 x 1000, although the per-tile set-up is amortised over
+// half as many channels.  Complex images need 340 registers at 32 channels (one wave per SIMD either way): 64.
+// AFHIP_DFT_MFMA_CT=64 / 32 overrides (A/B measurements).
+int main_ct(bool cplx)
+{
+    static const int env = getenv("AFHIP_DFT_MFMA_CT") ? atoi(getenv("AFHIP_DFT_MFMA_CT")) : 0;
+    if (env == 64 || (env == 32 && !cplx)) return env;
+    return cplx ? 64 : 32;
+}
+
 Plan make_plan(int64_t nsrc_pad, int64_t nchan, bool cplx)
 {
     Plan p;
-    const int64_t nit = nsrc_pad / 4, rem = nchan % 64;
-    p.nfull = nchan / 64 + (rem > 32 ? 1 : 0);
-    p.tail_ct = (rem == 0 || rem > 32) ? 0 : (rem <= 16 ? 16 : 32);
-    p.tail_c0 = (nchan / 64) * 64;
+    const int ct = main_ct(cplx), half = ct / 2;
+    const int64_t nit = nsrc_pad / 4, rem = nchan % ct;
+    p.ct = ct;
+    p.nfull = nchan / ct + (rem > half ? 1 : 0);
+    p.tail_ct = (rem == 0 || rem > half) ? 0 : ((ct == 64 && rem > 16) ? 32 : 16);
+    p.tail_c0 = (nchan / ct) * ct;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
     p.f0_off = take((size_t)(p.nfull + 1) * sizeof(double));
-    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(64, cplx) * sizeof(double));
+    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(ct, cplx) * sizeof(double));
     p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct, cplx) : 0) * sizeof(double));
     p.total = o;
     return p;
@@ -288,7 +305,7 @@ int run_tiles(const double *image, const double *uvw, const double *frequency, c
 bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex)
 {
     (void)image_is_complex;  // complex pixels: four MFMAs per channel instead of two
-    return ncorr == 4 && nchan >= 14 && nchan / 64 + 1 <= 65535;
+    return ncorr == 4 && nchan >= 14 && nchan / 32 + 1 <= 65535;
 }
 
 size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex)
@@ -307,7 +324,10 @@ int run_all(const double *image, const double *uvw, const double *frequency, con
     double *f0 = reinterpret_cast<double *>(ws + p.f0_off);
     const int64_t nit = nsrc_pad / 4;
     int rc = AF_OK;
-    if (p.nfull > 0)
+    if (p.nfull > 0 && p.ct == 32)
+        rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+    else if (p.nfull > 0)
         rc = run_tiles<64, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
                                  0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
     if (rc != AF_OK) return rc;
