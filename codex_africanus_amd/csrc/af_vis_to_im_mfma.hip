@@ -15,6 +15,8 @@
 // Reference semantics kept by the pack pass: a (row, chan) with any flagged correlation contributes
 // exactly nothing (zeros; a non-finite uvw row is zeroed in the header so its phasor is finite); an
 // UNFLAGGED cell of a non-finite row contributes NaN to every source, as p = NaN does in the reference.
+#include <stdlib.h>
+
 #include "af_mfma_phasor.h"
 #include "af_v2i_mfma.h"
 
@@ -47,10 +49,10 @@ __global__ void v2i_mfma_prep_freq(const double *__restrict__ freq, int64_t ncha
     if (!uniform) atomicAnd(&flags[3], 0);
 }
 
-__global__ void v2i_mfma_fill_tiles(int64_t *c0, int *ct, int64_t nfull, int tail_ct, int64_t tail_c0)
+__global__ void v2i_mfma_fill_tiles(int64_t *c0, int *ct, int64_t nfull, int main_ct, int tail_ct, int64_t tail_c0)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < nfull) { c0[t] = 64 * t; ct[t] = 64; }
+    if (t < nfull) { c0[t] = main_ct * t; ct[t] = main_ct; }
     if (t == nfull && tail_ct) { c0[t] = tail_c0; ct[t] = tail_ct; }
 }
 
@@ -102,7 +104,7 @@ template <int CT>
 __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
     const double *__restrict__ lmn, const double *__restrict__ uvw, const double *__restrict__ records,
     const double *__restrict__ tilef, const int *__restrict__ flags, double *__restrict__ partial, int64_t nsrc,
-    int64_t nrow, int64_t nstep, int64_t steps_per_part, int64_t nchan, int64_t c0_first)
+    int64_t nrow, int64_t nstep, int64_t steps_per_part, int64_t nchan, int64_t c0_first, int nsgroup, int npart)
 {
     if (flags[3] != 1) return;
     constexpr int STAGE = v_stage_doubles(CT);
@@ -112,13 +114,19 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = lane >> 4;  // the row of a step this lane computes the phasor of
     const int tile = blockIdx.y;
+    // XCD-aware order: the hardware deals workgroups b, b + 8, ... to one XCD.  Every source group of a row partition
+    // goes to ONE XCD (partition = 8 (slot / groups) + b % 8), so a partition's records are fetched into one L2 once and
+    // shared by its source groups instead of being fetched by all eight (measured: 41 GB fetched for 4 GB of records)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = slot % nsgroup, bz = (slot / nsgroup) * 8 + xcd;
+    if (bz >= npart) return;
     const int64_t c0 = c0_first + (int64_t)tile * CT;
     const double *__restrict__ rec = records + (int64_t)tile * nstep * STAGE;
-    int64_t src = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    int64_t src = (int64_t)bx * 64 + wave * 16 + (lane & 15);
     if (src >= nsrc) src = nsrc - 1;
     const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
     const double F0 = 64.0 * tilef[2 * tile], FD = 64.0 * tilef[2 * tile + 1];   // quarter turns -> 1/256 turns per metre (exact)
-    const int64_t it0 = (int64_t)blockIdx.z * steps_per_part;
+    const int64_t it0 = (int64_t)bz * steps_per_part;
     const int64_t it1 = (it0 + steps_per_part < nstep) ? it0 + steps_per_part : nstep;
     const int boff = k * 4 + (lane & 3);  // B operand (Re V, -Im V) of (row k, corr lane & 3)
 
@@ -195,10 +203,10 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
 
     // D lane = 16 i + 4 b + corr holds source 4 b + i
     const int osrc = 4 * ((lane >> 2) & 3) + (lane >> 4), ocorr = lane & 3;
-    const int64_t s = (int64_t)blockIdx.x * 64 + wave * 16 + osrc;
+    const int64_t s = (int64_t)bx * 64 + wave * 16 + osrc;
     if (s >= nsrc) return;
     const int nvalid = (int)((nchan - c0 < CT) ? (nchan - c0) : CT);
-    double *__restrict__ o = partial + (((int64_t)blockIdx.z * nsrc + s) * nchan + c0) * 4 + ocorr;
+    double *__restrict__ o = partial + (((int64_t)bz * nsrc + s) * nchan + c0) * 4 + ocorr;
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         if (j < nvalid) o[j * 4] = acc[j];
@@ -206,24 +214,36 @@ __global__ __launch_bounds__(THREADS) void v2i_mfma_kernel(
 }
 
 struct Plan {
+    int ct;              // width of the main tiles (v2i_main_ct)
     int64_t nfull;
     int tail_ct;
     int64_t tail_c0, nstep;
     size_t tilef_off, rec_off, tail_rec_off, total;
 };
 
+// Width of the band's main tiles.  32 channels (64 AGPRs + 180 VGPRs) put two waves on a SIMD where 64 channels (316
+// registers) leave one, which bought im_to_vis 4 % (af_im_to_vis_mfma.hip main_ct); measured here, same box: 23.1 ms
+// against 22.7 ms with 64 -- no gain, twice the partial-image blocks -- so 64 stays.  AFHIP_V2I_MFMA_CT=32 for A/B.
+int v2i_main_ct()
+{
+    static const int env = getenv("AFHIP_V2I_MFMA_CT") ? atoi(getenv("AFHIP_V2I_MFMA_CT")) : 0;
+    return env == 32 ? 32 : 64;
+}
+
 Plan make_plan(int64_t nrow, int64_t nchan)
 {
     Plan p;
-    const int64_t rem = nchan % 64;
+    const int ct = v2i_main_ct(), half = ct / 2;
+    const int64_t rem = nchan % ct;
+    p.ct = ct;
     p.nstep = af_cdiv(nrow > 0 ? nrow : 1, 4);
-    p.nfull = nchan / 64 + (rem > 32 ? 1 : 0);
-    p.tail_ct = (rem == 0 || rem > 32) ? 0 : (rem <= 16 ? 16 : 32);
-    p.tail_c0 = (nchan / 64) * 64;
+    p.nfull = nchan / ct + (rem > half ? 1 : 0);
+    p.tail_ct = (rem == 0 || rem > half) ? 0 : ((ct == 64 && rem > 16) ? 32 : 16);
+    p.tail_c0 = (nchan / ct) * ct;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
     p.tilef_off = take((size_t)(p.nfull + 1) * 2 * sizeof(double) + (size_t)(p.nfull + 1) * (sizeof(int64_t) + sizeof(int)));
-    p.rec_off = take((size_t)p.nfull * p.nstep * v_stage_doubles(64) * sizeof(double));
+    p.rec_off = take((size_t)p.nfull * p.nstep * v_stage_doubles(ct) * sizeof(double));
     p.tail_rec_off = take((size_t)(p.tail_ct ? p.nstep * v_stage_doubles(p.tail_ct) : 0) * sizeof(double));
     p.total = o;
     return p;
@@ -243,9 +263,12 @@ int run_tiles(const double2 *vis, const unsigned char *vflags, const double *uvw
         AF_LAUNCH_CHECK();
     }
     if (prof) af_prof_begin(st);
-    hipLaunchKernelGGL((v2i_mfma_kernel<CT>), dim3((unsigned)af_cdiv(nsrc, 64), (unsigned)ntile, (unsigned)npart),
-                       dim3(THREADS), 0, st, lmn, uvw, rec, tilef, flags, partial, nsrc, nrow, nstep, steps_per_part, nchan,
-                       c0);
+    const int64_t nsgroup = af_cdiv(nsrc, 64), part8 = af_cdiv(npart, 8) * 8;
+    AF_REQUIRE(nsgroup * part8 < (1LL << 31), "vis_to_im: %lld source groups x %lld row partitions", (long long)nsgroup,
+               (long long)part8);
+    hipLaunchKernelGGL((v2i_mfma_kernel<CT>), dim3((unsigned)(nsgroup * part8), (unsigned)ntile), dim3(THREADS), 0, st, lmn,
+                       uvw, rec, tilef, flags, partial, nsrc, nrow, nstep, steps_per_part, nchan, c0, (int)nsgroup,
+                       (int)npart);
     if (prof) af_prof_end(st);
     AF_LAUNCH_CHECK();
     return AF_OK;
@@ -255,7 +278,7 @@ int run_tiles(const double2 *vis, const unsigned char *vflags, const double *uvw
 
 bool af_v2i_mfma_eligible(int64_t nchan, int64_t ncorr)
 {
-    return ncorr == 4 && nchan >= 14 && nchan / 64 + 1 <= 65535;
+    return ncorr == 4 && nchan >= 14 && nchan / 32 + 1 <= 65535;
 }
 
 size_t af_v2i_mfma_workspace_bytes(int64_t nrow, int64_t nchan)
@@ -276,7 +299,7 @@ int af_v2i_mfma_run(const double *vis, const unsigned char *vflags, const double
     int64_t *tile_c0 = reinterpret_cast<int64_t *>(tilef + 2 * (p.nfull + 1));
     int *tile_ct = reinterpret_cast<int *>(tile_c0 + (p.nfull + 1));
     hipLaunchKernelGGL(v2i_mfma_fill_tiles, dim3((unsigned)af_cdiv(ntile, 64)), dim3(64), 0, st, tile_c0, tile_ct, p.nfull,
-                       p.tail_ct, p.tail_c0);
+                       p.ct, p.tail_ct, p.tail_c0);
     AF_LAUNCH_CHECK();
     hipLaunchKernelGGL(v2i_mfma_prep_freq, dim3((unsigned)af_cdiv(ntile, 64)), dim3(64), 0, st, frequency, nchan, tile_c0,
                        tile_ct, (int)ntile, sign, tilef, flags);
@@ -285,7 +308,10 @@ int af_v2i_mfma_run(const double *vis, const unsigned char *vflags, const double
     const int64_t steps_per_part = rows_per_part / 4;
     const double2 *v2 = reinterpret_cast<const double2 *>(vis);
     int rc = AF_OK;
-    if (p.nfull > 0)
+    if (p.nfull > 0 && p.ct == 32)
+        rc = run_tiles<32>(v2, vflags, uvw, lmn, flags, chan_any, tilef, partial, nsrc, nrow, p.nstep, nchan, 0, p.nfull,
+                           npart, steps_per_part, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+    else if (p.nfull > 0)
         rc = run_tiles<64>(v2, vflags, uvw, lmn, flags, chan_any, tilef, partial, nsrc, nrow, p.nstep, nchan, 0, p.nfull,
                            npart, steps_per_part, reinterpret_cast<double *>(ws + p.rec_off), true, st);
     if (rc != AF_OK) return rc;
