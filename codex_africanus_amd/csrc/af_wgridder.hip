@@ -554,6 +554,112 @@ __global__ void wg_finish(double2 *__restrict__ vis, const double *__restrict__ 
     vis[o] = v;
 }
 
+// ================= the adjoint: visibilities -> image (africanus/gridding/wgridder/vis2im.py:15-72, ducc0's ms2dirty) =====
+//     dirty[x, y] = (1 / n) sum_{r, c} Re( wgt vis exp(+2 pi i nu/c (u x + v y - w (n - 1))) )
+// (test_wgridder.py:18-46).  Exactly the transpose of the operator above, plane by plane: the visibilities are spread
+// with the same taps onto the w-plane grids, every grid is transformed back (rows along u, the nx image rows gathered
+// into the staging array, rows along v), multiplied by exp(-2 pi i w_k (n - 1)) and by the same taper A, and its real
+// part added to the image.
+
+// (small calls) one lane per visibility, hardware fp64 atomics into the planes
+template <int W>
+__global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__ uvw, const double *__restrict__ freq,
+                                                      int64_t nrow, int64_t nchan_b, int64_t chan0, int64_t nchan_total,
+                                                      double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
+                                                      double celly, double beta, double w0, double dw, int pk0, int pk1,
+                                                      int do_w, const unsigned char *__restrict__ mask,
+                                                      const double *__restrict__ wgt, const double2 *__restrict__ vis)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrow * nchan_b) return;
+    const int64_t r = i / nchan_b, c = i - r * nchan_b;
+    const int64_t o = r * nchan_total + chan0 + c;
+    if (mask && !mask[o]) return;
+    double2 val = vis[o];
+    if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
+    const double fl = freq[c] / AF_LIGHTSPEED;
+    constexpr double inv_half_w = 2.0 / (double)W;
+    double gw = 0.0;
+    int k0 = 0, k1 = 1;
+    if (do_w) {
+        gw = (uvw[3 * r + 2] * fl - w0) / dw;
+        if (!isfinite(gw)) return;
+        k0 = (int)ceil(gw - 0.5 * W);
+        k1 = k0 + W;
+        k0 = k0 < pk0 ? pk0 : k0;
+        k1 = k1 > pk1 ? pk1 : k1;
+        if (k0 >= k1) return;
+    }
+    const double gu = uvw[3 * r + WG_CU] * fl * cellx * (double)nu, gv = uvw[3 * r + WG_CV] * fl * celly * (double)nv;
+    if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return;
+    const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;
+    const int pu0 = wg_first_cell(gu, W, (int)nu), pv0 = wg_first_cell(gv, W, (int)nv);
+    double ku[W], kv[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        ku[t] = es_kernel(fu + (double)t, inv_half_w, beta);
+        kv[t] = es_kernel(fv + (double)t, inv_half_w, beta);
+    }
+    for (int k = k0; k < k1; ++k) {
+        const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+        double *__restrict__ grid = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * nu * nv);
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+            int pa = pu0 + a;
+            pa = pa >= nu ? pa - (int)nu : pa;
+            const double wa = kw * ku[a];
+#pragma unroll
+            for (int b = 0; b < W; ++b) {
+                int pb = pv0 + b;
+                pb = pb >= nv ? pb - (int)nv : pb;
+                const double wt = wa * kv[b];
+                double *cell = grid + 2 * ((int64_t)pa * nv + pb);
+                unsafeAtomicAdd(cell, wt * val.x);
+                unsafeAtomicAdd(cell + 1, wt * val.y);
+            }
+        }
+    }
+}
+
+// S[ix * nv + pv] = G[pv * nu + pu(ix)]: the nx image rows of a plane (transformed along u), v contiguous again
+__global__ __launch_bounds__(256) void wg_gather_rows(const double2 *__restrict__ G, int64_t nx, int64_t nu, int64_t nv,
+                                                      double2 *__restrict__ S)
+{
+    __shared__ double2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t ix0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t pv = pv0 + ty + 8 * j, ix = ix0 + tx;
+        int64_t pu = ix - nx / 2;
+        pu = pu < 0 ? pu + nu : pu;
+        tile[ty + 8 * j][tx] = (pv < nv && ix < nx) ? G[pv * nu + pu] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ix = ix0 + ty + 8 * j, pv = pv0 + tx;
+        if (ix < nx && pv < nv) S[ix * nv + pv] = tile[tx][ty + 8 * j];
+    }
+}
+
+// image[ix, iy] (+)= A Re( S[ix, pv(iy)] exp(-2 pi i w_k (n - 1)) )
+__global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ S, const double *__restrict__ A,
+                                                    const double *__restrict__ nm1, int64_t nx, int64_t ny, int64_t nv,
+                                                    double wk, int first, double *__restrict__ image)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx * ny) return;
+    const int64_t ix = i / ny, iy = i - ix * ny;
+    int64_t pv = iy - ny / 2;
+    pv = pv < 0 ? pv + nv : pv;
+    const double2 g = S[ix * nv + pv];
+    double sn, cs;
+    sincospi(2.0 * wk * nm1[i], &sn, &cs);
+    const double v = A[i] * (g.x * cs + g.y * sn);
+    image[i] = first ? v : image[i] + v;
+}
+
 struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, chunks, stage, grid, A, nm1, total; int nbins, ntiles, kb; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow, int64_t nvis_max)
@@ -601,7 +707,7 @@ int plan_for(int kind, int n, int batch, hipfftHandle *out)
     return AF_OK;
 }
 
-int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st)
+int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st, bool backward = false)
 {
     hipfftHandle plan;
     const int rc = plan_for(1, n, batch, &plan);
@@ -609,7 +715,7 @@ int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st)
     std::lock_guard<std::mutex> lk(g_plan_mu);              // a plan carries its stream: set and enqueue together
     hipfftResult fr = hipfftSetStream(plan, st);
     hipfftDoubleComplex *d = reinterpret_cast<hipfftDoubleComplex *>(at);
-    if (fr == HIPFFT_SUCCESS) fr = hipfftExecZ2Z(plan, d, d, HIPFFT_FORWARD);
+    if (fr == HIPFFT_SUCCESS) fr = hipfftExecZ2Z(plan, d, d, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
     AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT failed (%d)", (int)fr);
     return AF_OK;
 }
@@ -639,17 +745,15 @@ AF_EXPORT int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_n
     return (int64_t)ceil(span) + kernel_width + 1;
 }
 
-// One imaging band.  uvw (nrow,3) [m]; freq (nchan_band) [Hz]: the band's channels, which are columns chan0 .. of the
-// (nrow, nchan_total) arrays vis / wgt / mask; image (nx, ny) float64; corr_u (nx), corr_v (ny): 1 / psihat of the
-// padded axes; quad_t / quad_w (48): Gauss-Legendre nodes and weights on (0, 1); [wl_min, wl_max]: range of w nu / c
-// over the band's visibilities (host scalars: they size the plane loop).  vis columns of the band are overwritten.
-AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
-                                  int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx,
-                                  double celly, const double *corr_u, const double *corr_v, const double *quad_t,
-                                  const double *quad_w, int kernel_width, double beta, double wl_min, double wl_max,
-                                  double max_abs_nm1, int do_wstacking, const double *wgt, const unsigned char *mask,
-                                  double *vis, void *workspace, size_t workspace_bytes, void *stream)
+namespace {
+// both directions of one imaging band (adjoint: vis -> image_out, else image_in -> vis)
+int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
+           int64_t nchan_total, const double *image_in, double *image_out, int64_t nx, int64_t ny, double cellx,
+           double celly, const double *corr_u, const double *corr_v, const double *quad_t, const double *quad_w,
+           int kernel_width, double beta, double wl_min, double wl_max, double max_abs_nm1, int do_wstacking,
+           const double *wgt, const unsigned char *mask, double *vis, void *workspace, size_t workspace_bytes, void *stream)
 {
+    const double *image = image_in;
     AF_REQUIRE(nrow >= 0 && nchan_band >= 0 && nx >= 1 && ny >= 1 && chan0 >= 0 && chan0 + nchan_band <= nchan_total,
                "af_wgrid_im2vis_f64: bad extents");
     AF_REQUIRE(nx % 2 == 0 && ny % 2 == 0, "af_wgrid_im2vis_f64: image dimensions must be even (%lld x %lld)", (long long)nx,
@@ -657,8 +761,15 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
     AF_REQUIRE(kernel_width >= 4 && kernel_width <= WG_MAXW, "af_wgrid_im2vis_f64: kernel width %d not in 4..%d", kernel_width,
                WG_MAXW);
     hipStream_t st = af_stream(stream);
+    if (adjoint) {
+        AF_REQUIRE(image_out != nullptr, "af_wgrid_vis2im_f64: NULL image");
+        if (nrow == 0 || nchan_band == 0) {
+            AF_HIP(hipMemsetAsync(image_out, 0, (size_t)(nx * ny) * sizeof(double), st));
+            return AF_OK;
+        }
+    }
     if (nrow == 0 || nchan_band == 0) return AF_OK;
-    AF_REQUIRE(uvw && freq && image && corr_u && corr_v && quad_t && quad_w && vis, "af_wgrid_im2vis_f64: NULL array");
+    AF_REQUIRE(uvw && freq && (adjoint || image) && corr_u && corr_v && quad_t && quad_w && vis, "af_wgrid_im2vis_f64: NULL array");
     const int64_t nu = af_wgrid_padded(nx), nv = af_wgrid_padded(ny);
     AF_REQUIRE(nu < (1LL << 15) && nv < (1LL << 15), "af_wgrid_im2vis_f64: image too large");
     // as many resident planes as the workspace holds
@@ -691,12 +802,13 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
                        kernel_width, beta, dw, do_wstacking, A, nm1);
     AF_LAUNCH_CHECK();
     // the band's columns start from zero
-    AF_HIP(hipMemset2DAsync(vis + 2 * chan0, (size_t)nchan_total * 16, 0, (size_t)nchan_band * 16, (size_t)nrow, st));
+    if (!adjoint)
+        AF_HIP(hipMemset2DAsync(vis + 2 * chan0, (size_t)nchan_total * 16, 0, (size_t)nchan_band * 16, (size_t)nrow, st));
     const int *perm = nullptr;
     // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
     const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
-    if (!tiled && nrow >= 4096 && nrow < (1LL << 31)) {
+    if (!adjoint && !tiled && nrow >= 4096 && nrow < (1LL << 31)) {
         int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
         unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
         AF_HIP(hipMemsetAsync(hist, 0, WG_NBIN * sizeof(int), st));
@@ -740,7 +852,45 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
         AF_LAUNCH_CHECK();
     }
     af_prof_begin(st);
-    for (int pk0 = 0; pk0 < nplanes; pk0 += (int)resident) {
+    for (int pk0 = 0; adjoint && pk0 < nplanes; pk0 += (int)resident) {
+        const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
+        AF_HIP(hipMemsetAsync(grid, 0, (size_t)(pk1 - pk0) * (size_t)(nu * nv) * 16, st));
+#define AF_WG_LAUNCH(WC)                                                                                               \
+    hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,         \
+                       nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,         \
+                       reinterpret_cast<const double2 *>(vis))
+        switch (kernel_width) {
+        case 4: AF_WG_LAUNCH(4); break;
+        case 5: AF_WG_LAUNCH(5); break;
+        case 6: AF_WG_LAUNCH(6); break;
+        case 7: AF_WG_LAUNCH(7); break;
+        case 8: AF_WG_LAUNCH(8); break;
+        case 9: AF_WG_LAUNCH(9); break;
+        case 10: AF_WG_LAUNCH(10); break;
+        case 11: AF_WG_LAUNCH(11); break;
+        case 12: AF_WG_LAUNCH(12); break;
+        case 13: AF_WG_LAUNCH(13); break;
+        case 14: AF_WG_LAUNCH(14); break;
+        case 15: AF_WG_LAUNCH(15); break;
+        default: AF_WG_LAUNCH(16); break;
+        }
+#undef AF_WG_LAUNCH
+        AF_LAUNCH_CHECK();
+        for (int k = pk0; k < pk1; ++k) {
+            double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
+            int rc = wg_fft_rows((int)nu, (int)nv, gk, st, true);                // back along u, every column
+            if (rc != AF_OK) return rc;
+            hipLaunchKernelGGL(wg_gather_rows, dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st,
+                               gk, nx, nu, nv, S);
+            AF_LAUNCH_CHECK();
+            rc = wg_fft_rows((int)nv, (int)nx, S, st, true);                     // back along v, the image's rows only
+            if (rc != AF_OK) return rc;
+            hipLaunchKernelGGL(wg_add_plane, dim3(nb_img), dim3(256), 0, st, S, A, nm1, nx, ny, nv, w0 + k * dw,
+                               (int)(k == 0), image_out);
+            AF_LAUNCH_CHECK();
+        }
+    }
+    for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
         for (int k = pk0; k < pk1; ++k) {
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
@@ -783,12 +933,47 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
         AF_LAUNCH_CHECK();
     }
     af_prof_end(st);
-    if (wgt || mask) {
+    if (!adjoint && (wgt || mask)) {
         hipLaunchKernelGGL(wg_finish, dim3(nb_vis), dim3(256), 0, st, reinterpret_cast<double2 *>(vis), wgt, mask, nrow,
                            nchan_band, chan0, nchan_total);
         AF_LAUNCH_CHECK();
     }
     return AF_OK;
+}
+}  // namespace
+
+// One imaging band, image -> visibilities.  uvw (nrow,3) [m]; freq (nchan_band) [Hz]: the band's channels, which are
+// columns chan0 .. of the (nrow, nchan_total) arrays vis / wgt / mask; image (nx, ny) float64; corr_u (nx), corr_v (ny):
+// 1 / psihat of the padded axes; quad_t / quad_w (48): Gauss-Legendre nodes and weights on (0, 1); [wl_min, wl_max]:
+// range of w nu / c over the band's visibilities (host scalars: they size the plane loop).  vis columns of the band are
+// overwritten.
+AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
+                                  int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx,
+                                  double celly, const double *corr_u, const double *corr_v, const double *quad_t,
+                                  const double *quad_w, int kernel_width, double beta, double wl_min, double wl_max,
+                                  double max_abs_nm1, int do_wstacking, const double *wgt, const unsigned char *mask,
+                                  double *vis, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return wg_run(false, uvw, freq, nrow, nchan_band, chan0, nchan_total, image, nullptr, nx, ny, cellx, celly, corr_u, corr_v,
+                  quad_t, quad_w, kernel_width, beta, wl_min, wl_max, max_abs_nm1, do_wstacking, wgt, mask, vis, workspace,
+                  workspace_bytes, stream);
+}
+
+// The adjoint, visibilities -> image: image (nx, ny) float64 is OVERWRITTEN with the band's dirty image
+//     (1 / n) sum_{r, c} Re( wgt vis exp(+2 pi i nu/c (u x + v y - w (n - 1))) )
+// over the unmasked visibilities (mask != 0: used) of columns chan0 .. chan0 + nchan_band of vis / wgt / mask.  Same
+// geometry arguments and the same workspace (af_wgrid_im2vis_workspace_bytes) as af_wgrid_im2vis_f64, of which this is
+// the exact transpose (same planes, same taps).
+AF_EXPORT int af_wgrid_vis2im_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
+                                  int64_t nchan_total, const double *vis, int64_t nx, int64_t ny, double cellx,
+                                  double celly, const double *corr_u, const double *corr_v, const double *quad_t,
+                                  const double *quad_w, int kernel_width, double beta, double wl_min, double wl_max,
+                                  double max_abs_nm1, int do_wstacking, const double *wgt, const unsigned char *mask,
+                                  double *image, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return wg_run(true, uvw, freq, nrow, nchan_band, chan0, nchan_total, nullptr, image, nx, ny, cellx, celly, corr_u, corr_v,
+                  quad_t, quad_w, kernel_width, beta, wl_min, wl_max, max_abs_nm1, do_wstacking, wgt, mask,
+                  const_cast<double *>(vis), workspace, workspace_bytes, stream);
 }
 
 // releases the cached FFT plans (called by af_shutdown)

@@ -421,6 +421,18 @@ int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int
                         int do_wstacking, const double *wgt, const unsigned char *mask, double *vis, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The adjoint (replaces africanus.gridding.wgridder.dirty, africanus/gridding/wgridder/vis2im.py:15-72, i.e.
+ * ducc0.wgridder.ms2dirty): `image` (nx, ny) float64 is OVERWRITTEN with
+ *     (1 / n) sum_{r, c} Re( wgt vis exp(+2 pi i nu/c (u x + v y - w (n - 1))) )
+ * over the visibilities with mask != 0 of columns chan0 .. chan0 + nchan_band of vis (complex128) / wgt / mask.  Same
+ * geometry arguments and workspace as af_wgrid_im2vis_f64, whose exact transpose this is. */
+int af_wgrid_vis2im_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
+                        int64_t nchan_total, const double *vis, int64_t nx, int64_t ny, double cellx, double celly,
+                        const double *corr_u, const double *corr_v, const double *quad_t, const double *quad_w,
+                        int kernel_width, double beta, double wl_min, double wl_max, double max_abs_nm1,
+                        int do_wstacking, const double *wgt, const unsigned char *mask, double *image, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* Replaces africanus.calibration.utils.compute_and_corrupt_vis (calibration/utils/compute_and_corrupt_vis.py:73-152):
  * corrupt_vis with the model coherencies formed on the fly from a time-variable point-source model,
  *   source_vis = model[t,nu,dir] * exp(-2 pi i nu/c (u l + v m + w (n - 1))) / n,  n = sqrt(1 - l^2 - m^2),
