@@ -116,6 +116,9 @@ _SIGNATURES = {
     "af_wgrid_im2vis_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double,
                                    _vp, _vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "af_wgrid_vis2im_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double,
+                                   _vp, _vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "af_gridder_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "af_gridder_c128": (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _vp, _vp, _i64, _i64, _int, _vp, _int, _int,
                                _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),

@@ -1,2 +1,3 @@
-# Same public name as africanus/gridding/wgridder/__init__.py (the image -> visibility direction).
+# Same public names as africanus/gridding/wgridder/__init__.py.
 from .im2vis import model  # noqa: F401
+from .vis2im import dirty, residual, hessian  # noqa: F401

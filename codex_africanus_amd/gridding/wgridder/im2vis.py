@@ -37,42 +37,36 @@ def kernel_correction(n, n_padded, W, beta):
     return 1.0 / psihat
 
 
-def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None, epsilon=1e-5,
-          nthreads=1, do_wstacking=True):
-    """
-    ``V = R x``: visibilities (row, chan) of the model image ``x`` (band, nx, ny), channels ``freq_bin_idx[b] ..
-    + freq_bin_counts[b]`` taken from band ``b`` (bin starts are normalised by their minimum, as the reference does
-    for row chunks); ``cell`` / ``celly`` pixel sizes in radians; ``weights`` (row, chan) multiply the result
-    (whitened model); ``flag`` (row, chan): only visibilities with ``flag != 0`` are computed, the rest are 0;
-    ``epsilon``: accuracy with respect to the direct Fourier transform; ``do_wstacking`` False ignores w and n.
-    ``nthreads`` is accepted and ignored (the work runs on the GPU).
-
-    Same contract as ``africanus.gridding.wgridder.model`` (africanus/gridding/wgridder/im2vis.py:63-99).  The
-    reference delegates the arithmetic to ``ducc0.wgridder.dirty2ms`` (not vendored, not installed here: parity
-    unpinned); what its tests pin, and what holds here, is the accuracy contract of
-    africanus/gridding/wgridder/tests/test_wgridder.py:18-113: relative l2 error <= ``epsilon`` against
-    ``sum_xy x[x,y]/n exp(-2 pi i nu/c (u x + v y - w (n - 1)))``.  Algorithm: improved w-stacking (a separable
-    exponential-of-semicircle kernel in u, v and w; one zero-padded FFT per w-plane), csrc/af_wgridder.hip.
-    """
-    if celly is None:
-        celly = cell
-    if len(image.shape) != 3:
-        raise ValueError("image must have shape (band, nx, ny)")
-    nband, nx, ny = (int(s) for s in image.shape)
-    nrow, nchan = int(uvw.shape[0]), int(freq.shape[0])
-    if len(uvw.shape) != 2 or uvw.shape[1] != 3:
-        raise ValueError("uvw must have shape (row, 3)")
+def _bins(freq_bin_idx, freq_bin_counts, nband, nchan):
     fbi = np.asarray(freq_bin_idx.cpu() if _is_torch(freq_bin_idx) else freq_bin_idx).astype(np.int64)
     fbc = np.asarray(freq_bin_counts.cpu() if _is_torch(freq_bin_counts) else freq_bin_counts).astype(np.int64)
+    if nband is None:
+        nband = int(fbi.size)
     if fbi.shape != (nband,) or fbc.shape != (nband,):
         raise ValueError("freq_bin_idx and freq_bin_counts must have one entry per band")
     fbi = fbi - fbi.min() if nband else fbi
     if nband and (fbi.min() < 0 or (fbi + fbc).max() > nchan or fbc.min() < 0):
         raise ValueError("frequency bins exceed the channel axis")
-    for name, a in (("weights", weights), ("flag", flag)):
+    return fbi, fbc
+
+
+def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly,
+              epsilon, do_wstacking, out_dtype):
+    """Both directions of the wgridder operator, band by band (csrc/af_wgridder.hip): ``adjoint`` False: image (band, nx,
+    ny) -> visibilities (row, chan); True: visibilities -> image.  Geometry, planes and taps are the same for both, so
+    the two are exact transposes of each other."""
+    import ctypes
+    if celly is None:
+        celly = cell
+    nrow, nchan = int(uvw.shape[0]), int(freq.shape[0])
+    if len(uvw.shape) != 2 or uvw.shape[1] != 3:
+        raise ValueError("uvw must have shape (row, 3)")
+    nband = None if adjoint else int(image.shape[0])
+    fbi, fbc = _bins(freq_bin_idx, freq_bin_counts, nband, nchan)
+    nband = int(fbi.size)
+    for name, a in (("weights", weights), ("flag", flag), ("vis", vis)):
         if a is not None and tuple(int(s) for s in a.shape) != (nrow, nchan):
             raise ValueError("%s must have shape (row, chan)" % name)
-    out_dtype = np.result_type(np_dtype_of(image), np.complex64)
     W, beta = kernel_parameters(float(epsilon))
     if nx % 2 or ny % 2:
         # ducc0 requires even image sizes (the phase centre is the pixel nx/2, ny/2); so does this entry
@@ -92,24 +86,31 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
     else:
         wmin = wmax = 0.0
     fhost = np.asarray(freq.cpu() if _is_torch(freq) else freq, dtype=np.float64)
-    with Call(uvw, freq, image, weights, flag) as c:
+    with Call(uvw, freq, image, vis, weights, flag) as c:
         p_uvw, p_fr = c.inp(uvw, np.float64), c.inp(freq, np.float64)
-        p_img = c.inp(image, np.float64)
         p_wgt = c.inp(weights, np.float64)
         if flag is not None:
             flag = (flag != 0)
         p_mask = c.inp(flag, np.uint8 if not _is_torch(flag) else np.bool_)
         p_cu, p_cv, p_qt, p_qw = (c.inp(a, np.float64) for a in (corr_u, corr_v, qt, qw))
-        p_out, h = c.out((nrow, nchan), np.complex128)
-        if nrow * nchan:
-            _lib.call("af_memset", p_out, 0, nrow * nchan * 16, c.stream)     # channels outside every band stay 0
-        import ctypes
+        if adjoint:
+            p_in = c.inp(vis, np.complex128)
+            p_out, h = c.out((nband, nx, ny), np.float64)
+            entry = "af_wgrid_vis2im_f64"
+        else:
+            p_in = c.inp(image, np.float64)
+            p_out, h = c.out((nrow, nchan), np.complex128)
+            entry = "af_wgrid_im2vis_f64"
+            if nrow * nchan:
+                _lib.call("af_memset", p_out, 0, nrow * nchan * 16, c.stream)     # channels outside every band stay 0
         # per band: the range of w nu / c; the workspace holds as many w-plane grids as the largest band needs, within
         # PLANE_BUDGET bytes (beyond it the planes are worked through in batches)
         bands = []
         for b in range(nband):
             c0, nc = int(fbi[b]), int(fbc[b])
             if nc == 0 or nrow == 0:
+                if adjoint:
+                    _lib.call("af_memset", ctypes.c_void_p(p_out.value + 8 * b * nx * ny), 0, nx * ny * 8, c.stream)
                 continue
             f = fhost[c0:c0 + nc] / LIGHTSPEED
             cands = (wmin * f.min(), wmin * f.max(), wmax * f.min(), wmax * f.max())
@@ -122,8 +123,35 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
         ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny, resident, nrow, max([x[2] for x in bands] + [1])))
         p_ws = c.scratch(ws_bytes)
         for b, c0, nc, cands, npl in bands:
-            _lib.call("af_wgrid_im2vis_f64", p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,
-                      ctypes.c_void_p(p_img.value + 8 * b * nx * ny), nx, ny, float(cell), float(celly), p_cu, p_cv, p_qt,
+            img = ctypes.c_void_p((p_out if adjoint else p_in).value + 8 * b * nx * ny)
+            _lib.call(entry, p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,
+                      p_in if adjoint else img, nx, ny, float(cell), float(celly), p_cu, p_cv, p_qt,
                       p_qw, W, beta, float(min(cands)), float(max(cands)), float(max_nm1), int(bool(do_wstacking)), p_wgt,
-                      p_mask, p_out, p_ws, max(ws_bytes, 256), c.stream)
-        return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
+                      p_mask, img if adjoint else p_out, p_ws, max(ws_bytes, 256), c.stream)
+        native = np.float64 if adjoint else np.complex128
+        return c.result(h, cast=None if out_dtype == native else out_dtype)
+
+
+def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None, epsilon=1e-5,
+          nthreads=1, do_wstacking=True):
+    """
+    ``V = R x``: visibilities (row, chan) of the model image ``x`` (band, nx, ny), channels ``freq_bin_idx[b] ..
+    + freq_bin_counts[b]`` taken from band ``b`` (bin starts are normalised by their minimum, as the reference does
+    for row chunks); ``cell`` / ``celly`` pixel sizes in radians; ``weights`` (row, chan) multiply the result
+    (whitened model); ``flag`` (row, chan): only visibilities with ``flag != 0`` are computed, the rest are 0;
+    ``epsilon``: accuracy with respect to the direct Fourier transform; ``do_wstacking`` False ignores w and n.
+    ``nthreads`` is accepted and ignored (the work runs on the GPU).
+
+    Same contract as ``africanus.gridding.wgridder.model`` (africanus/gridding/wgridder/im2vis.py:63-99).  The
+    reference delegates the arithmetic to ``ducc0.wgridder.dirty2ms`` (not vendored, not installed here: parity
+    unpinned); what its tests pin, and what holds here, is the accuracy contract of
+    africanus/gridding/wgridder/tests/test_wgridder.py:18-113: relative l2 error <= ``epsilon`` against
+    ``sum_xy x[x,y]/n exp(-2 pi i nu/c (u x + v y - w (n - 1)))``.  Algorithm: improved w-stacking (a separable
+    exponential-of-semicircle kernel in u, v and w; one zero-padded FFT per w-plane), csrc/af_wgridder.hip.
+    """
+    if len(image.shape) != 3:
+        raise ValueError("image must have shape (band, nx, ny)")
+    nx, ny = int(image.shape[1]), int(image.shape[2])
+    out_dtype = np.result_type(np_dtype_of(image), np.complex64)
+    return _operator(False, uvw, freq, image, None, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly,
+                     epsilon, do_wstacking, out_dtype)

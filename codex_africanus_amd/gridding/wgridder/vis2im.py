@@ -1,0 +1,82 @@
+"""``dirty``, ``residual`` and ``hessian`` with the signatures of africanus/gridding/wgridder/{vis2im,im2residim,hessian}.py."""
+import numpy as np
+
+from ..._device import _is_torch, np_dtype_of
+from .im2vis import _operator, model
+
+
+def dirty(uvw, freq, vis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights=None, flag=None, celly=None,
+          epsilon=1e-5, nthreads=1, do_wstacking=True, double_accum=False):
+    """
+    ``I^D = R^H Sigma^-1 V``: dirty image (band, nx, ny) of the visibilities ``vis`` (row, chan), band ``b`` summed
+    over channels ``freq_bin_idx[b] .. + freq_bin_counts[b]``; ``weights`` (row, chan) multiply the visibilities;
+    ``flag`` (row, chan): only visibilities with ``flag != 0`` take part.  complex64 visibilities give a float32 image,
+    complex128 a float64 one (anything else raises, as the reference does).  ``nthreads`` and ``double_accum`` are
+    accepted and ignored: the work runs on the GPU, in float64.
+
+    Same contract as ``africanus.gridding.wgridder.dirty`` (africanus/gridding/wgridder/vis2im.py:15-116; arithmetic in
+    ducc0.wgridder.ms2dirty, not vendored: parity unpinned).  What the reference's tests pin, and what holds here
+    (africanus/gridding/wgridder/tests/test_wgridder.py:18-108): relative l2 error <= ``epsilon`` against
+    ``(1/n) sum_rc Re(w V exp(+2 pi i nu/c (u x + v y - w (n - 1))))``, and ``dirty`` is the adjoint of ``model``
+    (test_wgridder.py:111-188): here the exact transpose, same w-planes and taps (csrc/af_wgridder.hip).
+    """
+    dt = np_dtype_of(vis)
+    if dt == np.complex64:
+        real_type = np.float32
+    elif dt == np.complex128:
+        real_type = np.float64
+    else:
+        raise ValueError("Vis of incorrect type")
+    if len(vis.shape) != 2:
+        raise ValueError("vis must have shape (row, chan)")
+    return _operator(True, uvw, freq, None, vis, freq_bin_idx, freq_bin_counts, int(nx), int(ny), cell, weights, flag,
+                     celly, epsilon, do_wstacking, np.dtype(real_type))
+
+
+def _on_device(arrays):
+    """Composite operators keep their intermediates on the GPU: numpy inputs are uploaded once."""
+    import torch
+    host = not any(_is_torch(a) for a in arrays if a is not None)
+    if not host:
+        return False, arrays
+    return True, [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrays]
+
+
+def residual(uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None,
+             epsilon=1e-5, nthreads=1, do_wstacking=True, double_accum=False):
+    """
+    ``I^R = R^H Sigma^-1 (V - R x)`` (africanus/gridding/wgridder/im2residim.py:15-127): the model visibilities of
+    ``image`` (band, nx, ny) -- unweighted, flagged ones zero -- are subtracted from ``vis`` and the difference is
+    imaged with ``weights`` and ``flag``.  Result (band, nx, ny) in the image's dtype.  The visibility-sized
+    intermediate stays on the GPU.
+    """
+    out_dtype = np_dtype_of(image)
+    nx, ny = int(image.shape[1]), int(image.shape[2])
+    host, (uvw, freq, image, vis, weights, flag) = _on_device([uvw, freq, image, vis, weights, flag])
+    import torch
+    mvis = model(uvw, freq, image.to(torch.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly, epsilon,
+                 nthreads, do_wstacking)
+    rvis = vis.to(torch.complex128) - mvis
+    out = dirty(uvw, freq, rvis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly, epsilon, nthreads,
+                do_wstacking, double_accum)
+    out = out.to(getattr(torch, np.dtype(out_dtype).name))
+    return out.cpu().numpy() if host else out
+
+
+def hessian(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None, epsilon=1e-5,
+            nthreads=1, do_wstacking=True, double_accum=False):
+    """
+    ``R^H Sigma^-1 R x`` (africanus/gridding/wgridder/hessian.py:15-118): the unweighted model visibilities of
+    ``image`` imaged with ``weights`` and ``flag``.  Result (band, nx, ny) in the image's dtype; the visibilities never
+    leave the GPU.
+    """
+    out_dtype = np_dtype_of(image)
+    nx, ny = int(image.shape[1]), int(image.shape[2])
+    host, (uvw, freq, image, weights, flag) = _on_device([uvw, freq, image, weights, flag])
+    import torch
+    mvis = model(uvw, freq, image.to(torch.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly, epsilon,
+                 nthreads, do_wstacking)
+    out = dirty(uvw, freq, mvis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly, epsilon, nthreads,
+                do_wstacking, double_accum)
+    out = out.to(getattr(torch, np.dtype(out_dtype).name))
+    return out.cpu().numpy() if host else out

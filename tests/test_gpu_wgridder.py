@@ -154,3 +154,107 @@ def test_sorted_tile_path_in_plane_batches(monkeypatch):
     assert np.abs(batched - full).max() <= 1e-13 * np.abs(full).max()
     flat = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-6, do_wstacking=False)
     assert _l2error(flat, _explicit_degridder(uvw, freq, image[0], cell, cell, apply_w=False)) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the adjoint direction: dirty, residual, hessian (africanus/gridding/wgridder/{vis2im,im2residim,hessian}.py)
+
+def _explicit_gridder(uvw, freq, ms, wgt, nx, ny, cell, celly, apply_w=True, mask=None):
+    """test_wgridder.py:18-46 through the oracle's vis_to_im (sources = pixels, w negated, summed over channels)."""
+    x, y = np.meshgrid(*[-ss / 2 + np.arange(ss) for ss in (nx, ny)], indexing="ij")
+    x, y = x * cell, y * celly
+    v = ms if wgt is None else ms * wgt
+    if mask is not None:
+        v = v * (mask != 0)
+    if apply_w:
+        lm = np.stack([x.ravel(), y.ravel()], axis=1)
+        n = np.sqrt(1.0 - x ** 2 - y ** 2)
+        im = oracle.vis_to_im(v[:, :, None].astype(np.complex128), uvw * np.array([1.0, 1.0, -1.0]), lm, freq,
+                              np.zeros(v.shape + (1,), dtype=np.uint8), omp=True)
+        return im[:, :, 0].sum(axis=1).reshape(nx, ny) / n
+    ph = (uvw[:, None, 0, None] * x.ravel()[None, None, :] + uvw[:, None, 1, None] * y.ravel()[None, None, :]) \
+        * (freq / LIGHTSPEED)[None, :, None]
+    return (np.exp(2j * np.pi * ph) * v[:, :, None]).real.sum(axis=(0, 1)).reshape(nx, ny)
+
+
+@pytest.mark.parametrize("ny", (18, 64))
+@pytest.mark.parametrize("nchan, nband", [(1, 1), (7, 1), (7, 3)])
+@pytest.mark.parametrize("precision, epsilon", [("single", 1e-3), ("single", 1e-4), ("double", 1e-3), ("double", 1e-4),
+                                                ("double", 1e-7)])
+def test_dirty_meets_the_accuracy_contract(ny, nchan, nband, precision, epsilon):
+    """test_wgridder.py:48-108 (test_gridder): 16 x ny pixels, 5 degree field, 1000 rows, weights"""
+    from codex_africanus_amd.gridding.wgridder import dirty
+    nx, fov, nrow = 16, 5.0, 1000
+    cell, freq, uvw, fbi, fbc, _ = _case(nx, ny, fov, nrow, nchan, nband)
+    rng = np.random.default_rng(40)
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    wgt = rng.random((nrow, nchan))
+    ctype, rtype = (np.complex64, np.float32) if precision == "single" else (np.complex128, np.float64)
+    img = dirty(uvw, freq, ms.astype(ctype), fbi, fbc, nx, ny, cell, weights=wgt.astype(rtype), epsilon=epsilon)
+    assert img.shape == (fbi.size, nx, ny) and img.dtype == rtype
+    ms_used = ms.astype(ctype).astype(np.complex128)
+    for b in range(fbi.size):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref = _explicit_gridder(uvw, freq[ind], ms_used[:, ind], wgt.astype(rtype).astype(np.float64)[:, ind], nx, ny, cell, cell)
+        assert _l2error(img[b], ref) <= max(epsilon, 3e-7 if precision == "single" else 0)
+
+
+@pytest.mark.parametrize("nrow, nchan, tiled", [(600, 4, False), (6000, 24, True)])
+def test_dirty_is_the_adjoint_of_model(nrow, nchan, tiled):
+    """test_wgridder.py:111-188: <R x, v> == <x, R^H v> -- here to rounding, because both directions use the same
+    planes and taps; with flags, weights applied on one side each, two bands, non-square pixels; the small call takes
+    the per-visibility kernels, the large one the sorted tile kernels."""
+    from codex_africanus_amd.gridding.wgridder import dirty
+    nx, ny, nband = 30, 50, 2
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 12.0, nrow, nchan, nband, seed=2)
+    assert (nrow * (nchan // nband) >= 65536) == tiled
+    celly = cell * 1.2
+    rng = np.random.default_rng(9)
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.1).astype(np.uint8)
+    for eps in (1e-4, 1e-9):
+        vis = model(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, celly=celly, epsilon=eps)
+        img = dirty(uvw, freq, ms, fbi, fbc, nx, ny, cell, weights=wgt, flag=flag, celly=celly, epsilon=eps)
+        lhs = np.vdot(ms, vis).real           # Re <v, R x>
+        rhs = np.sum(image * img)             # <R^H v, x>
+        assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), np.abs(image).sum() * np.abs(img).max())
+    # and the contract for the large call
+    if tiled:
+        ref = _explicit_gridder(uvw, freq[:fbc[0]], ms[:, :fbc[0]], wgt[:, :fbc[0]], nx, ny, cell, celly, mask=flag[:, :fbc[0]])
+        assert _l2error(img[0], ref) <= 1e-9
+
+
+def test_residual_and_hessian_compose_model_and_dirty():
+    """test_wgridder.py:191-354: residual = dirty(vis - model(image)) with the weights on the imaging side only;
+    hessian = dirty(model(image)); results in the image's dtype; torch inputs give torch outputs."""
+    import torch
+    from codex_africanus_amd.gridding.wgridder import dirty, residual, hessian
+    nx, ny, nrow, nchan, nband = 20, 32, 900, 5, 2
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.5, nrow, nchan, nband, seed=4)
+    rng = np.random.default_rng(5)
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.1).astype(np.uint8)
+    mv = model(uvw, freq, image, fbi, fbc, cell, flag=flag, epsilon=1e-7)
+    res = residual(uvw, freq, image, ms, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=1e-7)
+    want = dirty(uvw, freq, ms - mv, fbi, fbc, nx, ny, cell, weights=wgt, flag=flag, epsilon=1e-7)
+    assert res.shape == image.shape and res.dtype == image.dtype
+    assert np.abs(res - want).max() <= 1e-12 * np.abs(want).max()
+    hes = hessian(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=1e-7)
+    want = dirty(uvw, freq, mv, fbi, fbc, nx, ny, cell, weights=wgt, flag=flag, epsilon=1e-7)
+    assert np.abs(hes - want).max() <= 1e-12 * np.abs(want).max()
+    # the Hessian is symmetric positive semi-definite: <y, H x> == <H y, x>, <x, H x> >= 0
+    other = rng.standard_normal(image.shape)
+    h2 = hessian(uvw, freq, other, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=1e-7)
+    assert abs(np.sum(other * hes) - np.sum(h2 * image)) <= 1e-10 * abs(np.sum(other * hes))
+    assert np.sum(image * hes) >= 0
+    f32 = residual(uvw, freq, image.astype(np.float32), ms, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=1e-4)
+    assert f32.dtype == np.float32
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dev = hessian(t(uvw), t(freq), t(image), fbi, fbc, cell, weights=t(wgt), flag=t(flag), epsilon=1e-7)
+    assert isinstance(dev, torch.Tensor) and np.abs(dev.cpu().numpy() - hes).max() <= 1e-12 * np.abs(hes).max()
+    with pytest.raises(ValueError, match="incorrect type"):
+        dirty(uvw, freq, ms.real, fbi, fbc, nx, ny, cell)
+    # no rows: a zero image
+    assert not dirty(uvw[:0], freq, ms[:0], fbi, fbc, nx, ny, cell).any()
