@@ -209,7 +209,7 @@ struct WgSort {
     const unsigned char *mask;
     int64_t nvis, nchan_b, chan0, nchan_total, nu, nv;
     double cellx, celly, w0, dw;
-    int W, do_w, nplanes, kb, nty;
+    int W, do_w, nplanes, kb, nty, tile;
 };
 // (in everything below "u" is the SLOW axis of the stored planes and "v" the fast one: the planes are v-major, so the
 // host hands uvw's v as this code's u -- component 1 -- and u as its v)
@@ -242,7 +242,7 @@ __device__ __forceinline__ int wg_vis_key(const WgSort &q, int64_t i)
         kb = kb >= q.kb ? q.kb - 1 : kb;
     }
     const int pu = wg_first_cell(gu, q.W, (int)q.nu), pv = wg_first_cell(gv, q.W, (int)q.nv);
-    return ((pu / WG_TILE) * q.nty + pv / WG_TILE) * q.kb + kb;
+    return ((pu / q.tile) * q.nty + pv / q.tile) * q.kb + kb;
 }
 // one atomic per run of equal keys among adjacent lanes; returns this lane's slot (or -1)
 __device__ __forceinline__ int wg_run_atomic(int *__restrict__ counter, int key, bool want_slot)
@@ -337,17 +337,17 @@ __global__ __launch_bounds__(256) void wg_vis_scatter(WgSort q, int *__restrict_
         if (slot >= 0) idx[slot] = (unsigned)i;
     }
 }
-// chunk table: (tile, first sorted index) of every <= 256 visibilities of one tile; *nchunks counts them
-__global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int2 *__restrict__ chunks,
+// chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them
+__global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int chunk, int2 *__restrict__ chunks,
                               int *__restrict__ nchunks)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const int lo = start[t * kb], hi = start[(t + 1) * kb];
-    const int n = (hi - lo + WG_CHUNK - 1) / WG_CHUNK;
+    const int n = (hi - lo + chunk - 1) / chunk;
     if (n == 0) return;
     const int base = atomicAdd(nchunks, n);
-    for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * WG_CHUNK);
+    for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
 }
 
 // one workgroup per chunk: vis[...] += sum over the resident planes [pk0, pk1) the chunk's visibilities touch
@@ -621,6 +621,149 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
     }
 }
 
+// (large calls) The visibilities sorted by (tile, first w-plane) -- exactly: one sort bucket per plane -- are taken
+// through LDS: ONE wave owns a chunk of <= 4096 visibilities of one tile and keeps the tile's cells of W consecutive
+// planes in a ring of LDS images (plane k in slot k mod W).  A visibility adds its W x W taps to its W planes with plain
+// LDS read-add-writes (its lanes hit distinct cells; the wave is alone on its images, so no atomics); when the sorted
+// list moves on to a higher first plane, the planes that can receive nothing more are added to the grids in memory
+// (hardware fp64 atomics: neighbouring tiles share the halo cells) and their slots cleared.  Every (chunk, plane) is
+// flushed once: W^3 atomics per visibility become (T + W - 1)^2 per (chunk, plane).
+constexpr int WG_GCHUNK = 4096;
+constexpr int WG_GKB = 256;          // planes the exact sort handles; beyond it the per-visibility kernel runs
+__host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 16 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
+template <int W>
+__global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
+                                                    int64_t nchan_b, int64_t chan0, int64_t nchan_total,
+                                                    double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
+                                                    double celly, double beta, double w0, double dw, int pk0, int pk1,
+                                                    int do_w, const unsigned *__restrict__ idx, const int *__restrict__ start,
+                                                    int kb, const int2 *__restrict__ chunks, const int *__restrict__ nchunks,
+                                                    const double *__restrict__ wgt, const double2 *__restrict__ vis)
+{
+    constexpr int T = wg_gtile(W), R = T + W - 1, RR = R * R;
+    constexpr int NT = 4 * W;                   // table doubles per visibility: val.re ku[], val.im ku[], kv[], kw[]
+    constexpr int NE = (RR + 63) / 64;          // region cells per lane
+    constexpr int NP = (W * W + 63) / 64;       // tap passes (one for W <= 8)
+    __shared__ double2 ring[W * RR];
+    __shared__ double tab[64 * NT];
+    if ((int)blockIdx.x >= *nchunks) return;
+    const int2 ch = chunks[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nty = (int)((nv + T - 1) / T);
+    const int tu = ch.x / nty, tv = ch.x - tu * nty;
+    int n = start[(ch.x + 1) * kb] - ch.y;
+    n = n > WG_GCHUNK ? WG_GCHUNK : n;
+    constexpr double inv_half_w = 2.0 / (double)W;
+    const int64_t plane = nu * nv;
+
+    for (int e = lane; e < W * RR; e += 64) ring[e] = make_double2(0.0, 0.0);
+    int gofs[NE];                               // this lane's region cells on the grid (wrapped)
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = lane + 64 * q, a = e / R, b = e - a * R;
+        gofs[q] = e < RR ? (int)(((tu * T + a) % nu) * nv + (tv * T + b) % nv) : -1;
+    }
+    int ta[NP], tcell[NP];                      // this lane's tap(s): row a, offset a R + b
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int t = lane + 64 * p;
+        ta[p] = t < W * W ? t / W : -1;
+        tcell[p] = t < W * W ? (t / W) * R + t % W : 0;
+    }
+    // plane k -> memory, slot cleared
+    auto retire = [&](int k) {
+        const int slot = ((k % W) + W) % W;
+        const bool live = k >= pk0 && k < pk1;
+        double *__restrict__ g = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * plane);
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            if (gofs[q] < 0) continue;
+            const double2 v = ring[slot * RR + lane + 64 * q];
+            if (v.x != 0.0 || v.y != 0.0) {
+                if (live) {
+                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q], v.x);
+                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q] + 1, v.y);
+                }
+                ring[slot * RR + lane + 64 * q] = make_double2(0.0, 0.0);
+            }
+        }
+    };
+    int kcur = 0;
+    bool started = false;
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+        // lane j: everything visibility base + j needs, into the table
+        int k0 = 0x7fffffff, lofs = 0;
+        if (base + lane < n) {
+            const unsigned i = idx[ch.y + base + lane];
+            const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
+            const int64_t o = (int64_t)r * nchan_total + chan0 + c;
+            double2 val = vis[o];
+            if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
+            const double fl = freq[c] / AF_LIGHTSPEED;
+            double gw = 0.0;
+            k0 = 0;
+            if (do_w) {
+                gw = (uvw[3 * (int64_t)r + 2] * fl - w0) / dw;
+                k0 = (int)ceil(gw - 0.5 * W);
+            }
+            const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
+            const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
+            const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;
+            double *__restrict__ t = tab + lane * NT;
+#pragma unroll
+            for (int a = 0; a < W; ++a) {
+                const double ku = es_kernel(fu + (double)a, inv_half_w, beta);
+                t[a] = val.x * ku;
+                t[W + a] = val.y * ku;
+                t[2 * W + a] = es_kernel(fv + (double)a, inv_half_w, beta);
+                t[3 * W + a] = do_w ? es_kernel((double)(k0 + a) - gw, inv_half_w, beta) : (a == 0 ? 1.0 : 0.0);
+            }
+            lofs = (wg_first_cell(gu, W, (int)nu) - tu * T) * R + wg_first_cell(gv, W, (int)nv) - tv * T;
+        }
+        __syncthreads();
+        const int nb = n - base < 64 ? n - base : 64;
+        for (int j = 0; j < nb; ++j) {
+            const int k0j = __builtin_amdgcn_readlane(k0, j), lofsj = __builtin_amdgcn_readlane(lofs, j);
+            if (!started) { kcur = k0j; started = true; }
+            if (k0j > kcur) {                    // planes below k0j are complete for this chunk
+                const int upto = k0j - kcur < W ? k0j : kcur + W;
+                for (int k = kcur; k < upto; ++k) retire(k);
+                kcur = k0j;
+            }
+            const double *__restrict__ t = tab + j * NT;
+            const int s0 = ((k0j % W) + W) % W;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (ta[p] < 0) continue;
+                const double kvb = t[2 * W + (tcell[p] - ta[p] * R)];
+                const double pre = t[ta[p]] * kvb, pim = t[W + ta[p]] * kvb;
+                const int cell = lofsj + tcell[p];
+                double2 v[W];
+#pragma unroll
+                for (int a = 0; a < W; ++a) {
+                    const int slot = s0 + a >= W ? s0 + a - W : s0 + a;
+                    v[a] = ring[slot * RR + cell];
+                }
+#pragma unroll
+                for (int a = 0; a < W; ++a) {
+                    const double kw = t[3 * W + a];
+                    v[a].x = fma(kw, pre, v[a].x);
+                    v[a].y = fma(kw, pim, v[a].y);
+                }
+#pragma unroll
+                for (int a = 0; a < W; ++a) {
+                    const int slot = s0 + a >= W ? s0 + a - W : s0 + a;
+                    ring[slot * RR + cell] = v[a];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (started)
+        for (int k = kcur; k < kcur + W; ++k) retire(k);
+}
+
 // S[ix * nv + pv] = G[pv * nu + pu(ix)]: the nx image rows of a plane (transformed along u), v contiguous again
 __global__ __launch_bounds__(256) void wg_gather_rows(const double2 *__restrict__ G, int64_t nx, int64_t nu, int64_t nv,
                                                       double2 *__restrict__ S)
@@ -660,9 +803,13 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, chunks, stage, grid, A, nm1, total; int nbins, ntiles, kb; };
+struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, chunks, stage, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
-WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow, int64_t nvis_max)
+int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
+// nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
+// the sort's tables: one bucket per (tile, plane) for the gridding direction)
+WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64_t nrow, int64_t nvis_max,
+           int64_t nplanes_total, int W)
 {
     WgWs w;
     size_t o = 0;
@@ -670,16 +817,17 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.hist = take(WG_NBIN * sizeof(int));
     w.perm = take((size_t)nrow * sizeof(int));
     w.key = take((size_t)nrow * sizeof(unsigned short));
-    // (the sort's tables are laid out for the largest bucket count: the layout must not depend on the call's w range)
-    w.ntiles = (int)(((nu + WG_TILE - 1) / WG_TILE) * ((nv + WG_TILE - 1) / WG_TILE));
-    w.kb = WG_KB;
-    w.nbins = w.ntiles * WG_KB;
+    w.ntiles = (int)wg_ntiles(nu, nv, WG_TILE);
+    w.gtiles = (int)wg_ntiles(nu, nv, wg_gtile(W));
+    const int64_t npl = nplanes_total < 1 ? 1 : nplanes_total;
+    const int64_t fwd = (int64_t)w.ntiles * wg_kb(npl), adj = npl <= WG_GKB ? (int64_t)w.gtiles * npl : 0;
+    w.nbins = (int)(fwd > adj ? fwd : adj);
     w.sums = take((size_t)(w.nbins / 1024 + 2) * sizeof(int));
     w.vcount = take((size_t)(w.nbins + 2) * sizeof(int));       // [nbins + 1] = the chunk counter
     w.vstart = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vcursor = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vidx = take((size_t)nvis_max * sizeof(unsigned));
-    w.chunks = take((size_t)(w.ntiles + nvis_max / WG_CHUNK + 1) * sizeof(int2));
+    w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / WG_CHUNK + 1) * sizeof(int2));
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
@@ -725,13 +873,17 @@ int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st, bool backward = f
 // padded grid size of an image axis: twice the pixels, rounded up to a multiple of 16 (FFT-friendly, even)
 AF_EXPORT int64_t af_wgrid_padded(int64_t n) { return n <= 0 ? 0 : ((2 * n + 15) / 16) * 16; }
 
-// `planes` = number of w-plane grids the workspace holds at a time (>= 1; the call works through the planes in batches of
-// that many: one pass over the visibilities per batch)
-// nchan_max: the largest number of channels of a band the workspace will be used for
-AF_EXPORT size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max)
+// Workspace of both directions.  `planes` = number of w-plane grids the workspace holds at a time (>= 1; a call works
+// through its planes in batches of that many: one pass over the visibilities per batch); nchan_max: the most channels of
+// a band, nplanes_total: the most w-planes (af_wgrid_planes) of a band the workspace will be used for; kernel_width: W.
+AF_EXPORT size_t af_wgrid_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max,
+                                          int64_t nplanes_total, int kernel_width)
 {
-    if (nx < 0 || ny < 0 || planes < 0 || nrow < 0 || nchan_max < 0) return 0;
-    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny), planes, nrow, nrow * nchan_max).total;
+    if (nx < 0 || ny < 0 || planes < 0 || nrow < 0 || nchan_max < 0 || nplanes_total < 0 || kernel_width < 4 ||
+        kernel_width > WG_MAXW)
+        return 0;
+    return wg_ws(nx, ny, af_wgrid_padded(nx), af_wgrid_padded(ny), planes, nrow, nrow * nchan_max, nplanes_total,
+                 kernel_width).total;
 }
 
 // number of w-planes a call will work through: the wrapper sizes its workspace with it
@@ -772,18 +924,6 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     AF_REQUIRE(uvw && freq && (adjoint || image) && corr_u && corr_v && quad_t && quad_w && vis, "af_wgrid_im2vis_f64: NULL array");
     const int64_t nu = af_wgrid_padded(nx), nv = af_wgrid_padded(ny);
     AF_REQUIRE(nu < (1LL << 15) && nv < (1LL << 15), "af_wgrid_im2vis_f64: image too large");
-    // as many resident planes as the workspace holds
-    const int64_t nvis = nrow * nchan_band;
-    const size_t one = wg_ws(nx, ny, nu, nv, 1, nrow, nvis).total, per_plane = (size_t)(nu * nv) * 16;
-    AF_REQUIRE(workspace != nullptr && workspace_bytes >= one, "af_wgrid_im2vis_f64: workspace too small (%zu < %zu)",
-               workspace_bytes, one);
-    const int64_t resident = 1 + (int64_t)((workspace_bytes - one) / per_plane);
-    const WgWs L = wg_ws(nx, ny, nu, nv, resident, nrow, nvis);
-    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_wgrid_im2vis_f64: workspace must be 256-byte aligned");
-    char *ws = static_cast<char *>(workspace);
-    double2 *grid = reinterpret_cast<double2 *>(ws + L.grid), *S = reinterpret_cast<double2 *>(ws + L.stage);
-    double *A = reinterpret_cast<double *>(ws + L.A), *nm1 = reinterpret_cast<double *>(ws + L.nm1);
-
     // plane geometry: spacing from the largest |n - 1| of the image at an oversampling of 2 along w
     double dw = 1.0, w0 = 0.0;
     int nplanes = 1;
@@ -797,6 +937,18 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_REQUIRE(span < 1e6, "af_wgrid_im2vis_f64: %g w-planes", span);
         nplanes = (int)ceil(span) + kernel_width + 1;
     }
+    // as many resident planes as the workspace holds
+    const int64_t nvis = nrow * nchan_band;
+    const size_t one = wg_ws(nx, ny, nu, nv, 1, nrow, nvis, nplanes, kernel_width).total, per_plane = (size_t)(nu * nv) * 16;
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= one, "af_wgrid_im2vis_f64: workspace too small (%zu < %zu)",
+               workspace_bytes, one);
+    const int64_t resident = 1 + (int64_t)((workspace_bytes - one) / per_plane);
+    const WgWs L = wg_ws(nx, ny, nu, nv, resident, nrow, nvis, nplanes, kernel_width);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_wgrid_im2vis_f64: workspace must be 256-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    double2 *grid = reinterpret_cast<double2 *>(ws + L.grid), *S = reinterpret_cast<double2 *>(ws + L.stage);
+    double *A = reinterpret_cast<double *>(ws + L.A), *nm1 = reinterpret_cast<double *>(ws + L.nm1);
+
     const unsigned nb_img = (unsigned)af_cdiv(nx * ny, 256), nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
     hipLaunchKernelGGL(wg_geometry, dim3(nb_img), dim3(256), 0, st, nx, ny, cellx, celly, corr_u, corr_v, quad_t, quad_w,
                        kernel_width, beta, dw, do_wstacking, A, nm1);
@@ -807,7 +959,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     const int *perm = nullptr;
     // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
-    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
+    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31) && (!adjoint || nplanes <= WG_GKB);
     if (!adjoint && !tiled && nrow >= 4096 && nrow < (1LL << 31)) {
         int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
         unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
@@ -821,16 +973,19 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_LAUNCH_CHECK();
         perm = pm;
     }
-    const int kb = wg_kb(nplanes), nbins = L.ntiles * kb;
+    // image -> vis: 32 x 32 tiles, <= 32 plane buckets (locality only); vis -> image: the ring kernel's tiles, one bucket
+    // per plane (it needs the exact order)
+    const int tile = adjoint ? wg_gtile(kernel_width) : WG_TILE, ntiles = adjoint ? L.gtiles : L.ntiles;
+    const int kb = adjoint ? nplanes : wg_kb(nplanes), nbins = ntiles * kb, chunk = adjoint ? WG_GCHUNK : WG_CHUNK;
     int *vcount = reinterpret_cast<int *>(ws + L.vcount), *vstart = reinterpret_cast<int *>(ws + L.vstart);
     const unsigned *vidx = reinterpret_cast<unsigned *>(ws + L.vidx);
     const int2 *chunks = reinterpret_cast<int2 *>(ws + L.chunks);
     const int *nchunks = vcount + nbins + 1;
-    const unsigned max_chunks = (unsigned)(L.ntiles + nvis / WG_CHUNK + 1);
+    const unsigned max_chunks = (unsigned)(ntiles + nvis / chunk + 1);
     if (tiled) {
         int *vcursor = reinterpret_cast<int *>(ws + L.vcursor);
         WgSort q{uvw, freq, mask, nvis, nchan_band, chan0, nchan_total, nv, nu, celly, cellx, w0, dw,
-                 kernel_width, do_wstacking, nplanes, kb, (int)((nu + WG_TILE - 1) / WG_TILE)};
+                 kernel_width, do_wstacking, nplanes, kb, (int)((nu + tile - 1) / tile), tile};
         AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
         int64_t blocks = af_cdiv(nvis, 256);
         if (blocks > 16384) blocks = 16384;
@@ -847,7 +1002,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, st, q, vcursor,
                            reinterpret_cast<unsigned *>(ws + L.vidx));
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(L.ntiles, 256)), dim3(256), 0, st, vstart, L.ntiles, kb,
+        hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
                            reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
         AF_LAUNCH_CHECK();
     }
@@ -856,9 +1011,14 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
         AF_HIP(hipMemsetAsync(grid, 0, (size_t)(pk1 - pk0) * (size_t)(nu * nv) * 16, st));
 #define AF_WG_LAUNCH(WC)                                                                                               \
-    hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,         \
-                       nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,         \
-                       reinterpret_cast<const double2 *>(vis))
+    if (tiled)                                                                                                         \
+        hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(64), 0, st, uvw, freq, nchan_band, chan0,         \
+                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
+                           kb, chunks, nchunks, wgt, reinterpret_cast<const double2 *>(vis));                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,     \
+                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,     \
+                           reinterpret_cast<const double2 *>(vis))
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
         case 5: AF_WG_LAUNCH(5); break;
@@ -962,7 +1122,7 @@ AF_EXPORT int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t
 // The adjoint, visibilities -> image: image (nx, ny) float64 is OVERWRITTEN with the band's dirty image
 //     (1 / n) sum_{r, c} Re( wgt vis exp(+2 pi i nu/c (u x + v y - w (n - 1))) )
 // over the unmasked visibilities (mask != 0: used) of columns chan0 .. chan0 + nchan_band of vis / wgt / mask.  Same
-// geometry arguments and the same workspace (af_wgrid_im2vis_workspace_bytes) as af_wgrid_im2vis_f64, of which this is
+// geometry arguments and the same workspace (af_wgrid_workspace_bytes) as af_wgrid_im2vis_f64, of which this is
 // the exact transpose (same planes, same taps).
 AF_EXPORT int af_wgrid_vis2im_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
                                   int64_t nchan_total, const double *vis, int64_t nx, int64_t ny, double cellx,

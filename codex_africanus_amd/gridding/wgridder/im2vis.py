@@ -120,7 +120,7 @@ def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx,
             bands.append((b, c0, nc, cands, npl))
         want = max([x[4] for x in bands] + [1])
         resident = max(1, min(want, PLANE_BUDGET // (nu * nv * 16)))
-        ws_bytes = int(lib.af_wgrid_im2vis_workspace_bytes(nx, ny, resident, nrow, max([x[2] for x in bands] + [1])))
+        ws_bytes = int(lib.af_wgrid_workspace_bytes(nx, ny, resident, nrow, max([x[2] for x in bands] + [1]), want, W))
         p_ws = c.scratch(ws_bytes)
         for b, c0, nc, cands, npl in bands:
             img = ctypes.c_void_p((p_out if adjoint else p_in).value + 8 * b * nx * ny)

@@ -412,7 +412,8 @@ int af_fused_predict_model_c128(const double *stokes, const double *spi, const d
  * enqueued on `stream`; uses hipFFT (plans cached per device and size, released by af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);
 /* planes: w-plane grids resident at a time (>= 1; af_wgrid_planes() of them = a single pass over the visibilities) */
-size_t af_wgrid_im2vis_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max);
+size_t af_wgrid_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max,
+                                int64_t nplanes_total, int kernel_width);
 int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking);
 int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
                         int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx, double celly,
