@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <cmath>
+#include <type_traits>
 #include <map>
 #include <mutex>
 
@@ -622,9 +623,9 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
 }
 
 // (large calls) The visibilities sorted by (tile, first w-plane) -- exactly: one sort bucket per plane -- are taken
-// through LDS: ONE wave owns a chunk of <= 4096 visibilities of one tile and keeps the tile's cells of W consecutive
+// through LDS: a workgroup owns a chunk of <= 4096 visibilities of one tile and keeps the tile's cells of W consecutive
 // planes in a ring of LDS images (plane k in slot k mod W).  A visibility adds its W x W taps to its W planes with plain
-// LDS read-add-writes (its lanes hit distinct cells; the wave is alone on its images, so no atomics); when the sorted
+// LDS read-add-writes (one lane per tap: distinct cells; every image belongs to one wave, so no atomics); when the sorted
 // list moves on to a higher first plane, the planes that can receive nothing more are added to the grids in memory
 // (hardware fp64 atomics: neighbouring tiles share the halo cells) and their slots cleared.  Every (chunk, plane) is
 // flushed once: W^3 atomics per visibility become (T + W - 1)^2 per (chunk, plane).
@@ -632,13 +633,13 @@ constexpr int WG_GCHUNK = 4096;
 constexpr int WG_GKB = 256;          // planes the exact sort handles; beyond it the per-visibility kernel runs
 __host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 16 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
 template <int W>
-__global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
-                                                    int64_t nchan_b, int64_t chan0, int64_t nchan_total,
-                                                    double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
-                                                    double celly, double beta, double w0, double dw, int pk0, int pk1,
-                                                    int do_w, const unsigned *__restrict__ idx, const int *__restrict__ start,
-                                                    int kb, const int2 *__restrict__ chunks, const int *__restrict__ nchunks,
-                                                    const double *__restrict__ wgt, const double2 *__restrict__ vis)
+__global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
+                                                     int64_t nchan_b, int64_t chan0, int64_t nchan_total,
+                                                     double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
+                                                     double celly, double beta, double w0, double dw, int pk0, int pk1,
+                                                     int do_w, const unsigned *__restrict__ idx, const int *__restrict__ start,
+                                                     int kb, const int2 *__restrict__ chunks, const int *__restrict__ nchunks,
+                                                     const double *__restrict__ wgt, const double2 *__restrict__ vis)
 {
     constexpr int T = wg_gtile(W), R = T + W - 1, RR = R * R;
     constexpr int NT = 4 * W;                   // table doubles per visibility: val.re ku[], val.im ku[], kv[], kw[]
@@ -648,7 +649,9 @@ __global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ u
     __shared__ double tab[64 * NT];
     if ((int)blockIdx.x >= *nchunks) return;
     const int2 ch = chunks[blockIdx.x];
-    const int lane = threadIdx.x;
+    // four waves share the chunk: every wave walks ALL its visibilities, but adds only to the ring slots it owns
+    // (slot % 4 == wave) -- no two waves ever touch the same LDS image, so no atomics and no barriers in the walk
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nty = (int)((nv + T - 1) / T);
     const int tu = ch.x / nty, tv = ch.x - tu * nty;
     int n = start[(ch.x + 1) * kb] - ch.y;
@@ -656,23 +659,25 @@ __global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ u
     constexpr double inv_half_w = 2.0 / (double)W;
     const int64_t plane = nu * nv;
 
-    for (int e = lane; e < W * RR; e += 64) ring[e] = make_double2(0.0, 0.0);
+    for (int e = tid; e < W * RR; e += 256) ring[e] = make_double2(0.0, 0.0);
     int gofs[NE];                               // this lane's region cells on the grid (wrapped)
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
         const int e = lane + 64 * q, a = e / R, b = e - a * R;
         gofs[q] = e < RR ? (int)(((tu * T + a) % nu) * nv + (tv * T + b) % nv) : -1;
     }
-    int ta[NP], tcell[NP];                      // this lane's tap(s): row a, offset a R + b
+    int ta[NP], tb[NP], tcell[NP];              // this lane's tap(s): row a, column b, offset a R + b
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int t = lane + 64 * p;
         ta[p] = t < W * W ? t / W : -1;
+        tb[p] = t < W * W ? t % W : 0;
         tcell[p] = t < W * W ? (t / W) * R + t % W : 0;
     }
-    // plane k -> memory, slot cleared
+    // plane k -> memory, slot cleared (by the wave that owns the slot)
     auto retire = [&](int k) {
         const int slot = ((k % W) + W) % W;
+        if ((slot & 3) != wave) return;
         const bool live = k >= pk0 && k < pk1;
         double *__restrict__ g = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * plane);
 #pragma unroll
@@ -692,14 +697,13 @@ __global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ u
     bool started = false;
     __syncthreads();
     for (int base = 0; base < n; base += 64) {
-        // lane j: everything visibility base + j needs, into the table
+        // the table of visibilities base .. base + 63: lane v of every wave works on visibility base + v; wave 0 writes
+        // val ku[], wave 1 kv[], wave 2 the plane weights; every wave keeps the visibility's first plane and offset
         int k0 = 0x7fffffff, lofs = 0;
         if (base + lane < n) {
             const unsigned i = idx[ch.y + base + lane];
             const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
             const int64_t o = (int64_t)r * nchan_total + chan0 + c;
-            double2 val = vis[o];
-            if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
             const double fl = freq[c] / AF_LIGHTSPEED;
             double gw = 0.0;
             k0 = 0;
@@ -709,54 +713,76 @@ __global__ __launch_bounds__(64) void wg_grid_tiles(const double *__restrict__ u
             }
             const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
             const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
-            const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;
             double *__restrict__ t = tab + lane * NT;
+            if (wave == 0) {
+                double2 val = vis[o];
+                if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
+                const double fu = ceil(gu - 0.5 * W) - gu;
 #pragma unroll
-            for (int a = 0; a < W; ++a) {
-                const double ku = es_kernel(fu + (double)a, inv_half_w, beta);
-                t[a] = val.x * ku;
-                t[W + a] = val.y * ku;
-                t[2 * W + a] = es_kernel(fv + (double)a, inv_half_w, beta);
-                t[3 * W + a] = do_w ? es_kernel((double)(k0 + a) - gw, inv_half_w, beta) : (a == 0 ? 1.0 : 0.0);
+                for (int a = 0; a < W; ++a) {
+                    const double ku = es_kernel(fu + (double)a, inv_half_w, beta);
+                    t[a] = val.x * ku;
+                    t[W + a] = val.y * ku;
+                }
+            } else if (wave == 1) {
+                const double fv = ceil(gv - 0.5 * W) - gv;
+#pragma unroll
+                for (int a = 0; a < W; ++a) t[2 * W + a] = es_kernel(fv + (double)a, inv_half_w, beta);
+            } else if (wave == 2) {
+#pragma unroll
+                for (int a = 0; a < W; ++a)
+                    t[3 * W + a] = do_w ? es_kernel((double)(k0 + a) - gw, inv_half_w, beta) : (a == 0 ? 1.0 : 0.0);
             }
             lofs = (wg_first_cell(gu, W, (int)nu) - tu * T) * R + wg_first_cell(gv, W, (int)nv) - tv * T;
         }
         __syncthreads();
         const int nb = n - base < 64 ? n - base : 64;
-        for (int j = 0; j < nb; ++j) {
-            const int k0j = __builtin_amdgcn_readlane(k0, j), lofsj = __builtin_amdgcn_readlane(lofs, j);
-            if (!started) { kcur = k0j; started = true; }
-            if (k0j > kcur) {                    // planes below k0j are complete for this chunk
-                const int upto = k0j - kcur < W ? k0j : kcur + W;
-                for (int k = kcur; k < upto; ++k) retire(k);
-                kcur = k0j;
+        // the walk, compiled once per wave number so that the slots a wave owns are compile-time constants (a dynamic
+        // ownership test per slot cost ~40 scalar branches per visibility)
+        auto walk = [&](auto wvc) {
+            constexpr int WV = decltype(wvc)::value;
+            constexpr int NS = (W - WV + 3) / 4;      // slots WV, WV + 4, ...
+            for (int j = 0; j < nb; ++j) {
+                const int k0j = __builtin_amdgcn_readlane(k0, j), lofsj = __builtin_amdgcn_readlane(lofs, j);
+                if (!started) { kcur = k0j; started = true; }
+                if (k0j > kcur) {                // planes below k0j are complete for this chunk
+                    const int upto = k0j - kcur < W ? k0j : kcur + W;
+                    for (int k = kcur; k < upto; ++k) retire(k);
+                    kcur = k0j;
+                }
+                if (NS == 0) continue;
+                const double *__restrict__ t = tab + j * NT;
+                const int s0 = ((k0j % W) + W) % W;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (ta[p] < 0) continue;
+                    const double kvb = t[2 * W + tb[p]];
+                    const double pre = t[ta[p]] * kvb, pim = t[W + ta[p]] * kvb;
+                    const int cell = lofsj + tcell[p];
+                    double2 v[NS > 0 ? NS : 1];
+                    double kw[NS > 0 ? NS : 1];
+#pragma unroll
+                    for (int m = 0; m < NS; ++m) {
+                        const int sl = WV + 4 * m;
+                        const int a = sl - s0 < 0 ? sl - s0 + W : sl - s0;      // the plane offset that lives in slot sl
+                        kw[m] = t[3 * W + a];
+                        v[m] = ring[sl * RR + cell];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NS; ++m) {
+                        v[m].x = fma(kw[m], pre, v[m].x);
+                        v[m].y = fma(kw[m], pim, v[m].y);
+                    }
+#pragma unroll
+                    for (int m = 0; m < NS; ++m) ring[(WV + 4 * m) * RR + cell] = v[m];
+                }
             }
-            const double *__restrict__ t = tab + j * NT;
-            const int s0 = ((k0j % W) + W) % W;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                if (ta[p] < 0) continue;
-                const double kvb = t[2 * W + (tcell[p] - ta[p] * R)];
-                const double pre = t[ta[p]] * kvb, pim = t[W + ta[p]] * kvb;
-                const int cell = lofsj + tcell[p];
-                double2 v[W];
-#pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    const int slot = s0 + a >= W ? s0 + a - W : s0 + a;
-                    v[a] = ring[slot * RR + cell];
-                }
-#pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    const double kw = t[3 * W + a];
-                    v[a].x = fma(kw, pre, v[a].x);
-                    v[a].y = fma(kw, pim, v[a].y);
-                }
-#pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    const int slot = s0 + a >= W ? s0 + a - W : s0 + a;
-                    ring[slot * RR + cell] = v[a];
-                }
-            }
+        };
+        switch (wave) {
+        case 0: walk(std::integral_constant<int, 0>{}); break;
+        case 1: walk(std::integral_constant<int, 1>{}); break;
+        case 2: walk(std::integral_constant<int, 2>{}); break;
+        default: walk(std::integral_constant<int, 3>{}); break;
         }
         __syncthreads();
     }
@@ -1012,7 +1038,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_HIP(hipMemsetAsync(grid, 0, (size_t)(pk1 - pk0) * (size_t)(nu * nv) * 16, st));
 #define AF_WG_LAUNCH(WC)                                                                                               \
     if (tiled)                                                                                                         \
-        hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(64), 0, st, uvw, freq, nchan_band, chan0,         \
+        hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,        \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
                            kb, chunks, nchunks, wgt, reinterpret_cast<const double2 *>(vis));                            \
     else                                                                                                               \
