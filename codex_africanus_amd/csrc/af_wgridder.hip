@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
 // flushed once: W^3 atomics per visibility become (T + W - 1)^2 per (chunk, plane).
 constexpr int WG_GCHUNK = 4096;
 constexpr int WG_GKB = 256;          // planes the exact sort handles; beyond it the per-visibility kernel runs
-__host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 16 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
+__host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 12 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
 template <int W>
 __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
                                                      int64_t nchan_b, int64_t chan0, int64_t nchan_total,
