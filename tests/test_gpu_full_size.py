@@ -161,3 +161,47 @@ def test_wgridder_full_size_c5():
     assert np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= eps
     twice = model(d_uvw, d_freq, d_img * 2.0, np.array([0]), np.array([nchan]), cell, epsilon=eps)
     assert torch.equal(twice, vis * 2.0)
+
+
+def test_wgridder_dirty_full_size_c5():
+    """The adjoint at configs[4]'s counts: 1e6 rows x 64 channels -> 4096^2 dirty image, epsilon 1e-5.  A few pixels
+    against the direct sum over ALL visibilities (CPU oracle), and <R x, v> == <x, R^H v> with the full-size model of a
+    sparse image -- to rounding, because the two directions share planes and taps."""
+    import torch
+    import oracle
+    from codex_africanus_amd.gridding.wgridder import dirty, model
+    dev = torch.device("cuda", 0)
+    npix, nrow, nchan, eps = 4096, 1000000, 64, 1e-5
+    cell = np.deg2rad(2.0 / 3600.0)
+    freq = np.linspace(0.856e9, 1.712e9, nchan)
+    rng = np.random.default_rng(1)
+    umax = 0.45 / cell * (299792458.0 / freq.max())
+    uvw = np.zeros((nrow, 3))
+    uvw[:, :2] = rng.uniform(-1, 1, (nrow, 2)) * umax
+    uvw[:, 2] = rng.uniform(-400, 400, nrow)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_uvw, d_freq = t(uvw), t(freq)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    d_vis = torch.randn(nrow, nchan, dtype=torch.complex128, device=dev, generator=gen)
+    d_wgt = torch.rand(nrow, nchan, dtype=torch.float64, device=dev, generator=gen)
+    fbi, fbc = np.array([0]), np.array([nchan])
+    img = dirty(d_uvw, d_freq, d_vis, fbi, fbc, npix, npix, cell, weights=d_wgt, epsilon=eps)
+    assert tuple(img.shape) == (1, npix, npix) and img.dtype == torch.float64
+    assert bool(torch.isfinite(img).all())
+    pix = rng.integers(0, npix, (5, 2))
+    x, y = (pix[:, 0] - npix / 2) * cell, (pix[:, 1] - npix / 2) * cell
+    n = np.sqrt(1 - x * x - y * y)
+    wv = (d_vis * d_wgt).cpu().numpy()
+    ref = oracle.vis_to_im(wv[:, :, None], uvw * np.array([1, 1, -1.0]), np.stack([x, y], 1), freq,
+                           np.zeros(wv.shape + (1,), np.uint8), omp=True)[:, :, 0].sum(axis=1) / n
+    got = img[0].cpu().numpy()[pix[:, 0], pix[:, 1]]
+    rms = float(torch.sqrt(torch.mean(img[0] ** 2)))
+    assert np.abs(got - ref).max() <= eps * rms * 10          # per pixel; the contract is an l2 one over the image
+    image = np.zeros((1, npix, npix))
+    nz = rng.integers(0, npix, (3000, 2))
+    image[0, nz[:, 0], nz[:, 1]] = rng.lognormal(0, 1, 3000)
+    d_img = t(image)
+    vis = model(d_uvw, d_freq, d_img, fbi, fbc, cell, weights=d_wgt, epsilon=eps)
+    lhs = float(torch.sum(d_vis.real * vis.real + d_vis.imag * vis.imag))
+    rhs = float(torch.sum(d_img * img))
+    assert abs(lhs - rhs) <= 1e-10 * float(torch.sum(d_img) * img.abs().max())

@@ -22,7 +22,7 @@ for w in $WORKLOADS; do
         --kernel-trace --output-format csv -d "$OUT/$w/sq2" -o sq2 -- python3 $ARGS > "$OUT/$w/sq2.log" 2>&1
 done
 # auxiliary benches: kernel-trace stats of each (per-kernel durations of the real launches)
-for t in bench_gridder bench_degridder bench_wgridder bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr; do
+for t in bench_gridder bench_degridder bench_wgridder bench_wgridder_dirty bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr; do
     [ -f tools/$t.py ] || continue
     mkdir -p "$OUT/aux/$t"
     python3 tools/$t.py > "$OUT/aux/$t/result.json" 2> "$OUT/aux/$t/stderr.log"
