@@ -211,6 +211,7 @@ struct WgSort {
     int64_t nvis, nchan_b, chan0, nchan_total, nu, nv;
     double cellx, celly, w0, dw;
     int W, do_w, nplanes, kb, nty, tile;
+    int exact, kfirst;      // exact: one bucket per first plane kfirst .. kfirst + kb - 1, other visibilities left out
 };
 // (in everything below "u" is the SLOW axis of the stored planes and "v" the fast one: the planes are v-major, so the
 // host hands uvw's v as this code's u -- component 1 -- and u as its v)
@@ -238,9 +239,14 @@ __device__ __forceinline__ int wg_vis_key(const WgSort &q, int64_t i)
         const double gw = (p[2] * fl - q.w0) / q.dw;
         if (!isfinite(gw)) return -1;
         double k0 = ceil(gw - 0.5 * q.W);
-        k0 = k0 < 0.0 ? 0.0 : (k0 > (double)(q.nplanes - 1) ? (double)(q.nplanes - 1) : k0);
-        kb = (int)(k0 * (double)q.kb / (double)q.nplanes);
-        kb = kb >= q.kb ? q.kb - 1 : kb;
+        if (q.exact) {
+            if (!(k0 >= (double)q.kfirst && k0 < (double)(q.kfirst + q.kb))) return -1;
+            kb = (int)k0 - q.kfirst;
+        } else {
+            k0 = k0 < 0.0 ? 0.0 : (k0 > (double)(q.nplanes - 1) ? (double)(q.nplanes - 1) : k0);
+            kb = (int)(k0 * (double)q.kb / (double)q.nplanes);
+            kb = kb >= q.kb ? q.kb - 1 : kb;
+        }
     }
     const int pu = wg_first_cell(gu, q.W, (int)q.nu), pv = wg_first_cell(gv, q.W, (int)q.nv);
     return ((pu / q.tile) * q.nty + pv / q.tile) * q.kb + kb;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
 // (hardware fp64 atomics: neighbouring tiles share the halo cells) and their slots cleared.  Every (chunk, plane) is
 // flushed once: W^3 atomics per visibility become (T + W - 1)^2 per (chunk, plane).
 constexpr int WG_GCHUNK = 4096;
-constexpr int WG_GKB = 256;          // planes the exact sort handles; beyond it the per-visibility kernel runs
+constexpr int WG_GKB = 256;          // buckets (first planes) of one exact sort: calls with more planes sort per batch of planes
 __host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 12 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
 template <int W>
 __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
@@ -846,7 +852,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.ntiles = (int)wg_ntiles(nu, nv, WG_TILE);
     w.gtiles = (int)wg_ntiles(nu, nv, wg_gtile(W));
     const int64_t npl = nplanes_total < 1 ? 1 : nplanes_total;
-    const int64_t fwd = (int64_t)w.ntiles * wg_kb(npl), adj = npl <= WG_GKB ? (int64_t)w.gtiles * npl : 0;
+    const int64_t fwd = (int64_t)w.ntiles * wg_kb(npl), adj = (int64_t)w.gtiles * (npl + W - 1 < WG_GKB ? npl + W - 1 : WG_GKB);
     w.nbins = (int)(fwd > adj ? fwd : adj);
     w.sums = take((size_t)(w.nbins / 1024 + 2) * sizeof(int));
     w.vcount = take((size_t)(w.nbins + 2) * sizeof(int));       // [nbins + 1] = the chunk counter
@@ -896,8 +902,19 @@ int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st, bool backward = f
 
 }  // namespace
 
-// padded grid size of an image axis: twice the pixels, rounded up to a multiple of 16 (FFT-friendly, even)
-AF_EXPORT int64_t af_wgrid_padded(int64_t n) { return n <= 0 ? 0 : ((2 * n + 15) / 16) * 16; }
+// padded grid size of an image axis: the smallest even 2-3-5-7-smooth number >= twice the pixels (an oversampling of at
+// least 2 with only the radices the FFT library has butterflies for: 2 x 4100 = 8200 = 2^3 5^2 41 would run a length-41
+// Bluestein pass, 8232 = 2^3 3 7^3 does not)
+AF_EXPORT int64_t af_wgrid_padded(int64_t n)
+{
+    if (n <= 0) return 0;
+    for (int64_t m = 2 * n + ((2 * n) & 1);; m += 2) {
+        int64_t r = m;
+        for (int64_t p : {2, 3, 5, 7})
+            while (r % p == 0) r /= p;
+        if (r == 1) return m;
+    }
+}
 
 // Workspace of both directions.  `planes` = number of w-plane grids the workspace holds at a time (>= 1; a call works
 // through its planes in batches of that many: one pass over the visibilities per batch); nchan_max: the most channels of
@@ -985,7 +1002,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     const int *perm = nullptr;
     // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
-    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31) && (!adjoint || nplanes <= WG_GKB);
+    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
     if (!adjoint && !tiled && nrow >= 4096 && nrow < (1LL << 31)) {
         int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
         unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
@@ -999,19 +1016,21 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_LAUNCH_CHECK();
         perm = pm;
     }
-    // image -> vis: 32 x 32 tiles, <= 32 plane buckets (locality only); vis -> image: the ring kernel's tiles, one bucket
-    // per plane (it needs the exact order)
+    // image -> vis: 32 x 32 tiles, <= 32 plane buckets (locality only), sorted once; vis -> image: the ring kernel's
+    // tiles and one bucket per first plane (it needs the exact order), sorted per batch of planes
     const int tile = adjoint ? wg_gtile(kernel_width) : WG_TILE, ntiles = adjoint ? L.gtiles : L.ntiles;
-    const int kb = adjoint ? nplanes : wg_kb(nplanes), nbins = ntiles * kb, chunk = adjoint ? WG_GCHUNK : WG_CHUNK;
+    const int chunk = adjoint ? WG_GCHUNK : WG_CHUNK;
     int *vcount = reinterpret_cast<int *>(ws + L.vcount), *vstart = reinterpret_cast<int *>(ws + L.vstart);
     const unsigned *vidx = reinterpret_cast<unsigned *>(ws + L.vidx);
     const int2 *chunks = reinterpret_cast<int2 *>(ws + L.chunks);
-    const int *nchunks = vcount + nbins + 1;
     const unsigned max_chunks = (unsigned)(ntiles + nvis / chunk + 1);
-    if (tiled) {
+    int kb = wg_kb(nplanes);
+    const int *nchunks = nullptr;
+    auto sort_visibilities = [&](int exact, int kfirst) -> int {
+        const int nbins = ntiles * kb;
         int *vcursor = reinterpret_cast<int *>(ws + L.vcursor);
         WgSort q{uvw, freq, mask, nvis, nchan_band, chan0, nchan_total, nv, nu, celly, cellx, w0, dw,
-                 kernel_width, do_wstacking, nplanes, kb, (int)((nu + tile - 1) / tile), tile};
+                 kernel_width, do_wstacking, nplanes, kb, (int)((nu + tile - 1) / tile), tile, exact, kfirst};
         AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
         int64_t blocks = af_cdiv(nvis, 256);
         if (blocks > 16384) blocks = 16384;
@@ -1031,11 +1050,24 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
                            reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
         AF_LAUNCH_CHECK();
+        nchunks = vcount + nbins + 1;
+        return AF_OK;
+    };
+    if (tiled && !adjoint) {
+        const int rc = sort_visibilities(0, 0);
+        if (rc != AF_OK) return rc;
     }
+    // planes per pass of the gridding direction: what is resident, and what one exact sort covers
+    const int gbatch = (int)resident < WG_GKB - kernel_width + 1 ? (int)resident : WG_GKB - kernel_width + 1;
     af_prof_begin(st);
-    for (int pk0 = 0; adjoint && pk0 < nplanes; pk0 += (int)resident) {
-        const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
+    for (int pk0 = 0; adjoint && pk0 < nplanes; pk0 += gbatch) {
+        const int pk1 = pk0 + gbatch < nplanes ? pk0 + gbatch : nplanes;
         AF_HIP(hipMemsetAsync(grid, 0, (size_t)(pk1 - pk0) * (size_t)(nu * nv) * 16, st));
+        if (tiled) {        // the visibilities whose first plane is pk0 - W + 1 .. pk1 - 1, by (tile, first plane)
+            kb = pk1 - pk0 + kernel_width - 1;
+            const int rc = sort_visibilities(1, pk0 - kernel_width + 1);
+            if (rc != AF_OK) return rc;
+        }
 #define AF_WG_LAUNCH(WC)                                                                                               \
     if (tiled)                                                                                                         \
         hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,        \
