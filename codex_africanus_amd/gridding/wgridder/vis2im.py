@@ -34,11 +34,16 @@ def dirty(uvw, freq, vis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights=N
 
 
 def _on_device(arrays):
-    """Composite operators keep their intermediates on the GPU: numpy inputs are uploaded once."""
-    import torch
+    """Composite operators keep their intermediates on the GPU: numpy inputs are uploaded once (through torch, the
+    device-memory plumbing of the host layer; an interpreter without torch -- a dask worker environment -- composes the
+    two calls through host memory instead)."""
     host = not any(_is_torch(a) for a in arrays if a is not None)
     if not host:
         return False, arrays
+    try:
+        import torch
+    except ImportError:
+        return None, arrays
     return True, [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrays]
 
 
@@ -53,6 +58,12 @@ def residual(uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, cell, weights
     out_dtype = np_dtype_of(image)
     nx, ny = int(image.shape[1]), int(image.shape[2])
     host, (uvw, freq, image, vis, weights, flag) = _on_device([uvw, freq, image, vis, weights, flag])
+    if host is None:
+        mvis = model(uvw, freq, np.asarray(image, dtype=np.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly,
+                     epsilon, nthreads, do_wstacking)
+        out = dirty(uvw, freq, np.asarray(vis, dtype=np.complex128) - mvis, freq_bin_idx, freq_bin_counts, nx, ny, cell,
+                    weights, flag, celly, epsilon, nthreads, do_wstacking, double_accum)
+        return out.astype(out_dtype, copy=False)
     import torch
     mvis = model(uvw, freq, image.to(torch.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly, epsilon,
                  nthreads, do_wstacking)
@@ -73,6 +84,12 @@ def hessian(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None,
     out_dtype = np_dtype_of(image)
     nx, ny = int(image.shape[1]), int(image.shape[2])
     host, (uvw, freq, image, weights, flag) = _on_device([uvw, freq, image, weights, flag])
+    if host is None:
+        mvis = model(uvw, freq, np.asarray(image, dtype=np.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly,
+                     epsilon, nthreads, do_wstacking)
+        out = dirty(uvw, freq, mvis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly, epsilon, nthreads,
+                    do_wstacking, double_accum)
+        return out.astype(out_dtype, copy=False)
     import torch
     mvis = model(uvw, freq, image.to(torch.float64), freq_bin_idx, freq_bin_counts, cell, None, flag, celly, epsilon,
                  nthreads, do_wstacking)

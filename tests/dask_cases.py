@@ -105,6 +105,7 @@ def main():
                                da.from_array(g1["frequency"], chunks=2)).compute()
         assert np.array_equal(ph, rime.phase_delay(g1["lm"], g1["uvw"], g1["frequency"]))
     producers_and_calibration()
+    wgridder_cases()
     stats = _lib.pool_stats(0)
     print("predict_vis cases: %d; placement devices %s policy %s; pool hits %d misses %d"
           % (ncase, placement.devices(), placement.get_policy(), stats["hits"], stats["misses"]))
@@ -176,6 +177,46 @@ def producers_and_calibration():
                 vis = np.arange(1.0, n + 1.0).reshape(vis_shape + ishape)
                 dvis = da.from_array(vis, chunks=chunks + tuple((s,) for s in ishape))
                 assert np.array_equal(da_convert(dvis, isch, osch).compute(), convert(vis, isch, osch))
+
+
+def wgridder_cases():
+    """dask front-ends of the wgridder operators (africanus/gridding/wgridder/dask.py:53-463) with the reference's test
+    chunking (tests/test_wgridder.py:357-600: rows in 3 chunks, one band per frequency chunk) against the array-level
+    calls: to epsilon, since every row chunk picks its own w-planes"""
+    from codex_africanus_amd.gridding.wgridder import model, dirty, residual, hessian
+    from codex_africanus_amd.gridding.wgridder import dask as wdask
+    rng = np.random.default_rng(420)
+    nx, ny, nrow, nchan, nband, eps = 30, 128, 3333, 8, 2, 1e-6
+    cell = 5.0 * np.pi / 180 / nx
+    freq = 1e9 + np.arange(nchan) * (1e9 / nchan)
+    uvw = (rng.random((nrow, 3)) - 0.5) / (cell * freq[-1] / 2.99792458e8)
+    step = nchan // nband
+    fbi, fbc = np.arange(0, nchan, step), np.full(nband, step)
+    image = rng.standard_normal((nband, nx, ny))
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.1).astype(np.uint8)
+    rows = (1111, 1111, 1111)
+    d_uvw, d_freq = da.from_array(uvw, chunks=(rows, 3)), da.from_array(freq, chunks=step)
+    d_fbi, d_fbc = da.from_array(fbi, chunks=1), da.from_array(fbc, chunks=1)
+    d_img = da.from_array(image, chunks=(1, nx, ny))
+    d_ms, d_wgt, d_flag = (da.from_array(a, chunks=(rows, step)) for a in (ms, wgt, flag))
+    l2 = lambda a, b: np.sqrt(np.sum(np.abs(a - b) ** 2) / np.sum(np.abs(b) ** 2))
+    with dask.config.set(scheduler="threads", num_workers=4):
+        vis = wdask.model(d_uvw, d_freq, d_img, d_fbi, d_fbc, cell, weights=d_wgt, flag=d_flag, epsilon=eps)
+        assert vis.shape == (nrow, nchan) and vis.dtype == np.complex128
+        assert l2(vis.compute(), model(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=eps)) <= 2 * eps
+        img = wdask.dirty(d_uvw, d_freq, d_ms, d_fbi, d_fbc, nx, ny, cell, weights=d_wgt, flag=d_flag, epsilon=eps)
+        assert img.shape == (nband, nx, ny) and img.dtype == np.float64
+        assert l2(img.compute(), dirty(uvw, freq, ms, fbi, fbc, nx, ny, cell, weights=wgt, flag=flag, epsilon=eps)) <= 2 * eps
+        img32 = wdask.dirty(d_uvw, d_freq, d_ms.astype(np.complex64), d_fbi, d_fbc, nx, ny, cell, epsilon=1e-4)
+        assert img32.dtype == np.float32 and img32.compute().dtype == np.float32
+        res = wdask.residual(d_uvw, d_freq, d_img, d_ms, d_fbi, d_fbc, cell, weights=d_wgt, flag=d_flag, epsilon=eps)
+        want = residual(uvw, freq, image, ms, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=eps)
+        assert res.shape == image.shape and l2(res.compute(), want) <= 4 * eps
+        hes = wdask.hessian(d_uvw, d_freq, d_img, d_fbi, d_fbc, cell, weights=d_wgt, flag=d_flag, epsilon=eps)
+        want = hessian(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=eps)
+        assert l2(hes.compute(), want) <= 4 * eps
 
 
 if __name__ == "__main__":

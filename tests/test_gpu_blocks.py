@@ -171,3 +171,51 @@ def test_block_ids_select_devices():
         assert placement.choose(devs=(0, 1, 2, 3)) == 1
     assert placement.choose(policy="none") is None
     assert _lib.get_device() in devs
+
+
+def test_wgridder_blocks_row_chunks_times_bands():
+    """The wgridder front-ends' block functions (codex_africanus_amd/gridding/wgridder/dask.py; reference
+    africanus/gridding/wgridder/dask.py:22-463) under the blockwise calling convention: blocks are (row chunk, band);
+    uvw arrives as a one-element list (its "three" axis is contracted), the image of ``model`` as a doubly nested one
+    (nx, ny contracted); ``dirty`` gives one image per row chunk, summed.  Every row chunk picks its own w-planes, so
+    chunked == unchunked to epsilon (test_wgridder.py:357-518), not to rounding."""
+    from codex_africanus_amd.gridding.wgridder import dask as wdask, model, dirty
+    rng = np.random.default_rng(420)
+    nx, ny, nrow, nchan, nband, eps = 30, 64, 3333, 8, 2, 1e-6
+    cell = 5.0 * np.pi / 180 / nx
+    freq = 1e9 + np.arange(nchan) * (1e9 / nchan)
+    uvw = (rng.random((nrow, 3)) - 0.5) / (cell * freq[-1] / 2.99792458e8)
+    step = nchan // nband
+    fbi = np.arange(0, nchan, step)
+    fbc = np.full(nband, step)
+    image = rng.standard_normal((nband, nx, ny))
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    wgt = rng.random((nrow, nchan))
+    flag = (rng.random((nrow, nchan)) > 0.1).astype(np.uint8)
+    rows = (1111, 1111, 1111)
+    C = Chunked
+    c_uvw, c_freq = C(uvw, (rows, (3,))), C(freq, ((step,) * nband,))
+    c_fbi, c_fbc = C(fbi, ((1,) * nband,)), C(fbc, ((1,) * nband,))
+    c_img = C(image, ((1,) * nband, (nx,), (ny,)))
+    c_ms, c_wgt, c_flag = (C(a, (rows, (step,) * nband)) for a in (ms, wgt, flag))
+    ids = C(np.arange(len(rows)), ((1,) * len(rows),))
+    kw = dict(cell=cell, celly=None, epsilon=eps, do_wstacking=True)
+    vis = blockwise(wdask._model_block, ("row", "chan"), c_uvw, ("row", "three"), c_freq, ("chan",),
+                    c_img, ("chan", "nx", "ny"), c_fbi, ("chan",), c_fbc, ("chan",), c_wgt, ("row", "chan"),
+                    c_flag, ("row", "chan"), ids, ("row",), **kw)
+    ref = model(uvw, freq, image, fbi, fbc, cell, weights=wgt, flag=flag, epsilon=eps)
+    assert vis.shape == ref.shape
+    assert np.sqrt(np.sum(np.abs(vis - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= 2 * eps
+    ims = blockwise(wdask._dirty_block, ("row", "chan", "nx", "ny"), c_uvw, ("row", "three"), c_freq, ("chan",),
+                    c_ms, ("row", "chan"), c_fbi, ("chan",), c_fbc, ("chan",), c_wgt, ("row", "chan"),
+                    c_flag, ("row", "chan"), ids, ("row",), nx=nx, ny=ny, **kw)
+    assert ims.shape == (len(rows), nband, nx, ny)
+    ref = dirty(uvw, freq, ms, fbi, fbc, nx, ny, cell, weights=wgt, flag=flag, epsilon=eps)
+    got = ims.sum(axis=0)
+    assert np.sqrt(np.sum((got - ref) ** 2) / np.sum(ref ** 2)) <= 2 * eps
+    # weights / flags absent: passed as None with index None
+    vis0 = blockwise(wdask._model_block, ("row", "chan"), c_uvw, ("row", "three"), c_freq, ("chan",),
+                     c_img, ("chan", "nx", "ny"), c_fbi, ("chan",), c_fbc, ("chan",), None, None, None, None,
+                     ids, ("row",), **kw)
+    ref0 = model(uvw, freq, image, fbi, fbc, cell, epsilon=eps)
+    assert np.sqrt(np.sum(np.abs(vis0 - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)) <= 2 * eps
