@@ -58,7 +58,7 @@ def parse():
     p.add_argument("--sources", type=int, default=1000)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "fused_dde", "degrid"])
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "fused_dde", "degrid", "wgrid"])
     p.add_argument("--pa", default="random", choices=["random", "common"],
                    help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
                         "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
@@ -405,7 +405,106 @@ class Degrid(object):
         }
 
 
-WORKLOADS = {"dft": Dft, "dft_complex": Dft, "fused_dde": FusedDde, "degrid": Degrid}
+class Wgrid(object):
+    """BASELINE configs[4] as named -- wgridder-style degridding of a 4096^2 model IMAGE onto 1e6 rows x 64 chan at
+    epsilon 1e-5 (7 x 7 x 7 taps, w-stacking): africanus/gridding/wgridder/im2vis.py:14-99 (arithmetic in the un-vendored
+    ducc0: the accuracy contract of gridding/wgridder/tests/test_wgridder.py:18-113 is what is checked).  Uniformly
+    random uv inside 0.45 of the grid, |w| <= 400 m; a sparse image (3000 non-zero pixels) so that the direct transform
+    of a row sample is affordable for the checker and the CPU baseline."""
+    EPS, CELL = 1e-5, 2.0
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        from codex_africanus_amd.gridding.wgridder.im2vis import kernel_parameters, kernel_correction, _quadrature
+        self.args, self._lib = args, _lib
+        nrow, nchan, npix = args.rows, args.chans, args.npix
+        self.freq = np.linspace(0.856e9, 1.712e9, nchan)
+        self.cell = cell = np.deg2rad(self.CELL / 3600.0)
+        rng = np.random.default_rng(2000 + args.seed + rank)
+        umax = 0.45 / cell * (299792458.0 / self.freq.max())
+        uvw = np.zeros((nrow, 3))
+        uvw[:, :2] = rng.uniform(-1, 1, (nrow, 2)) * umax
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        self.uvw = uvw
+        image = np.zeros((npix, npix))
+        nz = np.random.default_rng(args.seed).integers(0, npix, (3000, 2))
+        image[nz[:, 0], nz[:, 1]] = np.random.default_rng(args.seed + 1).lognormal(0, 1, 3000)
+        self.image = image
+        self.W, self.beta = kernel_parameters(self.EPS)
+        nu = int(lib.af_wgrid_padded(npix))
+        self.nu = nu
+        corr = kernel_correction(npix, nu, self.W, self.beta)
+        qt, qw = _quadrature()
+        emax = 2 * (npix / 2.0 * cell) ** 2
+        self.max_nm1 = emax / (np.sqrt(1.0 - emax) + 1.0)
+        fl = self.freq / 299792458.0
+        w = uvw[:, 2]
+        cands = (w.min() * fl.min(), w.min() * fl.max(), w.max() * fl.min(), w.max() * fl.max())
+        self.wl = (float(min(cands)), float(max(cands)))
+        self.nplanes = int(lib.af_wgrid_planes(self.wl[0], self.wl[1], float(self.max_nm1), self.W, 1))
+        self.dv = dict(uvw=t(uvw), freq=t(self.freq), image=t(image), cu=t(corr), qt=t(qt), qw=t(qw))
+        self.ws_bytes = int(lib.af_wgrid_workspace_bytes(npix, npix, self.nplanes, nrow, nchan, self.nplanes, self.W))
+        self.d_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.ncorr = 1
+        self.label = ("wgridder-style degridding of a %d^2 image, epsilon %g: %d taps per axis, %d w-planes of %d^2 "
+                      "(BASELINE configs[4] as named)" % (npix, self.EPS, self.W, self.nplanes, nu))
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_wgrid_im2vis_f64", P(v["uvw"]), P(v["freq"]), a.rows, a.chans, 0, a.chans, P(v["image"]),
+                       a.npix, a.npix, self.cell, self.cell, P(v["cu"]), P(v["cu"]), P(v["qt"]), P(v["qw"]), self.W,
+                       self.beta, self.wl[0], self.wl[1], float(self.max_nm1), 1, None, None, P(d_vis), P(self.d_ws),
+                       self.ws_bytes, stream)
+
+    def _direct(self, rows, omp):
+        import oracle
+        npix, cell = self.args.npix, self.cell
+        ix, iy = np.nonzero(self.image)
+        x, y = (ix - npix / 2) * cell, (iy - npix / 2) * cell
+        n = np.sqrt(1 - x * x - y * y)
+        src = np.broadcast_to((self.image[ix, iy] / n)[:, None, None], (ix.size, self.freq.size, 1)).copy()
+        return oracle.im_to_vis(src, self.uvw[rows] * np.array([1, 1, -1.0]), np.stack([x, y], 1), self.freq, omp=omp)
+
+    def reference_rows(self, rows):
+        return self._direct(rows, True), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        nvis = float(a.rows) * a.chans
+        # dominant kernel of the call = the visibility pass wg_degrid_tiles<W> (the other ~30 ms are hipFFT row
+        # transforms, transposes and the device sort).  Algorithmic HBM bytes of that launch: every cell of every
+        # w-plane read once + 16 B written per visibility + the sorted index (4 B) and uvw.
+        alg_bytes = float(self.nplanes) * self.nu * self.nu * 16 + nvis * 16 + nvis * 4 + a.rows * 24
+        taps = nvis * self.W ** 3
+        return dict(kernel="wg_degrid_tiles<%d>" % self.W, bound="hbm", alg_bytes=alg_bytes, alg_flops=taps * 4.0,
+                    channels_in_kernel=a.chans,
+                    note="the visibility pass of the call (sorted (tile, plane) chunks, tiles staged through LDS); the "
+                         "step also runs %d pruned plane transforms (hipFFT rows + transposes) and the device sort; "
+                         "fp64_max_abs_err here is against the direct transform, whose contract is an l2 error <= "
+                         "epsilon" % self.nplanes)
+
+    def cpu_baseline(self, target_core_seconds):
+        threads = _threads()
+        t0 = time.perf_counter()
+        self._direct(np.arange(16), False)
+        per_row = (time.perf_counter() - t0) / 16
+        n = int(max(threads * 8, min(self.args.rows, target_core_seconds / per_row)))
+        n -= n % threads
+        t0 = time.perf_counter()
+        self._direct(np.arange(n), True)
+        dt = time.perf_counter() - t0
+        return {
+            "value": n * self.args.chans / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "sample": "the reference's CPU path for this entry is ducc0.wgridder.dirty2ms (absent here: not vendored, "
+                      "not installed); timed instead: the direct transform the accuracy contract is stated against "
+                      "(oracle im_to_vis over the image's 3000 non-zero pixels, OpenMP over rows), %d rows x %d chan "
+                      "in %.2f s; its cost grows with the number of non-zero pixels, the wgridder's does not"
+                      % (n, self.args.chans, dt),
+            "single_thread_value": self.args.chans / per_row / 1e6,
+        }
+
+
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid}
 
 
 def pmc_traffic(workload, is_default_shape):

@@ -1059,7 +1059,6 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     }
     // planes per pass of the gridding direction: what is resident, and what one exact sort covers
     const int gbatch = (int)resident < WG_GKB - kernel_width + 1 ? (int)resident : WG_GKB - kernel_width + 1;
-    af_prof_begin(st);
     for (int pk0 = 0; adjoint && pk0 < nplanes; pk0 += gbatch) {
         const int pk1 = pk0 + gbatch < nplanes ? pk0 + gbatch : nplanes;
         AF_HIP(hipMemsetAsync(grid, 0, (size_t)(pk1 - pk0) * (size_t)(nu * nv) * 16, st));
@@ -1077,6 +1076,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,     \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,     \
                            reinterpret_cast<const double2 *>(vis))
+        af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
         case 5: AF_WG_LAUNCH(5); break;
@@ -1092,6 +1092,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         case 15: AF_WG_LAUNCH(15); break;
         default: AF_WG_LAUNCH(16); break;
         }
+        af_prof_end(st);
 #undef AF_WG_LAUNCH
         AF_LAUNCH_CHECK();
         for (int k = pk0; k < pk1; ++k) {
@@ -1132,6 +1133,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL((wg_degrid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,   \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, perm,    \
                            reinterpret_cast<double2 *>(vis))
+        af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
         case 5: AF_WG_LAUNCH(5); break;
@@ -1147,10 +1149,10 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         case 15: AF_WG_LAUNCH(15); break;
         default: AF_WG_LAUNCH(16); break;
         }
+        af_prof_end(st);
 #undef AF_WG_LAUNCH
         AF_LAUNCH_CHECK();
     }
-    af_prof_end(st);
     if (!adjoint && (wgt || mask)) {
         hipLaunchKernelGGL(wg_finish, dim3(nb_vis), dim3(256), 0, st, reinterpret_cast<double2 *>(vis), wgt, mask, nrow,
                            nchan_band, chan0, nchan_total);

@@ -205,3 +205,15 @@ def test_wgridder_dirty_full_size_c5():
     lhs = float(torch.sum(d_vis.real * vis.real + d_vis.imag * vis.imag))
     rhs = float(torch.sum(d_img * img))
     assert abs(lhs - rhs) <= 1e-10 * float(torch.sum(d_img) * img.abs().max())
+
+
+def test_bench_wgrid_workload_meets_the_contract():
+    """`bench.py --workload wgrid` (configs[4] as named) calls af_wgrid_im2vis_f64 directly with its own set-up: at a
+    reduced size its output meets the accuracy contract against the direct transform, the checker the bench itself uses."""
+    wl, vis, args = _workload("wgrid", rows=30000, chans=16, npix=512)
+    rows = np.linspace(0, args.rows - 1, 200).astype(np.int64)
+    ref, _ = wl.reference_rows(rows)
+    got = _sample(vis, rows)
+    assert np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= wl.EPS
+    r = wl.roofline(1e-3)
+    assert r["kernel"] == "wg_degrid_tiles<7>" and r["alg_bytes"] > 0

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex fused_dde degrid}"
+WORKLOADS="${WORKLOADS:-dft dft_complex fused_dde degrid wgrid}"
 for w in $WORKLOADS; do
     mkdir -p "$OUT/$w"
     ARGS="bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --check-rows 0"
