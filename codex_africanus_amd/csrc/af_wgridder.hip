@@ -31,6 +31,7 @@
 #include <mutex>
 
 #include "af_common.h"
+#include "af_wgrid_taps.h"
 
 namespace {
 
@@ -55,6 +56,43 @@ __device__ __forceinline__ double es_kernel(double t, double inv_half_w, double 
     const double x = t * inv_half_w;           // [-1, 1] inside the support
     const double s = 1.0 - x * x;
     return s > 0.0 ? exp(beta * (sqrt(s) - 1.0)) : 0.0;
+}
+
+// The W taps of a visibility along one axis: psi at offsets f, f + 1, ..., f + W - 1 from the visibility, f = (first cell)
+// - (position) in [-W/2, -W/2 + 1).  An exp and a sqrt in fp64 per tap cost ~150 instructions; for W <= 10 the taps come
+// from per-tap polynomials in u = 2 (f + W/2) - 1 instead (degree W + 2, Horner, coefficients in the kernel arguments =
+// scalar operands), as ducc0 does.  psi has a square-root singularity at the ends of its support, where it is ~10^-W:
+// the fit stalls at an absolute error of ~5 10^-(W+1) = epsilon / 200, which is what the accuracy contract can ignore;
+// the deconvolution keeps the exact psihat.  Every kernel of both directions takes its weights from this one function
+// (the transpose relation between `model` and `dirty` holds to rounding only if they do).
+constexpr int WG_POLYW = 10, WG_POLYD = WG_POLYW + 2;
+struct WgPoly { double c[WG_POLYW][WG_POLYD + 1]; };
+template <int W>
+__device__ __forceinline__ void wg_taps(const WgPoly &P, double f, double beta, double (&out)[W])
+{
+    if constexpr (W <= WG_POLYW) {
+        const double u = 2.0 * (f + 0.5 * (double)W) - 1.0;
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+            double acc = P.c[a][W + 2];
+#pragma unroll
+            for (int d = W + 1; d >= 0; --d) acc = fma(acc, u, P.c[a][d]);
+            out[a] = acc;
+        }
+    } else {
+        constexpr double inv_half_w = 2.0 / (double)W;
+#pragma unroll
+        for (int a = 0; a < W; ++a) out[a] = es_kernel(f + (double)a, inv_half_w, beta);
+    }
+}
+// the weight of plane k0 + a, a = k - k0 in 0 .. W - 1 (lane-dependent): a chain of selects, no indexed registers
+template <int W>
+__device__ __forceinline__ double wg_pick(const double (&kw)[W], int a)
+{
+    double r = 0.0;
+#pragma unroll
+    for (int t = 0; t < W; ++t) r = a == t ? kw[t] : r;
+    return r;
 }
 
 // A[x, y] = cu[x] cv[y] / (n psihat_w(dw (n - 1))) and nm1[x, y] = n - 1 (0 and A = cu cv without w-stacking);
@@ -365,7 +403,8 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
                                                        double cellx, double celly, double beta, double w0, double dw,
                                                        int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
-                                                       const int *__restrict__ nchunks, double2 *__restrict__ vis)
+                                                       const int *__restrict__ nchunks, double2 *__restrict__ vis,
+                                                       const WgPoly poly)
 {
     constexpr int R = WG_TILE + W - 1;
     constexpr int NL = (R * R + 255) / 256;
@@ -419,10 +458,11 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     __syncthreads();
 
     // this lane's visibility
-    constexpr double inv_half_w = 2.0 / (double)W;
-    double ku[W], kv[W], gw = 0.0;
-    int k0 = 0x7fffffff, k1 = -0x7fffffff, lofs = 0;
+    double ku[W], kv[W], kwv[W], gw = 0.0;
+    int k0 = 0x7fffffff, k1 = -0x7fffffff, k0u = 0, lofs = 0;
     int64_t o = 0;
+#pragma unroll
+    for (int t = 0; t < W; ++t) kwv[t] = t == 0 ? 1.0 : 0.0;       // without w-stacking: the one plane, weight 1
     const unsigned mine = place[tid];
     if (mine != NOBODY) {
         const unsigned i = mine;
@@ -435,16 +475,15 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
             k0 = (int)ceil(gw - 0.5 * W);
             k1 = k0 + W;
         }
+        k0u = k0;                                           // the first plane before clipping to the batch
         k0 = k0 < pk0 ? pk0 : k0;
         k1 = k1 > pk1 ? pk1 : k1;
         const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
         const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
         const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;   // first tap's offset
-#pragma unroll
-        for (int t = 0; t < W; ++t) {
-            ku[t] = es_kernel(fu + (double)t, inv_half_w, beta);
-            kv[t] = es_kernel(fv + (double)t, inv_half_w, beta);
-        }
+        wg_taps<W>(poly, fu, beta, ku);
+        wg_taps<W>(poly, fv, beta, kv);
+        if (do_w) wg_taps<W>(poly, (double)k0u - gw, beta, kwv);
         const int lu = wg_first_cell(gu, W, (int)nu) - tu * WG_TILE, lv = wg_first_cell(gv, W, (int)nv) - tv * WG_TILE;
         lofs = lu * R + lv;
         if (k0 >= k1) { k0 = 0x7fffffff; k1 = -0x7fffffff; }
@@ -493,7 +532,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
             for (int q = 0; q < NL; ++q) pre[q] = gofs[q] >= 0 ? g[gofs[q]] : make_double2(0.0, 0.0);
         }
         if (k >= k0 && k < k1) {
-            const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+            const double kw = wg_pick<W>(kwv, k - k0u);
             const double2 *__restrict__ cell = reg + lofs;
             double pre_ = 0.0, pim_ = 0.0;
 #pragma unroll
@@ -529,7 +568,8 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
                                                         const double2 *__restrict__ grids, int64_t nu, int64_t nv,
                                                         double cellx, double celly, double beta, double w0, double dw,
                                                         int pk0, int pk1, int do_w, const unsigned char *__restrict__ mask,
-                                                        const int *__restrict__ perm, double2 *__restrict__ vis)
+                                                        const int *__restrict__ perm, double2 *__restrict__ vis,
+                                                        const WgPoly poly)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrow * nchan_b) return;
@@ -538,14 +578,14 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
     const int64_t o = r * nchan_total + chan0 + c;
     if (mask && !mask[o]) return;
     const double fl = freq[c] / AF_LIGHTSPEED;
-    constexpr double inv_half_w = 2.0 / (double)W;
     double gw = 0.0;
-    int k0 = 0, k1 = 1;                                 // this visibility's planes [k0, k1), clipped to the batch
+    int k0 = 0, k1 = 1, k0u = 0;                        // this visibility's planes [k0, k1), clipped to the batch
     if (do_w) {
         gw = (uvw[3 * r + 2] * fl - w0) / dw;
         if (!isfinite(gw)) return;
         k0 = (int)ceil(gw - 0.5 * W);
         k1 = k0 + W;
+        k0u = k0;
         k0 = k0 < pk0 ? pk0 : k0;
         k1 = k1 > pk1 ? pk1 : k1;
         if (k0 >= k1) return;
@@ -553,18 +593,20 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
     const double gu = uvw[3 * r + WG_CU] * fl * cellx * (double)nu, gv = uvw[3 * r + WG_CV] * fl * celly * (double)nv;
     if (!(isfinite(gu) && isfinite(gv))) return;
     const int64_t iu0 = (int64_t)ceil(gu - 0.5 * W), iv0 = (int64_t)ceil(gv - 0.5 * W);
-    double ku[W], kv[W];
+    double ku[W], kv[W], kwv[W];
     int pu[W], pv[W];
 #pragma unroll
     for (int t = 0; t < W; ++t) {
-        ku[t] = es_kernel((double)(iu0 + t) - gu, inv_half_w, beta);
-        kv[t] = es_kernel((double)(iv0 + t) - gv, inv_half_w, beta);
+        kwv[t] = t == 0 ? 1.0 : 0.0;
         pu[t] = (int)(((iu0 + t) % nu + nu) % nu);
         pv[t] = (int)(((iv0 + t) % nv + nv) % nv);
     }
+    wg_taps<W>(poly, ceil(gu - 0.5 * W) - gu, beta, ku);
+    wg_taps<W>(poly, ceil(gv - 0.5 * W) - gv, beta, kv);
+    if (do_w) wg_taps<W>(poly, (double)k0u - gw, beta, kwv);
     double are = 0.0, aim = 0.0;
     for (int k = k0; k < k1; ++k) {
-        const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+        const double kw = wg_pick<W>(kwv, k - k0u);
         const double2 *__restrict__ grid = grids + (int64_t)(k - pk0) * nu * nv;
         double pre = 0.0, pim = 0.0;
 #pragma unroll
@@ -615,7 +657,8 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
                                                       double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
                                                       double celly, double beta, double w0, double dw, int pk0, int pk1,
                                                       int do_w, const unsigned char *__restrict__ mask,
-                                                      const double *__restrict__ wgt, const double2 *__restrict__ vis)
+                                                      const double *__restrict__ wgt, const double2 *__restrict__ vis,
+                                                      const WgPoly poly)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrow * nchan_b) return;
@@ -625,14 +668,14 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
     double2 val = vis[o];
     if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
     const double fl = freq[c] / AF_LIGHTSPEED;
-    constexpr double inv_half_w = 2.0 / (double)W;
     double gw = 0.0;
-    int k0 = 0, k1 = 1;
+    int k0 = 0, k1 = 1, k0u = 0;
     if (do_w) {
         gw = (uvw[3 * r + 2] * fl - w0) / dw;
         if (!isfinite(gw)) return;
         k0 = (int)ceil(gw - 0.5 * W);
         k1 = k0 + W;
+        k0u = k0;
         k0 = k0 < pk0 ? pk0 : k0;
         k1 = k1 > pk1 ? pk1 : k1;
         if (k0 >= k1) return;
@@ -641,14 +684,14 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
     if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return;
     const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;
     const int pu0 = wg_first_cell(gu, W, (int)nu), pv0 = wg_first_cell(gv, W, (int)nv);
-    double ku[W], kv[W];
+    double ku[W], kv[W], kwv[W];
 #pragma unroll
-    for (int t = 0; t < W; ++t) {
-        ku[t] = es_kernel(fu + (double)t, inv_half_w, beta);
-        kv[t] = es_kernel(fv + (double)t, inv_half_w, beta);
-    }
+    for (int t = 0; t < W; ++t) kwv[t] = t == 0 ? 1.0 : 0.0;
+    wg_taps<W>(poly, fu, beta, ku);
+    wg_taps<W>(poly, fv, beta, kv);
+    if (do_w) wg_taps<W>(poly, (double)k0u - gw, beta, kwv);
     for (int k = k0; k < k1; ++k) {
-        const double kw = do_w ? es_kernel((double)k - gw, inv_half_w, beta) : 1.0;
+        const double kw = wg_pick<W>(kwv, k - k0u);
         double *__restrict__ grid = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * nu * nv);
 #pragma unroll
         for (int a = 0; a < W; ++a) {
@@ -685,7 +728,8 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
                                                      double celly, double beta, double w0, double dw, int pk0, int pk1,
                                                      int do_w, const unsigned *__restrict__ idx, const int *__restrict__ start,
                                                      int kb, const int2 *__restrict__ chunks, const int *__restrict__ nchunks,
-                                                     const double *__restrict__ wgt, const double2 *__restrict__ vis)
+                                                     const double *__restrict__ wgt, const double2 *__restrict__ vis,
+                                                     const WgPoly poly)
 {
     constexpr int T = wg_gtile(W), R = T + W - 1, RR = R * R;
     constexpr int NT = 4 * W;                   // table doubles per visibility: val.re ku[], val.im ku[], kv[], kw[]
@@ -702,7 +746,6 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
     const int tu = ch.x / nty, tv = ch.x - tu * nty;
     int n = start[(ch.x + 1) * kb] - ch.y;
     n = n > WG_GCHUNK ? WG_GCHUNK : n;
-    constexpr double inv_half_w = 2.0 / (double)W;
     const int64_t plane = nu * nv;
 
     for (int e = tid; e < W * RR; e += 256) ring[e] = make_double2(0.0, 0.0);
@@ -712,13 +755,17 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
         const int e = lane + 64 * q, a = e / R, b = e - a * R;
         gofs[q] = e < RR ? (int)(((tu * T + a) % nu) * nv + (tv * T + b) % nv) : -1;
     }
-    int ta[NP], tb[NP], tcell[NP];              // this lane's tap(s): row a, column b, offset a R + b
+    // this lane's tap(s): row a, column b, offset a R + b -- dealt to the lanes so that the lane groups of the 16-byte
+    // LDS accesses repeat as few cells mod 16 (reads) / mod 8 (writes) as possible (af_wgrid_taps.h; in row-major lane
+    // order W = 7 paid 11 conflict cycles on top of the 12 of one read + write, and the LDS is what bounds this kernel)
+    static_assert(WgTaps<W>::NP == NP, "tap table and kernel disagree on the number of passes");
+    int ta[NP], tb[NP], tcell[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int t = lane + 64 * p;
-        ta[p] = t < W * W ? t / W : -1;
-        tb[p] = t < W * W ? t % W : 0;
-        tcell[p] = t < W * W ? (t / W) * R + t % W : 0;
+        const int t = WgTaps<W>::tap(p, lane);
+        ta[p] = t >= 0 ? t / W : -1;
+        tb[p] = t >= 0 ? t % W : 0;
+        tcell[p] = t >= 0 ? (t / W) * R + t % W : 0;
     }
     // plane k -> memory, slot cleared (by the wave that owns the slot)
     auto retire = [&](int k) {
@@ -726,14 +773,15 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
         if ((slot & 3) != wave) return;
         const bool live = k >= pk0 && k < pk1;
         double *__restrict__ g = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * plane);
+        double2 v[NE];                          // all the reads first: one LDS round trip per plane, not NE
+#pragma unroll
+        for (int q = 0; q < NE; ++q) v[q] = gofs[q] >= 0 ? ring[slot * RR + lane + 64 * q] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
-            if (gofs[q] < 0) continue;
-            const double2 v = ring[slot * RR + lane + 64 * q];
-            if (v.x != 0.0 || v.y != 0.0) {
+            if (v[q].x != 0.0 || v[q].y != 0.0) {
                 if (live) {
-                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q], v.x);
-                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q] + 1, v.y);
+                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q], v[q].x);
+                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q] + 1, v[q].y);
                 }
                 ring[slot * RR + lane + 64 * q] = make_double2(0.0, 0.0);
             }
@@ -742,45 +790,75 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
     int kcur = 0;
     bool started = false;
     __syncthreads();
-    for (int base = 0; base < n; base += 64) {
-        // the table of visibilities base .. base + 63: lane v of every wave works on visibility base + v; wave 0 writes
-        // val ku[], wave 1 kv[], wave 2 the plane weights; every wave keeps the visibility's first plane and offset
-        int k0 = 0x7fffffff, lofs = 0;
-        if (base + lane < n) {
+    // inputs of visibilities base .. base + 63 (lane v of every wave: visibility base + v): loaded one batch ahead, so
+    // that the two dependent memory round trips (sorted index -> row) hide behind the walk of the batch before
+    struct Inputs { double2 val; double u, v, w, fl; bool valid; };
+    auto load_inputs = [&](int base) {
+        Inputs in;
+        in.valid = base + lane < n;
+        in.val = make_double2(0.0, 0.0);
+        in.u = in.v = in.w = in.fl = 0.0;
+        if (in.valid) {
             const unsigned i = idx[ch.y + base + lane];
             const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
             const int64_t o = (int64_t)r * nchan_total + chan0 + c;
-            const double fl = freq[c] / AF_LIGHTSPEED;
+            in.fl = freq[c] / AF_LIGHTSPEED;
+            in.u = uvw[3 * (int64_t)r + WG_CU];
+            in.v = uvw[3 * (int64_t)r + WG_CV];
+            in.w = uvw[3 * (int64_t)r + 2];
+            if (wave == 0) {
+                in.val = vis[o];
+                if (wgt) { const double g = wgt[o]; in.val.x *= g; in.val.y *= g; }
+            }
+        }
+        return in;
+    };
+    Inputs nxt = load_inputs(0);
+    for (int base = 0; base < n; base += 64) {
+        // the table of visibilities base .. base + 63: wave 0 writes val ku[], wave 1 kv[], wave 2 the plane weights;
+        // every wave keeps the visibility's first plane and offset
+        const Inputs in = nxt;
+        int k0 = 0x7fffffff, lofs = 0;
+        if (in.valid) {
+            const double fl = in.fl;
             double gw = 0.0;
             k0 = 0;
             if (do_w) {
-                gw = (uvw[3 * (int64_t)r + 2] * fl - w0) / dw;
+                gw = (in.w * fl - w0) / dw;
                 k0 = (int)ceil(gw - 0.5 * W);
             }
-            const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
-            const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
+            const double gu = in.u * fl * cellx * (double)nu;
+            const double gv = in.v * fl * celly * (double)nv;
             double *__restrict__ t = tab + lane * NT;
+            double kk[W];
             if (wave == 0) {
-                double2 val = vis[o];
-                if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
-                const double fu = ceil(gu - 0.5 * W) - gu;
+                const double2 val = in.val;
+                wg_taps<W>(poly, ceil(gu - 0.5 * W) - gu, beta, kk);
 #pragma unroll
                 for (int a = 0; a < W; ++a) {
-                    const double ku = es_kernel(fu + (double)a, inv_half_w, beta);
-                    t[a] = val.x * ku;
-                    t[W + a] = val.y * ku;
+                    t[a] = val.x * kk[a];
+                    t[W + a] = val.y * kk[a];
                 }
             } else if (wave == 1) {
-                const double fv = ceil(gv - 0.5 * W) - gv;
+                wg_taps<W>(poly, ceil(gv - 0.5 * W) - gv, beta, kk);
 #pragma unroll
-                for (int a = 0; a < W; ++a) t[2 * W + a] = es_kernel(fv + (double)a, inv_half_w, beta);
+                for (int a = 0; a < W; ++a) t[2 * W + a] = kk[a];
             } else if (wave == 2) {
+                // the plane weights in SLOT order (plane k0 + a lives in slot (k0 + a) mod W): the walk then reads
+                // them at compile-time offsets and needs no per-visibility scalar arithmetic
+                int sl = ((k0 % W) + W) % W;
 #pragma unroll
-                for (int a = 0; a < W; ++a)
-                    t[3 * W + a] = do_w ? es_kernel((double)(k0 + a) - gw, inv_half_w, beta) : (a == 0 ? 1.0 : 0.0);
+                for (int a = 0; a < W; ++a) kk[a] = a == 0 ? 1.0 : 0.0;
+                if (do_w) wg_taps<W>(poly, (double)k0 - gw, beta, kk);
+#pragma unroll
+                for (int a = 0; a < W; ++a) {
+                    t[3 * W + sl] = kk[a];
+                    sl = sl + 1 == W ? 0 : sl + 1;
+                }
             }
             lofs = (wg_first_cell(gu, W, (int)nu) - tu * T) * R + wg_first_cell(gv, W, (int)nv) - tv * T;
         }
+        if (base + 64 < n) nxt = load_inputs(base + 64);
         __syncthreads();
         const int nb = n - base < 64 ? n - base : 64;
         // the walk, compiled once per wave number so that the slots a wave owns are compile-time constants (a dynamic
@@ -798,7 +876,6 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
                 }
                 if (NS == 0) continue;
                 const double *__restrict__ t = tab + j * NT;
-                const int s0 = ((k0j % W) + W) % W;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     if (ta[p] < 0) continue;
@@ -809,10 +886,8 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
                     double kw[NS > 0 ? NS : 1];
 #pragma unroll
                     for (int m = 0; m < NS; ++m) {
-                        const int sl = WV + 4 * m;
-                        const int a = sl - s0 < 0 ? sl - s0 + W : sl - s0;      // the plane offset that lives in slot sl
-                        kw[m] = t[3 * W + a];
-                        v[m] = ring[sl * RR + cell];
+                        kw[m] = t[3 * W + WV + 4 * m];
+                        v[m] = ring[(WV + 4 * m) * RR + cell];
                     }
 #pragma unroll
                     for (int m = 0; m < NS; ++m) {
@@ -908,6 +983,43 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     return w;
 }
 
+// per-tap polynomials of psi in u = 2 delta - 1, delta = (first tap's offset) + W/2 in [0, 1): interpolation at the
+// W + 3 Chebyshev nodes, converted to the monomial basis (degree <= 12: conditioning 2^12 eps, far below the fit's own
+// floor)
+void wg_make_poly(int W, double beta, WgPoly &P)
+{
+    for (auto &row : P.c)
+        for (double &x : row) x = 0.0;
+    if (W > WG_POLYW) return;
+    const int D = W + 2, n = D + 1;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (int a = 0; a < W; ++a) {
+        long double f[WG_POLYD + 1], cheb[WG_POLYD + 1];
+        for (int j = 0; j < n; ++j) {
+            const long double u = cosl(pi * (j + 0.5L) / n);                 // node in (-1, 1)
+            const long double t = (-0.5L * W + a + 0.5L * (u + 1.0L)) * (2.0L / W);
+            const long double s = 1.0L - t * t;
+            f[j] = expl((long double)beta * (sqrtl(s > 0.0L ? s : 0.0L) - 1.0L));
+        }
+        for (int k = 0; k < n; ++k) {
+            long double acc = 0.0L;
+            for (int j = 0; j < n; ++j) acc += f[j] * cosl(pi * k * (j + 0.5L) / n);
+            cheb[k] = acc * (k == 0 ? 1.0L : 2.0L) / n;
+        }
+        // sum_k cheb[k] T_k(u) -> monomials: T_0 = 1, T_1 = u, T_{k+1} = 2 u T_k - T_{k-1}
+        long double mono[WG_POLYD + 1] = {0}, tkm1[WG_POLYD + 1] = {0}, tk[WG_POLYD + 1] = {0}, tn[WG_POLYD + 1];
+        tkm1[0] = 1.0L;
+        tk[1] = 1.0L;
+        mono[0] += cheb[0];
+        for (int d = 0; d < n; ++d) mono[d] += cheb[1] * tk[d];
+        for (int k = 2; k < n; ++k) {
+            for (int d = 0; d < n; ++d) tn[d] = (d > 0 ? 2.0L * tk[d - 1] : 0.0L) - tkm1[d];
+            for (int d = 0; d < n; ++d) { mono[d] += cheb[k] * tn[d]; tkm1[d] = tk[d]; tk[d] = tn[d]; }
+        }
+        for (int d = 0; d < n; ++d) P.c[a][d] = (double)mono[d];
+    }
+}
+
 int plan_for(int kind, int n, int batch, hipfftHandle *out)
 {
     int dev = 0;
@@ -996,6 +1108,8 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     AF_REQUIRE(kernel_width >= 4 && kernel_width <= WG_MAXW, "af_wgrid_im2vis_f64: kernel width %d not in 4..%d", kernel_width,
                WG_MAXW);
     hipStream_t st = af_stream(stream);
+    WgPoly poly;
+    wg_make_poly(kernel_width, beta, poly);
     if (adjoint) {
         AF_REQUIRE(image_out != nullptr, "af_wgrid_vis2im_f64: NULL image");
         if (nrow == 0 || nchan_band == 0) {
@@ -1111,11 +1225,11 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (tiled)                                                                                                         \
         hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,        \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
-                           kb, chunks, nchunks, wgt, reinterpret_cast<const double2 *>(vis));                            \
+                           kb, chunks, nchunks, wgt, reinterpret_cast<const double2 *>(vis), poly);                      \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,     \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,     \
-                           reinterpret_cast<const double2 *>(vis))
+                           reinterpret_cast<const double2 *>(vis), poly)
         af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
@@ -1168,11 +1282,11 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (tiled)                                                                                                         \
         hipLaunchKernelGGL((wg_degrid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,      \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
-                           kb, chunks, nchunks, reinterpret_cast<double2 *>(vis));                                       \
+                           kb, chunks, nchunks, reinterpret_cast<double2 *>(vis), poly);                                 \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_degrid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,   \
                            nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, perm,    \
-                           reinterpret_cast<double2 *>(vis))
+                           reinterpret_cast<double2 *>(vis), poly)
         af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
