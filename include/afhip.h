@@ -406,12 +406,14 @@ int af_fused_predict_model_c128(const double *stokes, const double *spi, const d
  * One imaging band per call: freq (nchan_band) are columns chan0.. of the (nrow, nchan_total) arrays vis (complex128,
  * the band's columns are overwritten), wgt (float64 or NULL) and mask (bytes or NULL: 0 = skip, result 0).
  * image (nx, ny) float64; corr_u (nx) / corr_v (ny): 1 / Fourier transform of the kernel along the padded axes
- * (af_wgrid_padded); quad_t / quad_w (48): Gauss-Legendre nodes / weights on (0, 1); kernel_width W and beta: the
+ * (af_wgrid_padded: the smallest even 2-3-5-7-smooth size >= 2 n); quad_t / quad_w (48): Gauss-Legendre nodes / weights on (0, 1); kernel_width W and beta: the
  * exponential-of-semicircle kernel exp(beta (sqrt(1 - (2t/W)^2) - 1)); [wl_min, wl_max]: range of w nu / c over the
  * band (HOST scalars, they size the w-plane loop); max_abs_nm1: largest |n - 1| of the image.  All device work is
  * enqueued on `stream`; uses hipFFT (plans cached per device and size, released by af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);
-/* planes: w-plane grids resident at a time (>= 1; af_wgrid_planes() of them = a single pass over the visibilities) */
+/* Workspace of both directions.  planes: w-plane grids resident at a time (>= 1; af_wgrid_planes() of them = a single
+ * pass over the visibilities); nchan_max / nplanes_total: the most channels / w-planes of a band the workspace will serve;
+ * kernel_width: W (they size the tables of the on-device visibility sort).  Even image sizes only (as ducc0). */
 size_t af_wgrid_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max,
                                 int64_t nplanes_total, int kernel_width);
 int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking);
