@@ -40,6 +40,10 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 256;
+#ifndef AF_WIDE_WAVES
+#define AF_WIDE_WAVES 3
+#endif
+constexpr int WIDE_WAVES = AF_WIDE_WAVES;
 constexpr int MAXNC = 4;  // correlations per launch (ncorr is processed in chunks)
 
 // ---- workspace layout ------------------------------------------------------------
@@ -469,8 +473,10 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp_kernel(
 // in LDS; every wave then runs the four sources of the batch on its own tile.  One barrier per batch.
 // (l,m,n) of a batch come from `lgroups` (16 doubles per batch: [l,m,n,0] x 4), loaded rotated by
 // 4*w lanes so that row_newbcast:0..2 hands wave w its own source.
+// (the wide tiles of 1 / 2 correlations -- 32 x 1, 16 x 2 -- need 174 registers: asked to fit 168, three waves share a
+// SIMD instead of two; measured at C2's counts, same box: 2 correlations 18.87 -> 18.01 ms, 1 correlation 11.38 -> 11.40)
 template <int CT, int NC, bool CPLX, int NTERM>
-__global__ __launch_bounds__(ROWS_PER_BLOCK) void dft_recurrence_dpp4_kernel(
+__global__ __launch_bounds__(ROWS_PER_BLOCK, (!CPLX && CT >= 16 && CT * NC <= 32) ? WIDE_WAVES : 1) void dft_recurrence_dpp4_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ lgroups,
     const double *__restrict__ tilef, const int *__restrict__ flags, const int *__restrict__ colstate,
     const int *__restrict__ tilestate, double *__restrict__ out, int64_t nrow, int nsrc_pad, int64_t nchan,
