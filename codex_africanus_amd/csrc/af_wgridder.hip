@@ -513,7 +513,12 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
         const int e = tid + 256 * q, a = e / R, b = e - a * R;
-        gofs[q] = e < R * R ? (int64_t)((tu * WG_TILE + a) % nu) * nv + (tv * WG_TILE + b) % nv : -1;
+        // (a tile starts inside the grid and the region is at most one grid period long: one conditional subtraction
+        // per axis wraps it -- the 64-bit % of the first version cost as much as three planes of taps per chunk)
+        int gu_ = tu * WG_TILE + a, gv_ = tv * WG_TILE + b;
+        while (gu_ >= (int)nu) gu_ -= (int)nu;
+        while (gv_ >= (int)nv) gv_ -= (int)nv;
+        gofs[q] = e < R * R ? (int64_t)gu_ * nv + gv_ : -1;
     }
     const int64_t plane = nu * nv;
     double2 pre[NL];
@@ -591,15 +596,17 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
         if (k0 >= k1) return;
     }
     const double gu = uvw[3 * r + WG_CU] * fl * cellx * (double)nu, gv = uvw[3 * r + WG_CV] * fl * celly * (double)nv;
-    if (!(isfinite(gu) && isfinite(gv))) return;
-    const int64_t iu0 = (int64_t)ceil(gu - 0.5 * W), iv0 = (int64_t)ceil(gv - 0.5 * W);
+    if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return;
+    const int pu0 = wg_first_cell(gu, W, (int)nu), pv0 = wg_first_cell(gv, W, (int)nv);
     double ku[W], kv[W], kwv[W];
     int pu[W], pv[W];
 #pragma unroll
     for (int t = 0; t < W; ++t) {
         kwv[t] = t == 0 ? 1.0 : 0.0;
-        pu[t] = (int)(((iu0 + t) % nu + nu) % nu);
-        pv[t] = (int)(((iv0 + t) % nv + nv) % nv);
+        pu[t] = pu0 + t;
+        pv[t] = pv0 + t;
+        while (pu[t] >= (int)nu) pu[t] -= (int)nu;
+        while (pv[t] >= (int)nv) pv[t] -= (int)nv;
     }
     wg_taps<W>(poly, ceil(gu - 0.5 * W) - gu, beta, ku);
     wg_taps<W>(poly, ceil(gv - 0.5 * W) - gv, beta, kv);
@@ -753,7 +760,10 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
         const int e = lane + 64 * q, a = e / R, b = e - a * R;
-        gofs[q] = e < RR ? (int)(((tu * T + a) % nu) * nv + (tv * T + b) % nv) : -1;
+        int gu_ = tu * T + a, gv_ = tv * T + b;          // wrapped by subtraction: no 64-bit %
+        while (gu_ >= (int)nu) gu_ -= (int)nu;
+        while (gv_ >= (int)nv) gv_ -= (int)nv;
+        gofs[q] = e < RR ? (int)((int64_t)gu_ * nv + gv_) : -1;
     }
     // this lane's tap(s): row a, column b, offset a R + b -- dealt to the lanes so that the lane groups of the 16-byte
     // LDS accesses repeat as few cells mod 16 (reads) / mod 8 (writes) as possible (af_wgrid_taps.h; in row-major lane
