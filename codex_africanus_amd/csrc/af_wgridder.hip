@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
 {
     constexpr int T = wg_gtile(W), R = T + W - 1, RR = R * R;
     constexpr int NT = 4 * W;                   // table doubles per visibility: val.re ku[], val.im ku[], kv[], kw[]
-    constexpr int NE = (RR + 63) / 64;          // region cells per lane
+    constexpr int NE = (2 * RR + 63) / 64;      // doubles of the region per lane (flush)
     constexpr int NP = (W * W + 63) / 64;       // tap passes (one for W <= 8)
     __shared__ double2 ring[W * RR];
     __shared__ double tab[64 * NT];
@@ -756,14 +756,18 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
     const int64_t plane = nu * nv;
 
     for (int e = tid; e < W * RR; e += 256) ring[e] = make_double2(0.0, 0.0);
-    int gofs[NE];                               // this lane's region cells on the grid (wrapped)
+    // The flush works on DOUBLES, not cells: lane l of pass q takes double l + 64 q of the region's 2 R R (re, im
+    // interleaved), so that one atomic instruction covers whole contiguous runs of a grid row -- 64 consecutive doubles =
+    // four full 128-byte lines -- instead of every other double of twice as many lines (the flush atomics are what bounds
+    // this kernel: 4.8e9 of them per call at the ~1.6e11 / s the memory side sustains)
+    int gofs[NE];                               // grid offset (in doubles) of this lane's doubles of the region, wrapped
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
-        const int e = lane + 64 * q, a = e / R, b = e - a * R;
+        const int d = lane + 64 * q, e = d >> 1, a = e / R, b = e - a * R;
         int gu_ = tu * T + a, gv_ = tv * T + b;          // wrapped by subtraction: no 64-bit %
         while (gu_ >= (int)nu) gu_ -= (int)nu;
         while (gv_ >= (int)nv) gv_ -= (int)nv;
-        gofs[q] = e < RR ? (int)((int64_t)gu_ * nv + gv_) : -1;
+        gofs[q] = d < 2 * RR ? (int)(2 * ((int64_t)gu_ * nv + gv_) + (d & 1)) : -1;
     }
     // this lane's tap(s): row a, column b, offset a R + b -- dealt to the lanes so that the lane groups of the 16-byte
     // LDS accesses repeat as few cells mod 16 (reads) / mod 8 (writes) as possible (af_wgrid_taps.h; in row-major lane
@@ -783,17 +787,15 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
         if ((slot & 3) != wave) return;
         const bool live = k >= pk0 && k < pk1;
         double *__restrict__ g = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * plane);
-        double2 v[NE];                          // all the reads first: one LDS round trip per plane, not NE
+        double *__restrict__ rs = reinterpret_cast<double *>(ring + slot * RR);
+        double v[NE];                           // all the reads first: one LDS round trip per plane, not NE
 #pragma unroll
-        for (int q = 0; q < NE; ++q) v[q] = gofs[q] >= 0 ? ring[slot * RR + lane + 64 * q] : make_double2(0.0, 0.0);
+        for (int q = 0; q < NE; ++q) v[q] = gofs[q] >= 0 ? rs[lane + 64 * q] : 0.0;
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
-            if (v[q].x != 0.0 || v[q].y != 0.0) {
-                if (live) {
-                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q], v[q].x);
-                    unsafeAtomicAdd(g + 2 * (int64_t)gofs[q] + 1, v[q].y);
-                }
-                ring[slot * RR + lane + 64 * q] = make_double2(0.0, 0.0);
+            if (v[q] != 0.0) {
+                if (live) unsafeAtomicAdd(g + gofs[q], v[q]);
+                rs[lane + 64 * q] = 0.0;
             }
         }
     };
