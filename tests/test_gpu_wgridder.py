@@ -153,6 +153,15 @@ def test_sorted_tile_path_in_plane_batches(monkeypatch):
     monkeypatch.setattr(im2vis, "PLANE_BUDGET", 3 * nu * nu * 16)
     batched = model(uvw, freq, image, fbi, fbc, cell, flag=flag, epsilon=1e-6)
     assert np.abs(batched - full).max() <= 1e-13 * np.abs(full).max()
+    # the gridding direction in the same plane batches (one exact sort and one ring pass per batch)
+    from codex_africanus_amd.gridding.wgridder import dirty
+    rng = np.random.default_rng(6)
+    ms = rng.standard_normal((3000, 24)) + 1j * rng.standard_normal((3000, 24))
+    monkeypatch.undo()
+    img_full = dirty(uvw, freq, ms, fbi, fbc, 40, 40, cell, flag=flag, epsilon=1e-6)
+    monkeypatch.setattr(im2vis, "PLANE_BUDGET", 3 * nu * nu * 16)
+    img_batched = dirty(uvw, freq, ms, fbi, fbc, 40, 40, cell, flag=flag, epsilon=1e-6)
+    assert np.abs(img_batched - img_full).max() <= 1e-12 * np.abs(img_full).max()
     flat = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-6, do_wstacking=False)
     assert _l2error(flat, _explicit_degridder(uvw, freq, image[0], cell, cell, apply_w=False)) <= 1e-6
 
