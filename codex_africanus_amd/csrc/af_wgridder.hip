@@ -1,4 +1,5 @@
-// wgridder-style degridding: image -> visibilities with a requested accuracy against the direct transform.
+// wgridder-style degridding (image -> visibilities) and its exact transpose (visibilities -> image, further down) with
+// a requested accuracy against the direct transform.
 //
 // Counterpart of africanus.gridding.wgridder.model (africanus/gridding/wgridder/im2vis.py:14-61), whose arithmetic is
 // ducc0.wgridder.dirty2ms -- a third-party module (ducc0 >= 0.35, pyproject.toml:14) that is neither vendored in the
@@ -17,10 +18,12 @@
 //     psi(dw), and adds them to its sum.  Plane spacing dw = 1 / (2 sigma max|n - 1|).
 // The planes are built in batches of as many grids as the workspace holds; per batch ONE pass over the visibilities
 // takes every visibility through its own planes.  All work is enqueued on the caller's stream.
-// Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: 45 ms, profiles/r02_aux_bench_wgridder_*):
+// Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: 43 ms, the transpose 62 ms;
+// profiles/r02_aux_bench_wgridder*):
 //   * planes: pruned 2-D transform (wg_fill_rows -> hipFFT rows -> wg_transpose_rows -> hipFFT rows), v-major;
 //   * visibilities: counting sort by (32 x 32 tile, w-plane) on the device, chunks of <= 256 of one tile, the tile's
-//     cells of every plane staged through LDS (wg_degrid_tiles); small calls gather from memory (wg_degrid_planes).
+//     cells of every plane staged through LDS (wg_degrid_tiles); small calls gather from memory (wg_degrid_planes);
+//   * tap weights of all kernels from one function (wg_taps: per-tap polynomials for W <= 10).
 #include <hipfft/hipfft.h>
 
 #include <stdlib.h>
