@@ -644,9 +644,9 @@ int choose_ct(int64_t nchan, int nc_max, bool cplx)
     // candidates per correlation count: the accumulators of a tile are CT*NC complex numbers, so fewer correlations
     // afford wider tiles (the ~50-operation set-up per (row, source, tile) is then amortised over more channels)
     const int cands_c[2] = {11, 8};
-    const int cands_r4[2] = {13, 8}, cands_r2[4] = {26, 16, 13, 8}, cands_r1[4] = {52, 32, 13, 8};
+    const int cands_r4[2] = {13, 8}, cands_r2[5] = {26, 22, 16, 13, 8}, cands_r1[4] = {52, 32, 13, 8};
     const int *cands = cplx ? cands_c : nc_max == 1 ? cands_r1 : nc_max == 2 ? cands_r2 : cands_r4;
-    const int ncand = cplx ? 2 : nc_max <= 2 ? 4 : 2;
+    const int ncand = cplx ? 2 : nc_max == 2 ? 5 : nc_max == 1 ? 4 : 2;
     const int per_chan = 2 + 2 * nc_max * (cplx ? 2 : 1);
     int best = cands[0];
     int64_t best_cost = -1;
@@ -750,6 +750,7 @@ int launch_chunk_ct(bool cplx, int ct, int nc, const Args &a)
     case 52: return launch_chunk<52, 1, false>(a);
     case 32: return launch_chunk<32, 1, false>(a);
     case 26: return launch_chunk<26, 2, false>(a);
+    case 22: return launch_chunk<22, 2, false>(a);
     case 16: return launch_chunk<16, 2, false>(a);
     case 8: return launch_chunk_nc<8, false>(nc, a);
     default: return launch_chunk_nc<13, false>(nc, a);
@@ -763,8 +764,8 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
     if (nsrc < 0 || nchan < 0 || ncorr < 0) return 0;
     // sized for the widest padding any tile width can produce
     size_t m = 0;
-    const int cands[7] = {8, 11, 13, 16, 26, 32, 52};
-    for (int k = 0; k < 7; ++k) {
+    const int cands[8] = {8, 11, 13, 16, 22, 26, 32, 52};
+    for (int k = 0; k < 8; ++k) {
         WsLayout L;
         if (!ws_layout(L, nsrc, nchan, ncorr, image_is_complex, cands[k])) return 0;
         if (L.total > m) m = L.total;
