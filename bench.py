@@ -5,7 +5,7 @@ bench.py -- benchmarks of the RIME visibility-predict hot path on MI355X.
 A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
     vis = predict(...)                               # the workload's transform (below)
     chi2[nu] = sum |data - vis|^2                    # per-channel chi^2 of the shard
-    (N > 1) RCCL all-reduce of chi2 over xGMI         # the only cross-GPU exchange of the path
+    (N > 1) all-reduce of chi2                        # the only cross-GPU exchange of the path
 PER GPU (rows shard across GPUs, weak scaling: BASELINE configs[3] is 8e6 rows on 8 GPUs).
 Metric: Mvis/s = rows x chans / second / 1e6 (whole job).
 
@@ -15,10 +15,26 @@ Workloads (--workload), one per BASELINE config a single GPU can run:
     dft_complex  the same transform with complex brightness matrices (= the fused predict without DDEs)
     fused_dde    fused predict with per-antenna beam-cube DDEs, 64 antennas: BASELINE configs[2]
     degrid       convolutional degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7x7 taps: BASELINE configs[4]
+    wgrid        wgridder-style degridding of a 4096^2 image at epsilon 1e-5: BASELINE configs[4] as named
+The default run (N = 1, headline shape) also times every other workload for a few steps and reports them under
+"workloads" in the same JSON line (--extras none switches that off; --extras a,b picks some).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--rows R --chans C --sources S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: rows shard, nothing else moves.  Two executors:
+  --executor ranks    (default) one process per GPU, torch.distributed, chi^2 all-reduced by RCCL over xGMI.  Under
+                      a launcher (WORLD_SIZE set) this process is one rank.  WITHOUT a launcher `--gpus N` starts
+                      its N rank processes itself -- before this process makes any GPU call -- relays rank 0's
+                      JSON line and exits non-zero if any rank failed: it never falls through to one rank.
+  --executor threads  ONE process, N worker threads, row block k on device k % N through
+                      codex_africanus_amd.placement.block(k) -- the reference's "dask chunks on a thread pool"
+                      (africanus/rime/dask_predict.py:311-369, africanus/dft/dask.py:37-51) mapped to the GPUs of
+                      one node; the chi^2 partials are peer-copied to the first device and summed there.
+Fewer visible devices than N is an error unless AFHIP_BENCH_DEVICE=d puts every rank / worker on device d
+(then the ranks use gloo: RCCL refuses two ranks on one device).  "n_gpus" is the number of ranks / workers that
+actually reported.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   "roofline"     for the workload's dominant kernel: algorithmic flops (or bytes) per launch / its average
@@ -33,6 +49,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,32 +63,48 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz, vector or matrix
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth (degridder's gather view)
-PMC_ROUND = "r02"              # profiles/<round>_<workload>_pmc_summary.json
+PMC_ROUNDS = ("r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, newest first
+# the REAL reference (numba 0.54) measured in the build container: im_to_vis 10k x 16 x 100 x 4
+# on one core 0.263 Mvis/s = 38 ns per (row, chan, src); linear in sources -> 0.026 Mvis/s/core at 1000 sources
+NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
+                     "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
+                               "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
+EXTRA_WORKLOADS = ("dft_complex", "fused_dde", "degrid", "wgrid")
+DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--rows", type=int, default=1000000, help="rows PER GPU")
-    p.add_argument("--chans", type=int, default=64)
-    p.add_argument("--sources", type=int, default=1000)
+    p.add_argument("--rows", type=int, default=DEFAULT_SHAPE["rows"], help="rows PER GPU")
+    p.add_argument("--chans", type=int, default=DEFAULT_SHAPE["chans"])
+    p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
     p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "fused_dde", "degrid", "wgrid"])
+    p.add_argument("--extras", default="auto",
+                   help="other workloads timed for a few steps into \"workloads\" of the same JSON line: auto (all of "
+                        "them when N = 1, the workload is the headline and the shape is the default), all, none, or a "
+                        "comma list of " + ",".join(EXTRA_WORKLOADS))
+    p.add_argument("--extra-steps", type=int, default=5)
+    p.add_argument("--executor", default="ranks", choices=["ranks", "threads"],
+                   help="N > 1: one process per GPU (torch.distributed) or one process with N worker threads")
     p.add_argument("--pa", default="random", choices=["random", "common"],
                    help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
                         "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
                         "(a real array: coherent beam gathers)")
-    p.add_argument("--npix", type=int, default=4096, help="degrid: grid size")
-    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                   help="torch.distributed backend; nccl = RCCL over xGMI (default).  gloo exists to "
-                        "exercise the N>1 code path on a one-GPU box (with AFHIP_BENCH_DEVICE=0)")
+    p.add_argument("--npix", type=int, default=DEFAULT_SHAPE["npix"], help="degrid / wgrid: grid size")
+    p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                   help="torch.distributed backend; nccl = RCCL over xGMI.  auto = nccl, or gloo when "
+                        "AFHIP_BENCH_DEVICE puts the ranks on one device (the N > 1 code path on a one-GPU box)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
+    p.add_argument("--cpu-seconds", type=float, default=2.0,
+                   help="minimum wall time of the all-cores CPU baseline sample (the single-thread probe runs "
+                        ">= a quarter of it)")
     p.add_argument("--check-rows", type=int, default=256, help="rows checked against the oracle")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def _threads():
@@ -87,6 +121,38 @@ def _parallel_rows(fn, nrows, threads):
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(lambda k: fn(int(edges[k]), int(edges[k + 1])), range(threads)))
     return time.perf_counter() - t0
+
+
+def sized_cpu_sample(single, parallel, max_rows, threads, min_parallel_s):
+    """Sizes and times a CPU-baseline sample: `single(n)` runs n rows on one thread,
+    `parallel(n)` runs n rows on all `threads` and returns its wall time.
+      1. one discarded warm-up call (library paged in, OpenMP pool started, inputs touched);
+      2. single-thread probe grown until it runs >= max(0.5 s, min_parallel_s / 4);
+      3. all-threads sample grown until it runs >= min_parallel_s.
+    Returns dict(per_row_s, probe_rows, probe_s, rows, seconds)."""
+    min_probe_s = max(0.5, min_parallel_s / 4.0) if min_parallel_s >= 1.0 else min_parallel_s / 2.0
+    single(min(16, max_rows))
+    n, dt = min(16, max_rows), 0.0
+    for _ in range(8):
+        t0 = time.perf_counter()
+        single(n)
+        dt = time.perf_counter() - t0
+        if dt >= min_probe_s or n >= max_rows:
+            break
+        n = int(min(max_rows, max(2 * n, 1.25 * n * min_probe_s / max(dt, 1e-5))))
+    per_row, probe_rows, probe_s = dt / n, n, dt
+    q = max(threads, 1)
+    rows = int(min(max_rows, max(q * 8, 0.1 * min_parallel_s * q / per_row)))
+    rows = max(q, rows - rows % q)
+    parallel(min(rows, q * 2))                       # warm the worker threads
+    sec = 0.0
+    for _ in range(6):
+        sec = parallel(rows)
+        if sec >= min_parallel_s or rows >= max_rows - max_rows % q:
+            break
+        rows = int(min(max_rows, max(2 * rows, 1.25 * rows * min_parallel_s / max(sec, 1e-5))))
+        rows = max(q, rows - rows % q)
+    return dict(per_row_s=per_row, probe_rows=probe_rows, probe_s=probe_s, rows=rows, seconds=sec)
 
 
 # ------------------------------------------------------------------------------------------ workloads
@@ -161,25 +227,31 @@ class Dft(object):
                     note="fp64-pipe bound (MFMA f64 and VALU f64 share one 78.6 TFLOP/s pipe on gfx950), not "
                          "HBM-bound: nsrc phasors per 64-byte visibility; %d flop per (row, chan, src)" % (2 * fma))
 
-    def cpu_baseline(self, target_core_seconds):
+    def cpu_baseline(self, min_seconds):
         import oracle
         nchan, nsrc = self.freq.shape[0], self.lm.shape[0]
         threads = _threads()
-        t0 = time.perf_counter()
-        oracle.im_to_vis(self.image, self.uvw[:16], self.lm, self.freq, omp=False)
-        per_row = (time.perf_counter() - t0) / 16
-        rows = int(max(threads * 8, min(self.uvw.shape[0], target_core_seconds / per_row)))
-        rows -= rows % threads
-        t0 = time.perf_counter()
-        oracle.im_to_vis(self.image, self.uvw[:rows], self.lm, self.freq, omp=True)
-        dt = time.perf_counter() - t0
+
+        def single(n):
+            oracle.im_to_vis(self.image, self.uvw[:n], self.lm, self.freq, omp=False)
+
+        def parallel(n):
+            t0 = time.perf_counter()
+            oracle.im_to_vis(self.image, self.uvw[:n], self.lm, self.freq, omp=True)
+            return time.perf_counter() - t0
+
+        s = sized_cpu_sample(single, parallel, self.uvw.shape[0], threads, min_seconds)
+        one = nchan / s["per_row_s"] / 1e6
         return {
-            "value": rows * nchan / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "value": s["rows"] * nchan / s["seconds"] / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
             "sample": "oracle im_to_vis (C restatement of africanus/dft/kernels.py:33-67, OpenMP over rows), "
-                      "%d rows x %d chan x %d src x 4 corr fp64, %s image, in %.2f s; linear in rows; "
-                      "single-thread rate %.4f Mvis/s" % (rows, nchan, nsrc, "complex" if self.cplx else "real", dt,
-                                                          nchan / per_row / 1e6),
-            "single_thread_value": nchan / per_row / 1e6,
+                      "%d rows x %d chan x %d src x 4 corr fp64, %s image, in %.2f s on %d threads after a warm-up call; "
+                      "linear in rows; single-thread probe %d rows in %.2f s = %.4f Mvis/s"
+                      % (s["rows"], nchan, nsrc, "complex" if self.cplx else "real", s["seconds"], threads,
+                         s["probe_rows"], s["probe_s"], one),
+            "single_thread_value": one, "probe_rows": s["probe_rows"], "probe_seconds": s["probe_s"],
+            "sample_rows": s["rows"], "sample_seconds": s["seconds"],
+            "numba_calibration": NUMBA_CALIBRATION,
         }
 
 
@@ -289,7 +361,7 @@ class FusedDde(object):
                     note="fp64 VALU bound (same 78.6 TFLOP/s fp64 pipe as the matrix path): 2x2 complex Jones "
                          "algebra per (row, chan, src), 150 flop (SURVEY 8(d))")
 
-    def cpu_baseline(self, target_core_seconds):
+    def cpu_baseline(self, min_seconds):
         """One timestep of the workload through the oracle chain: beam_cube_dde for the timestep's 64 antennas
         (single thread, as the reference's numba kernel), then phase_delay -> einsum -> predict_vis on a row
         sample spread over the host threads (dask row chunks in the reference); the row part is scaled to the
@@ -298,15 +370,19 @@ class FusedDde(object):
         h, a = self.h, self.args
         threads = min(_threads(), 64)
         rows_t = np.arange(min(self.nbl, a.rows))
+        oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], h["lm"][:8], h["pa"][:1], h["pe"][:1],
+                             h["asc"], h["freq"])                                        # warm-up, discarded
         t0 = time.perf_counter()
         dde = oracle.beam_cube_dde(h["beam"], h["extents"], h["beam_freq_map"], h["lm"], h["pa"][:1], h["pe"][:1],
                                    h["asc"], h["freq"])
         t_beam = time.perf_counter() - t0
         tinv = np.zeros(len(rows_t), dtype=np.int64)
+        self._chain(rows_t[:2], dde, tinv[:2])                                           # warm-up, discarded
+        n1 = min(16, len(rows_t))
         t0 = time.perf_counter()
-        self._chain(rows_t[:4], dde, tinv[:4])
-        per_row = (time.perf_counter() - t0) / 4
-        per_thread = int(max(2, min(32, target_core_seconds / per_row / threads)))   # coh: 4 MB per row
+        self._chain(rows_t[:n1], dde, tinv[:n1])
+        per_row = (time.perf_counter() - t0) / n1
+        per_thread = int(max(2, min(32, 0.3 * min_seconds / per_row)))                   # coh: 4 MB per row
         n = min(len(rows_t), per_thread * threads)
         dt = _parallel_rows(lambda lo, hi: self._chain(rows_t[lo:hi], dde, tinv[lo:hi]) if hi > lo else None, n, threads)
         t_step = t_beam + dt * len(rows_t) / n
@@ -318,6 +394,7 @@ class FusedDde(object):
                       "%d threads in %.2f s scaled to the timestep's rows" % (len(rows_t), a.chans, a.sources,
                                                                              t_beam, n, threads, dt),
             "single_thread_value": a.chans / (per_row + t_beam / len(rows_t)) / 1e6,
+            "probe_rows": n1, "sample_rows": n, "sample_seconds": dt,
         }
 
 
@@ -385,23 +462,22 @@ class Degrid(object):
                     note="HBM view: 32 B written per visibility + the grid once; the kernel is bound by the "
                          "gather path (784 B of grid cells per visibility through L2), see 'gather'")
 
-    def cpu_baseline(self, target_core_seconds):
+    def cpu_baseline(self, min_seconds):
         threads = _threads()
         gh = self.d_grid.cpu().numpy()
-        t0 = time.perf_counter()
-        self._oracle(np.arange(64), gh)
-        per_row = (time.perf_counter() - t0) / 64
-        n = int(max(threads * 16, min(self.args.rows, target_core_seconds / per_row)))
-        n -= n % threads
-        rows = np.arange(n)
-        dt = _parallel_rows(lambda lo, hi: self._oracle(rows[lo:hi], gh), n, threads)
+        rows = np.arange(self.args.rows)
+        s = sized_cpu_sample(lambda n: self._oracle(rows[:n], gh),
+                             lambda n: _parallel_rows(lambda lo, hi: self._oracle(rows[lo:hi], gh), n, threads),
+                             self.args.rows, threads, min_seconds)
+        one = self.args.chans / s["per_row_s"] / 1e6
         return {
-            "value": n * self.args.chans / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "value": s["rows"] * self.args.chans / s["seconds"] / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
             "sample": "oracle degridder (C restatement of africanus/gridding/perleypolyhedron/degridder.py:15-175, "
-                      "packed gather policy), %d rows x %d chan on %d threads in %.2f s; linear in rows; "
-                      "single-thread rate %.3f Mvis/s" % (n, self.args.chans, threads, dt,
-                                                          self.args.chans / per_row / 1e6),
-            "single_thread_value": self.args.chans / per_row / 1e6,
+                      "packed gather policy), %d rows x %d chan on %d threads in %.2f s after a warm-up call; linear in "
+                      "rows; single-thread probe %d rows in %.2f s = %.3f Mvis/s"
+                      % (s["rows"], self.args.chans, threads, s["seconds"], s["probe_rows"], s["probe_s"], one),
+            "single_thread_value": one, "probe_rows": s["probe_rows"], "probe_seconds": s["probe_s"],
+            "sample_rows": s["rows"], "sample_seconds": s["seconds"],
         }
 
 
@@ -483,40 +559,44 @@ class Wgrid(object):
                          "fp64_max_abs_err here is against the direct transform, whose contract is an l2 error <= "
                          "epsilon" % self.nplanes)
 
-    def cpu_baseline(self, target_core_seconds):
+    def cpu_baseline(self, min_seconds):
         threads = _threads()
-        t0 = time.perf_counter()
-        self._direct(np.arange(16), False)
-        per_row = (time.perf_counter() - t0) / 16
-        n = int(max(threads * 8, min(self.args.rows, target_core_seconds / per_row)))
-        n -= n % threads
-        t0 = time.perf_counter()
-        self._direct(np.arange(n), True)
-        dt = time.perf_counter() - t0
+
+        def parallel(n):
+            t0 = time.perf_counter()
+            self._direct(np.arange(n), True)
+            return time.perf_counter() - t0
+
+        s = sized_cpu_sample(lambda n: self._direct(np.arange(n), False), parallel, self.args.rows, threads, min_seconds)
+        one = self.args.chans / s["per_row_s"] / 1e6
         return {
-            "value": n * self.args.chans / dt / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+            "value": s["rows"] * self.args.chans / s["seconds"] / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
             "sample": "the reference's CPU path for this entry is ducc0.wgridder.dirty2ms (absent here: not vendored, "
                       "not installed); timed instead: the direct transform the accuracy contract is stated against "
                       "(oracle im_to_vis over the image's 3000 non-zero pixels, OpenMP over rows), %d rows x %d chan "
-                      "in %.2f s; its cost grows with the number of non-zero pixels, the wgridder's does not"
-                      % (n, self.args.chans, dt),
-            "single_thread_value": self.args.chans / per_row / 1e6,
+                      "in %.2f s on %d threads; its cost grows with the number of non-zero pixels, the wgridder's does not"
+                      % (s["rows"], self.args.chans, s["seconds"], threads),
+            "single_thread_value": one, "probe_rows": s["probe_rows"], "probe_seconds": s["probe_s"],
+            "sample_rows": s["rows"], "sample_seconds": s["seconds"],
         }
 
 
 WORKLOADS = {"dft": Dft, "dft_complex": Dft, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid}
+METRIC = "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err"
 
 
 def pmc_traffic(workload, is_default_shape):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of THIS command; KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950 streaming reads -- an upper bound where reads are narrower)."""
+    prescribes for gfx950 streaming reads -- an upper bound where reads are narrower).  A constant of the committed
+    profile, not a measurement of this run (counters cannot be read from inside the process): "traffic_source" says
+    which file."""
     if not is_default_shape:
         return None, None
-    for name in ("%s_%s_pmc_summary.json" % (PMC_ROUND, workload), "r01_pmc_summary.json" if workload == "dft" else None,
-                 "r01_fused_pmc_summary.json" if workload == "fused_dde" else None):
-        if not name:
-            continue
+    names = ["%s_%s_pmc_summary.json" % (r, workload) for r in PMC_ROUNDS]
+    names += ["r01_pmc_summary.json"] if workload == "dft" else []
+    names += ["r01_fused_pmc_summary.json"] if workload == "fused_dde" else []
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             c = json.load(open(path))
@@ -525,39 +605,81 @@ def pmc_traffic(workload, is_default_shape):
     return None, None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+def is_default_shape(args):
+    return all(getattr(args, k) == v for k, v in DEFAULT_SHAPE.items())
 
+
+def roofline_entry(wl, args, workload, kernel_s):
+    r = wl.roofline(kernel_s)
+    traffic, traffic_src = pmc_traffic(workload, is_default_shape(args))
+    hbm_ach = r["alg_bytes"] / kernel_s / 1e9
+    fp_ach = r["alg_flops"] / kernel_s / 1e12
+    hbm = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
+           "algorithmic_bytes": r["alg_bytes"]}
+    fp64 = {"achieved": fp_ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp_ach / FP64_PEAK_TFLOPS,
+            "algorithmic_flops": r["alg_flops"]}
+    top = fp64 if r["bound"] == "mfma" else hbm
+    roof = {"kernel": r["kernel"], "bound": r["bound"], "achieved": top["achieved"], "peak": top["peak"],
+            "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "kernel_ms": kernel_s * 1e3, "channels_in_kernel": r["channels_in_kernel"], "note": r["note"],
+            "hbm": hbm, "fp64": fp64}
+    for k in ("gather", "executed"):
+        if k in r:
+            roof[k] = r[k]
+    return roof
+
+
+class Events(object):
+    """HIP events of the library's measurement hook (af_profile_events brackets the workload's dominant kernel on
+    the stream it is launched on); one pair per timed step."""
+
+    def __init__(self, _lib, steps):
+        self._lib, self.evs = _lib, []
+        for _ in range(steps):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.call("af_event_create", ctypes.byref(a))
+            _lib.call("af_event_create", ctypes.byref(b))
+            self.evs.append((a, b))
+
+    def arm(self, k):
+        self._lib.call("af_profile_events", self.evs[k][0], self.evs[k][1])
+
+    def disarm(self):
+        self._lib.call("af_profile_events", None, None)
+
+    def collect(self):
+        """Mean kernel seconds; destroys the events (call after the device is idle)."""
+        out = []
+        for a, b in self.evs:
+            ms = ctypes.c_float(0)
+            self._lib.call("af_event_elapsed_ms", a, b, ctypes.byref(ms))
+            out.append(ms.value)
+            self._lib.call("af_event_destroy", a)
+            self._lib.call("af_event_destroy", b)
+        self.evs = []
+        return float(np.mean(out)) / 1e3 if out else float("nan")
+
+
+def check_rows(wl, d_vis, nrow, n, dev):
+    """max |HIP - oracle| over a row sample of the benchmarked output (checker only)."""
     import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    dev_index = int(os.environ.get("AFHIP_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-        # build the communicator now (RCCL sets its rings up lazily, at the first collective): the timed
-        # region must not pay for it even when --warmup is 0
-        warm = torch.zeros(1, dtype=torch.float64, device=dev)
-        dist.all_reduce(warm)
-        torch.cuda.synchronize(dev)
+    rows = np.linspace(0, nrow - 1, min(n, nrow)).astype(np.int64)
+    ref, rows = wl.reference_rows(rows)
+    got = d_vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    return float(np.abs(got - ref.reshape(got.shape)).max())
 
+
+def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
+    """Times `steps` steps of one workload on this rank's device (all ranks call it together).  Returns the result
+    dict on rank 0, None elsewhere."""
+    import torch
     from codex_africanus_amd import _lib
     lib = _lib.load()
-
+    wargs = argparse.Namespace(**vars(args))
+    wargs.workload = workload
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     P = lambda x: ctypes.c_void_p(x.data_ptr())
-    wl = WORKLOADS[args.workload](args, rank, dev, lib, _lib, t)
+    wl = WORKLOADS[workload](wargs, rank, dev, lib, _lib, t)
     nrow, nchan, nsrc, ncorr = args.rows, args.chans, args.sources, wl.ncorr
     d_vis = torch.empty((nrow, nchan, ncorr), dtype=torch.complex128, device=dev)
     d_chi2 = torch.zeros(nchan, dtype=torch.float64, device=dev)
@@ -574,16 +696,9 @@ def main():
         if world > 1:
             dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-
-    # HIP events around the dominant kernel of every timed step, on its own stream
-    evs = []
-    for _ in range(args.steps):
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.call("af_event_create", ctypes.byref(a))
-        _lib.call("af_event_create", ctypes.byref(b))
-        evs.append((a, b))
+    ev = Events(_lib, steps)
 
     def barrier():
         if world > 1:
@@ -592,79 +707,339 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        _lib.call("af_profile_events", evs[k][0], evs[k][1])
+    for k in range(steps):
+        ev.arm(k)
         step()
-    _lib.call("af_profile_events", None, None)
+    ev.disarm()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    reported = 1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        reported = int(round(float(one.item())))
+    kernel_s = ev.collect()
+    if rank != 0:
+        return None
+    max_err = check_rows(wl, d_vis, nrow, args.check_rows, dev) if args.check_rows > 0 else None
+    res = {
+        "label": wl.label, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
+        "corrs": ncorr, "fp64_max_abs_err": max_err, "roofline": roofline_entry(wl, wargs, workload, kernel_s),
+    }
+    if cpu_seconds > 0 and world == 1:
+        res["cpu_baseline"] = wl.cpu_baseline(cpu_seconds)
+    return res
 
-    kernel_ms = []
-    for a, b in evs:
-        ms = ctypes.c_float(0)
-        _lib.call("af_event_elapsed_ms", a, b, ctypes.byref(ms))
-        kernel_ms.append(ms.value)
-        _lib.call("af_event_destroy", a)
-        _lib.call("af_event_destroy", b)
-    kernel_s = float(np.mean(kernel_ms)) / 1e3 if kernel_ms else float("nan")
 
-    # parity of the benchmarked output against the CPU oracle on a row sample (checker only)
-    max_err = None
-    if rank == 0 and args.check_rows > 0:
-        rows = np.linspace(0, nrow - 1, min(args.check_rows, nrow)).astype(np.int64)
-        ref, rows = wl.reference_rows(rows)
-        got = d_vis[torch.from_numpy(rows).to(dev)].cpu().numpy()
-        max_err = float(np.abs(got - ref.reshape(got.shape)).max())
+def headline_json(args, res, world_desc, backend_desc):
+    nrow, nchan, nsrc = args.rows, args.chans, args.sources
+    n = res["ranks_reported"]
+    out = {
+        "metric": METRIC, "value": res["value"], "unit": "Mvis/s",
+        "n_gpus": n, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": res["label"] + " + per-channel chi^2" + ("" if n == 1 else " + " + backend_desc),
+            "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": res["corrs"],
+            "rows_total": n * nrow, "phasor_mode": args.mode,
+            "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce (%s)"
+                        % (n, "none" if n == 1 else backend_desc),
+            "executor": world_desc,
+        },
+        "fp64_max_abs_err": res["fp64_max_abs_err"],
+        "roofline": res["roofline"],
+    }
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = res["cpu_baseline"]
+    return out
 
+
+def extras_requested(args, world):
+    e = args.extras
+    if e == "none":
+        return ()
+    if e == "auto":
+        return EXTRA_WORKLOADS if (world == 1 and args.workload == "dft" and is_default_shape(args)) else ()
+    names = EXTRA_WORKLOADS if e == "all" else tuple(x for x in e.split(",") if x)
+    bad = [x for x in names if x not in EXTRA_WORKLOADS]
+    if bad:
+        raise SystemExit("--extras: unknown workload(s) %s (choose from %s)" % (bad, ",".join(EXTRA_WORKLOADS)))
+    return tuple(x for x in names if x != args.workload)
+
+
+# ------------------------------------------------------------------------------------------ executor: ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_environments(n, port, base_env):
+    """The environment of each of the n rank processes `--gpus n` starts when no launcher did (pure arithmetic,
+    pinned by tests/test_bench_launcher.py): what `torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1` would export."""
+    envs = []
+    for r in range(n):
+        e = dict(base_env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                 AFHIP_BENCH_SELF_LAUNCHED="1")
+        envs.append(e)
+    return envs
+
+
+def visible_devices():
+    """Device count without initialising the GPU in this process (torch.cuda.device_count() does not, on this
+    image) -- the self-launching parent must stay GPU-free."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def require_devices(n, what):
+    have = visible_devices()
+    if have == 0:
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    shared = os.environ.get("AFHIP_BENCH_DEVICE")
+    if shared is not None:
+        if not (0 <= int(shared) < have):
+            raise SystemExit("AFHIP_BENCH_DEVICE=%s but %d device(s) are visible" % (shared, have))
+        return have
+    if have < n:
+        raise SystemExit("--gpus %d (%s) but only %d device(s) are visible; refusing to report a %d-GPU number "
+                         "(set AFHIP_BENCH_DEVICE=d to put every rank on device d for a functional test)"
+                         % (n, what, have, have))
+    return have
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher: start the N ranks (children of this GPU-free process), relay
+    rank 0's JSON line, fail if any rank fails."""
+    require_devices(args.gpus, "self-launched ranks")
+    envs = rank_environments(args.gpus, free_port(), os.environ)
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    text = out0.decode("utf-8", "replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if any(codes) or len(lines) != 1:
+        sys.stderr.write("bench.py: rank exit codes %s; rank 0 printed %d JSON line(s)\n%s\n" % (codes, len(lines), text[-2000:]))
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def run_ranks(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    import torch
+    import torch.distributed as dist
+    have = require_devices(1 if "AFHIP_BENCH_DEVICE" in os.environ else local_rank + 1, "rank %d" % rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    dev_index = int(os.environ.get("AFHIP_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = args.backend
+    if backend == "auto":
+        backend = "gloo" if "AFHIP_BENCH_DEVICE" in os.environ else "nccl"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+        # build the communicator now (RCCL sets its rings up lazily, at the first collective): the timed
+        # region must not pay for it even when --warmup is 0
+        warm = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(dev)
+    cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    res = measure(args, args.workload, args.steps, args.warmup, rank, world, dev, dist, cpu_s)
     if rank == 0:
-        total_vis = world * nrow * nchan
-        ms_per_step = elapsed / args.steps * 1e3
-        r = wl.roofline(kernel_s)
-        default_shape = (nrow, nchan, nsrc, args.mode, args.pa, args.npix) == (1000000, 64, 1000, "auto", "random", 4096)
-        traffic, traffic_src = pmc_traffic(args.workload, default_shape)
-        hbm_ach = r["alg_bytes"] / kernel_s / 1e9
-        fp_ach = r["alg_flops"] / kernel_s / 1e12
-        hbm = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
-               "algorithmic_bytes": r["alg_bytes"]}
-        fp64 = {"achieved": fp_ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp_ach / FP64_PEAK_TFLOPS,
-                "algorithmic_flops": r["alg_flops"]}
-        top = fp64 if r["bound"] == "mfma" else hbm
-        roof = {"kernel": r["kernel"], "bound": r["bound"], "achieved": top["achieved"], "peak": top["peak"],
-                "unit": top["unit"], "frac": top["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": kernel_s * 1e3, "channels_in_kernel": r["channels_in_kernel"], "note": r["note"],
-                "hbm": hbm, "fp64": fp64}
-        if "gather" in r:
-            roof["gather"] = r["gather"]
-        out = {
-            "metric": "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err",
-            "value": total_vis / (elapsed / args.steps) / 1e6,
-            "unit": "Mvis/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": wl.label + " + per-channel chi^2" + (
-                    "" if world == 1 else " + RCCL all-reduce" if args.backend == "nccl" else " + gloo all-reduce"),
-                "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": ncorr,
-                "rows_total": world * nrow, "phasor_mode": args.mode,
-                "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce (%s)"
-                            % (world, "none" if world == 1 else args.backend),
-            },
-            "fp64_max_abs_err": max_err,
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+        launcher = ("self-launched" if os.environ.get("AFHIP_BENCH_SELF_LAUNCHED") else "external launcher") if world > 1 else "single process"
+        desc = "ranks: one process per GPU (%s), %d of %d device(s) visible in use%s" % (
+            launcher, 1 if "AFHIP_BENCH_DEVICE" in os.environ else world, have,
+            ", all ranks on device %s" % os.environ["AFHIP_BENCH_DEVICE"] if "AFHIP_BENCH_DEVICE" in os.environ and world > 1 else "")
+        out = headline_json(args, res, desc, "RCCL all-reduce over xGMI" if backend == "nccl" else "gloo all-reduce")
+        extras = {}
+        for name in extras_requested(args, world):
+            torch.cuda.empty_cache()
+            try:
+                r = measure(args, name, max(1, min(args.extra_steps, args.steps)), 1, 0, 1, dev, dist, min(cpu_s, 1.0))
+            except Exception as exc:       # an extra must never cost the headline its line
+                extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                continue
+            roof = r["roofline"]
+            extras[name] = {
+                "label": r["label"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
+                "unit": "Mvis/s", "kernel_ms": roof["kernel_ms"], "fp64_max_abs_err": r["fp64_max_abs_err"],
+                "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "traffic_source")},
+            }
+            for k in ("gather", "executed"):
+                if k in roof:
+                    extras[name]["roofline"][k] = roof[k]
+            if "cpu_baseline" in r:
+                extras[name]["cpu_baseline"] = {k: r["cpu_baseline"][k] for k in
+                                                ("value", "unit", "cores", "kind", "sample", "single_thread_value")
+                                                if k in r["cpu_baseline"]}
+        if extras:
+            out["workloads"] = extras
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------- executor: threads
+def run_threads(args):
+    """One process, N worker threads, N devices: row block k -> device k % N through placement.block(k) (the dask
+    shape of africanus/rime/dask_predict.py:311-369).  Each worker's inputs are resident on its device; a step
+    submits one task per row block to the thread pool, every task enqueues transform + chi^2 on its worker's own
+    stream and peer-copies its chi^2 partial to the first device, where the partials are summed (stream-ordered by
+    events: no host synchronisation inside a step)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from codex_africanus_amd import _lib, placement
+    n = args.gpus
+    have = require_devices(n, "worker threads")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    lib = _lib.load()
+    shared = os.environ.get("AFHIP_BENCH_DEVICE")
+    if shared is not None:
+        devs = (int(shared),) * n
+    else:
+        devs = placement.parse_device_list(os.environ.get("AFHIP_DEVICES"), have)[:n]
+        if len(devs) < n:
+            raise SystemExit("--gpus %d but AFHIP_DEVICES names %d device(s)" % (n, len(devs)))
+    placement.set_devices(devs)
+    placement.set_policy("block")
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    nrow, nchan = args.rows, args.chans
+
+    class Worker(object):
+        pass
+
+    workers = []
+    for k in range(n):
+        w = Worker()
+        w.k, w.index = k, devs[k]
+        w.dev = torch.device("cuda", w.index)
+        with torch.cuda.device(w.dev):
+            t = lambda a, d=w.dev: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+            w.wl = WORKLOADS[args.workload](args, k, w.dev, lib, _lib, t)
+            w.stream = torch.cuda.Stream(device=w.dev)
+            w.sp = ctypes.c_void_p(w.stream.cuda_stream)
+            w.d_vis = torch.empty((nrow, nchan, w.wl.ncorr), dtype=torch.complex128, device=w.dev)
+            w.d_chi2 = torch.zeros(nchan, dtype=torch.float64, device=w.dev)
+            w.wl.predict(w.d_vis, w.sp, P)
+            w.stream.synchronize()
+            w.d_data = w.d_vis.clone()
+            w.d_data += 0.01
+            w.done = torch.cuda.Event()
+            torch.cuda.synchronize(w.dev)
+        workers.append(w)
+    ncorr = workers[0].wl.ncorr
+    dev0 = workers[0].dev
+    staging = torch.zeros((n, nchan), dtype=torch.float64, device=dev0)
+    total = torch.zeros(nchan, dtype=torch.float64, device=dev0)
+    reduce_stream = torch.cuda.Stream(device=dev0)
+    evs = [Events(_lib, args.steps) for _ in workers]
+    placed = [None] * n
+
+    def task(k, step_no):
+        w = workers[k]
+        with placement.block(k):                      # row block k -> devs[k % n]; af_set_device on this thread
+            placed[k] = placement.activate()
+        if step_no is not None:
+            evs[k].arm(step_no)
+        w.wl.predict(w.d_vis, w.sp, P)
+        _lib.call("af_chi2_c128", P(w.d_vis), P(w.d_data), None, nrow, nchan, ncorr, P(w.d_chi2), w.sp)
+        if step_no is not None:
+            evs[k].disarm()
+        with torch.cuda.stream(w.stream):
+            staging[k].copy_(w.d_chi2, non_blocking=True)      # xGMI peer copy (nchan doubles)
+            w.done.record(w.stream)
+        return k
+
+    pool = ThreadPoolExecutor(n)
+
+    def step(step_no):
+        done = list(pool.map(lambda k: task(k, step_no), range(n)))
+        for w in workers:
+            reduce_stream.wait_event(w.done)
+        with torch.cuda.stream(reduce_stream):
+            torch.sum(staging, dim=0, out=total)
+        return len(done)
+
+    def sync_all():
+        for w in workers:
+            w.stream.synchronize()
+        reduce_stream.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    sync_all()
+    if list(placed) != list(devs) and args.warmup:
+        raise SystemExit("placement put the row blocks on %s, expected %s" % (placed, list(devs)))
+    t0 = time.perf_counter()
+    reported = n
+    for s in range(args.steps):
+        reported = min(reported, step(s))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    pool.shutdown()
+    kernel_s = [e.collect() for e in evs]
+    chi2_sum = total.cpu().numpy()
+    chi2_check = sum(w.d_chi2.cpu().numpy() for w in workers)
+    if not np.allclose(chi2_sum, chi2_check, rtol=1e-12, atol=0):
+        raise SystemExit("chi^2 reduced across devices differs from the sum of the partials")
+    w0 = workers[0]
+    with torch.cuda.device(dev0):
+        max_err = check_rows(w0.wl, w0.d_vis, nrow, args.check_rows, dev0) if args.check_rows > 0 else None
+    res = {
+        "label": w0.wl.label, "ranks_reported": reported, "elapsed": elapsed, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "value": reported * nrow * nchan / (elapsed / args.steps) / 1e6,
+        "corrs": ncorr, "fp64_max_abs_err": max_err,
+        "roofline": roofline_entry(w0.wl, args, args.workload, float(np.mean(kernel_s))),
+    }
+    desc = "threads: one process, %d worker threads, row block k on device %s[k %% %d] (placement.block)" % (n, list(devs), n)
+    out = headline_json(args, res, desc, "peer copies of the partials to device %d, summed there" % devs[0])
+    out["per_device_kernel_ms"] = [1e3 * x for x in kernel_s]
+    out["config"]["devices"] = list(devs)
+    out["config"]["physical_devices"] = len(set(devs))
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.executor == "threads":
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--executor threads is one process; do not start it under a multi-rank launcher")
+        return run_threads(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))        # this process makes no GPU call, before or after
+    return run_ranks(args)
 
 
 if __name__ == "__main__":

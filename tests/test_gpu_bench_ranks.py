@@ -42,3 +42,75 @@ def test_two_ranks_share_the_rows_and_reduce_chi2():
     assert r["value"] > 0 and abs(r["value"] - 60000 * 64 / (r["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * r["value"]
     assert r["fp64_max_abs_err"] < 1e-8
     assert r["roofline"]["kernel_ms"] > 0
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--rows", "30000", "--sources", "200", "--no-cpu-baseline", "--check-rows", "64"]
+
+
+def _run(args, env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    out = p.stdout.decode("utf-8", "replace")
+    return p.returncode, [ln for ln in out.splitlines() if ln.startswith("{")], out, p.stderr.decode("utf-8", "replace")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AFHIP_BENCH_DEVICE",
+                                                            "AFHIP_DEVICES", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE) used to run ONE rank and print n_gpus 1."""
+    rc, lines, out, err = _run(["--gpus", "2"] + SMALL, _clean_env(AFHIP_BENCH_DEVICE="0"))
+    assert rc == 0, (out[-2000:], err[-4000:])
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rows_total"] == 60000
+    assert "self-launched" in r["config"]["executor"] and "gloo" in r["config"]["sharding"]
+    assert r["fp64_max_abs_err"] < 1e-8 and r["roofline"]["kernel_ms"] > 0
+    assert "workloads" not in r and "cpu_baseline" not in r
+
+
+def test_gpus_2_on_one_device_is_refused_not_downgraded():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    for extra in ([], ["--executor", "threads"]):
+        rc, lines, out, err = _run(["--gpus", "2"] + extra + SMALL, _clean_env())
+        assert rc != 0 and not lines, (out[-500:], err[-500:])
+        assert "only 1 device" in err
+
+
+def test_threads_executor_two_row_blocks_through_placement():
+    """One process, two worker threads, row block k -> placement.block(k); both blocks aliased onto device 0."""
+    rc, lines, out, err = _run(["--gpus", "2", "--executor", "threads"] + SMALL, _clean_env(AFHIP_BENCH_DEVICE="0"))
+    assert rc == 0, (out[-2000:], err[-4000:])
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rows_total"] == 60000 and r["config"]["devices"] == [0, 0]
+    assert r["config"]["physical_devices"] == 1 and r["config"]["executor"].startswith("threads")
+    assert len(r["per_device_kernel_ms"]) == 2 and min(r["per_device_kernel_ms"]) > 0
+    assert r["fp64_max_abs_err"] < 1e-8
+    assert abs(r["value"] - 60000 * 64 / (r["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * r["value"]
+
+
+def test_default_line_carries_the_other_single_gpu_configs():
+    """configs[2] and configs[4] in the driver's one line (here at a reduced shape, explicitly
+    requested; the default shape turns them on by itself)."""
+    rc, lines, out, err = _run(["--rows", "20000", "--sources", "100", "--steps", "2", "--warmup", "1", "--npix", "1024",
+                                "--extras", "all", "--extra-steps", "2", "--cpu-seconds", "0.2", "--check-rows", "32"],
+                               _clean_env())
+    assert rc == 0, (out[-2000:], err[-4000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
+    assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
+    w = r["workloads"]
+    assert set(w) == {"dft_complex", "fused_dde", "degrid", "wgrid"}
+    for name, e in w.items():
+        assert "error" not in e, (name, e)
+        assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
+        assert e["cpu_baseline"]["value"] > 0
+    assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
+    assert w["degrid"]["fp64_max_abs_err"] < 1e-9
