@@ -966,7 +966,7 @@ def run_threads(args):
     def task(k, step_no):
         w = workers[k]
         with placement.block(k):                      # row block k -> devs[k % n]; af_set_device on this thread
-            placed[k] = placement.activate()
+            placed[k] = placement.activate()[0]
         if step_no is not None:
             evs[k].arm(step_no)
         w.wl.predict(w.d_vis, w.sp, P)

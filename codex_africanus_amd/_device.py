@@ -136,6 +136,7 @@ class Call(object):
         self._keep = []
         self._owned = []
         self._dev_ctx = None
+        self._prev_device = None
         self.stream = None
 
     def __enter__(self):
@@ -146,9 +147,9 @@ class Call(object):
             self.stream = ctypes.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
         else:
             _lib.load()
-            # host mode: the block's device (placement: row-block index or calling thread), then this thread's
+            # host mode: the block's device when the call carries a row-block index (placement), then this thread's
             # own stream on it -- concurrent calls from dask worker threads do not meet on the NULL stream
-            placement.activate()
+            _, self._prev_device = placement.activate()
             self.stream = _lib.thread_stream() if _USE_POOL else None
         return self
 
@@ -165,6 +166,9 @@ class Call(object):
         self._keep = []
         if self._dev_ctx is not None:
             self._dev_ctx.__exit__(*exc)
+        if self._prev_device is not None:      # a re-placed call leaves the thread's device as it found it
+            placement.restore(self._prev_device)
+            self._prev_device = None
         return False
 
     # ---- inputs -------------------------------------------------------------------

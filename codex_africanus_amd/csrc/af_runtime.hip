@@ -129,6 +129,9 @@ AF_EXPORT int af_free_host(void *hptr)
 // Ordering contract: af_pool_free may be called as soon as the work that uses the block has been ENQUEUED on
 // the calling thread's stream (af_thread_stream) only if the next user runs on that same stream; the Python
 // host path synchronises its stream before it returns a block, so blocks are idle when they change threads.
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <list>
 #include <map>
 #include <mutex>
@@ -277,9 +280,41 @@ int pool_release(void *p, const char *who)
     return AF_OK;
 }
 
+// A worker thread that ends (dask / ThreadPoolExecutor churn) takes its streams with it: synchronised, destroyed and
+// struck from the pool's list, so a long-running process does not accumulate one hipStream per (thread, device) it
+// ever had.  The process's main thread (tid == pid) is exempt: its thread-locals are destroyed inside
+// exit(), next to the HIP runtime's own teardown, and its streams die with the process anyway.
+}  // namespace
+void af_wgrid_drop_stream(hipStream_t st);   // af_wgridder.hip: FFT plans are per stream
+namespace {
+
 struct ThreadStreams {
     uint64_t generation = 0;
     hipStream_t s[AF_MAX_DEVICES] = {};
+    ~ThreadStreams()
+    {
+        if ((long)getpid() == (long)syscall(SYS_gettid)) return;
+        Pool &P = pool();
+        {
+            std::lock_guard<std::mutex> g(P.mu);
+            if (generation != P.generation) return;          // af_shutdown already destroyed them
+            for (auto it = P.streams.begin(); it != P.streams.end();)
+                it = (it->first >= 0 && it->first < AF_MAX_DEVICES && s[it->first] == it->second) ? P.streams.erase(it) : it + 1;
+        }
+        int dev0 = 0;
+        const bool have_dev = hipGetDevice(&dev0) == hipSuccess;
+        for (int d = 0; d < AF_MAX_DEVICES; ++d) {
+            if (!s[d]) continue;
+            if (hipSetDevice(d) == hipSuccess) {
+                (void)hipStreamSynchronize(s[d]);
+                af_wgrid_drop_stream(s[d]);
+                (void)hipStreamDestroy(s[d]);
+            }
+            s[d] = nullptr;
+        }
+        if (have_dev) (void)hipSetDevice(dev0);
+        (void)hipGetLastError();
+    }
 };
 thread_local ThreadStreams t_streams;
 

@@ -41,18 +41,28 @@ namespace {
 constexpr int WG_MAXW = 16;
 constexpr int WG_QUAD = 48;   // Gauss-Legendre nodes handed over by the host for the kernel's Fourier transform
 
-// `batch` contiguous rows of length n, in place (kind is 1: kept for other layouts)
+// `batch` contiguous rows of length n, in place (kind is 1: kept for other layouts).  A hipFFT plan owns ONE work
+// buffer (rocFFT uses it for multi-kernel lengths such as 8192), so a plan may only ever have work in flight on one
+// stream: the stream is part of the key -- every host thread (af_thread_stream) and every caller stream gets its own
+// plan, and two dask workers transforming row chunks of equal size on one device no longer share scratch.
 struct PlanKey {
     int dev, kind, n, batch;
+    hipStream_t stream;
     bool operator<(const PlanKey &o) const
     {
         if (dev != o.dev) return dev < o.dev;
         if (kind != o.kind) return kind < o.kind;
-        return n != o.n ? n < o.n : batch < o.batch;
+        if (n != o.n) return n < o.n;
+        if (batch != o.batch) return batch < o.batch;
+        return stream < o.stream;
     }
 };
+struct PlanEntry { hipfftHandle plan; uint64_t tick; };
+constexpr size_t WG_MAX_PLANS = 96;   // beyond this the least recently used plan is destroyed (hipfftDestroy frees
+                                      // its work buffer with hipFree, which waits for the device: safe with work in flight)
 std::mutex g_plan_mu;
-std::map<PlanKey, hipfftHandle> g_plans;
+std::map<PlanKey, PlanEntry> g_plans;
+uint64_t g_plan_tick = 0;
 
 __device__ __forceinline__ double es_kernel(double t, double inv_half_w, double beta)
 {
@@ -1035,35 +1045,39 @@ void wg_make_poly(int W, double beta, WgPoly &P)
     }
 }
 
-int plan_for(int kind, int n, int batch, hipfftHandle *out)
+// enqueues `batch` in-place row transforms of length n on `st` with the plan of (device, n, batch, st); the lock covers
+// the plan table and the enqueue (two host threads that share a stream then enqueue one after the other, and stream
+// order keeps the shared work buffer safe)
+int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st, bool backward = false)
 {
     int dev = 0;
     AF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(g_plan_mu);
-    const PlanKey key{dev, kind, n, batch};
+    const PlanKey key{dev, 1, n, batch, st};
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
+        if (g_plans.size() >= WG_MAX_PLANS) {
+            auto lru = g_plans.begin();
+            for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
+                if (jt->second.tick < lru->second.tick) lru = jt;
+            (void)hipfftDestroy(lru->second.plan);
+            g_plans.erase(lru);
+        }
         hipfftHandle p;
-        hipfftResult r;
         int len[1] = {n};
-        r = hipfftPlanMany(&p, 1, len, len, 1, n, len, 1, n, HIPFFT_Z2Z, batch);
-        AF_REQUIRE(r == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT plan (kind %d, %d x %d) failed (%d)", kind, n, batch, (int)r);
-        it = g_plans.emplace(key, p).first;
+        hipfftResult r = hipfftPlanMany(&p, 1, len, len, 1, n, len, 1, n, HIPFFT_Z2Z, batch);
+        AF_REQUIRE(r == HIPFFT_SUCCESS, "af_wgrid: hipFFT plan (%d x %d) failed (%d)", n, batch, (int)r);
+        r = hipfftSetStream(p, st);
+        if (r != HIPFFT_SUCCESS) {
+            (void)hipfftDestroy(p);
+            AF_REQUIRE(false, "af_wgrid: hipfftSetStream failed (%d)", (int)r);
+        }
+        it = g_plans.emplace(key, PlanEntry{p, 0}).first;
     }
-    *out = it->second;
-    return AF_OK;
-}
-
-int wg_fft_rows(int n, int batch, double2 *at, hipStream_t st, bool backward = false)
-{
-    hipfftHandle plan;
-    const int rc = plan_for(1, n, batch, &plan);
-    if (rc != AF_OK) return rc;
-    std::lock_guard<std::mutex> lk(g_plan_mu);              // a plan carries its stream: set and enqueue together
-    hipfftResult fr = hipfftSetStream(plan, st);
+    it->second.tick = ++g_plan_tick;
     hipfftDoubleComplex *d = reinterpret_cast<hipfftDoubleComplex *>(at);
-    if (fr == HIPFFT_SUCCESS) fr = hipfftExecZ2Z(plan, d, d, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
-    AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid_im2vis_f64: hipFFT failed (%d)", (int)fr);
+    const hipfftResult fr = hipfftExecZ2Z(it->second.plan, d, d, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
+    AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid: hipFFT failed (%d)", (int)fr);
     return AF_OK;
 }
 
@@ -1365,10 +1379,24 @@ AF_EXPORT int af_wgrid_vis2im_f64(const double *uvw, const double *freq, int64_t
                   const_cast<double *>(vis), workspace, workspace_bytes, stream);
 }
 
+// releases the FFT plans bound to a stream that is about to be destroyed (a worker thread ending, af_runtime.hip)
+void af_wgrid_drop_stream(hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+        if (it->first.stream == st) {
+            (void)hipfftDestroy(it->second.plan);
+            it = g_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 // releases the cached FFT plans (called by af_shutdown)
 void af_wgrid_shutdown()
 {
     std::lock_guard<std::mutex> g(g_plan_mu);
-    for (auto &kv : g_plans) (void)hipfftDestroy(kv.second);
+    for (auto &kv : g_plans) (void)hipfftDestroy(kv.second.plan);
     g_plans.clear();
 }

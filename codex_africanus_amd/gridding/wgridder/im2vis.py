@@ -18,7 +18,11 @@ def kernel_parameters(epsilon):
     if not (epsilon > 0):
         raise ValueError("epsilon must be positive")
     W = int(math.ceil(math.log10(1.0 / min(epsilon, 0.1)))) + 2
-    W = max(4, min(W, 16))
+    if W > 16:
+        # 16 taps reach ~1e-14, the floor of a float64 transform of this size: a smaller epsilon cannot be met, and
+        # clamping silently would break the documented contract (ducc0 refuses such accuracies too)
+        raise ValueError("epsilon = %g is below what the float64 kernel can reach (>= 1e-14)" % epsilon)
+    W = max(4, W)
     return W, 2.30 * W
 
 
@@ -51,7 +55,7 @@ def _bins(freq_bin_idx, freq_bin_counts, nband, nchan):
 
 
 def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly,
-              epsilon, do_wstacking, out_dtype):
+              epsilon, do_wstacking, out_dtype, w_bounds=None):
     """Both directions of the wgridder operator, band by band (csrc/af_wgridder.hip): ``adjoint`` False: image (band, nx,
     ny) -> visibilities (row, chan); True: visibilities -> image.  Geometry, planes and taps are the same for both, so
     the two are exact transposes of each other."""
@@ -80,7 +84,15 @@ def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx,
         raise ValueError("the image extends beyond the horizon (l^2 + m^2 >= 1)")
     max_nm1 = eps_max / (math.sqrt(1.0 - eps_max) + 1.0) if do_wstacking else 0.0
     # range of w nu / c per band (host scalars: they size the w-plane loop)
-    if nrow:
+    # The number of w-planes sizes the workspace and the plane loop, so the range of w is needed on the HOST.  numpy
+    # inputs: free.  Device-resident uvw: reading min / max back waits for the tensor's producer (one host
+    # synchronisation per call) -- callers that want the call fully asynchronous pass ``w_bounds=(wmin, wmax)`` in
+    # metres (any superset of the true range gives the same accuracy; the planes cover the stated range).
+    if w_bounds is not None:
+        wmin, wmax = float(w_bounds[0]), float(w_bounds[1])
+        if not (wmin <= wmax):
+            raise ValueError("w_bounds must be (wmin, wmax) with wmin <= wmax")
+    elif nrow:
         wcol = uvw[:, 2]
         wmin, wmax = (float(wcol.min()), float(wcol.max()))
     else:
@@ -133,14 +145,16 @@ def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx,
 
 
 def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None, epsilon=1e-5,
-          nthreads=1, do_wstacking=True):
+          nthreads=1, do_wstacking=True, w_bounds=None):
     """
     ``V = R x``: visibilities (row, chan) of the model image ``x`` (band, nx, ny), channels ``freq_bin_idx[b] ..
     + freq_bin_counts[b]`` taken from band ``b`` (bin starts are normalised by their minimum, as the reference does
     for row chunks); ``cell`` / ``celly`` pixel sizes in radians; ``weights`` (row, chan) multiply the result
     (whitened model); ``flag`` (row, chan): only visibilities with ``flag != 0`` are computed, the rest are 0;
     ``epsilon``: accuracy with respect to the direct Fourier transform; ``do_wstacking`` False ignores w and n.
-    ``nthreads`` is accepted and ignored (the work runs on the GPU).
+    ``nthreads`` is accepted and ignored (the work runs on the GPU).  ``w_bounds=(wmin, wmax)`` (metres; an extension,
+    keyword only in spirit) spares a device-resident call the host read-back of the w range -- with it, and ``freq``
+    given as a numpy array, nothing in the call waits for the device.
 
     Same contract as ``africanus.gridding.wgridder.model`` (africanus/gridding/wgridder/im2vis.py:63-99).  The
     reference delegates the arithmetic to ``ducc0.wgridder.dirty2ms`` (not vendored, not installed here: parity
@@ -154,4 +168,4 @@ def model(uvw, freq, image, freq_bin_idx, freq_bin_counts, cell, weights=None, f
     nx, ny = int(image.shape[1]), int(image.shape[2])
     out_dtype = np.result_type(np_dtype_of(image), np.complex64)
     return _operator(False, uvw, freq, image, None, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights, flag, celly,
-                     epsilon, do_wstacking, out_dtype)
+                     epsilon, do_wstacking, out_dtype, w_bounds)

@@ -44,7 +44,13 @@ def _on_device(arrays):
         import torch
     except ImportError:
         return None, arrays
-    return True, [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrays]
+    # the device a host-mode call made here would run on: the row block's (placement.block, set by the dask front-end)
+    # or the thread's current HIP device -- not torch's current device, which an earlier call may have left anywhere
+    from ... import _lib, placement
+    _lib.load()
+    dev = placement.choose()
+    dev = torch.device("cuda", _lib.get_device() if dev is None else dev)
+    return True, [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrays]
 
 
 def residual(uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, cell, weights=None, flag=None, celly=None,

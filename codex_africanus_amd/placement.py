@@ -10,14 +10,17 @@ on A device.  Two rules, both pure arithmetic (tested on CPU):
                   array riding along the "row" axis); block k runs on device ``k % n_devices``.  Consecutive row
                   blocks, which the scheduler releases together, go to different GPUs, and the same block always
                   lands on the same GPU (deterministic, re-runnable).
-  * ``thread`` -- calls that carry no block index (plain function calls from user threads, or dask wrappers of
-                  other libraries calling ours) take the device of the calling thread: threads are numbered in
-                  order of first use and thread j is pinned to device ``j % n_devices``, so a pool of N >= n_devices
-                  worker threads drives every GPU.
+  * ``thread`` -- opt-in (``AFHIP_PLACEMENT=thread``): calls take the device of the calling thread, block index or
+                  not: threads are numbered in order of first use and thread j is pinned to device ``j % n_devices``,
+                  so a pool of N >= n_devices worker threads (e.g. another library's dask wrappers calling ours)
+                  drives every GPU.
 
-``AFHIP_PLACEMENT=block|thread|none`` (default ``block``: block index when there is one, thread otherwise;
-``thread``: ignore block indices; ``none``: never touch the device selection -- the caller's af_set_device /
-HIP_VISIBLE_DEVICES decides).  ``AFHIP_DEVICES=0,2,5`` restricts and orders the devices used.  Device-mode calls
+``AFHIP_PLACEMENT=block|thread|none`` (default ``block``: the block's device when the call carries a block index;
+a call WITHOUT one -- a plain function call -- runs on the calling thread's current HIP device, i.e. whatever the
+caller's af_set_device / torch.cuda.set_device / HIP_VISIBLE_DEVICES selected: a rank-per-GPU job keeps its rank's
+device; ``thread``: as above; ``none``: never touch the device selection).  ``AFHIP_DEVICES=0,2,5``
+restricts and orders the devices used.  A re-placed call restores the thread's previous device when it returns
+(``_device.Call.__exit__``), so a later torch op on the same thread lands where it did before.  Device-mode calls
 (torch ROCm tensors in) are never re-placed: they run where their tensors live.
 """
 import contextlib
@@ -109,23 +112,37 @@ def block(block_index):
 
 
 def choose(devs=None, policy=None):
-    """The device a host-mode call made now on this thread should run on, or None (= leave the selection alone)."""
+    """The device a host-mode call made now on this thread should be moved to, or None (= leave the thread's current
+    device alone: policy ``none``, or the default policy and no block index)."""
     policy = _policy if policy is None else policy
     if policy == "none":
+        return None
+    blk = getattr(_tls, "block", None)
+    if policy == "block" and blk is None:
         return None
     devs = devices() if devs is None else devs
     if not devs:
         return None
-    blk = getattr(_tls, "block", None)
-    if policy == "block" and blk is not None:
+    if policy == "block":
         return device_for_block(blk, devs)
     return device_for_thread(devs)
 
 
 def activate():
-    """Select the device of the call about to be made (host mode); returns the ordinal or None."""
+    """Select the device of the call about to be made (host mode).  Returns (chosen, previous): the ordinal now
+    current (None when the selection was left alone) and the ordinal to restore afterwards (None = nothing to do)."""
     dev = choose()
-    if dev is not None:
-        from . import _lib
+    if dev is None:
+        return None, None
+    from . import _lib
+    prev = _lib.get_device()
+    if prev != dev:
         _lib.set_device(dev)
-    return dev
+        return dev, prev
+    return dev, None
+
+
+def restore(prev):
+    if prev is not None:
+        from . import _lib
+        _lib.set_device(prev)

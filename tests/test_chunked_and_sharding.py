@@ -200,8 +200,10 @@ def test_placement_block_context_and_policies():
         assert placement.choose(devs=devs, policy="block") == 2
         # policy 'thread' ignores block indices
         assert placement.choose(devs=devs, policy="thread") == placement.device_for_thread(devs)
-    # without a block index the calling thread's device is used
-    assert placement.choose(devs=devs, policy="block") == placement.device_for_thread(devs)
+    # without a block index the default policy leaves the thread's current device alone (a plain call must
+    # not override the caller's af_set_device / a rank's own device); per-thread devices are opt-in
+    assert placement.choose(devs=devs, policy="block") is None
+    assert placement.choose(devs=devs, policy="thread") == placement.device_for_thread(devs)
 
 
 def test_placement_threads_cover_all_devices():
