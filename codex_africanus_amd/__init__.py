@@ -13,4 +13,12 @@ of include/afhip.h; there is no CPU fallback.
 """
 from ._lib import build, device_count, device_info, get_device, set_device  # noqa: F401
 
+
+def check_status(wait=True):
+    """Raise ``ValueError`` if a device-mode call made so far met an out-of-range index (its rows are NaN).  Such a
+    call cannot raise by itself -- nothing synchronises on the device path -- so the error surfaces at the next call
+    into the package, or here (``wait=True`` waits for the outstanding calls first)."""
+    from ._device import check_status as _cs
+    _cs(wait)
+
 __version__ = "0.1.0"

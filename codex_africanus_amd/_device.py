@@ -119,6 +119,76 @@ class _PinnedPool(object):
 _pinned = _PinnedPool()
 
 
+class _DeferredStatus(object):
+    """Status words of device-mode calls that could not be read when the call returned (nothing synchronises there).
+
+    A kernel that met an out-of-range index writes a flag into its workspace (and NaN into the rows concerned); the
+    wrapper copies that word into a slot of ONE page-locked int32 buffer on the call's stream and records an event.
+    Whenever the package next has a reason to look -- the start of any later call on any thread, a host-mode result,
+    ``codex_africanus_amd.check_status()`` (which waits) -- the completed slots are read and a set flag raises
+    ``ValueError`` with the message the call registered.  No host synchronisation is added to the device path."""
+    SLOTS = 256
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._buf = None
+        self._free = []
+        self._pending = []          # (slot, event, message)
+
+    def _ensure(self):
+        if self._buf is None:
+            import torch
+            self._buf = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+            self._free = list(range(self.SLOTS))
+
+    def watch(self, ws_tensor, offset_bytes, message):
+        import torch
+        with self._lock:
+            self._ensure()
+            if not self._free:
+                self._drain_locked(wait=True)
+            slot = self._free.pop()
+        word = ws_tensor[offset_bytes:offset_bytes + 4].view(torch.int32)
+        self._buf[slot:slot + 1].copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ws_tensor.device))
+        with self._lock:
+            self._pending.append((slot, ev, message))
+
+    def _drain_locked(self, wait):
+        bad, keep = [], []
+        for slot, ev, message in self._pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                flags = int(self._buf[slot])
+                self._free.append(slot)
+                if flags:
+                    bad.append(message(flags))
+            else:
+                keep.append((slot, ev, message))
+        self._pending = keep
+        return bad
+
+    def poll(self, wait=False):
+        if not self._pending:
+            return
+        with self._lock:
+            bad = self._drain_locked(wait)
+        if bad:
+            raise ValueError("; ".join(bad) + " (reported by an earlier device-mode call; its rows are NaN)")
+
+
+_deferred = _DeferredStatus()
+
+
+def check_status(wait=True):
+    """Raise ``ValueError`` if a device-mode call made so far met an out-of-range index (waits for those calls'
+    streams when ``wait``)."""
+    _deferred.poll(wait=wait)
+
+
 class Call(object):
     """Marshals the arrays of ONE API call; use as a context manager."""
 
@@ -135,11 +205,14 @@ class Call(object):
         self.device_mode = self.torch_device is not None
         self._keep = []
         self._owned = []
+        self._inputs = {}           # (id(array), dtype) -> device pointer: one upload / conversion per distinct input
+        self._status = None         # host mode: (device address of an int32 status word, message function)
         self._dev_ctx = None
         self._prev_device = None
         self.stream = None
 
     def __enter__(self):
+        _deferred.poll()            # an earlier device-mode call's index error surfaces here at the latest
         if self.device_mode:
             import torch
             self._dev_ctx = torch.cuda.device(self.torch_device)
@@ -177,6 +250,9 @@ class Call(object):
         if a is None:
             return None
         dtype = np.dtype(dtype)
+        key = (id(a), dtype.str)
+        if key in self._inputs:     # the same object passed twice (dde1_jones is dde2_jones): one buffer, one pointer
+            return ctypes.c_void_p(self._inputs[key])
         if self.device_mode:
             import torch
             if _is_torch(a):
@@ -188,13 +264,17 @@ class Call(object):
                 t = t.to(td)
             t = t.contiguous()
             self._keep.append(t)
+            self._keep.append(a)    # keeps id(a) unique for the lifetime of the call
+            self._inputs[key] = t.data_ptr()
             return ctypes.c_void_p(t.data_ptr())
         arr = np.ascontiguousarray(a, dtype=dtype)
         buf = _OwnedBuffer(arr.nbytes)
         self._owned.append(buf)
         self._keep.append(arr)
+        self._keep.append(a)
         if arr.nbytes:
             _lib.call("af_memcpy_h2d", buf.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, self.stream)
+        self._inputs[key] = buf.ptr
         return ctypes.c_void_p(buf.ptr)
 
     def scratch(self, nbytes):
@@ -203,10 +283,21 @@ class Call(object):
             import torch
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.torch_device)
             self._keep.append(t)
+            self._last_scratch = t
             return ctypes.c_void_p(t.data_ptr())
         buf = _OwnedBuffer(nbytes)
         self._owned.append(buf)
+        self._last_scratch = buf
         return ctypes.c_void_p(buf.ptr)
+
+    def watch_status(self, offset_bytes, message):
+        """The int32 at `offset_bytes` of the scratch block allocated last is a status word the kernels of this call
+        set on an index error; ``message(flags)`` describes it.  Host mode: read with the result (which
+        synchronises anyway) and raised there.  Device mode: deferred (_DeferredStatus).  Call after the launch."""
+        if self.device_mode:
+            _deferred.watch(self._last_scratch, offset_bytes, message)
+        else:
+            self._status = (self._last_scratch.ptr + offset_bytes, message)
 
     # ---- outputs --------------------------------------------------------------------
     def out(self, shape, dtype):
@@ -232,5 +323,10 @@ class Call(object):
             arr = np.empty(shape, dtype=dtype)
         if arr.nbytes:
             _lib.call("af_memcpy_d2h", arr.ctypes.data_as(ctypes.c_void_p), buf.ptr, arr.nbytes, self.stream)
+        flags = ctypes.c_int32(0)
+        if self._status is not None:
+            _lib.call("af_memcpy_d2h", ctypes.byref(flags), self._status[0], 4, self.stream)
         _lib.call("af_stream_synchronize", self.stream)
+        if self._status is not None and flags.value:
+            raise ValueError(self._status[1](flags.value))
         return arr if cast is None else arr.astype(cast, copy=False)

@@ -20,6 +20,8 @@ AF_DFT_AUTO, AF_DFT_EXACT, AF_DFT_RECURRENCE = 0, 1, 2
 AF_DFT_CLAMP_N = 0x100
 AF_DFT_VALU_ONLY = 0x200
 AF_JONES_DIAG, AF_JONES_2X2 = 1, 2
+AF_STATUS_TIME_INDEX, AF_STATUS_ANTENNA = 1, 2
+AF_PREDICT_VIS_STATUS_OFFSET = 8
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 

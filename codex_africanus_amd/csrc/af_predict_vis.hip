@@ -13,6 +13,22 @@
 // (each (s,t,a,chan) Jones is shared by every baseline of the antenna).
 // All complex arithmetic is spelled with explicitly rounded multiplies/adds in the
 // reference's operation order, so results are bit-identical to the numba path.
+//
+// Two kernels:
+//   * predict_vis_tile_kernel (DDE terms present, round 3): a workgroup owns RB rows x CT channels and walks the
+//     sources; per source the DDE terms of EVERY antenna of the block's timestep(s) for its CT channels are copied
+//     global -> LDS once (global_load_lds_dwordx4, coalesced, two sources ahead, three stages, one barrier per source)
+//     and every baseline of the block takes its two Jones from LDS.  The per-lane Jones gathers -- two thirds of the
+//     kernel's L2 -> L1 line requests, each 64-byte record its own line request -- are gone; source_coh still streams
+//     from HBM straight into registers, two sources ahead.  Blocks are numbered so that the chan tiles of a row block
+//     and the row blocks of a timestep share an XCD (its L2 then fetches a (source, timestep) Jones slab once).
+//   * predict_vis_kernel (everything else: no DDEs, odd layouts, antennas that do not fit LDS): lane per cell,
+//     per-lane gathers.
+// Index guard: a row whose time index (after the tmin shift) is not in [0, ntime) or whose
+// antennas are not in [0, nant) reads clamped indices, produces NaN in all its cells and sets a bit of the status
+// word at workspace + 8 (1: time index, 2: antenna); the host wrapper raises ValueError when it next synchronises.
+#include <stdlib.h>
+
 #include "af_common.h"
 
 namespace {
@@ -72,6 +88,20 @@ template <typename T, int NC> __device__ __forceinline__ void load_jones(const T
     }
 }
 
+// streamed once, never re-read: non-temporal loads keep source_coh from evicting the Jones slabs the XCD's L2 is
+// meant to hold (tile kernel)
+template <typename T, int NC> __device__ __forceinline__ void load_jones_nt(const T *p, Cx<T> (&j)[NC])
+{
+    typedef T native2 __attribute__((ext_vector_type(2)));
+    const native2 *q = reinterpret_cast<const native2 *>(p);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const native2 v = __builtin_nontemporal_load(q + c);
+        j[c].re = v.x;
+        j[c].im = v.y;
+    }
+}
+
 // a1 * bl * a2^H (predict.py:93-122); 2x2: A1 . (BL . A2^H)
 template <typename T, int NC, bool J2X2>
 __device__ __forceinline__ void jones_mul3(const Cx<T> (&a1)[NC], const Cx<T> (&bl)[NC], const Cx<T> (&a2)[NC],
@@ -109,6 +139,31 @@ __device__ __forceinline__ void jones_mul2(const Cx<T> (&a1)[NC], const Cx<T> (&
     }
 }
 
+// Index guard: clamps (ti, a1, a2) into their arrays, reports in *status; true = the row's result must be NaN.
+__device__ __forceinline__ bool guard_indices(int64_t &ti, int64_t &a1, int64_t &a2, int64_t ntime, int64_t nant,
+                                              int *status)
+{
+    int flags = 0;
+    if (ti < 0 || ti >= ntime) { flags |= AF_STATUS_TIME_INDEX; ti = ti < 0 ? 0 : (ntime > 0 ? ntime - 1 : 0); }
+    if (a1 < 0 || a1 >= nant) { flags |= AF_STATUS_ANTENNA; a1 = 0; }
+    if (a2 < 0 || a2 >= nant) { flags |= AF_STATUS_ANTENNA; a2 = 0; }
+    if (flags) atomicOr(status, flags);
+    return flags != 0;
+}
+
+template <typename T, int NC> __device__ __forceinline__ void store_cell(T *p, const Cx<T> (&acc)[NC], bool bad)
+{
+    typename R<T>::vec2 *o = reinterpret_cast<typename R<T>::vec2 *>(p);
+    const T nan = (T)__builtin_nan("");
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        typename R<T>::vec2 v;
+        v.x = bad ? nan : acc[c].re;
+        v.y = bad ? nan : acc[c].im;
+        o[c] = v;
+    }
+}
+
 // tmin = min(time_index) (predict.py:597) without a host round trip
 template <typename I>
 __global__ void time_min_kernel(const I *__restrict__ time_index, int64_t nrow, long long *__restrict__ tmin)
@@ -131,7 +186,8 @@ __global__ __launch_bounds__(THREADS) void predict_vis_kernel(
     const I *__restrict__ time_index, const I *__restrict__ ant1, const I *__restrict__ ant2, int64_t nrow,
     const T *__restrict__ dde1, const T *__restrict__ coh, const T *__restrict__ dde2,
     const T *__restrict__ die1, const T *__restrict__ bvis, const T *__restrict__ die2, int64_t nsrc,
-    int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p, T *__restrict__ out)
+    int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p, int *__restrict__ status,
+    T *__restrict__ out)
 {
     const int64_t cell = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     const int64_t ncell = nrow * nchan;
@@ -139,10 +195,12 @@ __global__ __launch_bounds__(THREADS) void predict_vis_kernel(
     const int64_t r = cell / nchan, f = cell - r * nchan;
     const bool have_dies = die1 != nullptr;
     int64_t ti = 0, a1 = 0, a2 = 0;
+    bool bad = false;
     if (HAVE_DDES || have_dies) {
         ti = (int64_t)time_index[r] - (int64_t)(*tmin_p);
         a1 = (int64_t)ant1[r];
         a2 = (int64_t)ant2[r];
+        bad = guard_indices(ti, a1, a2, ntime, nant, status);
     }
     constexpr int CS = NC * 2;  // reals per cell
     Cx<T> acc[NC];
@@ -192,13 +250,209 @@ __global__ __launch_bounds__(THREADS) void predict_vis_kernel(
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = rr[c];
     }
-    typename R<T>::vec2 *o = reinterpret_cast<typename R<T>::vec2 *>(out + cell * CS);
+    store_cell<T, NC>(out + cell * CS, acc, bad);
+}
+
+// ---- (row block, chan tile) kernel: per-antenna DDE terms staged in LDS once per source ---------------------
+// block -> (row block, chan tile): the dispatcher deals consecutive blocks round-robin over the 8 XCDs, so block i
+// lives on XCD i % 8; the j = i / 8-th block of an XCD takes chan tile j % nct of that XCD's (j / nct)-th row block,
+// and an XCD's row blocks come in groups of G consecutive ones (~ one timestep) before the next XCD's group starts.
+template <typename T, typename I, int NC, bool J2X2, bool HAVE_COH, int CT, int TB, int CPT>
+__global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
+    const I *__restrict__ time_index, const I *__restrict__ ant1, const I *__restrict__ ant2, int64_t nrow,
+    const T *__restrict__ dde1, const T *__restrict__ coh, const T *__restrict__ dde2,
+    const T *__restrict__ die1, const T *__restrict__ bvis, const T *__restrict__ die2, int64_t nsrc,
+    int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p, int *__restrict__ status,
+    T *__restrict__ out, int nct, int64_t nrb, int group, int ts_max, int stage_reals, int trips_max)
+{
+    constexpr int RS = TB / CT;                      // rows per cell slot: a thread owns rows rl + k RS, k < CPT
+    constexpr int RB = RS * CPT;                     // rows per block
+    constexpr int CS = NC * 2;                       // reals per cell
+    constexpr int UNIT = 16 / (int)sizeof(T);        // reals per 16-byte unit
+    constexpr int SEG_UNITS = CT * CS / UNIT;        // units per (timestep, antenna) segment of the tile
+    static_assert(CT * CS % UNIT == 0, "a tile segment is whole 16-byte units");
+    extern __shared__ double2 tile_lds[];
+    __shared__ long long t_lo_hi[2];
+
+    const int64_t i = blockIdx.x;
+    const int xcd = (int)(i & 7);
+    const int64_t j = i >> 3;
+    const int ct = (int)(j % nct);
+    const int64_t q = j / nct;
+    const int64_t rb = ((q / group) * 8 + xcd) * group + q % group;
+    if (rb >= nrb) return;
+
+    const int tid = threadIdx.x;
+    const int fl = tid % CT, rl = tid / CT;
+    const int64_t f0 = (int64_t)ct * CT, f = f0 + fl;
+    const int64_t fc = f < nchan ? f : nchan - 1;
+    int64_t ti[CPT], a1[CPT], a2[CPT], cell[CPT];
+    bool bad[CPT], live[CPT];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        typename R<T>::vec2 v;
-        v.x = acc[c].re;
-        v.y = acc[c].im;
-        o[c] = v;
+    for (int k = 0; k < CPT; ++k) {
+        const int64_t r = rb * RB + k * RS + rl;
+        live[k] = r < nrow && f < nchan;
+        const int64_t rc = r < nrow ? r : nrow - 1;  // rows past the end read the last row's indices
+        ti[k] = (int64_t)time_index[rc] - (int64_t)(*tmin_p);
+        a1[k] = (int64_t)ant1[rc];
+        a2[k] = (int64_t)ant2[rc];
+        bad[k] = guard_indices(ti[k], a1[k], a2[k], ntime, nant, status);
+        cell[k] = rc * nchan + fc;
+    }
+
+    // the block's timestep range (bad indices arrive clamped)
+    if (tid == 0) { t_lo_hi[0] = 0x7fffffffffffffffLL; t_lo_hi[1] = 0; }   // clamped indices are >= 0: unsigned atomics
+    __syncthreads();
+    if (fl == 0) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            atomicMin((unsigned long long *)&t_lo_hi[0], (unsigned long long)ti[k]);
+            atomicMax((unsigned long long *)&t_lo_hi[1], (unsigned long long)ti[k]);
+        }
+    }
+    __syncthreads();
+    const int64_t tlo = t_lo_hi[0];
+    const int tsb = (int)(t_lo_hi[1] - tlo) + 1;
+    const bool use_lds = tsb <= ts_max;              // block-uniform; otherwise per-lane gathers
+    const int trips = (tsb * (int)nant * SEG_UNITS + TB - 1) / TB;   // copy instructions per wave and source (<= trips_max)
+
+    const int64_t ncell = nrow * nchan;
+    Cx<T> acc[CPT][NC];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[k][c].re = acc[k][c].im = (T)0;
+
+    const int64_t sstride_dde = ntime * nant * nchan * CS;
+    const int64_t sstride_coh = ncell * CS;
+
+    if (use_lds) {
+        // Three LDS stages: in iteration s the coherencies of source s + 1 are requested into registers, THEN the
+        // copy of source s + 2's Jones terms is issued, source s is computed from stage s % 3, and the wait at the end
+        // leaves exactly that copy outstanding (every wave issues the same `trips` copy instructions per source --
+        // lanes past the end of the block's segment list re-copy the last unit into the stage's padding -- so the
+        // count is one immediate per trip count).  One barrier per source.
+        T *lds = reinterpret_cast<T *>(tile_lds);
+        const int units = tsb * (int)nant * SEG_UNITS;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int64_t seg_stride = nchan * CS;       // reals between antennas of one (source, timestep)
+        // a tile that sticks out of the band copies the band's LAST CT channels instead (never reads past the array;
+        // nchan >= CT is a launch condition) and its lanes find channel f at position f - f0c of the segment
+        const int64_t f0c = f0 + CT <= nchan ? f0 : nchan - CT;
+        const int flc = f < nchan ? (int)(f - f0c) : 0;
+        int o1[CPT], o2[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            o1[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a1[k]) * CT + flc) * CS;
+            o2[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a2[k]) * CT + flc) * CS;
+        }
+        const T *src_t = dde1 + tlo * nant * seg_stride + f0c * CS;
+
+        auto stage_load = [&](int64_t s, int st) {
+            const T *src0 = src_t + s * sstride_dde;
+            T *dst0 = lds + st * stage_reals;
+            for (int t = 0; t < trips; ++t) {
+                const int ebase = t * TB + wave * 64;    // wave-uniform
+                int u = ebase + lane;
+                u = u < units ? u : units - 1;
+                const int seg = u / SEG_UNITS, k = u - seg * SEG_UNITS;
+                const T *g = src0 + (int64_t)seg * seg_stride + k * UNIT;
+                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst0 + ebase * UNIT));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            }
+        };
+        // wait until only the youngest `trips` vector-memory operations of this wave (one source's copy) are outstanding
+        auto wait_keep_one_copy = [&]() {
+            switch (trips) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+
+        Cx<T> cur[CPT][NC], nxt[CPT][NC];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (HAVE_COH) load_jones<T, NC>(coh + cell[k] * CS, cur[k]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) nxt[k][c].re = nxt[k][c].im = (T)0;
+        }
+        stage_load(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nsrc > 1) stage_load(1, 1);
+        __syncthreads();
+        int st = 0;
+        for (int64_t s = 0; s < nsrc; ++s) {
+            if (HAVE_COH && s + 1 < nsrc) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) load_jones<T, NC>(coh + (s + 1) * sstride_coh + cell[k] * CS, nxt[k]);
+            }
+            const bool more = s + 2 < nsrc;
+            if (more) stage_load(s + 2, st >= 1 ? st - 1 : 2);     // (st + 2) % 3
+            const T *base = lds + st * stage_reals;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                Cx<T> j1[NC], j2[NC], rr[NC];
+                load_jones<T, NC>(base + o1[k], j1);
+                load_jones<T, NC>(base + o2[k], j2);
+                if (HAVE_COH) jones_mul3<T, NC, J2X2>(j1, cur[k], j2, rr);
+                else jones_mul2<T, NC, J2X2>(j1, j2, rr);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[k][c] = cadd(acc[k][c], rr[c]);
+            }
+            if (more) wait_keep_one_copy();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (HAVE_COH) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) cur[k][c] = nxt[k][c];
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const T *p1 = dde1 + ((ti[k] * nant + a1[k]) * nchan + fc) * CS;
+            const T *p2 = dde2 + ((ti[k] * nant + a2[k]) * nchan + fc) * CS;
+            for (int64_t s = 0; s < nsrc; ++s) {
+                Cx<T> j1[NC], jb[NC], j2[NC], rr[NC];
+                load_jones<T, NC>(p1 + s * sstride_dde, j1);
+                load_jones<T, NC>(p2 + s * sstride_dde, j2);
+                if (HAVE_COH) {
+                    load_jones<T, NC>(coh + s * sstride_coh + cell[k] * CS, jb);
+                    jones_mul3<T, NC, J2X2>(j1, jb, j2, rr);
+                } else {
+                    jones_mul2<T, NC, J2X2>(j1, j2, rr);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[k][c] = cadd(acc[k][c], rr[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        if (!live[k]) continue;
+        if (bvis != nullptr) {
+            Cx<T> b[NC];
+            load_jones<T, NC>(bvis + cell[k] * CS, b);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[k][c] = cadd(acc[k][c], b[c]);
+        }
+        if (die1 != nullptr) {
+            Cx<T> g1[NC], g2[NC], rr[NC];
+            load_jones<T, NC>(die1 + ((ti[k] * nant + a1[k]) * nchan + f) * CS, g1);
+            load_jones<T, NC>(die2 + ((ti[k] * nant + a2[k]) * nchan + f) * CS, g2);
+            jones_mul3<T, NC, J2X2>(g1, acc[k], g2, rr);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[k][c] = rr[c];
+        }
+        store_cell<T, NC>(out + cell[k] * CS, acc[k], bad[k]);
     }
 }
 
@@ -209,9 +463,68 @@ struct PArgs {
     const void *dde1, *coh, *dde2, *die1, *bvis, *die2;
     int64_t nsrc, ntime, nant, nchan;
     long long *tmin;
+    int *status;
     void *out;
     hipStream_t st;
 };
+
+constexpr int TILE_LDS_BUDGET = 144 * 1024;   // of the CU's 160 KiB (the kernel keeps 16 bytes of static LDS)
+
+inline int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// (row block, chan tile) kernel: returns AF_ENOTSUP when the shape does not suit it (caller falls back)
+template <typename T, typename I, int NC, bool J2X2, bool HAVE_COH, int CT, int TB, int CPT>
+int launch_tile(const PArgs &a)
+{
+    constexpr int CS = NC * 2, RB = TB / CT * CPT;
+    const size_t seg_bytes = (size_t)CT * CS * sizeof(T);                 // one antenna of one timestep
+    const size_t per_ts = (size_t)a.nant * seg_bytes;
+    if (per_ts == 0 || a.nchan < CT) return AF_ENOTSUP;
+    // a stage holds ts timesteps, padded to whole copy trips of TB x 16 bytes; three stages (two sources ahead).
+    // ts = 2 lets a block straddle a timestep boundary; ts = 1 leaves room for more workgroups per CU and sends
+    // the straddling blocks (1 in 16 at 2016 rows per timestep) through per-lane gathers.
+    auto stage_bytes = [&](int ts) { return af_align_up((size_t)ts * per_ts, (size_t)TB * 16); };
+    int ts_max = env_int("AFHIP_PREDICT_TILE_TS", 1);
+    ts_max = ts_max < 1 ? 1 : ts_max > 2 ? 2 : ts_max;
+    while (ts_max > 1 && 3 * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) --ts_max;
+    if (3 * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) return AF_ENOTSUP;
+    const size_t lds = 3 * stage_bytes(ts_max);
+    const int stage_reals = (int)(stage_bytes(ts_max) / sizeof(T));
+    const int trips_max = (int)(stage_bytes(ts_max) / ((size_t)TB * 16));
+    if (trips_max > 4) return AF_ENOTSUP;                                  // the counted waits cover 1..4 trips
+    const int nct = (int)af_cdiv(a.nchan, CT);
+    const int64_t nrb = af_cdiv(a.nrow, RB);
+    const int group = 2048 / RB > 0 ? 2048 / RB : 1;                      // ~ one 64-antenna timestep of rows per XCD turn
+    const int64_t nrb_padded = af_cdiv(nrb, 8 * (int64_t)group) * 8 * group;
+    const int64_t blocks = nrb_padded * nct;
+    if (blocks >= (1LL << 31)) return AF_ENOTSUP;
+    auto kernel = predict_vis_tile_kernel<T, I, NC, J2X2, HAVE_COH, CT, TB, CPT>;
+    if (lds + 256 > 64 * 1024)   // dynamic + the kernel's static LDS beyond the default 64 KiB limit
+        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(TB), lds, a.st, (const I *)a.time_index, (const I *)a.ant1,
+                       (const I *)a.ant2, a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2,
+                       (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan,
+                       a.tmin, a.status, (T *)a.out, nct, nrb, group, ts_max, stage_reals, trips_max);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+
+// whether the tile kernel applies: DDE terms (dde1 == dde2 as every caller passes them -- the stage holds ONE array),
+// 16-byte aligned antenna segments, enough rows to fill the chip
+template <typename T, int NC>
+bool tile_applies(const PArgs &a)
+{
+    constexpr int CS = NC * 2;
+    if (env_int("AFHIP_PREDICT_TILE", 1) == 0) return false;
+    if (!a.dde1 || a.dde1 != a.dde2 || a.nsrc < 1) return false;
+    if ((a.nchan * CS * sizeof(T)) % 16 != 0 || ((uintptr_t)a.dde1 & 15)) return false;
+    if (a.nchan < 4 || a.nrow * a.nchan < (int64_t)1 << 16) return false;
+    return true;
+}
 
 template <typename T, typename I, int NC, bool J2X2, bool HAVE_DDES, bool HAVE_COH>
 int launch(const PArgs &a)
@@ -221,7 +534,7 @@ int launch(const PArgs &a)
     hipLaunchKernelGGL((predict_vis_kernel<T, I, NC, J2X2, HAVE_DDES, HAVE_COH>), dim3((unsigned)blocks),
                        dim3(THREADS), 0, a.st, (const I *)a.time_index, (const I *)a.ant1, (const I *)a.ant2,
                        a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2, (const T *)a.die1,
-                       (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan, a.tmin,
+                       (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan, a.tmin, a.status,
                        (T *)a.out);
     AF_LAUNCH_CHECK();
     return AF_OK;
@@ -231,6 +544,23 @@ template <typename T, typename I, int NC, bool J2X2>
 int launch_presence(const PArgs &a)
 {
     const bool ddes = a.dde1 != nullptr, coh = a.coh != nullptr;
+    if (ddes && tile_applies<T, NC>(a)) {
+        // 16 bytes per cell at least: CT = 4 cells of a 2x2 c128 (64 B) make 256-byte segments; narrower cells take
+        // wider tiles so that a segment stays >= 128 bytes
+        constexpr int CT = (NC * 2 * sizeof(T) >= 64) ? 4 : (NC * 2 * sizeof(T) >= 32) ? 8 : 16;
+        int rc;
+        if constexpr (sizeof(T) == 8 && sizeof(I) == 4 && NC == 4 && J2X2) {
+            // measurement hook (tools/bench_predict_tile.py): other tile shapes for the c128 2x2 case
+            const int ct = env_int("AFHIP_PREDICT_TILE_CT", CT), tb = env_int("AFHIP_PREDICT_TILE_TB", 512);
+            const int cpt = env_int("AFHIP_PREDICT_TILE_CPT", 1);
+            if (coh && ct == 8 && tb == 1024 && cpt == 1) rc = launch_tile<T, I, NC, J2X2, true, 8, 1024, 1>(a);
+            else if (coh && ct == 4 && tb == 512 && cpt == 2) rc = launch_tile<T, I, NC, J2X2, true, 4, 512, 2>(a);
+            else rc = coh ? launch_tile<T, I, NC, J2X2, true, CT, 512, 1>(a) : launch_tile<T, I, NC, J2X2, false, CT, 512, 1>(a);
+        } else {
+            rc = coh ? launch_tile<T, I, NC, J2X2, true, CT, 512, 1>(a) : launch_tile<T, I, NC, J2X2, false, CT, 512, 1>(a);
+        }
+        if (rc != AF_ENOTSUP) return rc;
+    }
     if (ddes && coh) return launch<T, I, NC, J2X2, true, true>(a);
     if (ddes) return launch<T, I, NC, J2X2, true, false>(a);
     if (coh) return launch<T, I, NC, J2X2, false, true>(a);
@@ -266,12 +596,13 @@ int predict_vis(const void *time_index, const void *ant1, const void *ant2, int 
     if (nrow == 0 || nchan == 0) return AF_OK;
     AF_REQUIRE(out != nullptr, "af_predict_vis: out is NULL");
     AF_REQUIRE(time_index && ant1 && ant2, "af_predict_vis: NULL index array");
-    AF_REQUIRE(workspace != nullptr && workspace_bytes >= sizeof(long long),
-               "af_predict_vis: workspace too small");
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= 16, "af_predict_vis: workspace too small");
     hipStream_t st = af_stream(stream);
     long long *tmin = static_cast<long long *>(workspace);
-    // tmin <- INT64_MAX (0x7f7f... is large enough and byte-settable), then device-side min
+    int *status = reinterpret_cast<int *>(tmin + 1);
+    // tmin <- INT64_MAX (0x7f7f... is large enough and byte-settable), then device-side min; status <- 0
     AF_HIP(hipMemsetAsync(tmin, 0x7f, sizeof(long long), st));
+    AF_HIP(hipMemsetAsync(status, 0, 8, st));
     if (dde1 != nullptr || die1 != nullptr) {
         int64_t blocks = af_cdiv(nrow, 256 * 8);
         if (blocks > 1024) blocks = 1024;
@@ -287,7 +618,7 @@ int predict_vis(const void *time_index, const void *ant1, const void *ant2, int 
     a.time_index = time_index; a.ant1 = ant1; a.ant2 = ant2; a.index_bytes = index_bytes; a.nrow = nrow;
     a.dde1 = dde1; a.coh = coh; a.dde2 = dde2; a.die1 = die1; a.bvis = bvis; a.die2 = die2;
     a.nsrc = (dde1 || coh) ? nsrc : 0; a.ntime = ntime; a.nant = nant; a.nchan = nchan;
-    a.tmin = tmin; a.out = out; a.st = st;
+    a.tmin = tmin; a.status = status; a.out = out; a.st = st;
     return index_bytes == 4 ? launch_layout<T, int32_t>(a, ncorr, jones_kind)
                             : launch_layout<T, int64_t>(a, ncorr, jones_kind);
 }

@@ -104,7 +104,8 @@ def _check_indices(time_index, antenna1, antenna2, ntime, nant, have_jones):
     """Index ranges the kernel relies on when per-antenna terms are gathered.  The reference reads out of bounds (or
     raises an IndexError under numba's boundscheck); on the device a bad index is an out-of-bounds read that can kill
     the context, so host-resident (numpy) index arrays are checked here -- O(row), negligible next to the upload.
-    Device-resident index tensors are trusted (checking would cost a device -> host synchronisation per call)."""
+    Device-resident index tensors are checked by the kernels themselves (clamped read, NaN rows, a status word the
+    wrapper turns into a ValueError when it next synchronises: ``_index_status_message``)."""
     if not have_jones or any(not isinstance(a, np.ndarray) for a in (time_index, antenna1, antenna2)):
         return
     if time_index.size == 0:
@@ -116,6 +117,15 @@ def _check_indices(time_index, antenna1, antenna2, ntime, nant, have_jones):
     hi = max(int(antenna1.max()), int(antenna2.max()))
     if lo < 0 or hi >= nant:
         raise ValueError("antenna indices span [%d, %d], the Jones terms hold %d antennas" % (lo, hi, nant))
+
+
+def _index_status_message(flags, ntime, nant):
+    parts = []
+    if flags & _lib.AF_STATUS_TIME_INDEX:
+        parts.append("time_index - min(time_index) reaches beyond the %d timesteps of the Jones terms" % ntime)
+    if flags & _lib.AF_STATUS_ANTENNA:
+        parts.append("antenna1 / antenna2 hold indices outside the %d antennas of the Jones terms" % nant)
+    return "predict_vis: " + " and ".join(parts)
 
 
 def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None, dde2_jones=None,
@@ -207,6 +217,8 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
         _lib.call(fn, p_ti, p_a1, p_a2, ib, nrow, *ptrs, nsrc, ntime, nant, nchan, ncorr,
                   _lib.AF_JONES_2X2 if jones_type == JONES_2X2 else _lib.AF_JONES_DIAG,
                   p_out, p_ws, ws_bytes, c.stream)
+        if have_ddes or have_dies:
+            c.watch_status(_lib.AF_PREDICT_VIS_STATUS_OFFSET, lambda flags: _index_status_message(flags, ntime, nant))
         return c.result(h)
 
 

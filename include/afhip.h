@@ -174,7 +174,15 @@ int af_vis_to_im_f64(const double *vis, const double *uvw, const double *lm, con
  * Absent terms are NULL.  ncorr in {1,2,4}; jones_kind AF_JONES_2X2 requires
  * ncorr == 4.  Sums run over sources in ascending order with the reference's
  * operation order and no fp contraction, so results are bit-identical to the
- * numba path.  `workspace`: >= af_predict_vis_workspace_bytes() device bytes. */
+ * numba path.  `workspace`: >= af_predict_vis_workspace_bytes() device bytes.
+ * Index guard (the reference fails under numba's boundscheck, predict.py:597-607): a row whose normalised time
+ * index is outside [0, ntime) or whose antennas are outside [0, nant) reads clamped indices, gets NaN in all its
+ * cells, and sets AF_STATUS_TIME_INDEX / AF_STATUS_ANTENNA in the int32 status word at workspace + 8 (zeroed by
+ * the call, valid once the stream has passed the call); the entry itself still returns AF_OK (it does not
+ * synchronise).  Only calls with DDE or DIE terms read the index arrays. */
+#define AF_STATUS_TIME_INDEX 1
+#define AF_STATUS_ANTENNA 2
+#define AF_PREDICT_VIS_STATUS_OFFSET 8
 size_t af_predict_vis_workspace_bytes(void);
 int af_predict_vis_c128(const void *time_index, const void *antenna1, const void *antenna2,
                         int index_bytes, int64_t nrow, const double *dde1_jones,
