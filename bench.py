@@ -356,8 +356,21 @@ class FusedDde(object):
         # E X E^H 112 + 4 complex MACs 32 (SURVEY's count, kept so that rounds compare)
         alg_bytes = (nrow * nchan * 64 + nrow * 36 + self.LW * self.MH * self.NUD * 4 * 24
                      + self.ntime * self.NANT * (8 + nchan * 16) + self.NANT * nchan * 16 + nsrc * nchan * 64)
+        # what the kernel actually issues (counted in the ISA of the unrolled, grouped, wave-specialised instantiation:
+        # tools/count_fused_isa.sh): 63 fp64 VALU instructions per (row, chan, src) in the accumulating waves + 344
+        # per 512 Jones terms in the sampling waves (one term per 31.5 units at 64 antennas); an fp64 instruction
+        # occupies its SIMD for 4 cycles, so the pipe's capacity is 256 CU x 4 SIMD x 16 lanes x clock lane-instructions/s
+        units = float(nrow) * nchan * nsrc
+        terms = float(nsrc) * self.ntime * self.NANT * nchan
+        fp64_lane_instr = 63.0 * units + (344.0 * 64 / 512) * terms
+        cap = 256 * 4 * 16 * 2.4e9
+        executed = {"fp64_instructions_per_unit": fp64_lane_instr / units, "flop_equivalent_per_unit": 2 * fp64_lane_instr / units,
+                    "fp64_pipe_occupancy_at_2.4GHz": fp64_lane_instr / kernel_s / cap,
+                    "note": "fraction of the fp64 pipe's issue slots (4 cycles per wave instruction) the kernel fills at the "
+                            "nominal 2.4 GHz; the chip holds ~2.03 GHz under this all-VALU fp64 mix, i.e. x 1.18 at the "
+                            "clock it runs at"}
         return dict(kernel="fused_predict_kernel", bound="mfma", alg_flops=float(nrow) * nchan * nsrc * 150.0,
-                    alg_bytes=float(alg_bytes), channels_in_kernel=nchan,
+                    alg_bytes=float(alg_bytes), channels_in_kernel=nchan, executed=executed,
                     note="fp64 VALU bound (same 78.6 TFLOP/s fp64 pipe as the matrix path): 2x2 complex Jones "
                          "algebra per (row, chan, src), 150 flop (SURVEY 8(d))")
 
