@@ -1,0 +1,518 @@
+// im_to_vis with float32 inputs and a complex64 result, computed natively in single precision (round 3).
+//
+// Replaces africanus/dft/kernels.py:33-67 for the case every input is float32: the reference then runs its whole
+// loop in float32 (result dtype by promotion, africanus/dft/kernels.py:26-31, africanus/util/type_inference.py:24-26),
+// including the phase C (l u + m v + n w) nu -- thousands of radians for kilometre baselines: 1.4e-4 of the peak
+// visibility in error at 4 km (golden G13).  Here the PHASORS are float64 and only the products are float32:
+//   * fp64 VALU, per (row, source, channel tile): q = l u + m v + n w, the phasor at the tile's first channel and the
+//     channel-step phasor from the 256-entry LDS table of af_sincos.h (~2e-16), then the three-term recurrence
+//     y[j+1] = 2 cos(d) y[j] - y[j-1] along the tile in fp64; every phasor is rounded to float32 once (6e-8);
+//   * fp32 MATRIX pipe, per channel: v_mfma_f32_4x4x1_16b_f32 -- sixteen 4x4x1 outer products -- with
+//       A = the source's pixels: ONE register holds 16 blocks x 4 floats = the 4 correlations of 16 channels, and the
+//           instruction's CBSZ = 4 / ABID = k fields broadcast block k (channel k) to all sixteen blocks,
+//       B = the lane's own phasor component (lane = row: block b, column j = lane 4 b + j),
+//       D = 4 registers per lane = the 4 correlations of the lane's row (layout measured: tools/probe/probe_mfma_f32.hip),
+//     i.e. acc[chan][0..3] += pixel[chan][0..3] * y in one instruction where the VALU needs four, with a wave-uniform
+//     operand at no cost (no DPP, no scalar loads, no LDS) and the accumulators in AGPRs.  Two MFMAs per channel for a
+//     real image (re, im), four for a complex one (records carry (re, im, -im): the MFMA cannot negate an operand).
+// The matrix pipe and the fp64 VALU are different pipes, so the recurrence of one wave runs beside the MFMAs of its SIMD
+// partner; the kernel is bound by the fp64 VALU work (2 FMA + 2 conversions per channel + ~35 operations of set-up per
+// tile), at about half the cycles per channel of the fp64 MFMA kernel (whose MACs share the fp64 pipe with its
+// recurrence).  Accuracy: every phasor is the correctly rounded float32 of an fp64-accurate value, so the result is as
+// close to the float64 transform of the float32 inputs as float32 sums allow -- closer than the reference's float32
+// loop in every regime (tests/test_gpu_f32.py: golden G3 at metre baselines, G13 at 4 km).
+//
+// Frequencies.  A float32 frequency axis is never an exact arithmetic progression (64-128 Hz of rounding at L band),
+// and over a 4 km baseline that rounding is worth 1.2e-4 of the peak visibility -- as much as the reference's own
+// error (G13).  The prep pass classifies the band on the device: 0 = every tile exactly uniform (to 2 ulp of float64):
+// plain recurrence; 1 = uniform to within float32 rounding: recurrence on the tile's least-squares grid plus the
+// first-order correction y_c (1 + i q kappa_c), kappa_c = 2 pi (nu_c - grid_c) / c (3 float32 operations per channel,
+// second-order term < 1e-7); 2 = anything else: `dft_f32_exact_kernel`, one fp64 sincos per (row, source, channel).
+// AF_DFT_RECURRENCE (the caller asserts a uniform band) runs class 1 as class 0; AF_DFT_EXACT forces class 2.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "af_common.h"
+#include "af_sincos.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS = 256;
+constexpr int G32 = 64;   // floats per record register = 16 MFMA blocks x 4
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for32(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for32<I + 1, N>(f);
+    }
+}
+
+struct Ws32 {
+    size_t flags, lmn, srcbad, tilef, kappa, freqc, colstate, tilestate, records, total;
+    int64_t ntile;
+    int ct, groups;
+};
+
+// MFMA blocks (of 4 correlations) a channel takes in a record: (re) or (re, im, -im)
+constexpr int blocks_per_chan(bool cplx) { return cplx ? 3 : 1; }
+// channels per record register (16 blocks)
+constexpr int chans_per_reg(bool cplx) { return 16 / blocks_per_chan(cplx); }
+constexpr int groups_of(int ct, bool cplx) { return (ct + chans_per_reg(cplx) - 1) / chans_per_reg(cplx); }
+
+// channel-tile width: 2 x CT accumulator quads = 8 CT AGPRs; 16 channels (128 AGPRs) leave room for two waves per
+// SIMD (AFHIP_F32_CT=22 / 32: wider tiles for A/B runs; complex images 15 / 20 / 30: whole 5-channel registers)
+int tile_width(bool cplx)
+{
+    static const int want = getenv("AFHIP_F32_CT") ? atoi(getenv("AFHIP_F32_CT")) : 16;
+    if (cplx) return want >= 32 ? 30 : want >= 22 ? 20 : 15;
+    return want >= 32 ? 32 : want >= 22 ? 22 : 16;
+}
+
+Ws32 ws32_layout(int64_t nsrc, int64_t nchan, int64_t ncorr, int is_complex)
+{
+    Ws32 L;
+    L.ct = tile_width(is_complex != 0);
+    L.ntile = af_cdiv(nchan > 0 ? nchan : 1, L.ct);
+    L.groups = groups_of(L.ct, is_complex != 0);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    L.flags = take(16 * sizeof(int));
+    L.lmn = take((size_t)(nsrc > 0 ? nsrc : 1) * 4 * sizeof(double));
+    L.srcbad = take((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
+    L.tilef = take((size_t)L.ntile * 2 * sizeof(double));
+    L.kappa = take((size_t)L.ntile * L.ct * sizeof(float));
+    L.freqc = take((size_t)(nchan > 0 ? nchan : 1) * sizeof(double));
+    L.colstate = take((size_t)L.ntile * L.ct * (ncorr > 0 ? ncorr : 1) * sizeof(int));
+    L.tilestate = take((size_t)L.ntile * sizeof(int));
+    L.records = take((size_t)L.ntile * (nsrc > 0 ? nsrc : 1) * L.groups * G32 * sizeof(float));
+    L.total = o;
+    return L;
+}
+
+// n = sqrt(1 - l^2 - m^2) - 1 (kernels.py:54, unclamped) in float64 from the float32 coordinates
+__global__ void f32_prep_src(const float *__restrict__ lm, int64_t nsrc, double *__restrict__ lmn, int *__restrict__ srcbad)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const double l = (double)lm[2 * s], m = (double)lm[2 * s + 1];
+    double n = 1.0 - l * l - m * m;
+    n = sqrt(n) - 1.0;
+    const bool bad = !(isfinite(l) && isfinite(m) && isfinite(n));
+    srcbad[s] = bad ? 1 : 0;
+    lmn[4 * s + 0] = bad ? 0.0 : l;
+    lmn[4 * s + 1] = bad ? 0.0 : m;
+    lmn[4 * s + 2] = bad ? 0.0 : n;
+    lmn[4 * s + 3] = 0.0;
+}
+
+// per tile: the grid (first frequency, step) in turns per metre, the residuals kappa, the band's class
+__global__ void f32_prep_freq(const float *__restrict__ freq, int64_t nchan, int64_t ntile, int CT, int sign,
+                              double *__restrict__ tilef, float *__restrict__ kappa, double *__restrict__ freqc,
+                              int *__restrict__ flags)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntile) return;
+    const int64_t c0 = t * CT;
+    const int64_t nc = nchan - c0 < CT ? nchan - c0 : CT;
+    // least-squares line through the tile's channels (equal to the end-point line for an exact progression)
+    double sx = 0.0, sy = 0.0, sxx = 0.0, sxy = 0.0;
+    const double fref = (double)freq[c0];
+    for (int64_t j = 0; j < nc; ++j) {
+        const double y = (double)freq[c0 + j] - fref;
+        sx += (double)j; sy += y; sxx += (double)j * j; sxy += (double)j * y;
+    }
+    double df = 0.0, f0 = fref;
+    if (nc > 1) {
+        const double den = (double)nc * sxx - sx * sx;
+        df = ((double)nc * sxy - sx * sy) / den;
+        f0 = fref + (sy - df * sx) / (double)nc;
+    }
+    // an exact progression must come out exactly: prefer the end-point line when it reproduces every channel
+    const double dfe = nc > 1 ? ((double)freq[c0 + nc - 1] - fref) / (double)(nc - 1) : 0.0;
+    bool exact = isfinite(fref) && isfinite(dfe);
+    for (int64_t j = 0; j < nc && exact; ++j) {
+        const double f = (double)freq[c0 + j], pred = fref + (double)j * dfe;
+        if (!(fabs(f - pred) <= 2.0 * 2.220446049250313e-16 * fmax(fabs(f), fabs(pred)))) exact = false;
+    }
+    if (exact) { f0 = fref; df = dfe; }
+    int cls = exact ? 0 : 1;
+    const double s1 = (double)sign / AF_LIGHTSPEED;
+    for (int64_t j = 0; j < CT; ++j) {
+        double eps = 0.0;
+        if (j < nc) {
+            const double f = (double)freq[c0 + j];
+            eps = f - (f0 + (double)j * df);
+            // float32 rounding of a value near f: half an ulp = |f| 2^-24; allow four
+            if (!(fabs(eps) <= 4.0 * 5.9604644775390625e-08 * fabs(f))) cls = 2;
+            freqc[c0 + j] = 4.0 * f * s1;      // quarter turns per metre (dft_f32_exact_kernel)
+        }
+        kappa[t * CT + j] = (float)(6.283185307179586 * eps * s1);
+    }
+    if (!isfinite(f0) || !isfinite(df)) cls = 2;
+    tilef[2 * t + 0] = f0 * s1;
+    tilef[2 * t + 1] = df * s1;
+    atomicMax(&flags[0], cls);
+}
+
+// records: [tile][source][groups * 64] floats; register g, block k of it = channel g * CPR + k / BPC of the tile,
+// plane k % BPC of (re | re, im, -im), floats = correlations 0..3 (zero beyond ncorr).  Zero beyond nchan and for
+// sources whose (l, m, n) is not finite (their effect goes through colstate).
+template <typename P>
+__global__ void f32_pack_records(const P *__restrict__ image, int cplx, int64_t nsrc, int64_t nchan, int64_t ncorr,
+                                 int64_t ntile, int CT, int groups, const int *__restrict__ srcbad,
+                                 float *__restrict__ rec)
+{
+    const int W = cplx ? 2 : 1, BPC = cplx ? 3 : 1, CPR = 16 / BPC;
+    const int64_t per = (int64_t)groups * G32;
+    const int64_t total = ntile * nsrc * per;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t slot = i % per, s = (i / per) % nsrc, tile = i / (per * nsrc);
+        const int g = (int)(slot / G32), blk = (int)(slot % G32) / 4, c = (int)(slot % 4);
+        const int j = g * CPR + blk / BPC, plane = blk % BPC;
+        const int64_t ch = tile * CT + j;
+        float v = 0.0f;
+        if (blk < CPR * BPC && j < CT && ch < nchan && c < ncorr && !srcbad[s]) {
+            const P *px = image + ((s * nchan + ch) * ncorr + c) * W;
+            v = plane == 0 ? (float)px[0] : plane == 1 ? (float)px[W - 1] : -(float)px[W - 1];
+        }
+        rec[i] = v;
+    }
+}
+
+// column state per (chan, corr): the reference's `if image[s,nu,c]:` (kernels.py:64) only matters when a phasor is
+// not finite: an all-zero column stays exactly 0 (state 1), a non-finite source with a nonzero pixel poisons it (2)
+__global__ __launch_bounds__(64) void f32_colstate(const float *__restrict__ image, int W, int64_t nsrc, int64_t nchan,
+                                                   int64_t ncorr, int CT, const int *__restrict__ srcbad,
+                                                   int *__restrict__ colstate, int *__restrict__ tilestate)
+{
+    const int64_t i = blockIdx.x;
+    const int64_t c = i % ncorr, ch = i / ncorr;
+    int state = 0;
+    if (ch < nchan) {
+        bool any_nz = false, poison = false;
+        for (int64_t s = threadIdx.x; s < nsrc; s += 64) {
+            const float *px = image + ((s * nchan + ch) * ncorr + c) * W;
+            const bool nz = (px[0] != 0.0f) || (W == 2 && px[1] != 0.0f);
+            any_nz |= nz;
+            poison |= (nz && srcbad[s]);
+        }
+        const bool w_nz = __ballot(any_nz) != 0ULL, w_poison = __ballot(poison) != 0ULL;
+        state = w_poison ? 2 : (w_nz ? 0 : 1);
+    }
+    if (threadIdx.x == 0) {
+        colstate[i] = state;
+        if (state) atomicOr(&tilestate[ch / CT], state);
+    }
+}
+
+// rows of 64 lanes through LDS, out as fully coalesced 8-byte stores (per-lane stores at a row stride of
+// nchan * ncorr * 8 bytes leave partially written lines behind)
+template <int CT, int NC>
+__device__ __forceinline__ void store_tile32(const v4f (&are)[CT], const v4f (&aim)[CT], float2 *stage, float *out,
+                                             int64_t row0, int64_t nrow, int64_t nchan, int64_t c0, int wave, int lane,
+                                             const int *__restrict__ colstate, int tstate)
+{
+    constexpr int PER_ROW = CT * NC;
+    constexpr int STRIDE = PER_ROW + 1;
+    const int64_t seg_chans = nchan - c0 < CT ? nchan - c0 : CT;
+    const int seg_len = (int)(seg_chans * NC);
+    for (int pass = 0; pass < ROWS / 64; ++pass) {
+        if (wave == pass) {
+            float2 *dst = stage + lane * STRIDE;
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dst[j * NC + c] = make_float2(are[j][c], aim[j][c]);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * PER_ROW; e += ROWS) {
+            const int rl = e / PER_ROW, col = e - rl * PER_ROW;
+            const int64_t row = row0 + pass * 64 + rl;
+            if (row < nrow && col < seg_len) {
+                float2 v = stage[rl * STRIDE + col];
+                if (tstate) {   // block-uniform: rare zero-column / NaN-source semantics
+                    const int st = colstate[c0 * NC + col];
+                    if (st == 1) v = make_float2(0.0f, 0.0f);
+                    if (st == 2) v = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+                }
+                reinterpret_cast<float2 *>(out)[(row * nchan + c0) * NC + col] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid: (ceil(nrow / 256), tiles); block 256 = 4 waves of 64 consecutive rows on tile blockIdx.y.
+template <int CT, int NC, bool CPLX, bool CORR>
+__global__ __launch_bounds__(ROWS, (CT <= 16 ? 2 : 1)) void dft_f32_kernel(
+    const float *__restrict__ uvw, const float *__restrict__ records, const double *__restrict__ lmn,
+    const double *__restrict__ tilef, const float *__restrict__ kappa, const int *__restrict__ flags,
+    const int *__restrict__ colstate, const int *__restrict__ tilestate, float *__restrict__ out, int64_t nrow,
+    int nsrc, int64_t nchan, int want_class)
+{
+    if (flags[0] != want_class) return;   // decided on the device by f32_prep_freq
+    __shared__ float2 stage[64 * (CT * NC + 1)];
+    __shared__ double2 ptab[PHASOR_TABLE];
+    table_phasor_init(ptab, threadIdx.x, ROWS);
+    __syncthreads();
+    constexpr int BPC = blocks_per_chan(CPLX), CPR = chans_per_reg(CPLX);
+    constexpr int NG = groups_of(CT, CPLX);
+    const int tile = blockIdx.y;
+    const int64_t c0 = (int64_t)tile * CT;
+    int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x;
+    if (row >= nrow) row = nrow - 1;
+    const double u = (double)uvw[3 * row], v = (double)uvw[3 * row + 1], w = (double)uvw[3 * row + 2];
+    // turns per metre -> 1/256 turns per metre (table_phasor's unit: an exact scaling)
+    const double F0 = 256.0 * tilef[2 * tile], FD = 256.0 * tilef[2 * tile + 1];
+    float kap[CT];
+    if constexpr (CORR) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) kap[j] = kappa[tile * CT + j];   // wave-uniform: scalar registers
+    }
+    v4f are[CT], aim[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) are[j] = aim[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int lane = threadIdx.x & 63;
+    const float *__restrict__ rec = records + (int64_t)tile * nsrc * (NG * G32) + lane;
+    float R[NG], Rn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) R[g] = rec[g * G32];
+
+#pragma unroll 1
+    for (int s = 0; s < nsrc; ++s) {
+        const int sn = s + 1 < nsrc ? s + 1 : s;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) Rn[g] = rec[(int64_t)sn * (NG * G32) + g * G32];
+        const double l = lmn[4 * s], m = lmn[4 * s + 1], n = lmn[4 * s + 2];
+        const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
+        double y0r, y0i, dr, di;
+        table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
+        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
+        const float qf = (float)q;
+        const double k2 = __dadd_rn(dr, dr);
+        double y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
+        double y1i = fma(y0r, di, __dmul_rn(y0i, dr));
+        // phase 1, fp64 VALU only: the tile's phasors, rounded to float32 once.  phase 2, matrix pipe only: the MFMAs
+        // back to back.  (Interleaved instruction by instruction a lone wave pays ~10 cycles at every MFMA <-> VALU
+        // switch -- measured, tools/probe/probe_mfma_f32.hip: 16 MFMAs 152 cycles, 16 fp64 FMAs 108, alternating 340 --
+        // whereas whole phases of different waves of a SIMD overlap.)
+        float yr[CT], yi[CT];
+        static_for32<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            double yrd, yid;
+            if constexpr (j == 0) { yrd = y0r; yid = y0i; }
+            else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
+            else {
+                yrd = fma(k2, y1r, -y0r);
+                yid = fma(k2, y1i, -y0i);
+                y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+            }
+            yr[j] = (float)yrd; yi[j] = (float)yid;
+            if constexpr (CORR) {   // y (1 + i theta), theta = q kappa_j
+                const float th = qf * kap[j];
+                const float cr = fmaf(-th, yi[j], yr[j]), ci = fmaf(th, yr[j], yi[j]);
+                yr[j] = cr; yi[j] = ci;
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for32<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int g = j / CPR, b0 = (j % CPR) * BPC;
+            if constexpr (CPLX) {
+                are[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yr[j], are[j], 4, b0, 0);       // + re * yr
+                aim[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yr[j], aim[j], 4, b0 + 1, 0);   // + im * yr
+            } else {
+                are[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yr[j], are[j], 4, b0, 0);
+                aim[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yi[j], aim[j], 4, b0, 0);
+            }
+        });
+        if constexpr (CPLX) {
+            static_for32<0, CT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int g = j / CPR, b0 = (j % CPR) * BPC;
+                are[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yi[j], are[j], 4, b0 + 2, 0);   // - im * yi
+                aim[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[g], yi[j], aim[j], 4, b0, 0);       // + re * yi
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) R[g] = Rn[g];
+    }
+    store_tile32<CT, NC>(are, aim, stage, out, (int64_t)blockIdx.x * ROWS, nrow, nchan, c0,
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, colstate, tilestate[tile]);
+}
+
+// any band: one phasor per (row, source, channel), phase in fp64 turns.  grid: (ceil(nrow / 256), nchan).
+template <int NC, bool CPLX>
+__global__ __launch_bounds__(ROWS) void dft_f32_exact_kernel(
+    const float *__restrict__ uvw, const float *__restrict__ image, const double *__restrict__ lmn,
+    const int *__restrict__ srcbad, const double *__restrict__ freqc, const int *__restrict__ flags,
+    const int *__restrict__ colstate, float *__restrict__ out, int64_t nrow, int nsrc, int64_t nchan, int want_class)
+{
+    if (want_class >= 0 && flags[0] != want_class) return;
+    constexpr int W = CPLX ? 2 : 1;
+    const int64_t ch = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x;
+    if (row >= nrow) return;
+    const double u = (double)uvw[3 * row], v = (double)uvw[3 * row + 1], w = (double)uvw[3 * row + 2];
+    const double fc = freqc[ch];
+    float acc[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = 0.0f;
+    for (int s = 0; s < nsrc; ++s) {
+        if (srcbad[s]) continue;   // wave-uniform; such sources act through colstate
+        const double l = lmn[4 * s], m = lmn[4 * s + 1], n = lmn[4 * s + 2];
+        const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
+        double yrd, yid;
+        sincos_quarter_turns<7>(__dmul_rn(q, fc), yrd, yid);       // fc in quarter turns per metre
+        const float yr = (float)yrd, yi = (float)yid;
+        const float *px = image + ((int64_t)s * nchan + ch) * NC * W;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if constexpr (CPLX) {
+                const float pr = px[2 * c], pi = px[2 * c + 1];
+                acc[c][0] = fmaf(pr, yr, fmaf(-pi, yi, acc[c][0]));
+                acc[c][1] = fmaf(pi, yr, fmaf(pr, yi, acc[c][1]));
+            } else {
+                const float p = px[c];
+                acc[c][0] = fmaf(p, yr, acc[c][0]);
+                acc[c][1] = fmaf(p, yi, acc[c][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float2 o = make_float2(acc[c][0], acc[c][1]);
+        const int st = colstate[ch * NC + c];
+        if (st == 1) o = make_float2(0.0f, 0.0f);
+        if (st == 2) o = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        reinterpret_cast<float2 *>(out)[(row * nchan + ch) * NC + c] = o;
+    }
+}
+
+struct Args32 {
+    const float *uvw, *image;
+    char *ws;
+    const Ws32 *L;
+    float *out;
+    int64_t nrow, nchan;
+    int nsrc, mode;
+    hipStream_t st;
+};
+
+template <int CT, int NC, bool CPLX>
+int launch32(const Args32 &a)
+{
+    const Ws32 &L = *a.L;
+    const dim3 grid((unsigned)af_cdiv(a.nrow, ROWS), (unsigned)L.ntile), block(ROWS);
+    const float *rec = reinterpret_cast<const float *>(a.ws + L.records);
+    const double *lmn = reinterpret_cast<const double *>(a.ws + L.lmn), *tilef = reinterpret_cast<const double *>(a.ws + L.tilef);
+    const float *kappa = reinterpret_cast<const float *>(a.ws + L.kappa);
+    const int *flags = reinterpret_cast<const int *>(a.ws + L.flags), *colstate = reinterpret_cast<const int *>(a.ws + L.colstate);
+    const int *tilestate = reinterpret_cast<const int *>(a.ws + L.tilestate);
+    if (a.mode != AF_DFT_EXACT) {
+        af_prof_begin(a.st);
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, false>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 0);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, true>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 1);
+        af_prof_end(a.st);
+        AF_LAUNCH_CHECK();
+    }
+    const dim3 gridx((unsigned)af_cdiv(a.nrow, ROWS), (unsigned)a.nchan);
+    hipLaunchKernelGGL((dft_f32_exact_kernel<NC, CPLX>), gridx, block, 0, a.st, a.uvw, a.image, lmn,
+                       reinterpret_cast<const int *>(a.ws + L.srcbad), reinterpret_cast<const double *>(a.ws + L.freqc), flags,
+                       colstate, a.out, a.nrow, a.nsrc, a.nchan, a.mode == AF_DFT_EXACT ? -1 : 2);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+
+template <bool CPLX>
+int launch32_nc(const Args32 &a, int64_t ncorr)
+{
+    constexpr int CT0 = CPLX ? 15 : 16, CT1 = CPLX ? 20 : 22, CT2 = CPLX ? 30 : 32;
+    const int ct = a.L->ct;
+    if (ncorr == 4) return ct == CT2 ? launch32<CT2, 4, CPLX>(a) : ct == CT1 ? launch32<CT1, 4, CPLX>(a) : launch32<CT0, 4, CPLX>(a);
+    if (ct != CT0) {
+        af_set_error("af_im_to_vis_f32: AFHIP_F32_CT applies to 4 correlations only");
+        return AF_EINVAL;
+    }
+    if (ncorr == 2) return launch32<CT0, 2, CPLX>(a);
+    return launch32<CT0, 1, CPLX>(a);
+}
+
+}  // namespace
+
+AF_EXPORT size_t af_im_to_vis_f32_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t ncorr, int image_is_complex)
+{
+    if (nsrc < 0 || nchan < 0 || ncorr < 0) return 0;
+    return ws32_layout(nsrc, nchan, ncorr, image_is_complex).total;
+}
+
+AF_EXPORT int af_im_to_vis_f32(const float *image, int image_is_complex, const float *uvw, const float *lm,
+                               const float *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                               int convention, int mode, float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
+               "convention not in ('fourier', 'casa')");
+    AF_REQUIRE(mode == AF_DFT_AUTO || mode == AF_DFT_EXACT || mode == AF_DFT_RECURRENCE, "af_im_to_vis_f32: unknown mode %d", mode);
+    AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_im_to_vis_f32: negative extent");
+    AF_REQUIRE(nsrc < (1LL << 31), "af_im_to_vis_f32: nsrc too large");
+    if (!(ncorr == 0 || ncorr == 1 || ncorr == 2 || ncorr == 4)) {
+        af_set_error("af_im_to_vis_f32: %lld correlations (1, 2 or 4 have a float32 kernel; promote to float64 for others)",
+                     (long long)ncorr);
+        return AF_ENOTSUP;
+    }
+    hipStream_t st = af_stream(stream);
+    if (nrow == 0 || nchan == 0 || ncorr == 0) return AF_OK;
+    AF_REQUIRE(out != nullptr && uvw != nullptr && frequency != nullptr, "af_im_to_vis_f32: NULL array");
+    if (nsrc == 0) {   // np.zeros output (kernels.py:45)
+        AF_HIP(hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)(nrow * nchan * ncorr), st));
+        return AF_OK;
+    }
+    AF_REQUIRE(image != nullptr && lm != nullptr, "af_im_to_vis_f32: NULL array");
+    const Ws32 L = ws32_layout(nsrc, nchan, ncorr, image_is_complex);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total, "af_im_to_vis_f32: workspace too small (%zu < %zu)",
+               workspace_bytes, L.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_im_to_vis_f32: workspace must be 256-byte aligned");
+    AF_REQUIRE(L.ntile <= 65535 && nchan <= 65535, "af_im_to_vis_f32: too many channels");
+    char *ws = static_cast<char *>(workspace);
+    const int W = image_is_complex ? 2 : 1;
+    AF_HIP(hipMemsetAsync(ws + L.flags, 0, 16 * sizeof(int), st));
+    AF_HIP(hipMemsetAsync(ws + L.tilestate, 0, (size_t)L.ntile * sizeof(int), st));
+    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc,
+                       reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad));
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(f32_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan, L.ntile, L.ct,
+                       convention, reinterpret_cast<double *>(ws + L.tilef), reinterpret_cast<float *>(ws + L.kappa),
+                       reinterpret_cast<double *>(ws + L.freqc), reinterpret_cast<int *>(ws + L.flags));
+    AF_LAUNCH_CHECK();
+    if (mode == AF_DFT_RECURRENCE)   // the caller asserts a uniform band: the grid of every tile, no correction
+        AF_HIP(hipMemsetAsync(ws + L.flags, 0, sizeof(int), st));
+    {
+        const int64_t total = L.ntile * nsrc * (int64_t)L.groups * G32;
+        int64_t blocks = af_cdiv(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((f32_pack_records<float>), dim3((unsigned)blocks), dim3(256), 0, st, image, image_is_complex ? 1 : 0, nsrc, nchan, ncorr,
+                           L.ntile, L.ct, L.groups, reinterpret_cast<const int *>(ws + L.srcbad),
+                           reinterpret_cast<float *>(ws + L.records));
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(f32_colstate, dim3((unsigned)(L.ntile * L.ct * ncorr)), dim3(64), 0, st, image, W, nsrc, nchan,
+                           ncorr, L.ct, reinterpret_cast<const int *>(ws + L.srcbad), reinterpret_cast<int *>(ws + L.colstate),
+                           reinterpret_cast<int *>(ws + L.tilestate));
+        AF_LAUNCH_CHECK();
+    }
+    Args32 a;
+    a.uvw = uvw; a.image = image; a.ws = ws; a.L = &L; a.out = out; a.nrow = nrow; a.nchan = nchan; a.nsrc = (int)nsrc;
+    a.mode = mode; a.st = st;
+    return image_is_complex ? launch32_nc<true>(a, ncorr) : launch32_nc<false>(a, ncorr);
+}

@@ -62,7 +62,11 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
     ``frequency`` (chan,) -> complex (row, chan, corr); output dtype ``dtype`` or
     ``result_type(complex64, image, uvw, lm, frequency)``; ``n`` is NOT clamped (NaN outside
     the unit disc, kernels.py:54) and zero pixels are skipped (kernels.py:64).
-    Arithmetic is always float64 on the device; a complex64 result is rounded once at the end.
+    Arithmetic is float64 on the device, with one exception: when EVERY input is single precision (float32 / complex64
+    image, float32 uvw, lm and frequency) and the result is complex64 -- the case in which the reference runs its whole
+    loop in float32 -- ``af_im_to_vis_f32`` computes phases in float64 and phasors, recurrence and sums in float32
+    (csrc/af_im_to_vis_f32.hip: at least as close to the float64 transform of those inputs as the reference's float32
+    loop, at about twice the float64 rate).  ``AFHIP_DFT_F32=0`` keeps such calls on the float64 path.
     """
     if convention not in _lib.CONVENTION:
         raise ValueError("convention not in ('fourier', 'casa')")
@@ -82,6 +86,19 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
     if int(lm.shape[0]) != nsrc or tuple(frequency.shape) != (nchan,):
         raise ValueError("image (source, chan, corr), lm (source, 2) and frequency (chan,) disagree")
     is_cplx = img_dt.kind == "c"
+    single = (out_dtype == np.dtype(np.complex64) and img_dt in (np.dtype(np.float32), np.dtype(np.complex64))
+              and all(np_dtype_of(a) == np.dtype(np.float32) for a in (uvw, lm, frequency))
+              and ncorr in (1, 2, 4) and get_mode() != "valu" and os.environ.get("AFHIP_DFT_F32", "1") != "0")
+    if single:
+        with Call(image, uvw, lm, frequency) as c:
+            p_img = c.inp(image, np.complex64 if is_cplx else np.float32)
+            p_uvw, p_lm, p_fr = c.inp(uvw, np.float32), c.inp(lm, np.float32), c.inp(frequency, np.float32)
+            p_out, h = c.out((nrow, nchan, ncorr), np.complex64)
+            ws_bytes = int(_lib.load().af_im_to_vis_f32_workspace_bytes(nsrc, nchan, ncorr, int(is_cplx)))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_im_to_vis_f32", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
+                      _lib.CONVENTION[convention], _MODES[get_mode()], p_out, p_ws, max(ws_bytes, 256), c.stream)
+            return c.result(h)
     with Call(image, uvw, lm, frequency) as c:
         p_img = c.inp(image, np.complex128 if is_cplx else np.float64)
         p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)

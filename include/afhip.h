@@ -144,6 +144,20 @@ int af_im_to_vis_f64(const double *image, int image_is_complex, const double *uv
                      int64_t nchan, int64_t ncorr, int convention, int mode, double *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* im_to_vis for single-precision callers: float32 image (complex64 when image_is_complex), uvw, lm and frequency ->
+ * complex64 out.  The reference runs this case entirely in float32 (result dtype by promotion,
+ * africanus/dft/kernels.py:26-31, africanus/util/type_inference.py:24-26); here phases are formed in float64 from the
+ * promoted inputs, phasors / channel recurrence / sums are float32 (csrc/af_im_to_vis_f32.hip).  Contract: at least as
+ * close to the float64 transform of the same inputs as the reference's float32 loop.  ncorr in {1, 2, 4}
+ * (AF_ENOTSUP otherwise: promote and call af_im_to_vis_f64).  Same zero-pixel / NaN-source semantics, same `mode`
+ * values (AF_DFT_RECURRENCE additionally asserts that the float32 frequency axis is meant to be uniform: its
+ * rounding is then not followed channel by channel). */
+size_t af_im_to_vis_f32_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t ncorr, int image_is_complex);
+int af_im_to_vis_f32(const float *image, int image_is_complex, const float *uvw, const float *lm,
+                     const float *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                     int convention, int mode, float *out, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
 /* ---- vis_to_im --------------------------------------------------------------
  * Replaces africanus.dft.vis_to_im (africanus/dft/kernels.py:72-148), the adjoint of im_to_vis.
  *   vis (nrow,nchan,ncorr) complex128; uvw (nrow,3); lm (nsrc,2); frequency (nchan);
