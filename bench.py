@@ -13,6 +13,7 @@ Workloads (--workload), one per BASELINE config a single GPU can run:
     dft          im_to_vis, real 4-correlation image: BASELINE configs[1], the HEADLINE and the default
                  (1e6 rows x 64 chan x 1000 point sources x 4 corr, fp64)
     dft_complex  the same transform with complex brightness matrices (= the fused predict without DDEs)
+    dft_f32      the same transform for single-precision callers (float32 in, complex64 out; af_im_to_vis_f32)
     fused_dde    fused predict with per-antenna beam-cube DDEs, 64 antennas: BASELINE configs[2]
     degrid       convolutional degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7x7 taps: BASELINE configs[4]
     wgrid        wgridder-style degridding of a 4096^2 image at epsilon 1e-5: BASELINE configs[4] as named
@@ -69,7 +70,7 @@ PMC_ROUNDS = ("r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, n
 NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
                      "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
                                "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
-EXTRA_WORKLOADS = ("dft_complex", "fused_dde", "degrid", "wgrid")
+EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid")
 DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
 
 
@@ -83,7 +84,7 @@ def parse(argv=None):
     p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "fused_dde", "degrid", "wgrid"])
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid"])
     p.add_argument("--extras", default="auto",
                    help="other workloads timed for a few steps into \"workloads\" of the same JSON line: auto (all of "
                         "them when N = 1, the workload is the headline and the shape is the default), all, none, or a "
@@ -253,6 +254,75 @@ class Dft(object):
             "sample_rows": s["rows"], "sample_seconds": s["seconds"],
             "numba_calibration": NUMBA_CALIBRATION,
         }
+
+
+class DftF32(object):
+    """im_to_vis with every input float32 -> complex64 (af_im_to_vis_f32: fp64 phasors, fp32 matrix-pipe sums): the
+    single-precision call of africanus/dft/kernels.py:26-31, at BASELINE configs[1]'s counts.  Not the headline (that is
+    fp64); its step has no chi^2 (the chi^2 entry is complex128).  Errors are against the float64 transform of the
+    same float32 inputs."""
+    vis_dtype, chi2 = "complex64", False
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        from codex_africanus_amd.testing import synthetic_inputs, real_image
+        self.args, self._lib = args, _lib
+        nrow, nchan, nsrc = args.rows, args.chans, args.sources
+        self.ncorr = 4
+        d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
+        rng = np.random.default_rng(1000 + args.seed + rank)
+        uvw = np.empty((nrow, 3), np.float32)
+        uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        self.image, self.uvw = real_image(d).astype(np.float32), uvw
+        self.lm, self.freq = d["lm"].astype(np.float32), d["frequency"].astype(np.float32)
+        self.dv = [t(a) for a in (self.image, self.uvw, self.lm, self.freq)]
+        self.ws_bytes = int(lib.af_im_to_vis_f32_workspace_bytes(nsrc, nchan, 4, 0))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.label = "im_to_vis DFT predict in single precision (float32 in, complex64 out; BASELINE configs[1]'s counts)"
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_im_to_vis_f32", P(v[0]), 0, P(v[1]), P(v[2]), P(v[3]), a.sources, a.rows, a.chans, 4,
+                       self._lib.CONVENTION["fourier"], self._lib.AF_DFT_AUTO, P(d_vis), P(self.d_ws), self.ws_bytes, stream)
+
+    def reference_rows(self, rows):
+        import oracle
+        f = lambda x: x.astype(np.float64)
+        return oracle.im_to_vis(f(self.image), f(self.uvw[rows]), f(self.lm), f(self.freq), omp=True), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        units = float(a.rows) * a.chans * a.sources
+        # per (row, chan, src): 2 fp64 FMA (recurrence) + 2 fp64->fp32 conversions + 3 fp32 (band correction) on the VALU,
+        # 8 fp32 MACs on the matrix pipe (v_mfma_f32_4x4x1_16b: 8 issue cycles per 256 MACs = the fp32 vector rate);
+        # counted as the fp64 headline counts it: 20 flop per unit (2 FMA + 8 MAC), against the fp64 pipe's peak, so the
+        # fraction compares directly with the headline's
+        return dict(kernel="dft_f32_kernel<16,4,false,true>", bound="mfma", alg_flops=units * 20.0,
+                    alg_bytes=float(a.rows) * a.chans * 32 + a.rows * 12.0 + a.sources * a.chans * 16.0,
+                    channels_in_kernel=a.chans,
+                    note="single precision: fp64 phasors (VALU) + fp32 MACs (matrix pipe, 4x4x1 blocks, pixels broadcast by "
+                         "CBSZ/ABID); 20 flop per (row, chan, src) as for the fp64 headline, quoted against the fp64 peak")
+
+    def cpu_baseline(self, min_seconds):
+        import oracle
+        threads = _threads()
+        f = lambda x: x.astype(np.float64)
+        img, lm, fr = f(self.image), f(self.lm), f(self.freq)
+
+        def parallel(n):
+            t0 = time.perf_counter()
+            oracle.im_to_vis(img, f(self.uvw[:n]), lm, fr, omp=True, dtype=np.complex64)
+            return time.perf_counter() - t0
+
+        s = sized_cpu_sample(lambda n: oracle.im_to_vis(img, f(self.uvw[:n]), lm, fr, omp=False, dtype=np.complex64), parallel,
+                             self.uvw.shape[0], threads, min_seconds)
+        one = a_chans = self.args.chans / s["per_row_s"] / 1e6
+        return {"value": s["rows"] * self.args.chans / s["seconds"] / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+                "sample": "oracle im_to_vis with complex64 accumulation (the reference's dtype=complex64 loop, fp64 phases), "
+                          "%d rows in %.2f s on %d threads" % (s["rows"], s["seconds"], threads),
+                "single_thread_value": one}
 
 
 class FusedDde(object):
@@ -594,7 +664,7 @@ class Wgrid(object):
         }
 
 
-WORKLOADS = {"dft": Dft, "dft_complex": Dft, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid}
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid}
 METRIC = "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err"
 
 
@@ -694,20 +764,23 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
     P = lambda x: ctypes.c_void_p(x.data_ptr())
     wl = WORKLOADS[workload](wargs, rank, dev, lib, _lib, t)
     nrow, nchan, nsrc, ncorr = args.rows, args.chans, args.sources, wl.ncorr
-    d_vis = torch.empty((nrow, nchan, ncorr), dtype=torch.complex128, device=dev)
+    have_chi2 = getattr(wl, "chi2", True)
+    d_vis = torch.empty((nrow, nchan, ncorr), dtype=getattr(torch, getattr(wl, "vis_dtype", "complex128")), device=dev)
     d_chi2 = torch.zeros(nchan, dtype=torch.float64, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     # "observed" data for the chi^2: the model itself plus a fixed perturbation (one extra predict)
     wl.predict(d_vis, stream, P)
-    d_data = d_vis.clone()
-    d_data += 0.01
+    if have_chi2:
+        d_data = d_vis.clone()
+        d_data += 0.01
 
     def step():
         wl.predict(d_vis, stream, P)
-        _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
-        if world > 1:
-            dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
+        if have_chi2:
+            _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
+            if world > 1:
+                dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
 
     for _ in range(warmup):
         step()
@@ -741,7 +814,7 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
         return None
     max_err = check_rows(wl, d_vis, nrow, args.check_rows, dev) if args.check_rows > 0 else None
     res = {
-        "label": wl.label, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
+        "label": wl.label, "has_chi2": have_chi2, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
         "corrs": ncorr, "fp64_max_abs_err": max_err, "roofline": roofline_entry(wl, wargs, workload, kernel_s),
     }
@@ -758,7 +831,8 @@ def headline_json(args, res, world_desc, backend_desc):
         "n_gpus": n, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": res["label"] + " + per-channel chi^2" + ("" if n == 1 else " + " + backend_desc),
+            "workload": res["label"] + (" + per-channel chi^2" if res.get("has_chi2", True) else " (no chi^2 in the step)")
+                        + ("" if n == 1 else " + " + backend_desc),
             "rows_per_gpu": nrow, "chans": nchan, "sources": nsrc, "corrs": res["corrs"],
             "rows_total": n * nrow, "phasor_mode": args.mode,
             "sharding": "rows over %d GPU(s), no data-path collective; chi2 (nchan,) all-reduce (%s)"
@@ -899,7 +973,8 @@ def run_ranks(args):
                 continue
             roof = r["roofline"]
             extras[name] = {
-                "label": r["label"], "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"],
+                "label": r["label"] + ("" if r.get("has_chi2", True) else " (no chi^2 in the step)"), "steps": r["steps"],
+                "ms_per_step": r["ms_per_step"], "value": r["value"],
                 "unit": "Mvis/s", "kernel_ms": roof["kernel_ms"], "fp64_max_abs_err": r["fp64_max_abs_err"],
                 "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                   "traffic_source")},
@@ -930,6 +1005,8 @@ def run_threads(args):
     from concurrent.futures import ThreadPoolExecutor
     from codex_africanus_amd import _lib, placement
     n = args.gpus
+    if not getattr(WORKLOADS[args.workload], "chi2", True):
+        raise SystemExit("--executor threads reduces the chi^2 across devices: workload %s has none" % args.workload)
     have = require_devices(n, "worker threads")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")

@@ -107,10 +107,11 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
     assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
     w = r["workloads"]
-    assert set(w) == {"dft_complex", "fused_dde", "degrid", "wgrid"}
+    assert set(w) == {"dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid"}
     for name, e in w.items():
         assert "error" not in e, (name, e)
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
         assert e["cpu_baseline"]["value"] > 0
     assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
+    assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
