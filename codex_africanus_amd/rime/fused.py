@@ -141,9 +141,7 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             raise ValueError("corr_schema must be a 2 x 2 schema, e.g. [['XX', 'XY'], ['YX', 'YY']]")
         if int(stokes.shape[0]) != nsrc or int(spi.shape[0]) != nsrc or tuple(ref_freq.shape) != (nsrc,):
             raise ValueError("stokes, spi, ref_freq and lm disagree on the number of sources")
-        if gauss_shape is not None and beam is None:
-            raise ValueError("gauss_shape without a beam is not fused yet")
-        if beam is None:
+        if beam is None and gauss_shape is None:
             # no DDEs: the model-level direct transform, phase_delay's clamped n
             vis = _model_dft(stokes, spi, ref_freq, uvw, lm, frequency, m_base, m_tabs, m_npol, convention)
             if die1_jones is None and base_vis is None:
@@ -153,6 +151,29 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         flat_spectrum = False
     elif brightness is None:
         raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
+    if gauss_shape is not None and not have_beam:
+        # Gaussian sources without a beam: the phase x shape x brightness sum is what the fused kernel's accumulating
+        # stage evaluates once its Jones terms are the identity -- a 2 x 2 x 2 cube of identity matrices sampled
+        # anywhere gives E = 1 (bilinear weights sum to one; the amplitude-preserving normalisation of
+        # africanus/rime/fast_beam_cubes.py:227-235 maps 1 to 1 and the zero off-diagonals to 0), so G = E X = X and
+        # V = sum_s shape K X_s, the einsum("srf,srf,sfij->srfij") + source sum of africanus/rime/examples/predict.py:107-134.
+        # (The direct-transform kernels cannot carry the shape: their per-source operand is a (chan, corr) pixel, the
+        # shape depends on the row.)  Costs the full Jones algebra of the fused kernel: see DESIGN.md 3.3.
+        ti_h = np.asarray(_host(time_index))
+        nant_i = int(max(int(np.asarray(_host(antenna1)).max(initial=0)), int(np.asarray(_host(antenna2)).max(initial=0)))) + 1
+        ntime_i = int(ti_h.max() - ti_h.min()) + 1 if ti_h.size else 1
+        fr_h = np.asarray(_host(frequency), dtype=np.float64)
+        ident = np.zeros((2, 2, 2, 2, 2), dtype=np.complex128)
+        ident[..., 0, 0] = ident[..., 1, 1] = 1.0
+        beam = ident
+        beam_lm_extents = np.array([[-2.0, 2.0], [-2.0, 2.0]])
+        lo, hi = (float(fr_h.min()), float(fr_h.max())) if fr_h.size else (1.0, 2.0)
+        beam_freq_map = np.array([0.5 * lo, 2.0 * hi + 1.0])          # every channel inside the cube: no lm scaling
+        parallactic_angles = np.zeros((ntime_i, nant_i))
+        point_errors = np.zeros((ntime_i, nant_i, nchan, 2))
+        antenna_scaling = np.ones((nant_i, nchan, 2))
+        beam_args = (beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
+        have_beam = True
     bshape = tuple(int(s) for s in brightness.shape) if brightness is not None else (nsrc, nchan, 2, 2)
     if bshape == (nsrc, 2, 2):
         flat_spectrum = True
@@ -180,9 +201,6 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             p_mb = c.inp(m_base, np.int32)
         p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
         conv = _lib.CONVENTION[convention]
-        if not have_beam and gauss_shape is not None:
-            raise ValueError("gauss_shape without a beam is not fused yet: multiply model.shape.gaussian into "
-                             "the coherencies, or use rime.wsclean_predict for single-correlation components")
         if not have_beam:
             # sum_s K X_s: the direct transform with a complex image and phase_delay's clamped n
             ws_bytes = int(_lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, 4, 1))

@@ -204,3 +204,38 @@ def test_fused_plan_is_reusable_and_checked():
         rime.fused_predict_vis(d["time_index"][:-1], d["ant1"][:-1], d["ant2"][:-1], d["lm"], d["uvw"][:-1], *args[2:], plan=plan)
     with pytest.raises(ValueError, match="antenna index out of range"):
         rime.fused_plan(d["time_index"], d["ant1"] + 20, d["ant2"], 12)
+
+
+def test_gaussian_sources_without_a_beam():
+    """VERDICT r2 'missing 3': gauss_shape with no beam used to raise.  The call now runs the fused kernel with identity
+    Jones terms: V = sum_s shape K X_s = predict_vis over einsum("srf,srf,sfij->srfij", phase, shape, brightness)
+    (africanus/rime/examples/predict.py:107-134, africanus/model/shape/gaussian_shape.py:21-62); with DIE terms and
+    base_vis on top; numpy and device-resident inputs"""
+    import torch
+    d = _problem(23, 900, 6, 21, 12)
+    rng = np.random.default_rng(6)
+    nsrc = d["lm"].shape[0]
+    sp = np.stack([rng.uniform(0, 3e-4, nsrc), rng.uniform(0, 2e-4, nsrc), rng.uniform(0, np.pi, nsrc)], axis=1)
+    sp[::4] = 0.0
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"])
+    shape = oracle.gaussian_shape(d["uvw"], d["frequency"], sp)
+    coh = np.einsum("srf,srf,sfij->srfij", phase, shape, d["X"])
+    ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, None, None, None)
+    out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                                 gauss_shape=sp)
+    assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-9 * _scale(d)
+    # all point sources: equal to the plain no-beam call
+    zero = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                                  gauss_shape=np.zeros((nsrc, 3)))
+    plain = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"])
+    assert np.abs(zero - plain).max() <= 1e-9 * _scale(d)
+    # device resident, with gains and base visibilities
+    dev = torch.device("cuda:0")
+    ntime = int(d["time_index"].max()) + 1
+    die = (rng.standard_normal((ntime, 12, 6, 2, 2)) + 1j * rng.standard_normal((ntime, 12, 6, 2, 2)))
+    bvis = rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    got = rime.fused_predict_vis(T(d["time_index"]), T(d["ant1"]), T(d["ant2"]), T(d["lm"]), T(d["uvw"]), T(d["frequency"]),
+                                 T(d["X"]), die1_jones=T(die), base_vis=T(bvis), die2_jones=T(die), gauss_shape=T(sp))
+    ref2 = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], None, coh, None, die, bvis, die)
+    assert np.abs(got.cpu().numpy() - ref2).max() <= 1e-9 * np.abs(ref2).max()
