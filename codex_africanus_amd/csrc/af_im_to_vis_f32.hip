@@ -450,6 +450,242 @@ int launch32_nc(const Args32 &a, int64_t ncorr)
     return launch32<CT0, 1, CPLX>(a);
 }
 
+
+// =====================================================================================================================
+// vis_to_im in single precision (africanus/dft/kernels.py:104-146 with complex64 visibilities and float32 coordinates):
+//     im[s,nu,c] = sum_r [no correlation of (r,nu) flagged] ( cos p Re V - sin p Im V ),  p = C (l u + m v + n w) nu
+// the machinery above with rows and sources swapped: a lane owns one SOURCE and a tile of CT channels x 4 real
+// accumulators (one MFMA quad per channel), the wave walks the rows of its row partition; a row's record holds the
+// planes (Re V, -Im V) of the tile's channels (2 blocks per channel, 8 channels per register), flag-masked by the
+// pack pass; phasors in fp64 (table + recurrence), rounded to float32 once, then
+//     acc[chan] += (Re V) yr ; acc[chan] += (-Im V) yi          (two MFMAs per channel).
+// Partial images per row partition are added in partition order (fp64 sums) by v2i32_reduce.
+struct WsV32 {
+    size_t flags, lmn, srcbad, tilef, kappa, freqc, uvw, chan_any, records, partial, total;
+    int64_t ntile, npart, rows_per_part;
+    int ct, groups;
+};
+
+constexpr int V32_CT = 32;
+
+WsV32 wsv32_layout(int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr)
+{
+    WsV32 L;
+    L.ct = V32_CT;
+    L.ntile = af_cdiv(nchan > 0 ? nchan : 1, L.ct);
+    L.groups = L.ct / 8;
+    const int64_t nsg = af_cdiv(nsrc > 0 ? nsrc : 1, ROWS);
+    int64_t npart = af_cdiv(2048, nsg * L.ntile);
+    const int64_t most = af_cdiv(nrow > 0 ? nrow : 1, 256);           // at least 256 rows per partition
+    if (npart > most) npart = most;
+    if (npart < 1) npart = 1;
+    L.rows_per_part = af_cdiv(nrow > 0 ? nrow : 1, npart);
+    L.npart = af_cdiv(nrow > 0 ? nrow : 1, L.rows_per_part);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
+    L.flags = take(16 * sizeof(int));
+    L.lmn = take((size_t)(nsrc > 0 ? nsrc : 1) * 4 * sizeof(double));
+    L.srcbad = take((size_t)(nsrc > 0 ? nsrc : 1) * sizeof(int));
+    L.tilef = take((size_t)L.ntile * 2 * sizeof(double));
+    L.kappa = take((size_t)L.ntile * L.ct * sizeof(float));
+    L.freqc = take((size_t)(nchan > 0 ? nchan : 1) * sizeof(double));
+    L.uvw = take((size_t)(nrow > 0 ? nrow : 1) * 4 * sizeof(double));
+    L.chan_any = take((size_t)L.ntile * L.ct * sizeof(int));
+    L.records = take((size_t)L.ntile * (nrow > 0 ? nrow : 1) * L.groups * G32 * sizeof(float));
+    L.partial = take((size_t)L.npart * (nsrc > 0 ? nsrc : 1) * (nchan > 0 ? nchan : 1) * 4 * sizeof(float));
+    L.total = o;
+    return L;
+}
+
+// (u, v, w, 0) of every row in fp64, zeros for a non-finite row (its unflagged cells become NaN in the records)
+__global__ void v2i32_prep_rows(const float *__restrict__ uvw, int64_t nrow, double *__restrict__ uvw64)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const double a = (double)uvw[3 * r], b = (double)uvw[3 * r + 1], c = (double)uvw[3 * r + 2];
+    const bool ok = isfinite(a) && isfinite(b) && isfinite(c);
+    uvw64[4 * r + 0] = ok ? a : 0.0; uvw64[4 * r + 1] = ok ? b : 0.0; uvw64[4 * r + 2] = ok ? c : 0.0;
+    uvw64[4 * r + 3] = ok ? 0.0 : 1.0;
+}
+
+// records: [tile][row][groups * 64] floats; register g, block k = channel 8 g + k / 2 of the tile, plane k % 2 of
+// (Re V, -Im V), floats = correlations 0..3.  Zero for flagged (row, chan) cells (ANY correlation flagged,
+// kernels.py:139-140), channels beyond the band and correlations beyond ncorr; NaN for unflagged cells of a
+// non-finite row.  chan_any[chan] = some row of the channel is unflagged.
+__global__ void v2i32_pack(const float2 *__restrict__ vis, const unsigned char *__restrict__ vflags,
+                           const double *__restrict__ uvw64, int64_t nrow, int64_t nchan, int64_t ncorr, int64_t ntile,
+                           int CT, int groups, float *__restrict__ rec, int *__restrict__ chan_any)
+{
+    const int64_t per = (int64_t)groups * G32;
+    const int64_t total = ntile * nrow * per;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t slot = i % per, r = (i / per) % nrow, tile = i / (per * nrow);
+        const int g = (int)(slot / G32), blk = (int)(slot % G32) / 4, c = (int)(slot % 4);
+        const int j = g * 8 + blk / 2, plane = blk % 2;
+        const int64_t ch = tile * CT + j;
+        float v = 0.0f;
+        if (j < CT && ch < nchan) {
+            const unsigned char *f = vflags + (r * nchan + ch) * ncorr;
+            bool flagged = false;
+            for (int k = 0; k < (int)ncorr; ++k) flagged |= f[k] != 0;
+            if (!flagged) {
+                if (c == 0 && plane == 0) chan_any[ch] = 1;   // benign race: all writers store 1
+                if (c < ncorr) {
+                    const float2 x = vis[(r * nchan + ch) * ncorr + c];
+                    v = plane == 0 ? x.x : -x.y;
+                    if (uvw64[4 * r + 3] != 0.0) v = __builtin_nanf("");
+                }
+            }
+        }
+        rec[i] = v;
+    }
+}
+
+// grid: (ceil(nsrc / 256), tiles, row partitions); block 256 = 4 waves of 64 consecutive sources
+template <int CT, bool CORR>
+__global__ __launch_bounds__(ROWS, 2) void v2i_f32_kernel(
+    const double *__restrict__ lmn, const double *__restrict__ uvw64, const float *__restrict__ records,
+    const double *__restrict__ tilef, const float *__restrict__ kappa, const int *__restrict__ flags,
+    float *__restrict__ partial, int64_t nsrc, int64_t nrow, int64_t rows_per_part, int64_t nchan, int want_class)
+{
+    if (flags[0] != want_class) return;
+    __shared__ double2 ptab[PHASOR_TABLE];
+    table_phasor_init(ptab, threadIdx.x, ROWS);
+    __syncthreads();
+    constexpr int NG = CT / 8;
+    const int tile = blockIdx.y;
+    const int64_t c0 = (int64_t)tile * CT;
+    int64_t src = (int64_t)blockIdx.x * ROWS + threadIdx.x;
+    const bool valid = src < nsrc;
+    if (!valid) src = nsrc - 1;
+    const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
+    const double F0 = 256.0 * tilef[2 * tile], FD = 256.0 * tilef[2 * tile + 1];
+    float kap[CT];
+    if constexpr (CORR) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) kap[j] = kappa[tile * CT + j];
+    }
+    v4f acc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_part;
+    const int64_t r1 = r0 + rows_per_part < nrow ? r0 + rows_per_part : nrow;
+    const int lane = threadIdx.x & 63;
+    const float *__restrict__ rec = records + (int64_t)tile * nrow * (NG * G32) + lane;
+    float R[NG], Rn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) R[g] = rec[r0 * (NG * G32) + g * G32];
+
+#pragma unroll 1
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t rn = r + 1 < r1 ? r + 1 : r;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) Rn[g] = rec[rn * (NG * G32) + g * G32];
+        const double u = uvw64[4 * r], v = uvw64[4 * r + 1], w = uvw64[4 * r + 2];   // wave-uniform: scalar loads
+        const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
+        double y0r, y0i, dr, di;
+        table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
+        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
+        const float qf = (float)q;
+        const double k2 = __dadd_rn(dr, dr);
+        double y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
+        double y1i = fma(y0r, di, __dmul_rn(y0i, dr));
+        float yr[CT], yi[CT];
+        static_for32<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            double yrd, yid;
+            if constexpr (j == 0) { yrd = y0r; yid = y0i; }
+            else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
+            else {
+                yrd = fma(k2, y1r, -y0r);
+                yid = fma(k2, y1i, -y0i);
+                y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+            }
+            yr[j] = (float)yrd; yi[j] = (float)yid;
+            if constexpr (CORR) {
+                const float th = qf * kap[j];
+                const float cr = fmaf(-th, yi[j], yr[j]), ci = fmaf(th, yr[j], yi[j]);
+                yr[j] = cr; yi[j] = ci;
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for32<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[j / 8], yr[j], acc[j], 4, (j % 8) * 2, 0);        // + Re V cos
+        });
+        static_for32<0, CT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[j / 8], yi[j], acc[j], 4, (j % 8) * 2 + 1, 0);    // - Im V sin
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) R[g] = Rn[g];
+    }
+    if (!valid) return;
+    float *__restrict__ o = partial + (((int64_t)blockIdx.z * nsrc + src) * nchan + c0) * 4;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+        if (c0 + j < nchan) *reinterpret_cast<float4 *>(o + j * 4) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+}
+
+// any band: one fp64 sincos per (source, row, channel).  grid: (ceil(nsrc / 256), nchan, row partitions)
+__global__ __launch_bounds__(ROWS) void v2i_f32_exact_kernel(
+    const double *__restrict__ lmn, const double *__restrict__ uvw64, const float2 *__restrict__ vis,
+    const unsigned char *__restrict__ vflags, const double *__restrict__ freqc, const int *__restrict__ flags,
+    float *__restrict__ partial, int64_t nsrc, int64_t nrow, int64_t rows_per_part, int64_t nchan, int ncorr,
+    int want_class)
+{
+    if (want_class >= 0 && flags[0] != want_class) return;
+    const int64_t ch = blockIdx.y;
+    int64_t src = (int64_t)blockIdx.x * ROWS + threadIdx.x;
+    const bool valid = src < nsrc;
+    if (!valid) src = nsrc - 1;
+    const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
+    const double fc = freqc[ch];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_part;
+    const int64_t r1 = r0 + rows_per_part < nrow ? r0 + rows_per_part : nrow;
+    for (int64_t r = r0; r < r1; ++r) {
+        const unsigned char *f = vflags + (r * nchan + ch) * ncorr;
+        bool flagged = false;
+        for (int k = 0; k < ncorr; ++k) flagged |= f[k] != 0;
+        if (flagged) continue;   // wave-uniform
+        const double u = uvw64[4 * r], v = uvw64[4 * r + 1], w = uvw64[4 * r + 2];
+        const bool badrow = uvw64[4 * r + 3] != 0.0;
+        const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
+        double yrd, yid;
+        sincos_quarter_turns<7>(__dmul_rn(q, fc), yrd, yid);
+        const float yr = badrow ? __builtin_nanf("") : (float)yrd, yi = badrow ? __builtin_nanf("") : (float)yid;
+        for (int c = 0; c < ncorr; ++c) {
+            const float2 x = vis[(r * nchan + ch) * ncorr + c];
+            acc[c] = fmaf(x.x, yr, fmaf(-x.y, yi, acc[c]));
+        }
+    }
+    if (!valid) return;
+    float *__restrict__ o = partial + (((int64_t)blockIdx.z * nsrc + src) * nchan + ch) * 4;
+    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// out[s, chan, c] = sum over the row partitions, in partition order (fp64 sums); exactly 0 for a channel without an
+// unflagged row; NaN for a source outside the unit disc (p = NaN in the reference) where the channel has data
+__global__ void v2i32_reduce(const float *__restrict__ partial, const int *__restrict__ chan_any,
+                             const int *__restrict__ srcbad, int64_t npart, int64_t nsrc, int64_t nchan, int ncorr,
+                             float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (source, chan, corr)
+    if (i >= nsrc * nchan * ncorr) return;
+    const int c = (int)(i % ncorr);
+    const int64_t ch = (i / ncorr) % nchan, s = i / (ncorr * nchan);
+    double sum = 0.0;
+    for (int64_t p = 0; p < npart; ++p) sum += (double)partial[((p * nsrc + s) * nchan + ch) * 4 + c];
+    float v = (float)sum;
+    if (!chan_any[ch]) v = 0.0f;
+    else if (srcbad[s]) v = __builtin_nanf("");
+    out[i] = v;
+}
+
 }  // namespace
 
 AF_EXPORT size_t af_im_to_vis_f32_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t ncorr, int image_is_complex)
@@ -515,4 +751,86 @@ AF_EXPORT int af_im_to_vis_f32(const float *image, int image_is_complex, const f
     a.uvw = uvw; a.image = image; a.ws = ws; a.L = &L; a.out = out; a.nrow = nrow; a.nchan = nchan; a.nsrc = (int)nsrc;
     a.mode = mode; a.st = st;
     return image_is_complex ? launch32_nc<true>(a, ncorr) : launch32_nc<false>(a, ncorr);
+}
+
+AF_EXPORT size_t af_vis_to_im_f32_workspace_bytes(int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr)
+{
+    if (nsrc < 0 || nrow < 0 || nchan < 0 || ncorr < 0) return 0;
+    return wsv32_layout(nsrc, nrow, nchan, ncorr).total;
+}
+
+AF_EXPORT int af_vis_to_im_f32(const float *vis, const float *uvw, const float *lm, const float *frequency,
+                               const unsigned char *flags, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                               int convention, int mode, float *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
+               "convention not in ('fourier', 'casa')");
+    AF_REQUIRE(mode == AF_DFT_AUTO || mode == AF_DFT_EXACT || mode == AF_DFT_RECURRENCE, "af_vis_to_im_f32: unknown mode %d", mode);
+    AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_vis_to_im_f32: negative extent");
+    if (!(ncorr == 0 || ncorr == 1 || ncorr == 2 || ncorr == 4)) {
+        af_set_error("af_vis_to_im_f32: %lld correlations (1, 2 or 4 have a float32 kernel; promote to float64 for others)",
+                     (long long)ncorr);
+        return AF_ENOTSUP;
+    }
+    hipStream_t st = af_stream(stream);
+    if (nsrc == 0 || nchan == 0 || ncorr == 0) return AF_OK;
+    AF_REQUIRE(out != nullptr, "af_vis_to_im_f32: out is NULL");
+    if (nrow == 0) {   // np.zeros output (kernels.py:96)
+        AF_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)(nsrc * nchan * ncorr), st));
+        return AF_OK;
+    }
+    AF_REQUIRE(vis && uvw && lm && frequency && flags, "af_vis_to_im_f32: NULL array");
+    const WsV32 L = wsv32_layout(nsrc, nrow, nchan, ncorr);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= L.total, "af_vis_to_im_f32: workspace too small (%zu < %zu)",
+               workspace_bytes, L.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_vis_to_im_f32: workspace must be 256-byte aligned");
+    AF_REQUIRE(L.ntile <= 65535 && nchan <= 65535 && L.npart <= 65535, "af_vis_to_im_f32: too many channels / partitions");
+    char *ws = static_cast<char *>(workspace);
+    int *wflags = reinterpret_cast<int *>(ws + L.flags), *chan_any = reinterpret_cast<int *>(ws + L.chan_any);
+    double *lmn = reinterpret_cast<double *>(ws + L.lmn), *uvw64 = reinterpret_cast<double *>(ws + L.uvw);
+    int *srcbad = reinterpret_cast<int *>(ws + L.srcbad);
+    float *rec = reinterpret_cast<float *>(ws + L.records), *partial = reinterpret_cast<float *>(ws + L.partial);
+    AF_HIP(hipMemsetAsync(wflags, 0, 16 * sizeof(int), st));
+    AF_HIP(hipMemsetAsync(chan_any, 0, (size_t)L.ntile * L.ct * sizeof(int), st));
+    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, lmn, srcbad);
+    AF_LAUNCH_CHECK();
+    // vis_to_im's 'fourier' is exp(+2 pi i ...): the opposite sign of im_to_vis (kernels.py:113-118)
+    hipLaunchKernelGGL(f32_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan, L.ntile, L.ct,
+                       -convention, reinterpret_cast<double *>(ws + L.tilef), reinterpret_cast<float *>(ws + L.kappa),
+                       reinterpret_cast<double *>(ws + L.freqc), wflags);
+    AF_LAUNCH_CHECK();
+    if (mode == AF_DFT_RECURRENCE) AF_HIP(hipMemsetAsync(wflags, 0, sizeof(int), st));
+    hipLaunchKernelGGL(v2i32_prep_rows, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow, uvw64);
+    AF_LAUNCH_CHECK();
+    {
+        const int64_t total = L.ntile * nrow * (int64_t)L.groups * G32;
+        int64_t blocks = af_cdiv(total, 256);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(v2i32_pack, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(vis), flags,
+                           uvw64, nrow, nchan, ncorr, L.ntile, L.ct, L.groups, rec, chan_any);
+        AF_LAUNCH_CHECK();
+    }
+    const double *tilef = reinterpret_cast<const double *>(ws + L.tilef);
+    const float *kappa = reinterpret_cast<const float *>(ws + L.kappa);
+    const dim3 block(ROWS);
+    const unsigned nsg = (unsigned)af_cdiv(nsrc, ROWS);
+    if (mode != AF_DFT_EXACT) {
+        const dim3 grid(nsg, (unsigned)L.ntile, (unsigned)L.npart);
+        af_prof_begin(st);
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, false>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial, nsrc,
+                           nrow, L.rows_per_part, nchan, 0);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, true>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial, nsrc,
+                           nrow, L.rows_per_part, nchan, 1);
+        af_prof_end(st);
+        AF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(v2i_f32_exact_kernel, dim3(nsg, (unsigned)nchan, (unsigned)L.npart), block, 0, st, lmn, uvw64,
+                       reinterpret_cast<const float2 *>(vis), flags, reinterpret_cast<const double *>(ws + L.freqc), wflags, partial,
+                       nsrc, nrow, L.rows_per_part, nchan, (int)ncorr, mode == AF_DFT_EXACT ? -1 : 2);
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(v2i32_reduce, dim3((unsigned)af_cdiv(nsrc * nchan * ncorr, 256)), dim3(256), 0, st, partial, chan_any, srcbad,
+                       L.npart, nsrc, nchan, (int)ncorr, out);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
 }

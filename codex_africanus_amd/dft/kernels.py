@@ -141,6 +141,21 @@ def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
     nsrc = int(lm.shape[0])
     if int(uvw.shape[0]) != nrow or tuple(frequency.shape) != (nchan,):
         raise ValueError("vis (row, chan, corr), uvw (row, 3) and frequency (chan,) disagree")
+    single = (out_dtype == np.dtype(np.float32) and vdt in (np.dtype(np.complex64), np.dtype(np.float32))
+              and all(np_dtype_of(a) == np.dtype(np.float32) for a in (uvw, lm, frequency))
+              and ncorr in (1, 2, 4) and os.environ.get("AFHIP_DFT_F32", "1") != "0")
+    if single:   # every input single precision: phasors in float64, products and sums in float32 (af_vis_to_im_f32)
+        with Call(vis, uvw, lm, frequency, flags) as c:
+            p_vis = c.inp(vis, np.complex64)
+            p_uvw, p_lm, p_fr = c.inp(uvw, np.float32), c.inp(lm, np.float32), c.inp(frequency, np.float32)
+            p_fl = c.inp(flags, np.uint8)
+            p_out, h = c.out((nsrc, nchan, ncorr), np.float32)
+            ws_bytes = int(_lib.load().af_vis_to_im_f32_workspace_bytes(nsrc, nrow, nchan, ncorr))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_vis_to_im_f32", p_vis, p_uvw, p_lm, p_fr, p_fl, nsrc, nrow, nchan, ncorr,
+                      _lib.CONVENTION[convention], _MODES[get_mode()] & ~_lib.AF_DFT_VALU_ONLY, p_out, p_ws,
+                      max(ws_bytes, 256), c.stream)
+            return c.result(h)
     with Call(vis, uvw, lm, frequency, flags) as c:
         p_vis = c.inp(vis, np.complex128)
         p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)

@@ -158,6 +158,15 @@ int af_im_to_vis_f32(const float *image, int image_is_complex, const float *uvw,
                      int convention, int mode, float *out, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* vis_to_im for single-precision callers: complex64 vis, float32 uvw / lm / frequency -> float32 image (the reference
+ * computes this case in float32, africanus/dft/kernels.py:84-93); phasors in float64, products and sums in float32
+ * (csrc/af_im_to_vis_f32.hip), partial images of the row partitions added in float64.  Same flag / non-finite
+ * semantics as af_vis_to_im_f64; ncorr in {1, 2, 4} (AF_ENOTSUP otherwise). */
+size_t af_vis_to_im_f32_workspace_bytes(int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr);
+int af_vis_to_im_f32(const float *vis, const float *uvw, const float *lm, const float *frequency,
+                     const unsigned char *flags, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                     int convention, int mode, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- vis_to_im --------------------------------------------------------------
  * Replaces africanus.dft.vis_to_im (africanus/dft/kernels.py:72-148), the adjoint of im_to_vis.
  *   vis (nrow,nchan,ncorr) complex128; uvw (nrow,3); lm (nsrc,2); frequency (nchan);

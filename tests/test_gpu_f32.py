@@ -150,3 +150,73 @@ def test_full_size_c2_float32_linearity_and_sample():
     truth = _truth(img, uvw[rows], lm, fr)
     got = v1[torch.from_numpy(rows).to(dev)].cpu().numpy()
     assert np.abs(got - truth).max() < 1e-4 * np.abs(truth).max()
+
+
+# ------------------------------------------------------------------------------------------- vis_to_im, single precision
+def _truth_v2i(vis, uvw, lm, fr, flags, conv="fourier"):
+    return oracle.vis_to_im(vis.astype(np.complex128), uvw.astype(np.float64), lm.astype(np.float64),
+                            fr.astype(np.float64), flags, convention=conv)
+
+
+@pytest.mark.parametrize("kind", ["linspace", "exact"])
+def test_vis_to_im_f32_closer_than_the_reference(kind):
+    """G13: the REAL reference's float32 vis_to_im (africanus/dft/kernels.py:72-148 with complex64 visibilities and
+    float32 coordinates) at 4 km baselines, 300 rows x 24 chan x 4 corr -> 12 sources, 5 % flags"""
+    vis, uvw, lm, flags = G13["v2i_vis"], G13["v2i_uvw"], G13["v2i_lm"], G13["v2i_flags"]
+    fr, ref32 = G13["v2i_%s_freq" % kind], G13["v2i_%s_im" % kind]
+    got = dft.vis_to_im(vis, uvw, lm, fr, flags)
+    assert got.dtype == np.float32 and got.shape == ref32.shape
+    truth = _truth_v2i(vis, uvw, lm, fr, flags)
+    scale = np.abs(truth).max()
+    e_ours, e_ref = np.abs(got - truth).max() / scale, np.abs(ref32 - truth).max() / scale
+    assert e_ours < 0.25 * e_ref, (kind, e_ours, e_ref)
+    assert e_ours < 3e-5
+
+
+@pytest.mark.parametrize("ncorr", [1, 2, 4])
+def test_vis_to_im_f32_shapes_flags_nonfinite_and_adjointness(ncorr):
+    """several row partitions and channel tiles (5000 rows, 70 channels), a fully flagged channel (stays exactly 0), a
+    non-finite uvw row (its unflagged cells poison every source, flagged ones nothing), a source outside the unit
+    disc (NaN where the channel has data), 'casa', the per-channel kernel, and <y, R x> = <R^H y, x> against
+    af_im_to_vis_f32"""
+    rng = np.random.default_rng(40 + ncorr)
+    nrow, nchan, nsrc = 5000, 70, 37
+    lm = ((rng.random((nsrc, 2)) - 0.5) * 0.1).astype(np.float32)
+    uvw = ((rng.random((nrow, 3)) - 0.5) * 8e3).astype(np.float32)
+    uvw[:, 2] *= np.float32(0.1)
+    fr = np.linspace(0.9e9, 1.6e9, nchan).astype(np.float32)
+    vis = (rng.standard_normal((nrow, nchan, ncorr)) + 1j * rng.standard_normal((nrow, nchan, ncorr))).astype(np.complex64)
+    flags = rng.random((nrow, nchan, ncorr)) < 0.03
+    flags[:, 11, :] = True
+    for conv in ("fourier", "casa"):
+        got = dft.vis_to_im(vis, uvw, lm, fr, flags, convention=conv)
+        truth = _truth_v2i(vis, uvw, lm, fr, flags, conv)
+        assert got.dtype == np.float32 and np.all(got[:, 11, :] == 0)
+        assert np.abs(got - truth).max() < 3e-5 * np.abs(truth).max()
+    with dft.mode("exact"):
+        ex = dft.vis_to_im(vis, uvw, lm, fr, flags)
+    assert np.abs(ex - truth_f(vis, uvw, lm, fr, flags)).max() < 3e-5 * np.abs(truth).max()
+    # adjointness with the single-precision forward transform (unflagged cells only)
+    keep = ~flags.any(axis=2)
+    x = rng.standard_normal((nsrc, nchan, ncorr)).astype(np.float32)
+    rx = dft.im_to_vis(x, uvw, lm, fr)                       # im_to_vis 'fourier' = exp(-i ...); vis_to_im 'fourier' = exp(+i ...)
+    lhs = np.sum((vis.conj() * rx).real[keep])               # <y, R x> over unflagged cells, real part
+    rhs = np.sum(dft.vis_to_im(vis.conj(), uvw, lm, fr, flags, convention="casa").astype(np.float64) * x)
+    assert abs(lhs - rhs) < 2e-4 * (abs(lhs) + np.abs(vis).sum() * 1e-3)
+    # non-finite row and source
+    uvw2 = uvw.copy()
+    uvw2[123] = np.nan
+    flags2 = flags.copy()
+    flags2[123, 5, :] = True
+    g2 = dft.vis_to_im(vis, uvw2, lm, fr, flags2)
+    t2 = _truth_v2i(vis, uvw2, lm, fr, flags2)
+    assert np.array_equal(np.isnan(g2), np.isnan(t2))
+    assert not np.isnan(g2[:, 5, :]).any() and np.all(g2[:, 11, :] == 0)
+    lm2 = lm.copy()
+    lm2[3] = [0.9, 0.8]
+    g3 = dft.vis_to_im(vis, uvw, lm2, fr, flags)
+    assert np.isnan(g3[3, 0]).all() and np.all(g3[3, 11] == 0) and not np.isnan(np.delete(g3, 3, axis=0)).any()
+
+
+def truth_f(vis, uvw, lm, fr, flags):
+    return _truth_v2i(vis, uvw, lm, fr, flags)

@@ -31,6 +31,12 @@ SGPR_SPILL_OK = ("af_fused_predict.hip", "af_degridder.hip", "af_calibration.hip
     ("af_fused_predict.hip", ("fused_predict_kernelILb0ELb0E", "fused_predict_kernelILb1ELb0E",
                               "fused_predict_kernelILb0ELb1E", "fused_predict_kernelILb1ELb1E"), 12, 256),
     ("af_degridder.hip", ("degrid_coop_kernel", "degrid_kernel"), 4, 256),
+    # round 3.  predict_vis (row block, chan tile): asm-issued LDS copies retired by counted vmcnt waits; the default
+    # instantiations (one cell per lane) must leave two 512-lane workgroups per CU: <= 128 registers
+    ("af_predict_vis.hip", ("predict_vis_tile_kernelIdiLi4ELb1ELb1ELi4ELi512ELi1E", "predict_vis_tile_kernelIflLi4ELb1ELb1E",
+                            "predict_vis_tile_kernelIdlLi2ELb0ELb0E"), 3, 128),
+    # single-precision transforms: accumulator quads + phasor arrays fit two waves per SIMD
+    ("af_im_to_vis_f32.hip", ("dft_f32_kernelILi16E", "dft_f32_kernelILi15E", "v2i_f32_kernelILi32E"), 10, 256),
     ("af_calibration.hip", ("calib_kernel",), 16, 256),
 ])
 def test_counted_wait_kernels_have_no_scratch(tmp_path, source, kernels, min_seen, reg_cap):

@@ -2,17 +2,19 @@
 # rocprofv3 evidence for one round: every bench.py workload (kernel-trace stats + PMC passes, each in its own run:
 # counters are never combined with other trace domains) and the auxiliary benches.  On the GPU box, from the repo root:
 #   gpurun --timeout 2400 -- 'bash tools/profile_round.sh'
-# then here: python tools/summarize_round.py r02
+# then here: python tools/summarize_round.py r03
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex fused_dde degrid wgrid}"
+WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 fused_dde degrid wgrid}"
+# the line the driver gets: headline + every other single-GPU workload under "workloads"
+python3 bench.py > "$OUT/default_line.json" 2> "$OUT/default_stderr.log"
 for w in $WORKLOADS; do
     mkdir -p "$OUT/$w"
-    ARGS="bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --check-rows 0"
-    python3 bench.py --workload $w > "$OUT/$w/bench_line.json" 2> "$OUT/$w/bench_stderr.log"
+    ARGS="bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --check-rows 0 --extras none"
+    python3 bench.py --workload $w --extras none > "$OUT/$w/bench_line.json" 2> "$OUT/$w/bench_stderr.log"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w/stats" -o stats -- python3 $ARGS > "$OUT/$w/stats.log" 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/$w/fetch" -o fetch -- python3 $ARGS > "$OUT/$w/fetch.log" 2>&1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/$w/write" -o write -- python3 $ARGS > "$OUT/$w/write.log" 2>&1
@@ -22,7 +24,7 @@ for w in $WORKLOADS; do
         --kernel-trace --output-format csv -d "$OUT/$w/sq2" -o sq2 -- python3 $ARGS > "$OUT/$w/sq2.log" 2>&1
 done
 # auxiliary benches: kernel-trace stats of each (per-kernel durations of the real launches)
-for t in bench_gridder bench_degridder bench_wgridder bench_wgridder_dirty bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr; do
+for t in bench_degridder bench_wgridder bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr bench_predict_tile bench_im_to_vis_f32; do
     [ -f tools/$t.py ] || continue
     mkdir -p "$OUT/aux/$t"
     python3 tools/$t.py > "$OUT/aux/$t/result.json" 2> "$OUT/aux/$t/stderr.log"

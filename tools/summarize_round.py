@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-DOMINANT = {"dft": "dft_mfma_kernel", "dft_complex": "dft_mfma_kernel", "fused_dde": "fused_predict_kernel",
+DOMINANT = {"dft": "dft_mfma_kernel", "dft_complex": "dft_mfma_kernel", "dft_f32": "dft_f32_kernel", "fused_dde": "fused_predict_kernel",
             "degrid": "degrid_coop_kernel", "wgrid": "wg_degrid_tiles"}
 
 
@@ -26,7 +26,12 @@ def find(base, suffix):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    dl = os.path.join(SRC, "default_line.json")
+    if os.path.exists(dl):
+        lines = [x for x in open(dl).read().splitlines() if x.startswith("{")]
+        if lines:
+            open(os.path.join(DST, "%s_bench_default_line.json" % tag), "w").write(lines[-1] + "\n")
     for w, dom in DOMINANT.items():
         base = os.path.join(SRC, w)
         if not os.path.isdir(base):
