@@ -123,6 +123,29 @@ __device__ __forceinline__ void jones_mul3(const Cx<T> (&a1)[NC], const Cx<T> (&
     }
 }
 
+// jones_mul3 in two steps with identical operations and order: x = bl . a2^H, then r = a1 . x
+template <typename T, int NC, bool J2X2>
+__device__ __forceinline__ void jones_right(const Cx<T> (&bl)[NC], const Cx<T> (&a2)[NC], Cx<T> (&x)[NC])
+{
+    if constexpr (J2X2) {
+        Cx<T> xxH = cconj(a2[0]), xyH = cconj(a2[1]), yxH = cconj(a2[2]), yyH = cconj(a2[3]);
+        x[0] = cadd(cmul(bl[0], xxH), cmul(bl[1], xyH));
+        x[1] = cadd(cmul(bl[0], yxH), cmul(bl[1], yyH));
+        x[2] = cadd(cmul(bl[2], xxH), cmul(bl[3], xyH));
+        x[3] = cadd(cmul(bl[2], yxH), cmul(bl[3], yyH));
+    }
+}
+template <typename T, int NC, bool J2X2>
+__device__ __forceinline__ void jones_left(const Cx<T> (&a1)[NC], const Cx<T> (&x)[NC], Cx<T> (&r)[NC])
+{
+    if constexpr (J2X2) {
+        r[0] = cadd(cmul(a1[0], x[0]), cmul(a1[1], x[2]));
+        r[1] = cadd(cmul(a1[0], x[1]), cmul(a1[1], x[3]));
+        r[2] = cadd(cmul(a1[2], x[0]), cmul(a1[3], x[2]));
+        r[3] = cadd(cmul(a1[2], x[1]), cmul(a1[3], x[3]));
+    }
+}
+
 // a1 * a2^H (predict.py:129-147)
 template <typename T, int NC, bool J2X2>
 __device__ __forceinline__ void jones_mul2(const Cx<T> (&a1)[NC], const Cx<T> (&a2)[NC], Cx<T> (&r)[NC])
@@ -456,6 +479,288 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
     }
 }
 
+// ---- (row block, chan tile) kernel, streamed form ----------------------------------------------------------------
+// Measured on the form above (profiles/r03_aux_bench_predict_tile_pmc_hbm.json): FETCH 24.4 GB for 17.2 GB of
+// coherencies -- essentially every per-source Jones copy (0.5 byte per coherency byte at 128 rows per block) comes from
+// beyond the XCD's L2, whatever the block order and the cache policy of the coherency loads -- and 24.4 GB in 3.9 ms IS
+// the 6.3 TB/s the fabric delivers: the kernel's time is its fetch.  So the copy has to serve more rows: here a
+// workgroup of 512 lanes owns K sub-blocks of 128 rows (K cells per lane) and ONE copy of a source's Jones terms serves
+// all of them: 0.5 / K byte per coherency byte.  K = 2 for 64-byte cells (c128 2 x 2: four sub-blocks need more than the
+// 256 registers of two waves per SIMD -- the compiler spills, and a spill is a vector-memory operation inside counted
+// waits), K = 4 for narrower cells.  The registers that takes are free because
+// the coherencies travel through LDS too: a ring of three 32 KB coherency tiles (one sub-block of one source each),
+// copied by global_load_lds_dwordx4 two tiles ahead, beside two Jones slots of up to TWO timesteps each (a block of
+// K x 128 rows straddles a timestep boundary one time in 16 / K at 2016 rows per timestep) = exactly the CU's 160 KB at
+// 64 antennas, c128 2 x 2.  Every load of
+// the loop is an asm-issued LDS copy, counted by one vmcnt immediate per tile step; one barrier per tile step.  Same
+// arithmetic in the same order: bit-identical.
+template <typename T, typename I, int NC, bool J2X2, int CT, int TB, int K>
+__global__ __launch_bounds__(TB) void predict_vis_stream_kernel(
+    const I *__restrict__ time_index, const I *__restrict__ ant1, const I *__restrict__ ant2, int64_t nrow,
+    const T *__restrict__ dde1, const T *__restrict__ coh, const T *__restrict__ dde2,
+    const T *__restrict__ die1, const T *__restrict__ bvis, const T *__restrict__ die2, int64_t nsrc,
+    int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p, int *__restrict__ status,
+    T *__restrict__ out, int nct, int64_t nrb, int group, int ts_max, int jones_reals, int coh_reals)
+{
+    constexpr int RS = TB / CT;                      // rows of a sub-block
+    constexpr int RB = RS * K;                       // rows of the block
+    constexpr int CS = NC * 2;
+    constexpr int UNIT = 16 / (int)sizeof(T);
+    constexpr int SEG_UNITS = CT * CS / UNIT;        // units per (timestep, antenna) Jones segment = per row of a coherency tile
+    static_assert(CT * CS % UNIT == 0, "a tile segment is whole 16-byte units");
+    constexpr int COH_UNITS = RS * SEG_UNITS;
+    constexpr int TRIPS_C = (COH_UNITS + TB - 1) / TB;
+    extern __shared__ double2 tile_lds[];
+    T *lds = reinterpret_cast<T *>(tile_lds);
+    T *ldsJ = lds;                                   // 2 slots of jones_reals
+    T *ldsC = lds + 2 * jones_reals;                 // 3 slots of coh_reals
+    long long *t_lo_hi = reinterpret_cast<long long *>(ldsC + 2 * coh_reals);   // scratch in the third coherency slot, before the loop
+
+    const int64_t i = blockIdx.x;
+    const int xcd = (int)(i & 7);
+    const int64_t jb_ = i >> 3;
+    const int ct = (int)(jb_ % nct);
+    const int64_t q = jb_ / nct;
+    const int64_t rb = ((q / group) * 8 + xcd) * group + q % group;
+    if (rb >= nrb) return;
+
+    const int tid = threadIdx.x;
+    const int fl = tid % CT, rl = tid / CT;
+    const int64_t f0 = (int64_t)ct * CT, f = f0 + fl;
+    const int64_t fc = f < nchan ? f : nchan - 1;
+    // per-cell state is RE-DERIVED where it is needed (prologue, fallback, epilogue) instead of being kept: K cells x
+    // (time, two antennas, cell index) in 64 bits would cost 32 registers the accumulators need
+    auto cell_state = [&](int k, int64_t &ti, int64_t &a1, int64_t &a2, int64_t &cell, bool &live) -> bool {
+        // the pointers pass through an empty asm so that the compiler re-reads the indices at every use instead of
+        // keeping K x 4 64-bit values of the prologue alive across the source loop for the epilogue
+        const I *tp = time_index, *p1 = ant1, *p2 = ant2;
+        asm volatile("" : "+s"(tp), "+s"(p1), "+s"(p2));
+        const int64_t r = rb * RB + k * RS + rl;
+        live = r < nrow && f < nchan;
+        const int64_t rc = r < nrow ? r : nrow - 1;
+        ti = (int64_t)tp[rc] - (int64_t)(*tmin_p);
+        a1 = (int64_t)p1[rc];
+        a2 = (int64_t)p2[rc];
+        cell = rc * nchan + fc;
+        return guard_indices(ti, a1, a2, ntime, nant, status);
+    };
+    if (tid == 0) { t_lo_hi[0] = 0x7fffffffffffffffLL; t_lo_hi[1] = 0; }
+    __syncthreads();
+    if (fl == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int64_t ti, a1, a2, cell; bool live;
+            cell_state(k, ti, a1, a2, cell, live);
+            atomicMin((unsigned long long *)&t_lo_hi[0], (unsigned long long)ti);
+            atomicMax((unsigned long long *)&t_lo_hi[1], (unsigned long long)ti);
+        }
+    }
+    __syncthreads();
+    const int64_t tlo = t_lo_hi[0];
+    const int tsb = (int)(t_lo_hi[1] - tlo) + 1;
+    // block-uniform; the array's last, partial block takes the per-lane gathers too (no clamping in the copy loops)
+    const bool use_lds = tsb <= ts_max && rb * RB + RB <= nrow;
+    __syncthreads();                                 // the scratch is about to be reused as a coherency slot
+
+    const int64_t ncell = nrow * nchan;
+    Cx<T> acc[K][NC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[k][c].re = acc[k][c].im = (T)0;
+    const int64_t sstride_dde = ntime * nant * nchan * CS;
+    const int64_t sstride_coh = ncell * CS;
+
+    // base_vis, DIE terms, store (predict.py:329-367) for cell k
+    struct Cell { Cx<T> c[NC]; };
+    auto finish_cell = [&](int k, Cell cellv) {
+        Cx<T> (&v)[NC] = cellv.c;
+        int64_t ti, a1, a2, cell; bool live;
+        const bool bad = cell_state(k, ti, a1, a2, cell, live);
+        if (!live) return;
+        if (bvis != nullptr) {
+            Cx<T> b[NC];
+            load_jones<T, NC>(bvis + cell * CS, b);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = cadd(v[c], b[c]);
+        }
+        if (die1 != nullptr) {
+            Cx<T> g1[NC], g2[NC], rr[NC];
+            load_jones<T, NC>(die1 + ((ti * nant + a1) * nchan + f) * CS, g1);
+            load_jones<T, NC>(die2 + ((ti * nant + a2) * nchan + f) * CS, g2);
+            jones_mul3<T, NC, J2X2>(g1, v, g2, rr);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = rr[c];
+        }
+        store_cell<T, NC>(out + cell * CS, v, bad);
+    };
+
+    if (use_lds) {
+        const int units_j = tsb * (int)nant * SEG_UNITS;
+        const int trips_j = (units_j + TB - 1) / TB;
+        const int wave = tid >> 6;
+        const int64_t seg_stride = nchan * CS;
+        const int64_t f0c = f0 + CT <= nchan ? f0 : nchan - CT;     // a tile that sticks out copies the band's last CT channels
+        const int flc = f < nchan ? (int)(f - f0c) : 0;
+        int o1[K], o2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int64_t ti, a1, a2, cell; bool live;
+            cell_state(k, ti, a1, a2, cell, live);
+            o1[k] = (((int)(ti - tlo) * (int)nant + (int)a1) * CT + flc) * CS;
+            o2[k] = (((int)(ti - tlo) * (int)nant + (int)a2) * CT + flc) * CS;
+        }
+        const int oc = (rl * CT + flc) * CS;
+        const T *src_j = dde1 + tlo * nant * seg_stride + f0c * CS;
+        const T *src_c = coh + f0c * CS;
+        auto dma = [&](const T *g, T *dst) {
+            const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)dst);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+        };
+        // every wave issues the same number of copy instructions (lanes past the end re-copy the last unit into padding).
+        // Per-lane source offsets are worked out ONCE (they do not depend on the source); a copy is then one 64-bit add.
+        constexpr int MAXTJ = 8;
+        int offj[MAXTJ];                              // reals from the source's first segment: < 2^31 (one block's timesteps)
+#pragma unroll
+        for (int t = 0; t < MAXTJ; ++t) {
+            int u = t * TB + tid;
+            u = u < units_j ? u : units_j - 1;
+            const int seg = u / SEG_UNITS, kk = u - seg * SEG_UNITS;
+            offj[t] = seg * (int)seg_stride + kk * UNIT;
+        }
+        // coherency tile of sub-block k: rows rb RB + k RS + row; offsets relative to the block's first row
+        int offc[TRIPS_C];
+#pragma unroll
+        for (int t = 0; t < TRIPS_C; ++t) {
+            int u = t * TB + tid;
+            u = u < COH_UNITS ? u : COH_UNITS - 1;
+            const int row = u / SEG_UNITS, kk = u - row * SEG_UNITS;
+            offc[t] = row * (int)seg_stride + kk * UNIT;
+        }
+        const T *src_cb = src_c + rb * RB * seg_stride;          // block-uniform
+        const int64_t sub_stride = (int64_t)RS * seg_stride;
+        auto load_jones_stage = [&](int sslot, const T *sj) {
+            T *dst0 = ldsJ + sslot * jones_reals;
+#pragma unroll
+            for (int t = 0; t < MAXTJ; ++t)
+                if (t < trips_j) dma(sj + offj[t], dst0 + (t * TB + wave * 64) * UNIT);
+        };
+        auto load_coh_tile = [&](int cslot, int k, const T *sc) {    // sc: the source's slab at the block's first row
+            T *dst0 = ldsC + cslot * coh_reals;
+            const T *sk = sc + k * sub_stride;
+#pragma unroll
+            for (int t = 0; t < TRIPS_C; ++t) dma(sk + offc[t], dst0 + (t * TB + wave * 64) * UNIT);
+        };
+        auto wait_keep = [&](int n) {                // all but the youngest n copy instructions have landed
+            switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+        // tile steps n = K s + k; coherency slot n % 3, Jones slot s % 2; the step after next is requested first
+        const T *sj_next = src_j + sstride_dde;       // Jones of source s + 1
+        int cs_req = 2 % 3, k_req = 2 % K;           // slot / sub-block of the NEXT tile to request (step n + 2)
+        const T *sc_req = src_cb + (2 / K) * sstride_coh;
+        load_jones_stage(0, src_j);
+        load_coh_tile(0, 0, src_cb);
+        if (nsrc * K > 1) { load_coh_tile(1, 1 % K, src_cb + (1 / K) * sstride_coh); wait_keep(TRIPS_C); }
+        else wait_keep(0);
+        __syncthreads();
+        int cslot = 0;
+        for (int64_t s = 0; s < nsrc; ++s) {
+            const T *jbase = ldsJ + (int)(s & 1) * jones_reals;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                int outstanding = 0;                 // copies issued in this step: they may stay in flight over the barrier
+                if (s * K + k + 2 < nsrc * K) {
+                    load_coh_tile(cs_req, k_req, sc_req);
+                    outstanding += TRIPS_C;
+                    cs_req = cs_req == 2 ? 0 : cs_req + 1;
+                    if (++k_req == K) { k_req = 0; sc_req += sstride_coh; }
+                }
+                if (k == 0 && s + 1 < nsrc) {
+                    load_jones_stage((int)((s + 1) & 1), sj_next);
+                    sj_next += sstride_dde;
+                    outstanding += trips_j;
+                }
+                const T *cbase = ldsC + cslot * coh_reals;
+                {
+                    // operands loaded when they are needed (coherency and right-hand Jones first, the left-hand Jones
+                    // after their product): the scheduler otherwise front-loads all twelve reads of every sub-block
+                    Cx<T> jb[NC], j2[NC], x[NC], j1[NC], rr[NC];
+                    load_jones<T, NC>(cbase + oc, jb);
+                    if constexpr (J2X2) {            // A1 . (BL . A2^H)
+                        load_jones<T, NC>(jbase + o2[k], j2);
+                        jones_right<T, NC, J2X2>(jb, j2, x);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_jones<T, NC>(jbase + o1[k], j1);
+                        jones_left<T, NC, J2X2>(j1, x, rr);
+                    } else {                         // (a1 bl) conj(a2), element by element
+                        load_jones<T, NC>(jbase + o1[k], j1);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) x[c] = cmul(j1[c], jb[c]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_jones<T, NC>(jbase + o2[k], j2);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) rr[c] = cmul(x[c], cconj(j2[c]));
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[k][c] = cadd(acc[k][c], rr[c]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (outstanding == TRIPS_C) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TRIPS_C) : "memory");
+                else wait_keep(outstanding);
+                __syncthreads();
+                cslot = cslot == 2 ? 0 : cslot + 1;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            int64_t ti, a1, a2, cell; bool live;
+            cell_state(k, ti, a1, a2, cell, live);
+            const T *p1 = dde1 + ((ti * nant + a1) * nchan + fc) * CS;
+            const T *p2 = dde2 + ((ti * nant + a2) * nchan + fc) * CS;
+            Cell sumc;
+            Cx<T> (&sum)[NC] = sumc.c;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum[c].re = sum[c].im = (T)0;
+            for (int64_t s = 0; s < nsrc; ++s) {
+                Cx<T> j1[NC], jb[NC], j2[NC], rr[NC];
+                load_jones<T, NC>(p1 + s * sstride_dde, j1);
+                load_jones<T, NC>(p2 + s * sstride_dde, j2);
+                load_jones<T, NC>(coh + s * sstride_coh + cell * CS, jb);
+                jones_mul3<T, NC, J2X2>(j1, jb, j2, rr);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sum[c] = cadd(sum[c], rr[c]);
+            }
+            finish_cell(k, sumc);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        Cell v;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v.c[c] = acc[k][c];
+        finish_cell(k, v);
+    }
+}
+
 struct PArgs {
     const void *time_index, *ant1, *ant2;
     int index_bytes;
@@ -513,6 +818,39 @@ int launch_tile(const PArgs &a)
     return AF_OK;
 }
 
+// streamed form: needs source_coh, and 2 Jones slots + 3 coherency tiles within the CU's 160 KB
+template <typename T, typename I, int NC, bool J2X2, int CT, int TB, int K>
+int launch_stream(const PArgs &a)
+{
+    constexpr int CS = NC * 2, RB = TB / CT * K;
+    const size_t seg_bytes = (size_t)CT * CS * sizeof(T);
+    if (a.nant == 0 || a.nchan < CT || a.coh == nullptr || ((uintptr_t)a.coh & 15) != 0) return AF_ENOTSUP;
+    const size_t coh_bytes = af_align_up((size_t)(TB / CT) * seg_bytes, (size_t)TB * 16);
+    auto jones_bytes = [&](int ts) { return af_align_up((size_t)ts * a.nant * seg_bytes, (size_t)TB * 16); };
+    const size_t lds_cap = 160 * 1024;
+    int ts_max = 2;
+    while (ts_max > 0 && 2 * jones_bytes(ts_max) + 3 * coh_bytes > lds_cap) --ts_max;
+    if (ts_max < 1) return AF_ENOTSUP;
+    if (jones_bytes(ts_max) / ((size_t)TB * 16) > 8 || jones_bytes(ts_max) / ((size_t)TB * 16) + coh_bytes / ((size_t)TB * 16) > 12)
+        return AF_ENOTSUP;   // the kernel's copy loops cover <= 8 Jones trips, its counted waits <= 12 instructions
+    const size_t lds = 2 * jones_bytes(ts_max) + 3 * coh_bytes;
+    const int nct = (int)af_cdiv(a.nchan, CT);
+    const int64_t nrb = af_cdiv(a.nrow, RB);
+    const int group = 2048 / RB > 0 ? 2048 / RB : 1;
+    const int64_t nrb_padded = af_cdiv(nrb, 8 * (int64_t)group) * 8 * group;
+    const int64_t blocks = nrb_padded * nct;
+    if (blocks >= (1LL << 31)) return AF_ENOTSUP;
+    auto kernel = predict_vis_stream_kernel<T, I, NC, J2X2, CT, TB, K>;
+    AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(TB), lds, a.st, (const I *)a.time_index, (const I *)a.ant1,
+                       (const I *)a.ant2, a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2,
+                       (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan,
+                       a.tmin, a.status, (T *)a.out, nct, nrb, group, ts_max, (int)(jones_bytes(ts_max) / sizeof(T)),
+                       (int)(coh_bytes / sizeof(T)));
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+
 // whether the tile kernel applies: DDE terms (dde1 == dde2 as every caller passes them -- the stage holds ONE array),
 // 16-byte aligned antenna segments, enough rows to fill the chip
 template <typename T, int NC>
@@ -549,6 +887,14 @@ int launch_presence(const PArgs &a)
         // wider tiles so that a segment stays >= 128 bytes
         constexpr int CT = (NC * 2 * sizeof(T) >= 64) ? 4 : (NC * 2 * sizeof(T) >= 32) ? 8 : 16;
         int rc;
+        // the streamed form is opt-in: on the same box it measures within 3 % of the form below (4.57-4.69 against
+        // 4.75 TB/s; tools/bench_predict_tile.py) -- its smaller fetch is paid for with one workgroup per CU
+        if (coh && env_int("AFHIP_PREDICT_STREAM", 0) != 0) {
+            // sub-blocks per workgroup: 4 where the accumulators leave room (<= 32 bytes per cell), else 2
+            constexpr int KSUB = (NC * 2 * sizeof(T) >= 64) ? 2 : 4;
+            rc = launch_stream<T, I, NC, J2X2, CT, 512, KSUB>(a);
+            if (rc != AF_ENOTSUP) return rc;
+        }
         if constexpr (sizeof(T) == 8 && sizeof(I) == 4 && NC == 4 && J2X2) {
             // measurement hook (tools/bench_predict_tile.py): other tile shapes for the c128 2x2 case
             const int ct = env_int("AFHIP_PREDICT_TILE_CT", CT), tb = env_int("AFHIP_PREDICT_TILE_TB", 512);

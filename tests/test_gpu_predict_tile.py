@@ -153,3 +153,19 @@ def test_index_guard_through_the_c_abi():
     assert status == _lib.AF_STATUS_ANTENNA
     o = out.cpu().numpy()
     assert np.isnan(o[7]).all() and np.isfinite(np.delete(o, 7, axis=0)).all()
+
+
+@pytest.mark.parametrize("corrs", [(2, 2), (2,), (1,)])
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_streamed_form_bit_exact(monkeypatch, corrs, dtype):
+    """AFHIP_PREDICT_STREAM=1: coherencies through LDS as well, K sub-blocks per workgroup share one Jones copy (opt-in,
+    measured alternative of the tile kernel): same bits as the oracle on blocks inside a timestep, straddling two,
+    spanning more (per-lane gathers), band remainders and the array's partial last block"""
+    monkeypatch.setenv("AFHIP_PREDICT_STREAM", "1")
+    for shape in SHAPES:
+        nrow, nchan, nsrc, nant, rpt = shape
+        d = _case(np.random.default_rng(nrow), nrow, nchan, nsrc, nant, rpt, corrs, dtype=dtype)
+        for die, bvis in ((None, None), (d["die"], d["bvis"])):
+            got = rime.predict_vis(d["ti"], d["a1"], d["a2"], d["dde"], d["coh"], d["dde"], die, bvis, die)
+            ref = oracle.predict_vis(d["ti"], d["a1"], d["a2"], d["dde"], d["coh"], d["dde"], die, bvis, die)
+            assert_array_equal(got, ref)

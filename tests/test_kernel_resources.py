@@ -35,6 +35,9 @@ SGPR_SPILL_OK = ("af_fused_predict.hip", "af_degridder.hip", "af_calibration.hip
     # instantiations (one cell per lane) must leave two 512-lane workgroups per CU: <= 128 registers
     ("af_predict_vis.hip", ("predict_vis_tile_kernelIdiLi4ELb1ELb1ELi4ELi512ELi1E", "predict_vis_tile_kernelIflLi4ELb1ELb1E",
                             "predict_vis_tile_kernelIdlLi2ELb0ELb0E"), 3, 128),
+    # ... and its streamed form (every load of the loop an asm-issued LDS copy, counted waits): a spill would add
+    # vector-memory operations to the count; one 512-lane workgroup per CU = two waves per SIMD: <= 256 registers
+    ("af_predict_vis.hip", ("predict_vis_stream_kernel",), 16, 256),
     # single-precision transforms: accumulator quads + phasor arrays fit two waves per SIMD
     ("af_im_to_vis_f32.hip", ("dft_f32_kernelILi16E", "dft_f32_kernelILi15E", "v2i_f32_kernelILi32E"), 10, 256),
     ("af_calibration.hip", ("calib_kernel",), 16, 256),

@@ -34,11 +34,12 @@ coh, dde, die, bv = rc(s, r, c, 2, 2), rc(s, ntime, a, c, 2, 2), rc(ntime, a, c,
 b_coh = coh.numel() * 16 + r * c * 64
 b_all = b_coh + dde.numel() * 16 + die.numel() * 16 + bv.numel() * 16
 out = {}
-variants = [("lane per cell", dict(AFHIP_PREDICT_TILE="0"))]
+variants = [("lane per cell", dict(AFHIP_PREDICT_TILE="0")),
+            ("streamed form (coherencies through LDS, 2 sub-blocks share a Jones copy)", dict(AFHIP_PREDICT_TILE="1", AFHIP_PREDICT_STREAM="1"))]
 for ct, tb, cpt in ((4, 512, 1), (4, 512, 2), (8, 1024, 1)):
     for ts in (1, 2):
         variants.append(("tile CT=%d TB=%d cells/thread=%d stage-of-%d-timestep(s)" % (ct, tb, cpt, ts),
-                         dict(AFHIP_PREDICT_TILE="1", AFHIP_PREDICT_TILE_CT=str(ct), AFHIP_PREDICT_TILE_TB=str(tb),
+                         dict(AFHIP_PREDICT_TILE="1", AFHIP_PREDICT_STREAM="0", AFHIP_PREDICT_TILE_CT=str(ct), AFHIP_PREDICT_TILE_TB=str(tb),
                               AFHIP_PREDICT_TILE_TS=str(ts), AFHIP_PREDICT_TILE_CPT=str(cpt))))
 ref = None
 for name, env in variants:
