@@ -1058,7 +1058,10 @@ def run_threads(args):
     staging = torch.zeros((n, nchan), dtype=torch.float64, device=dev0)
     total = torch.zeros(nchan, dtype=torch.float64, device=dev0)
     reduce_stream = torch.cuda.Stream(device=dev0)
-    evs = [Events(_lib, args.steps) for _ in workers]
+    evs = []
+    for w in workers:                    # a HIP event belongs to the device that is current when it is created
+        with torch.cuda.device(w.dev):
+            evs.append(Events(_lib, args.steps))
     placed = [None] * n
 
     def task(k, step_no):
@@ -1103,7 +1106,10 @@ def run_threads(args):
     sync_all()
     elapsed = time.perf_counter() - t0
     pool.shutdown()
-    kernel_s = [e.collect() for e in evs]
+    kernel_s = []
+    for w, e in zip(workers, evs):
+        with torch.cuda.device(w.dev):
+            kernel_s.append(e.collect())
     chi2_sum = total.cpu().numpy()
     chi2_check = sum(w.d_chi2.cpu().numpy() for w in workers)
     if not np.allclose(chi2_sum, chi2_check, rtol=1e-12, atol=0):
