@@ -100,6 +100,7 @@ def parse(argv=None):
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
                    help="torch.distributed backend; nccl = RCCL over xGMI.  auto = nccl, or gloo when "
                         "AFHIP_BENCH_DEVICE puts the ranks on one device (the N > 1 code path on a one-GPU box)")
+    p.add_argument("--launch-timeout", type=int, default=3600, help="self-launched ranks: seconds before they are killed")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=2.0,
                    help="minimum wall time of the all-cores CPU baseline sample (the single-thread probe runs "
@@ -923,8 +924,14 @@ def launch_ranks(args, argv):
     procs = []
     for r, e in enumerate(envs):
         procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    try:
+        out0, _ = procs[0].communicate(timeout=args.launch_timeout)
+        codes = [procs[0].returncode] + [p.wait(timeout=60) for p in procs[1:]]
+    except subprocess.TimeoutExpired:        # a rank that never met the rendezvous must not hang the driver
+        for p in procs:
+            p.kill()
+        sys.stderr.write("bench.py: the ranks did not finish within %d s; killed\n" % args.launch_timeout)
+        return 1
     text = out0.decode("utf-8", "replace")
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     if any(codes) or len(lines) != 1:
