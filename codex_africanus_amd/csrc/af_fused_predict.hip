@@ -248,6 +248,33 @@ __device__ __forceinline__ void cmac(C2 &acc, C2 a, C2 b)
     acc.im = fma(a.im, b.re, acc.im);
 }
 
+// exp(-t) for t >= 0 (the Gaussian envelope): t log2(e) = n + f, |f| <= 1/2, 2^-n by v_ldexp_f64, 2^-f = exp(-f ln 2) by
+// its Taylor series to degree 11 on |f ln 2| <= 0.347 (next term 2e-14 relative): 17 fp64 operations and four live
+// registers, where the library routine's inlined body (~30 operations, a dozen temporaries) put the Gaussian variants
+// of the 12-wave kernel over their 168 registers.  The fused chain is checked to 1e-9 against the oracle, not bit for bit.
+__device__ __forceinline__ double exp_neg(double t)
+{
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double x = __dmul_rn(t, 1.4426950408889634);
+    const double a = __dadd_rn(x, MAGIC);
+    const int n = __double2loint(a);
+    const double f = __dsub_rn(x, __dsub_rn(a, MAGIC));          // [-0.5, 0.5]
+    const double y = __dmul_rn(f, -0.6931471805599453);            // exp(y), |y| <= 0.347
+    double p = 1.0 / 39916800.0;
+    p = fma(p, y, 1.0 / 3628800.0);
+    p = fma(p, y, 1.0 / 362880.0);
+    p = fma(p, y, 1.0 / 40320.0);
+    p = fma(p, y, 1.0 / 5040.0);
+    p = fma(p, y, 1.0 / 720.0);
+    p = fma(p, y, 1.0 / 120.0);
+    p = fma(p, y, 1.0 / 24.0);
+    p = fma(p, y, 1.0 / 6.0);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.0);
+    p = fma(p, y, 1.0);
+    return t > 1400.0 ? 0.0 : ldexp(p, -n);                        // below the denormals: exactly 0 as exp() gives
+}
+
 // exp(2 pi i x / PH_TABLE) for x = q * f4 * PH_TABLE / 4 (f4 in quarter turns per metre): the table phasor of
 // af_sincos.h with a four times finer table (16 KB of LDS): exp(2 pi i k / 1024) from the table times a residual
 // rotation |theta| <= pi / 1024 = 3.1e-3 by sin = theta - theta^3 / 6 (next term 2.3e-15) and cos = 1 - theta^2 / 2 +
@@ -533,7 +560,7 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
                     for (int k = 0; k < RPT; ++k) {
                         // u nu = us * (nu / FT): the rows keep only their scaled coordinates (registers)
                         const double u1 = (us[k] * gem - vs[k] * gel) * ger * GK, v1 = (us[k] * gel + vs[k] * gem) * GK;
-                        shape[k] = exp(-(u1 * u1 + v1 * v1));
+                        shape[k] = exp_neg(u1 * u1 + v1 * v1);
                     }
                 }
             }
@@ -896,9 +923,9 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
         return AF_OK;
     };
 #define AF_FUSED_PICK(NPC, STC, GRC)                                                                                     \
-    (ws_mode ? (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, true, 0, false>, THREADS + THREADS / 2)        \
+    (ws_mode ? (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, true, 0, GRC>, THREADS + THREADS / 2)        \
                               : launch(fused_predict_kernel<true, false, NPC, true, STC, GRC>, THREADS + THREADS / 2))      \
-                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, true, 0, false>, THREADS + THREADS / 2)       \
+                     : (gauss ? launch(fused_predict_kernel<false, true, NPC, true, 0, GRC>, THREADS + THREADS / 2)       \
                               : launch(fused_predict_kernel<false, false, NPC, true, STC, GRC>, THREADS + THREADS / 2)))    \
              : (feed ? (gauss ? launch(fused_predict_kernel<true, true, NPC, false, 0, false>, THREADS)                     \
                               : launch(fused_predict_kernel<true, false, NPC, false, 0, false>, THREADS))                   \
@@ -907,12 +934,12 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     // the grouped form (items of af_fused_plan_groups) exists for the wave-specialised kernels; the 64-antenna-stride,
     // 8-sources-per-batch case (BASELINE configs[2]) has its source loop unrolled
     static const int unroll_env = getenv("AFHIP_FUSED_UNROLL") ? atoi(getenv("AFHIP_FUSED_UNROLL")) : 1;   // A/B hook
-    AF_REQUIRE(groups == nullptr || !gauss, "af_fused_predict_c128: Gaussian shapes take the row-range plan "
-                                            "(af_fused_plan_rows): the grouped kernel with them exceeds 168 registers");
     AF_REQUIRE(groups == nullptr || ws_mode, "af_fused_predict_c128: grouped items need the wave-specialised kernel "
                                              "(AFHIP_FUSED_WS != 0, at most ~230 antennas): plan with af_fused_plan_rows");
     // (the unrolled source loop is for the variants without Gaussian shapes: eight inlined exp() bodies do not fit the
     // registers of three waves per SIMD)
+    // (the unrolled source loop stays with the variants without Gaussian shapes: eight inlined envelope evaluations beside
+    // the Jones algebra need ~3 KB of scratch per lane; the ROLLED grouped form fits with 7 spilled registers)
     const bool unroll = NPv == 64 && ws_mode && st == 8 && unroll_env && !gauss;
     if (groups != nullptr) {
         if (unroll) rc = AF_FUSED_PICK(64, 8, true);

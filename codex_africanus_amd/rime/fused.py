@@ -53,7 +53,7 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True):
     Plan of a row layout for :func:`fused_predict_vis` with DDEs (host side, O(row)): runs of consecutive rows with
     equal ``time_index`` become workgroup items.  ``grouped`` (default): rows are dealt in 2 x 2 blocks of baselines that
     share their antennas' Jones terms (``af_fused_plan_groups``: 5 instead of 8 LDS reads per (row, source); up to ~230
-    antennas, no Gaussian shapes); otherwise plain row ranges (``af_fused_plan_rows``).  ``nant`` = the antenna extent
+    antennas); otherwise plain row ranges (``af_fused_plan_rows``).  ``nant`` = the antenna extent
     of the per-antenna arrays (parallactic_angles.shape[1]).
     """
     ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
@@ -219,12 +219,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             if tuple(antenna_scaling.shape) != (nant, nchan, 2):
                 raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
             if plan is None:
-                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=gauss_shape is None)
+                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True)
             if plan.nrow != nrow or plan.nant != nant or plan.nsteps > ntime:
                 raise ValueError("plan was made for %d rows, %d antennas, %d timesteps; the call has %d, %d, %d"
                                  % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
-            if plan.groups is not None and gauss_shape is not None:
-                raise ValueError("Gaussian shapes need a plan made with grouped=False")
             n_items = ctypes.c_int64(plan.n_items)
             p_items = c.inp(plan.device(plan.items, c), np.int32)
             p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
