@@ -63,6 +63,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz, vector or matrix
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak (64 flop/clk/SIMD)
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth (degridder's gather view)
 PMC_ROUNDS = ("r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, newest first
 # the REAL reference (numba 0.54) measured in the build container: im_to_vis 10k x 16 x 100 x 4
@@ -258,7 +259,7 @@ class Dft(object):
 
 
 class DftF32(object):
-    """im_to_vis with every input float32 -> complex64 (af_im_to_vis_f32: fp64 phasors, fp32 matrix-pipe sums): the
+    """im_to_vis with every input float32 -> complex64 (af_im_to_vis_f32: fp64 phases, float32 phasors and sums): the
     single-precision call of africanus/dft/kernels.py:26-31, at BASELINE configs[1]'s counts.  Not the headline (that is
     fp64); its step has no chi^2 (the chi^2 entry is complex128).  Errors are against the float64 transform of the
     same float32 inputs."""
@@ -296,15 +297,17 @@ class DftF32(object):
     def roofline(self, kernel_s):
         a = self.args
         units = float(a.rows) * a.chans * a.sources
-        # per (row, chan, src): 2 fp64 FMA (recurrence) + 2 fp64->fp32 conversions + 3 fp32 (band correction) on the VALU,
-        # 8 fp32 MACs on the matrix pipe (v_mfma_f32_4x4x1_16b: 8 issue cycles per 256 MACs = the fp32 vector rate);
-        # counted as the fp64 headline counts it: 20 flop per unit (2 FMA + 8 MAC), against the fp64 pipe's peak, so the
-        # fraction compares directly with the headline's
-        return dict(kernel="dft_f32_kernel<16,4,false,true>", bound="mfma", alg_flops=units * 20.0,
+        # per (row, chan, src), kilometre baselines (the float32 "chain" form): one complex rotation of the recurrence
+        # (2 mul + 2 fma = 6 flop, two packed instructions) on the fp32 VALU + 8 fp32 MACs (16 flop) on the matrix pipe
+        # (v_mfma_f32_4x4x1_16b: 8 issue cycles per 256 MACs = the fp32 vector rate): 22 flop per unit against the fp32
+        # peak (the band correction of a rounded float32 axis, 2 more fma, is overhead, not algorithm)
+        return dict(kernel="dft_f32_kernel<16,4,false,true,true>", bound="mfma", alg_flops=units * 22.0,
+                    peak_tflops=FP32_PEAK_TFLOPS,
                     alg_bytes=float(a.rows) * a.chans * 32 + a.rows * 12.0 + a.sources * a.chans * 16.0,
                     channels_in_kernel=a.chans,
-                    note="single precision: fp64 phasors (VALU) + fp32 MACs (matrix pipe, 4x4x1 blocks, pixels broadcast by "
-                         "CBSZ/ABID); 20 flop per (row, chan, src) as for the fp64 headline, quoted against the fp64 peak")
+                    note="single precision: fp64 phase -> float32 anchor and step phasors, packed float32 rotation recurrence "
+                         "(VALU) + fp32 MACs (matrix pipe, 4x4x1 blocks, pixels broadcast by CBSZ/ABID); 22 flop per "
+                         "(row, chan, src) against the fp32 peak (157.3 TFLOP/s)")
 
     def cpu_baseline(self, min_seconds):
         import oracle
@@ -708,7 +711,8 @@ def roofline_entry(wl, args, workload, kernel_s):
     fp_ach = r["alg_flops"] / kernel_s / 1e12
     hbm = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
            "algorithmic_bytes": r["alg_bytes"]}
-    fp64 = {"achieved": fp_ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp_ach / FP64_PEAK_TFLOPS,
+    peak = r.get("peak_tflops", FP64_PEAK_TFLOPS)      # the pipe the workload computes on (fp64 unless it says fp32)
+    fp64 = {"achieved": fp_ach, "peak": peak, "unit": "TFLOP/s", "frac": fp_ach / peak,
             "algorithmic_flops": r["alg_flops"]}
     top = fp64 if r["bound"] == "mfma" else hbm
     roof = {"kernel": r["kernel"], "bound": r["bound"], "achieved": top["achieved"], "peak": top["peak"],

@@ -39,6 +39,7 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int ROWS = 256;
 constexpr int G32 = 64;   // floats per record register = 16 MFMA blocks x 4
@@ -94,8 +95,113 @@ Ws32 ws32_layout(int64_t nsrc, int64_t nchan, int64_t ncorr, int is_complex)
     return L;
 }
 
+// flags[0] = the band's class (f32_prep_freq); [2..4] = non-negative floats (bit patterns, atomicMax as unsigned):
+// max |uvw|^2 over the rows, max (l^2 + m^2 + n^2) over the sources, max |nu| / c -- their product bounds the phase
+constexpr int FLAG_ROW_REACH = 2, FLAG_SRC_REACH = 3, FLAG_FREQ_REACH = 4;
+
+__global__ __launch_bounds__(256) void f32_rows_reach(const float *__restrict__ uvw, int64_t nrow, int *__restrict__ flags)
+{
+    float best = 0.0f;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (int64_t)gridDim.x * blockDim.x) {
+        const float u = uvw[3 * r], v = uvw[3 * r + 1], w = uvw[3 * r + 2];
+        const float d = u * u + v * v + w * w;
+        if (isfinite(d)) best = fmaxf(best, d);
+    }
+    for (int o = 32; o; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(flags) + FLAG_ROW_REACH, __float_as_uint(best));
+}
+
+// Largest phase of the call in radians (an upper bound).  The float32 recurrence below ("chain") carries ~1e-7 of a
+// phasor's magnitude per step; the reference's float32 loop carries 6e-8 of the PHASE (radians): beyond ~100 rad the
+// chain is the closer of the two by a wide margin, below it the fp64-phasor kernel keeps the contract (golden G3)
+constexpr float CHAIN_REACH_RAD = 100.0f;
+__device__ __forceinline__ bool chain_regime(const int *__restrict__ flags)
+{
+    const float reach = 6.2831855f * sqrtf(__int_as_float(flags[FLAG_ROW_REACH]) * __int_as_float(flags[FLAG_SRC_REACH])) *
+                        __int_as_float(flags[FLAG_FREQ_REACH]);
+    return reach >= CHAIN_REACH_RAD;
+}
+
+// exp(2 pi i x / 1024) in float32 from a phase x kept in float64: k = rint(x) by the 1.5 * 2^52 trick (the integer is
+// the low word of the sum: no conversion), theta = x - k in [-0.5, 0.5] table steps, table[k mod 1024] (float32, 8 KB of
+// LDS) times (1 - t^2 / 2 + i t), t = 2 pi theta / 1024 <= 3.1e-3 (next terms 4.8e-9 and 3.5e-12): 5 fp64 + 9 fp32
+// operations where the fp64 table phasor takes ~14 fp64 and two conversions.  Non-finite x -> NaN.
+constexpr int CHAIN_TABLE = 1024;
+constexpr int CHAIN_ROWS = 256;   // (512 with a barrier per source, so that the two waves of a SIMD run their float32 phases
+                                  // together, measured slower: 19.5 against 17.7 ms at C2's counts)
+
+// Packed float32 forms of the recurrence.  ONE wave issues a vector instruction every ~5 cycles whether it is
+// v_fma_f32 or v_pk_fma_f32 (tools/probe/probe_f32_issue.hip: 4.5-5.0 / 5.0; two waves together 2.3 / 4.4), and in this
+// kernel a wave's float32 phase runs while its SIMD partner is held by its MFMAs: the packed forms halve the phase.
+// y = (re, im) in a register pair, s = (cos, sin):  y s  = (re c - im s, im c + re s) as  t = (-im s, re s) then
+// fma(y, (c, c), t) -- per component the same two roundings as the scalar form (product, then fma).  Outputs are
+// early-clobber: a packed instruction whose HIGH result reads the LOW half of a source (op_sel_hi 0) must not have
+// that source as its destination.
+__device__ __forceinline__ v2f rot_up(v2f y, v2f s)
+{
+    v2f t, r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=&v"(t) : "v"(y), "v"(s));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(y), "v"(s), "v"(t));
+    return r;
+}
+// y conj(s) = (re c + im s, im c - re s)
+__device__ __forceinline__ v2f rot_down(v2f y, v2f s)
+{
+    v2f t, r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=&v"(t) : "v"(y), "v"(s));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(y), "v"(s), "v"(t));
+    return r;
+}
+// a step of both chains, products first: up = a s, down = b conj(s)
+__device__ __forceinline__ void rot_both(v2f a, v2f b, v2f s, v2f &up, v2f &down)
+{
+    v2f t, u;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=&v"(t) : "v"(a), "v"(s));
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=&v"(u) : "v"(b), "v"(s));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=&v"(up) : "v"(a), "v"(s), "v"(t));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=&v"(down) : "v"(b), "v"(s), "v"(u));
+}
+// (q kappa_j, q kappa_j+1) from q in the low half of q2
+__device__ __forceinline__ v2f theta_pair(v2f q2, v2f kap2)
+{
+    v2f r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=&v"(r) : "v"(q2), "v"(kap2));
+    return r;
+}
+// y (1 + i theta) = (re - theta im, im + theta re), theta = the low (HI = 0) or high (HI = 1) half of th
+template <int HI> __device__ __forceinline__ v2f first_order(v2f y, v2f th)
+{
+    v2f r;
+    if constexpr (HI == 0)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=&v"(r) : "v"(y), "v"(th));
+    else
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=&v"(r) : "v"(y), "v"(th));
+    return r;
+}
+__device__ __forceinline__ void chain_table_init(float2 *tab, int tid, int nthreads)
+{
+    for (int k = tid; k < CHAIN_TABLE; k += nthreads) {
+        double sn, cs;
+        sincospi(2.0 * (double)k / (double)CHAIN_TABLE, &sn, &cs);
+        tab[k] = make_float2((float)cs, (float)sn);
+    }
+}
+__device__ __forceinline__ void chain_phasor(const float2 *tab, double x, float &re, float &im)
+{
+    const double MAGIC = 6755399441055744.0;
+    const double a = __dadd_rn(x, MAGIC);
+    const int k = __double2loint(a);
+    const float th = (float)__dsub_rn(x, __dsub_rn(a, MAGIC));
+    const float2 t = tab[k & (CHAIN_TABLE - 1)];
+    const float sn = __fmul_rn(th, 6.1359231515425649e-03f);                        // 2 pi / 1024
+    const float cs = fmaf(__fmul_rn(th, th), -1.8824776459647568e-05f, 1.0f);       // (2 pi / 1024)^2 / 2
+    re = fmaf(t.x, cs, -__fmul_rn(t.y, sn));
+    im = fmaf(t.x, sn, __fmul_rn(t.y, cs));
+}
+
 // n = sqrt(1 - l^2 - m^2) - 1 (kernels.py:54, unclamped) in float64 from the float32 coordinates
-__global__ void f32_prep_src(const float *__restrict__ lm, int64_t nsrc, double *__restrict__ lmn, int *__restrict__ srcbad)
+__global__ void f32_prep_src(const float *__restrict__ lm, int64_t nsrc, double *__restrict__ lmn, int *__restrict__ srcbad,
+                             int *__restrict__ flags)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
@@ -104,6 +210,7 @@ __global__ void f32_prep_src(const float *__restrict__ lm, int64_t nsrc, double 
     n = sqrt(n) - 1.0;
     const bool bad = !(isfinite(l) && isfinite(m) && isfinite(n));
     srcbad[s] = bad ? 1 : 0;
+    if (!bad) atomicMax(reinterpret_cast<unsigned *>(flags) + FLAG_SRC_REACH, __float_as_uint((float)(l * l + m * m + n * n)));
     lmn[4 * s + 0] = bad ? 0.0 : l;
     lmn[4 * s + 1] = bad ? 0.0 : m;
     lmn[4 * s + 2] = bad ? 0.0 : n;
@@ -150,6 +257,7 @@ __global__ void f32_prep_freq(const float *__restrict__ freq, int64_t nchan, int
             // float32 rounding of a value near f: half an ulp = |f| 2^-24; allow four
             if (!(fabs(eps) <= 4.0 * 5.9604644775390625e-08 * fabs(f))) cls = 2;
             freqc[c0 + j] = 4.0 * f * s1;      // quarter turns per metre (dft_f32_exact_kernel)
+            if (isfinite(f)) atomicMax(reinterpret_cast<unsigned *>(flags) + FLAG_FREQ_REACH, __float_as_uint((float)fabs(f * s1)));
         }
         kappa[t * CT + j] = (float)(6.283185307179586 * eps * s1);
     }
@@ -214,7 +322,7 @@ __global__ __launch_bounds__(64) void f32_colstate(const float *__restrict__ ima
 
 // rows of 64 lanes through LDS, out as fully coalesced 8-byte stores (per-lane stores at a row stride of
 // nchan * ncorr * 8 bytes leave partially written lines behind)
-template <int CT, int NC>
+template <int CT, int NC, int TB = ROWS>
 __device__ __forceinline__ void store_tile32(const v4f (&are)[CT], const v4f (&aim)[CT], float2 *stage, float *out,
                                              int64_t row0, int64_t nrow, int64_t nchan, int64_t c0, int wave, int lane,
                                              const int *__restrict__ colstate, int tstate)
@@ -223,7 +331,7 @@ __device__ __forceinline__ void store_tile32(const v4f (&are)[CT], const v4f (&a
     constexpr int STRIDE = PER_ROW + 1;
     const int64_t seg_chans = nchan - c0 < CT ? nchan - c0 : CT;
     const int seg_len = (int)(seg_chans * NC);
-    for (int pass = 0; pass < ROWS / 64; ++pass) {
+    for (int pass = 0; pass < TB / 64; ++pass) {
         if (wave == pass) {
             float2 *dst = stage + lane * STRIDE;
 #pragma unroll
@@ -232,7 +340,7 @@ __device__ __forceinline__ void store_tile32(const v4f (&are)[CT], const v4f (&a
                 for (int c = 0; c < NC; ++c) dst[j * NC + c] = make_float2(are[j][c], aim[j][c]);
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * PER_ROW; e += ROWS) {
+        for (int e = threadIdx.x; e < 64 * PER_ROW; e += TB) {
             const int rl = e / PER_ROW, col = e - rl * PER_ROW;
             const int64_t row = row0 + pass * 64 + rl;
             if (row < nrow && col < seg_len) {
@@ -250,31 +358,44 @@ __device__ __forceinline__ void store_tile32(const v4f (&are)[CT], const v4f (&a
 }
 
 // grid: (ceil(nrow / 256), tiles); block 256 = 4 waves of 64 consecutive rows on tile blockIdx.y.
-template <int CT, int NC, bool CPLX, bool CORR>
-__global__ __launch_bounds__(ROWS, (CT <= 16 ? 2 : 1)) void dft_f32_kernel(
+// CHAIN: the tile's phasors by a float32 rotation recurrence outwards from the tile's middle channel (anchor and step
+// from `chain_phasor`: fp64 phase, float32 table) instead of the fp64 three-term recurrence: 4 float32 operations per
+// channel (8 cycles) where the fp64 form takes 2 FMA + 2 conversions (16), and a third of the set-up.  `force_chain`:
+// -1 = by the call's phase bound (`chain_regime`), 0 / 1 = AFHIP_F32_CHAIN.
+template <int CT, int NC, bool CPLX, bool CORR, bool CHAIN>
+__global__ __launch_bounds__((CHAIN ? CHAIN_ROWS : ROWS), (CT <= 16 ? 2 : 1)) void dft_f32_kernel(
     const float *__restrict__ uvw, const float *__restrict__ records, const double *__restrict__ lmn,
     const double *__restrict__ tilef, const float *__restrict__ kappa, const int *__restrict__ flags,
     const int *__restrict__ colstate, const int *__restrict__ tilestate, float *__restrict__ out, int64_t nrow,
-    int nsrc, int64_t nchan, int want_class)
+    int nsrc, int64_t nchan, int want_class, int force_chain)
 {
     if (flags[0] != want_class) return;   // decided on the device by f32_prep_freq
+    if ((force_chain >= 0 ? force_chain != 0 : chain_regime(flags)) != CHAIN) return;
+    constexpr int TB = CHAIN ? CHAIN_ROWS : ROWS;
     __shared__ float2 stage[64 * (CT * NC + 1)];
-    __shared__ double2 ptab[PHASOR_TABLE];
-    table_phasor_init(ptab, threadIdx.x, ROWS);
+    __shared__ double2 ptab[CHAIN ? 1 : PHASOR_TABLE];
+    __shared__ float2 ftab[CHAIN ? CHAIN_TABLE : 1];
+    if constexpr (CHAIN) chain_table_init(ftab, threadIdx.x, TB);
+    else table_phasor_init(ptab, threadIdx.x, TB);
     __syncthreads();
     constexpr int BPC = blocks_per_chan(CPLX), CPR = chans_per_reg(CPLX);
     constexpr int NG = groups_of(CT, CPLX);
     const int tile = blockIdx.y;
     const int64_t c0 = (int64_t)tile * CT;
-    int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x;
+    int64_t row = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (row >= nrow) row = nrow - 1;
     const double u = (double)uvw[3 * row], v = (double)uvw[3 * row + 1], w = (double)uvw[3 * row + 2];
     // turns per metre -> 1/256 turns per metre (table_phasor's unit: an exact scaling)
     const double F0 = 256.0 * tilef[2 * tile], FD = 256.0 * tilef[2 * tile + 1];
-    float kap[CT];
+    // chain: the anchor channel's frequency and the step in 1/1024 turns per metre
+    constexpr int JA = CT / 2;
+    const double FA = (double)CHAIN_TABLE * fma((double)JA, tilef[2 * tile + 1], tilef[2 * tile]);
+    const double FS = (double)CHAIN_TABLE * tilef[2 * tile + 1];
+    float kap[CT + 1];
     if constexpr (CORR) {
 #pragma unroll
         for (int j = 0; j < CT; ++j) kap[j] = kappa[tile * CT + j];   // wave-uniform: scalar registers
+        kap[CT] = 0.0f;
     }
     v4f are[CT], aim[CT];
 #pragma unroll
@@ -293,30 +414,65 @@ __global__ __launch_bounds__(ROWS, (CT <= 16 ? 2 : 1)) void dft_f32_kernel(
         for (int g = 0; g < NG; ++g) Rn[g] = rec[(int64_t)sn * (NG * G32) + g * G32];
         const double l = lmn[4 * s], m = lmn[4 * s + 1], n = lmn[4 * s + 2];
         const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
-        double y0r, y0i, dr, di;
-        table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
-        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
         const float qf = (float)q;
-        const double k2 = __dadd_rn(dr, dr);
-        double y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
-        double y1i = fma(y0r, di, __dmul_rn(y0i, dr));
+        float yr[CT], yi[CT];
+        double y0r, y0i, y1r, y1i, k2;
+        if constexpr (CHAIN) {
+            v2f y[CT], st;
+            {
+                float ar, ai, sr, si;
+                chain_phasor(ftab, __dmul_rn(q, FA), ar, ai);
+                chain_phasor(ftab, __dmul_rn(q, FS), sr, si);
+                y[JA] = v2f{ar, ai};
+                st = v2f{sr, si};
+            }
+            // two independent chains, a step of each in turn (the asm statements are volatile: they keep this order,
+            // and the s_nop below stays between the last of them and the first MFMA)
+            static_for32<1, JA + 1>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (JA + k < CT) rot_both(y[JA + k - 1], y[JA - k + 1], st, y[JA + k], y[JA - k]);
+                else y[JA - k] = rot_down(y[JA - k + 1], st);     // downwards: times the conjugate step
+            });
+            if constexpr (CORR) {                       // y (1 + i theta_j), theta_j = q kappa_j
+                const v2f q2 = {qf, qf};
+                static_for32<0, (CT + 1) / 2>([&](auto jc) {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const v2f th = theta_pair(q2, v2f{kap[j], kap[j + 1]});
+                    y[j] = first_order<0>(y[j], th);
+                    if constexpr (j + 1 < CT) y[j + 1] = first_order<1>(y[j + 1], th);
+                });
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) { yr[j] = y[j].x; yi[j] = y[j].y; }
+            // an MFMA must not read a register within two wait states of the VALU instruction that wrote it; the
+            // compiler keeps that distance for instructions it knows, not for the asm statements above
+            asm volatile("s_nop 1" ::: "memory");
+        } else {
+            double dr, di;
+            table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
+            table_phasor(ptab, __dmul_rn(q, FD), dr, di);
+            k2 = __dadd_rn(dr, dr);
+            y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
+            y1i = fma(y0r, di, __dmul_rn(y0i, dr));
+        }
         // phase 1, fp64 VALU only: the tile's phasors, rounded to float32 once.  phase 2, matrix pipe only: the MFMAs
         // back to back.  (Interleaved instruction by instruction a lone wave pays ~10 cycles at every MFMA <-> VALU
         // switch -- measured, tools/probe/probe_mfma_f32.hip: 16 MFMAs 152 cycles, 16 fp64 FMAs 108, alternating 340 --
         // whereas whole phases of different waves of a SIMD overlap.)
-        float yr[CT], yi[CT];
         static_for32<0, CT>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            double yrd, yid;
-            if constexpr (j == 0) { yrd = y0r; yid = y0i; }
-            else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
-            else {
-                yrd = fma(k2, y1r, -y0r);
-                yid = fma(k2, y1i, -y0i);
-                y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+            if constexpr (!CHAIN) {
+                double yrd, yid;
+                if constexpr (j == 0) { yrd = y0r; yid = y0i; }
+                else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
+                else {
+                    yrd = fma(k2, y1r, -y0r);
+                    yid = fma(k2, y1i, -y0i);
+                    y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+                }
+                yr[j] = (float)yrd; yi[j] = (float)yid;
             }
-            yr[j] = (float)yrd; yi[j] = (float)yid;
-            if constexpr (CORR) {   // y (1 + i theta), theta = q kappa_j
+            if constexpr (CORR && !CHAIN) {   // y (1 + i theta), theta = q kappa_j
                 const float th = qf * kap[j];
                 const float cr = fmaf(-th, yi[j], yr[j]), ci = fmaf(th, yr[j], yi[j]);
                 yr[j] = cr; yi[j] = ci;
@@ -346,8 +502,8 @@ __global__ __launch_bounds__(ROWS, (CT <= 16 ? 2 : 1)) void dft_f32_kernel(
 #pragma unroll
         for (int g = 0; g < NG; ++g) R[g] = Rn[g];
     }
-    store_tile32<CT, NC>(are, aim, stage, out, (int64_t)blockIdx.x * ROWS, nrow, nchan, c0,
-                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, colstate, tilestate[tile]);
+    store_tile32<CT, NC, TB>(are, aim, stage, out, (int64_t)blockIdx.x * TB, nrow, nchan, c0,
+                             __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, colstate, tilestate[tile]);
 }
 
 // any band: one phasor per (row, source, channel), phase in fp64 turns.  grid: (ceil(nrow / 256), nchan).
@@ -420,11 +576,20 @@ int launch32(const Args32 &a)
     const int *tilestate = reinterpret_cast<const int *>(a.ws + L.tilestate);
     if (a.mode != AF_DFT_EXACT) {
         af_prof_begin(a.st);
-        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, false>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
-                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 0);
+        // (band class) x (phasor form): decided on the device, three of the four launches return at once
+        static const int force = getenv("AFHIP_F32_CHAIN") ? atoi(getenv("AFHIP_F32_CHAIN")) : -1;
+        const dim3 gridc((unsigned)af_cdiv(a.nrow, CHAIN_ROWS), (unsigned)L.ntile), blockc(CHAIN_ROWS);
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, false, true>), gridc, blockc, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 0, force);
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, true>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
-                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 1);
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, true, true>), gridc, blockc, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 1, force);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, false, false>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 0, force);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((dft_f32_kernel<CT, NC, CPLX, true, false>), grid, block, 0, a.st, a.uvw, rec, lmn, tilef, kappa, flags,
+                           colstate, tilestate, a.out, a.nrow, a.nsrc, a.nchan, 1, force);
         af_prof_end(a.st);
         AF_LAUNCH_CHECK();
     }
@@ -544,15 +709,20 @@ __global__ void v2i32_pack(const float2 *__restrict__ vis, const unsigned char *
 }
 
 // grid: (ceil(nsrc / 256), tiles, row partitions); block 256 = 4 waves of 64 consecutive sources
-template <int CT, bool CORR>
+// CHAIN: phasors as in dft_f32_kernel<..., CHAIN> (float32 rotation recurrence from the tile's middle channel).
+template <int CT, bool CORR, bool CHAIN>
 __global__ __launch_bounds__(ROWS, 2) void v2i_f32_kernel(
     const double *__restrict__ lmn, const double *__restrict__ uvw64, const float *__restrict__ records,
     const double *__restrict__ tilef, const float *__restrict__ kappa, const int *__restrict__ flags,
-    float *__restrict__ partial, int64_t nsrc, int64_t nrow, int64_t rows_per_part, int64_t nchan, int want_class)
+    float *__restrict__ partial, int64_t nsrc, int64_t nrow, int64_t rows_per_part, int64_t nchan, int want_class,
+    int force_chain)
 {
     if (flags[0] != want_class) return;
-    __shared__ double2 ptab[PHASOR_TABLE];
-    table_phasor_init(ptab, threadIdx.x, ROWS);
+    if ((force_chain >= 0 ? force_chain != 0 : chain_regime(flags)) != CHAIN) return;
+    __shared__ double2 ptab[CHAIN ? 1 : PHASOR_TABLE];
+    __shared__ float2 ftab[CHAIN ? CHAIN_TABLE : 1];
+    if constexpr (CHAIN) chain_table_init(ftab, threadIdx.x, ROWS);
+    else table_phasor_init(ptab, threadIdx.x, ROWS);
     __syncthreads();
     constexpr int NG = CT / 8;
     const int tile = blockIdx.y;
@@ -562,10 +732,15 @@ __global__ __launch_bounds__(ROWS, 2) void v2i_f32_kernel(
     if (!valid) src = nsrc - 1;
     const double l = lmn[4 * src], m = lmn[4 * src + 1], n = lmn[4 * src + 2];
     const double F0 = 256.0 * tilef[2 * tile], FD = 256.0 * tilef[2 * tile + 1];
-    float kap[CT];
+    // chain: the anchor channel's frequency and the step in 1/1024 turns per metre
+    constexpr int JA = CT / 2;
+    const double FA = (double)CHAIN_TABLE * fma((double)JA, tilef[2 * tile + 1], tilef[2 * tile]);
+    const double FS = (double)CHAIN_TABLE * tilef[2 * tile + 1];
+    float kap[CT + 1];
     if constexpr (CORR) {
 #pragma unroll
         for (int j = 0; j < CT; ++j) kap[j] = kappa[tile * CT + j];
+        kap[CT] = 0.0f;
     }
     v4f acc[CT];
 #pragma unroll
@@ -585,31 +760,59 @@ __global__ __launch_bounds__(ROWS, 2) void v2i_f32_kernel(
         for (int g = 0; g < NG; ++g) Rn[g] = rec[rn * (NG * G32) + g * G32];
         const double u = uvw64[4 * r], v = uvw64[4 * r + 1], w = uvw64[4 * r + 2];   // wave-uniform: scalar loads
         const double q = fma(n, w, fma(m, v, __dmul_rn(l, u)));
-        double y0r, y0i, dr, di;
-        table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
-        table_phasor(ptab, __dmul_rn(q, FD), dr, di);
         const float qf = (float)q;
-        const double k2 = __dadd_rn(dr, dr);
-        double y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
-        double y1i = fma(y0r, di, __dmul_rn(y0i, dr));
         float yr[CT], yi[CT];
-        static_for32<0, CT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            double yrd, yid;
-            if constexpr (j == 0) { yrd = y0r; yid = y0i; }
-            else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
-            else {
-                yrd = fma(k2, y1r, -y0r);
-                yid = fma(k2, y1i, -y0i);
-                y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+        if constexpr (CHAIN) {
+            v2f y[CT], st;
+            {
+                float ar, ai, sr, si;
+                chain_phasor(ftab, __dmul_rn(q, FA), ar, ai);
+                chain_phasor(ftab, __dmul_rn(q, FS), sr, si);
+                y[JA] = v2f{ar, ai};
+                st = v2f{sr, si};
             }
-            yr[j] = (float)yrd; yi[j] = (float)yid;
+            static_for32<1, JA + 1>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (JA + k < CT) rot_both(y[JA + k - 1], y[JA - k + 1], st, y[JA + k], y[JA - k]);
+                else y[JA - k] = rot_down(y[JA - k + 1], st);
+            });
             if constexpr (CORR) {
-                const float th = qf * kap[j];
-                const float cr = fmaf(-th, yi[j], yr[j]), ci = fmaf(th, yr[j], yi[j]);
-                yr[j] = cr; yi[j] = ci;
+                const v2f q2 = {qf, qf};
+                static_for32<0, (CT + 1) / 2>([&](auto jc) {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    const v2f th = theta_pair(q2, v2f{kap[j], kap[j + 1]});
+                    y[j] = first_order<0>(y[j], th);
+                    if constexpr (j + 1 < CT) y[j + 1] = first_order<1>(y[j + 1], th);
+                });
             }
-        });
+#pragma unroll
+            for (int j = 0; j < CT; ++j) { yr[j] = y[j].x; yi[j] = y[j].y; }
+            asm volatile("s_nop 1" ::: "memory");   // VALU write -> MFMA read: two wait states (see dft_f32_kernel)
+        } else {
+            double y0r, y0i, dr, di;
+            table_phasor(ptab, __dmul_rn(q, F0), y0r, y0i);
+            table_phasor(ptab, __dmul_rn(q, FD), dr, di);
+            const double k2 = __dadd_rn(dr, dr);
+            double y1r = fma(y0r, dr, -__dmul_rn(y0i, di));
+            double y1i = fma(y0r, di, __dmul_rn(y0i, dr));
+            static_for32<0, CT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double yrd, yid;
+                if constexpr (j == 0) { yrd = y0r; yid = y0i; }
+                else if constexpr (j == 1) { yrd = y1r; yid = y1i; }
+                else {
+                    yrd = fma(k2, y1r, -y0r);
+                    yid = fma(k2, y1i, -y0i);
+                    y0r = y1r; y0i = y1i; y1r = yrd; y1i = yid;
+                }
+                yr[j] = (float)yrd; yi[j] = (float)yid;
+                if constexpr (CORR) {
+                    const float th = qf * kap[j];
+                    const float cr = fmaf(-th, yi[j], yr[j]), ci = fmaf(th, yr[j], yi[j]);
+                    yr[j] = cr; yi[j] = ci;
+                }
+            });
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for32<0, CT>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -726,8 +929,15 @@ AF_EXPORT int af_im_to_vis_f32(const float *image, int image_is_complex, const f
     AF_HIP(hipMemsetAsync(ws + L.flags, 0, 16 * sizeof(int), st));
     AF_HIP(hipMemsetAsync(ws + L.tilestate, 0, (size_t)L.ntile * sizeof(int), st));
     hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc,
-                       reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad));
+                       reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad),
+                       reinterpret_cast<int *>(ws + L.flags));
     AF_LAUNCH_CHECK();
+    {
+        int64_t blocks = af_cdiv(nrow, 256 * 16);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(f32_rows_reach, dim3((unsigned)blocks), dim3(256), 0, st, uvw, nrow, reinterpret_cast<int *>(ws + L.flags));
+        AF_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(f32_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan, L.ntile, L.ct,
                        convention, reinterpret_cast<double *>(ws + L.tilef), reinterpret_cast<float *>(ws + L.kappa),
                        reinterpret_cast<double *>(ws + L.freqc), reinterpret_cast<int *>(ws + L.flags));
@@ -792,7 +1002,7 @@ AF_EXPORT int af_vis_to_im_f32(const float *vis, const float *uvw, const float *
     float *rec = reinterpret_cast<float *>(ws + L.records), *partial = reinterpret_cast<float *>(ws + L.partial);
     AF_HIP(hipMemsetAsync(wflags, 0, 16 * sizeof(int), st));
     AF_HIP(hipMemsetAsync(chan_any, 0, (size_t)L.ntile * L.ct * sizeof(int), st));
-    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, lmn, srcbad);
+    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, lmn, srcbad, wflags);
     AF_LAUNCH_CHECK();
     // vis_to_im's 'fourier' is exp(+2 pi i ...): the opposite sign of im_to_vis (kernels.py:113-118)
     hipLaunchKernelGGL(f32_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan, L.ntile, L.ct,
@@ -802,6 +1012,12 @@ AF_EXPORT int af_vis_to_im_f32(const float *vis, const float *uvw, const float *
     if (mode == AF_DFT_RECURRENCE) AF_HIP(hipMemsetAsync(wflags, 0, sizeof(int), st));
     hipLaunchKernelGGL(v2i32_prep_rows, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow, uvw64);
     AF_LAUNCH_CHECK();
+    {
+        int64_t blocks = af_cdiv(nrow, 256 * 16);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(f32_rows_reach, dim3((unsigned)blocks), dim3(256), 0, st, uvw, nrow, wflags);
+        AF_LAUNCH_CHECK();
+    }
     {
         const int64_t total = L.ntile * nrow * (int64_t)L.groups * G32;
         int64_t blocks = af_cdiv(total, 256);
@@ -817,11 +1033,18 @@ AF_EXPORT int af_vis_to_im_f32(const float *vis, const float *uvw, const float *
     if (mode != AF_DFT_EXACT) {
         const dim3 grid(nsg, (unsigned)L.ntile, (unsigned)L.npart);
         af_prof_begin(st);
-        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, false>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial, nsrc,
-                           nrow, L.rows_per_part, nchan, 0);
+        static const int force = getenv("AFHIP_F32_CHAIN") ? atoi(getenv("AFHIP_F32_CHAIN")) : -1;
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, false, true>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial,
+                           nsrc, nrow, L.rows_per_part, nchan, 0, force);
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, true>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial, nsrc,
-                           nrow, L.rows_per_part, nchan, 1);
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, true, true>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial,
+                           nsrc, nrow, L.rows_per_part, nchan, 1, force);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, false, false>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial,
+                           nsrc, nrow, L.rows_per_part, nchan, 0, force);
+        AF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((v2i_f32_kernel<V32_CT, true, false>), grid, block, 0, st, lmn, uvw64, rec, tilef, kappa, wflags, partial,
+                           nsrc, nrow, L.rows_per_part, nchan, 1, force);
         af_prof_end(st);
         AF_LAUNCH_CHECK();
     }

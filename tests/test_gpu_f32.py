@@ -1,5 +1,7 @@
 """
-af_im_to_vis_f32: float32 inputs -> complex64, phases in float64, phasors / recurrence / sums in float32
+af_im_to_vis_f32: float32 inputs -> complex64, phases in float64, sums in float32; phasors by the fp64 recurrence
+rounded once (calls whose phases stay below ~100 rad: golden G3) or by the float32 rotation recurrence from an
+fp64-phase anchor (everything larger: G13, the sweep below)
 (csrc/af_im_to_vis_f32.hip; the reference case is africanus/dft/kernels.py:26-31 with every input float32, where its
 whole loop runs in float32).  Contract: CLOSER to the float64 transform of the same float32 inputs
 than the reference's own float32 result.  The reference's float32 results are (a) the recorded golden vector
@@ -82,6 +84,24 @@ def test_against_the_float64_transform_more_rows_and_tiles(cplx, ncorr):
         got = dft.im_to_vis(img, uvw, lm, fr)
         truth = _truth(img, uvw, lm, fr)
         assert np.abs(got - truth).max() < 3e-5 * np.abs(truth).max()
+
+
+@pytest.mark.parametrize("scale", [0.5, 8.0, 60.0, 500.0, 4e3, 3e4])
+def test_both_phasor_forms_across_baseline_lengths(scale):
+    """The library picks the phasor form on the device from a bound of the call's largest phase (rows' max |uvw| x
+    sources' max |lmn| x max frequency, ~100 rad): metre baselines take the fp64 recurrence, kilometre baselines the
+    float32 rotation recurrence.  Either side of the switch, both band classes, real and complex pixels: within 3e-6
+    of the peak visibility of the float64 transform (the float32 sums alone carry ~1e-6; the reference's float32 loop
+    is at 1e-4 from ~4 km on, golden G13)."""
+    rng = np.random.default_rng(int(scale * 10) + 3)
+    for uniform in (False, True):
+        for cplx in (False, True):
+            img, uvw, lm, fr = _inputs(rng, 60, 300, 40, 4, cplx, scale=scale, uniform_f32=uniform)
+            got = dft.im_to_vis(img, uvw, lm, fr)
+            truth = _truth(img, uvw, lm, fr)
+            peak = np.abs(truth).max()
+            e_ours = np.abs(got - truth).max() / peak
+            assert e_ours < 3e-6, (scale, uniform, cplx, e_ours)
 
 
 def test_modes_classes_and_device_resident():
