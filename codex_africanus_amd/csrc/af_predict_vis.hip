@@ -280,6 +280,10 @@ __global__ __launch_bounds__(THREADS) void predict_vis_kernel(
 // block -> (row block, chan tile): the dispatcher deals consecutive blocks round-robin over the 8 XCDs, so block i
 // lives on XCD i % 8; the j = i / 8-th block of an XCD takes chan tile j % nct of that XCD's (j / nct)-th row block,
 // and an XCD's row blocks come in groups of G consecutive ones (~ one timestep) before the next XCD's group starts.
+// Default since round 3 ("rows first", group < 0): within an XCD's turn the G row blocks of ONE chan tile come first,
+// then the next chan tile -- the ~64 workgroups resident on an XCD then copy the same Jones segments (same timestep, same
+// channels) and all but the first find them in the XCD's L2: 4.75 -> 5.15 TB/s with DDE terms, the rate of the kernel
+// without any gathers (tools/bench_predict_tile.py; AFHIP_PREDICT_ROWS_FIRST=0 restores chan tiles first).
 template <typename T, typename I, int NC, bool J2X2, bool HAVE_COH, int CT, int TB, int CPT>
 __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
     const I *__restrict__ time_index, const I *__restrict__ ant1, const I *__restrict__ ant2, int64_t nrow,
@@ -300,9 +304,20 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
     const int64_t i = blockIdx.x;
     const int xcd = (int)(i & 7);
     const int64_t j = i >> 3;
-    const int ct = (int)(j % nct);
-    const int64_t q = j / nct;
-    const int64_t rb = ((q / group) * 8 + xcd) * group + q % group;
+    int ct;
+    int64_t rb;
+    if (group < 0) {
+        // rows first: the `group` row blocks of an XCD's turn (~ one timestep) take the same chan tile one after the
+        // other, so that the workgroups resident together on an XCD copy the SAME Jones segments
+        const int g = -group;
+        const int64_t turn = j / ((int64_t)nct * g), within = j % ((int64_t)nct * g);
+        ct = (int)(within / g);
+        rb = (turn * 8 + xcd) * g + within % g;
+    } else {
+        ct = (int)(j % nct);
+        const int64_t q = j / nct;
+        rb = ((q / group) * 8 + xcd) * group + q % group;
+    }
     if (rb >= nrb) return;
 
     const int tid = threadIdx.x;
@@ -519,9 +534,18 @@ __global__ __launch_bounds__(TB) void predict_vis_stream_kernel(
     const int64_t i = blockIdx.x;
     const int xcd = (int)(i & 7);
     const int64_t jb_ = i >> 3;
-    const int ct = (int)(jb_ % nct);
-    const int64_t q = jb_ / nct;
-    const int64_t rb = ((q / group) * 8 + xcd) * group + q % group;
+    int ct;
+    int64_t rb;
+    if (group < 0) {    // rows first (see predict_vis_tile_kernel)
+        const int g = -group;
+        const int64_t turn = jb_ / ((int64_t)nct * g), within = jb_ % ((int64_t)nct * g);
+        ct = (int)(within / g);
+        rb = (turn * 8 + xcd) * g + within % g;
+    } else {
+        ct = (int)(jb_ % nct);
+        const int64_t q = jb_ / nct;
+        rb = ((q / group) * 8 + xcd) * group + q % group;
+    }
     if (rb >= nrb) return;
 
     const int tid = threadIdx.x;
@@ -813,7 +837,8 @@ int launch_tile(const PArgs &a)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(TB), lds, a.st, (const I *)a.time_index, (const I *)a.ant1,
                        (const I *)a.ant2, a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2,
                        (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan,
-                       a.tmin, a.status, (T *)a.out, nct, nrb, group, ts_max, stage_reals, trips_max);
+                       a.tmin, a.status, (T *)a.out, nct, nrb, env_int("AFHIP_PREDICT_ROWS_FIRST", 1) ? -group : group, ts_max,
+                       stage_reals, trips_max);
     AF_LAUNCH_CHECK();
     return AF_OK;
 }
@@ -845,7 +870,8 @@ int launch_stream(const PArgs &a)
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(TB), lds, a.st, (const I *)a.time_index, (const I *)a.ant1,
                        (const I *)a.ant2, a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2,
                        (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan,
-                       a.tmin, a.status, (T *)a.out, nct, nrb, group, ts_max, (int)(jones_bytes(ts_max) / sizeof(T)),
+                       a.tmin, a.status, (T *)a.out, nct, nrb, env_int("AFHIP_PREDICT_ROWS_FIRST", 1) ? -group : group, ts_max,
+                       (int)(jones_bytes(ts_max) / sizeof(T)),
                        (int)(coh_bytes / sizeof(T)));
     AF_LAUNCH_CHECK();
     return AF_OK;

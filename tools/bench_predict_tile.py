@@ -41,8 +41,11 @@ for ct, tb, cpt in ((4, 512, 1), (4, 512, 2), (8, 1024, 1)):
         variants.append(("tile CT=%d TB=%d cells/thread=%d stage-of-%d-timestep(s)" % (ct, tb, cpt, ts),
                          dict(AFHIP_PREDICT_TILE="1", AFHIP_PREDICT_STREAM="0", AFHIP_PREDICT_TILE_CT=str(ct), AFHIP_PREDICT_TILE_TB=str(tb),
                               AFHIP_PREDICT_TILE_TS=str(ts), AFHIP_PREDICT_TILE_CPT=str(cpt))))
+for name, env in list(variants[2:]):
+    variants.append((name + ", rows first", dict(env, AFHIP_PREDICT_ROWS_FIRST="1")))
 ref = None
 for name, env in variants:
+    os.environ["AFHIP_PREDICT_ROWS_FIRST"] = "0"
     os.environ.update(env)
     v = rime.predict_vis(ti, a1, a2, dde, coh, dde, die, bv, die)
     if ref is None:
