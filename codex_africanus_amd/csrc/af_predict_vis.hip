@@ -827,7 +827,12 @@ int launch_tile(const PArgs &a)
     if (trips_max > 4) return AF_ENOTSUP;                                  // the counted waits cover 1..4 trips
     const int nct = (int)af_cdiv(a.nchan, CT);
     const int64_t nrb = af_cdiv(a.nrow, RB);
-    const int group = 2048 / RB > 0 ? 2048 / RB : 1;                      // ~ one 64-antenna timestep of rows per XCD turn
+    // row blocks per XCD turn.  Rows first: the ~64 resident workgroups of an XCD are `group` row blocks x 64 / group chan
+    // tiles -- more row blocks = more sharing of a Jones segment (fetch 1 + 0.5 / group bytes per coherency byte), more
+    // chan tiles = longer contiguous pieces of a row in flight (DRAM pages).  Measured on two boxes (tools/
+    // ab_predict_order.py): 16 / 8 / 4 row blocks 5.15 / - / - TB/s on one, 4.50 / 4.55 / 4.62 on the other: 8.
+    int group = env_int("AFHIP_PREDICT_ROWS_FIRST", 1) ? (1024 / RB > 0 ? 1024 / RB : 1) : (2048 / RB > 0 ? 2048 / RB : 1);
+    if (env_int("AFHIP_PREDICT_GROUP", 0) > 0) group = env_int("AFHIP_PREDICT_GROUP", 0);   // measurement hook
     const int64_t nrb_padded = af_cdiv(nrb, 8 * (int64_t)group) * 8 * group;
     const int64_t blocks = nrb_padded * nct;
     if (blocks >= (1LL << 31)) return AF_ENOTSUP;

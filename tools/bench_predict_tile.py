@@ -43,9 +43,13 @@ for ct, tb, cpt in ((4, 512, 1), (4, 512, 2), (8, 1024, 1)):
                               AFHIP_PREDICT_TILE_TS=str(ts), AFHIP_PREDICT_TILE_CPT=str(cpt))))
 for name, env in list(variants[2:]):
     variants.append((name + ", rows first", dict(env, AFHIP_PREDICT_ROWS_FIRST="1")))
+for g in (4, 8, 32, 64):
+    variants.append(("tile CT=4 TB=512 cells/thread=1 stage-of-1-timestep(s), rows first, %d row blocks per XCD turn" % g,
+                     dict(variants[2][1], AFHIP_PREDICT_ROWS_FIRST="1", AFHIP_PREDICT_GROUP=str(g))))
 ref = None
 for name, env in variants:
     os.environ["AFHIP_PREDICT_ROWS_FIRST"] = "0"
+    os.environ["AFHIP_PREDICT_GROUP"] = "0"
     os.environ.update(env)
     v = rime.predict_vis(ti, a1, a2, dde, coh, dde, die, bv, die)
     if ref is None:
