@@ -3,10 +3,15 @@
 // Replaces africanus/dft/kernels.py:33-67 for the case every input is float32: the reference then runs its whole
 // loop in float32 (result dtype by promotion, africanus/dft/kernels.py:26-31, africanus/util/type_inference.py:24-26),
 // including the phase C (l u + m v + n w) nu -- thousands of radians for kilometre baselines: 1.4e-4 of the peak
-// visibility in error at 4 km (golden G13).  Here the PHASORS are float64 and only the products are float32:
-//   * fp64 VALU, per (row, source, channel tile): q = l u + m v + n w, the phasor at the tile's first channel and the
-//     channel-step phasor from the 256-entry LDS table of af_sincos.h (~2e-16), then the three-term recurrence
-//     y[j+1] = 2 cos(d) y[j] - y[j-1] along the tile in fp64; every phasor is rounded to float32 once (6e-8);
+// visibility in error at 4 km (golden G13).  Here the PHASES are float64 and everything after them float32:
+//   * fp64 VALU, per (row, source, channel tile): q = l u + m v + n w and two phases.
+//       - calls whose phases can exceed ~100 rad (`chain_regime`, decided on the device from max |uvw|, max |lmn| and
+//         max nu): the phase of the tile's MIDDLE channel and the channel step, reduced in fp64 (`chain_phasor`), give
+//         float32 anchor and step phasors from a 1024-entry float32 table; the tile's other phasors follow by a
+//         float32 rotation recurrence outwards from the anchor (packed v_pk_mul_f32 / v_pk_fma_f32, <= CT / 2 steps);
+//       - metre baselines, where the reference's float32 loop is itself at the float32 floor: the fp64 table phasors
+//         of af_sincos.h (~2e-16) and the fp64 three-term recurrence y[j+1] = 2 cos(d) y[j] - y[j-1], every phasor
+//         rounded to float32 once (golden G3 asks for that);
 //   * fp32 MATRIX pipe, per channel: v_mfma_f32_4x4x1_16b_f32 -- sixteen 4x4x1 outer products -- with
 //       A = the source's pixels: ONE register holds 16 blocks x 4 floats = the 4 correlations of 16 channels, and the
 //           instruction's CBSZ = 4 / ABID = k fields broadcast block k (channel k) to all sixteen blocks,
@@ -15,12 +20,11 @@
 //     i.e. acc[chan][0..3] += pixel[chan][0..3] * y in one instruction where the VALU needs four, with a wave-uniform
 //     operand at no cost (no DPP, no scalar loads, no LDS) and the accumulators in AGPRs.  Two MFMAs per channel for a
 //     real image (re, im), four for a complex one (records carry (re, im, -im): the MFMA cannot negate an operand).
-// The matrix pipe and the fp64 VALU are different pipes, so the recurrence of one wave runs beside the MFMAs of its SIMD
-// partner; the kernel is bound by the fp64 VALU work (2 FMA + 2 conversions per channel + ~35 operations of set-up per
-// tile), at about half the cycles per channel of the fp64 MFMA kernel (whose MACs share the fp64 pipe with its
-// recurrence).  Accuracy: every phasor is the correctly rounded float32 of an fp64-accurate value, so the result is as
-// close to the float64 transform of the float32 inputs as float32 sums allow -- closer than the reference's float32
-// loop in every regime (tests/test_gpu_f32.py: golden G3 at metre baselines, G13 at 4 km).
+// An 8-cycle MFMA holds the SIMD's vector issue for its whole duration, so nothing overlaps it: a source iteration is
+// its VALU instructions (~4.7 cycles each from one wave) plus 8 cycles per MFMA; per channel the chain form issues two
+// packed float32 instructions where the fp64 form issues 2 FMA + 2 conversions (DESIGN.md 3.10 has the budget and the
+// measured times).  Accuracy: closer to the float64 transform of the float32 inputs than the reference's float32
+// loop in every regime (tests/test_gpu_f32.py: golden G3 at metre baselines, G13 at 4 km, a sweep in between).
 //
 // Frequencies.  A float32 frequency axis is never an exact arithmetic progression (64-128 Hz of rounding at L band),
 // and over a 4 km baseline that rounding is worth 1.2e-4 of the peak visibility -- as much as the reference's own

@@ -58,9 +58,14 @@ def main():
             cc = find(os.path.join(base, sub), "counter_collection.csv")
             if not cc:
                 continue
-            rows = [r for r in csv.DictReader(open(cc)) if dom in r["Kernel_Name"]]
+            # the dominant INSTANTIATION (the stats row with the largest total): some entries launch several
+            # instantiations of which all but one return at once (af_im_to_vis_f32: band class x phasor form)
+            full = summary.get("kernel")
+            allrows = [r for r in csv.DictReader(open(cc)) if dom in r["Kernel_Name"]]
+            rows = [r for r in allrows if r["Kernel_Name"] == full] or allrows
             if not rows:
                 continue
+            names = set(r["Kernel_Name"] for r in rows)
             with open(os.path.join(DST, "%s_%s_pmc_%s.csv" % (tag, w, sub)), "w", newline="") as f:
                 wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
                 wr.writeheader()
@@ -73,7 +78,7 @@ def main():
             kt = find(os.path.join(base, sub), "kernel_trace.csv")
             if kt:
                 dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))
-                       if dom in r["Kernel_Name"]]
+                       if r["Kernel_Name"] in names]
                 if dur:
                     summary["avg_ns_under_pmc_%s" % sub] = sum(dur) / len(dur)
         if "SQ_LDS_BANK_CONFLICT" in summary and summary.get("SQ_LDS_IDX_ACTIVE"):
