@@ -9,6 +9,8 @@
 // cube and its amplitude (computed once per call: the reference takes |.| of every gathered voxel) are
 // read-only and L2/Infinity-Cache resident.  Arithmetic keeps the reference's operation order with
 // explicitly rounded operations (no contraction).
+#include <stdlib.h>
+
 #include "af_common.h"
 #include "af_beam_device.h"
 
@@ -70,9 +72,9 @@ __global__ void beam_pack_kernel(const typename BeamOps<T>::vec2 *__restrict__ b
 }
 
 // beam_sample_corr (af_beam_device.h) reading the packed records: same operations in the same order
-template <typename T>
+template <typename T, typename I>
 __device__ __forceinline__ typename BeamOps<T>::vec2 beam_sample_rec(const T *__restrict__ rec,
-                                                                     const BeamVoxels<T, int64_t> &vx, int c)
+                                                                     const BeamVoxels<T, I> &vx, int c)
 {
     using O = BeamOps<T>;
     using V2 = typename O::vec2;
@@ -137,7 +139,65 @@ __global__ __launch_bounds__(256) void beam_cube_dde_kernel(
     BeamVoxels<T> vx;
     beam_voxels<T, int64_t>(grid, lm[2 * s], lm[2 * s + 1], sin_pa, cos_pa, pe[0], pe[1], as[0], as[1], freq_data[3 * f + 0],
                    freq_data[3 * f + 1], (int)freq_data[3 * f + 2], ncorr, vx);
-    reinterpret_cast<V2 *>(out)[lane_idx] = beam_sample_rec<T>(vrec, vx, c);
+    reinterpret_cast<V2 *>(out)[lane_idx] = beam_sample_rec<T, int64_t>(vrec, vx, c);
+}
+
+// AFHIP_BEAM_BLOCK=0: the flat-index kernel above (measurement hook, read per call)
+inline bool beam_block_enabled()
+{
+    const char *v = getenv("AFHIP_BEAM_BLOCK");
+    return !(v && v[0] == '0');
+}
+
+// The cube-wide constants (two divisions) once per call instead of once per lane.
+template <typename T>
+__global__ void beam_grid_kernel(const T *__restrict__ lm_ext, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                                 BeamGrid<T> *__restrict__ grid)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *grid = beam_grid<T>(lm_ext, beam_lw, beam_mh, beam_nud);
+}
+
+// The same sampling with the index arithmetic taken out of the lanes (round 3).  The kernel above spends ~650 of its
+// ~850 vector instructions per lane on integers: four 64-bit divisions to split the flat index into (source, time,
+// antenna, chan, corr), 64-bit voxel offsets, and the two divisions of the cube constants.  Here the grid is
+// (antenna x chan chunks, time, source): the block's (s, t) -- and a, when an antenna fills a block -- are scalars, a
+// lane's (chan, corr) a shift and a mask
+// (NCL = log2(ncorr), or -1: one 32-bit division), the voxel offsets 32-bit (I) and the constants read from `grid`.
+// Same floating-point operations in the same order: bit-identical to the kernel above.
+template <typename T, typename I, int NCL>
+__global__ __launch_bounds__(256) void beam_cube_dde_block_kernel(
+    const T *__restrict__ vrec, const BeamGrid<T> *__restrict__ gridp, int ncorr, const T *__restrict__ lm,
+    const T *__restrict__ pa_sc, int ntime, int nant, const T *__restrict__ point_errors,
+    const T *__restrict__ antenna_scaling, const T *__restrict__ freq_data, int nchan, int chunks, T *__restrict__ out)
+{
+    using V2 = typename B<T>::vec2;
+    const int lanes = nchan * ncorr;                       // per (source, time, antenna)
+    int a, j;
+    if (chunks > 0) {                                      // `chunks` blocks of 256 lanes per antenna
+        a = (int)blockIdx.x;
+        int chunk = 0;
+        if (chunks > 1) { a = (int)(blockIdx.x / (unsigned)chunks); chunk = (int)blockIdx.x - a * chunks; }
+        j = chunk * 256 + (int)threadIdx.x;
+    } else {                                               // 2^-chunks lanes per antenna, 256 >> -chunks antennas per block
+        const int sh = -chunks;
+        a = (int)blockIdx.x * (256 >> sh) + ((int)threadIdx.x >> sh);
+        j = (int)threadIdx.x & ((1 << sh) - 1);
+    }
+    const int t = (int)blockIdx.y, s = (int)blockIdx.z;
+    if (j >= lanes || a >= nant) return;
+    int f, c;
+    if constexpr (NCL >= 0) { f = j >> NCL; c = j & ((1 << NCL) - 1); }
+    else { f = (int)((unsigned)j / (unsigned)ncorr); c = j - f * ncorr; }
+    const BeamGrid<T> grid = *gridp;
+    const int64_t ta = (int64_t)t * nant + a;
+    const T sin_pa = pa_sc[2 * ta], cos_pa = pa_sc[2 * ta + 1];
+    const T *pe = point_errors + (ta * nchan + f) * 2;
+    const T *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
+    BeamVoxels<T, I> vx;
+    beam_voxels<T, I, I>(grid, lm[2 * s], lm[2 * s + 1], sin_pa, cos_pa, pe[0], pe[1], as[0], as[1], freq_data[3 * f + 0],
+                         freq_data[3 * f + 1], (int)freq_data[3 * f + 2], ncorr, vx);
+    const int64_t base = (((int64_t)s * ntime + t) * nant + a) * lanes;
+    reinterpret_cast<V2 *>(out)[base + j] = beam_sample_rec<T, I>(vrec, vx, c);
 }
 
 template <typename T>
@@ -155,7 +215,7 @@ int freq_grid_interp(const T *frequency, int64_t nchan, const T *beam_freq_map, 
 
 template <typename T>
 struct BeamWs {
-    size_t freq_data, pa_sc, babs, total;
+    size_t freq_data, pa_sc, babs, grid, total;
 };
 
 template <typename T>
@@ -168,6 +228,7 @@ BeamWs<T> beam_ws(int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, int64_t nc
     w.freq_data = take((size_t)nchan * 3 * sizeof(T));
     w.pa_sc = take((size_t)ntime * nant * 2 * sizeof(T));
     w.babs = take((size_t)beam_lw * beam_mh * beam_nud * ncorr * 4 * sizeof(T));  // (re, im, |.|, 0) records
+    w.grid = take(sizeof(BeamGrid<T>));
     w.total = o;
     return w;
 }
@@ -207,6 +268,36 @@ int beam_cube_dde(const T *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_
     hipLaunchKernelGGL((beam_parangle_kernel<T>), dim3((unsigned)af_cdiv(ntime * nant, 256)), dim3(256), 0, st,
                        parallactic_angles, ntime * nant, pa_sc);
     AF_LAUNCH_CHECK();
+    // block-indexed kernel: (source, time, antenna) from the grid, 32-bit offsets into the records
+    const int64_t lanes = nchan * ncorr;
+    if (beam_block_enabled() && ntime <= 65535 && nsrc <= 65535 && lanes < (1LL << 24) &&
+        nvox * 4 < (1LL << 31) && nant < (1LL << 20)) {
+        // >= 129 lanes per antenna: whole 256-lane blocks per antenna; fewer: a power-of-two slot per antenna, several
+        // antennas per block
+        int64_t chunks = af_cdiv(lanes, 256), xblocks = nant * chunks;
+        if (lanes <= 128) {
+            int sh = 0;
+            while ((1 << sh) < lanes) ++sh;
+            chunks = -sh;
+            xblocks = af_cdiv(nant, 256 >> sh);
+        }
+        if (xblocks < (1LL << 31)) {
+            BeamGrid<T> *gridp = reinterpret_cast<BeamGrid<T> *>(ws + W.grid);
+            hipLaunchKernelGGL((beam_grid_kernel<T>), dim3(1), dim3(64), 0, st, beam_lm_extents, beam_lw, beam_mh, beam_nud, gridp);
+            AF_LAUNCH_CHECK();
+            const dim3 g((unsigned)xblocks, (unsigned)ntime, (unsigned)nsrc), b(256);
+#define AF_BEAM_LAUNCH(NCL)                                                                                            \
+    hipLaunchKernelGGL((beam_cube_dde_block_kernel<T, int, NCL>), g, b, 0, st, babs, gridp, ncorr, lm, pa_sc, (int)ntime,    \
+                       (int)nant, point_errors, antenna_scaling, freq_data, (int)nchan, (int)chunks, out)
+            if (ncorr == 4) AF_BEAM_LAUNCH(2);
+            else if (ncorr == 2) AF_BEAM_LAUNCH(1);
+            else if (ncorr == 1) AF_BEAM_LAUNCH(0);
+            else AF_BEAM_LAUNCH(-1);
+#undef AF_BEAM_LAUNCH
+            AF_LAUNCH_CHECK();
+            return AF_OK;
+        }
+    }
     const int64_t blocks = af_cdiv(total * ncorr, 256);
     AF_REQUIRE(blocks < (1LL << 31), "af_beam_cube_dde: problem too large for one launch");
     hipLaunchKernelGGL((beam_cube_dde_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, babs, beam_lw, beam_mh,

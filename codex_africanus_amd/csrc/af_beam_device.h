@@ -61,7 +61,9 @@ __device__ __forceinline__ BeamGrid<T> beam_grid(const T *__restrict__ lm_ext, i
 
 // (l, m) of the source, (sin, cos) of the parallactic angle, pointing error, antenna scaling and
 // the channel's freq_data triple -> voxel offsets and weights (:117-163).
-template <typename T, typename I>
+// J = the integer type of the offset arithmetic (int when the whole cube indexes within 31 bits: a 64-bit multiply is
+// four to six instructions on this machine).
+template <typename T, typename I, typename J = int64_t>
 __device__ __forceinline__ void beam_voxels(const BeamGrid<T> &g, T l, T m, T sin_pa, T cos_pa, T pe_l, T pe_m,
                                             T as_l, T as_m, T freq_scale, T nud, int gc0, int ncorr,
                                             BeamVoxels<T, I> &vx)
@@ -83,13 +85,13 @@ __device__ __forceinline__ void beam_voxels(const BeamGrid<T> &g, T l, T m, T si
         T t2 = vm < g.mmaxf ? vm : g.mmaxf; vm = zero > t2 ? zero : t2;
     }
     const int gl0 = (int)O::floor_(vl), gm0 = (int)O::floor_(vm);
-    const int64_t gl1 = (gl0 + 1 < g.lmaxi) ? gl0 + 1 : g.lmaxi;
-    const int64_t gm1 = (gm0 + 1 < g.mmaxi) ? gm0 + 1 : g.mmaxi;
+    const J gl1 = (gl0 + 1 < (J)g.lmaxi) ? (J)(gl0 + 1) : (J)g.lmaxi;
+    const J gm1 = (gm0 + 1 < (J)g.mmaxi) ? (J)(gm0 + 1) : (J)g.mmaxi;
     const T ld = O::sub(vl, (T)gl0), md = O::sub(vm, (T)gm0);
     const T omld = O::sub(one, ld), ommd = O::sub(one, md);
-    const int64_t GL[8] = {gl0, gl1, gl0, gl1, gl0, gl1, gl0, gl1};
-    const int64_t GM[8] = {gm0, gm0, gm1, gm1, gm0, gm0, gm1, gm1};
-    const int64_t GC[8] = {gc0, gc0, gc0, gc0, gc1, gc1, gc1, gc1};
+    const J GL[8] = {(J)gl0, gl1, (J)gl0, gl1, (J)gl0, gl1, (J)gl0, gl1};
+    const J GM[8] = {(J)gm0, (J)gm0, gm1, gm1, (J)gm0, (J)gm0, gm1, gm1};
+    const J GC[8] = {(J)gc0, (J)gc0, (J)gc0, (J)gc0, (J)gc1, (J)gc1, (J)gc1, (J)gc1};
     vx.wt[0] = O::mul(O::mul(omld, ommd), nud);
     vx.wt[1] = O::mul(O::mul(ld, ommd), nud);
     vx.wt[2] = O::mul(O::mul(omld, md), nud);
@@ -99,7 +101,7 @@ __device__ __forceinline__ void beam_voxels(const BeamGrid<T> &g, T l, T m, T si
     vx.wt[6] = O::mul(O::mul(omld, md), inv_nud);
     vx.wt[7] = O::mul(O::mul(ld, md), inv_nud);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) vx.off[k] = (I)(((GL[k] * g.beam_mh + GM[k]) * g.beam_nud + GC[k]) * ncorr);
+    for (int k = 0; k < 8; ++k) vx.off[k] = (I)(((GL[k] * (J)g.beam_mh + GM[k]) * (J)g.beam_nud + GC[k]) * (J)ncorr);
 }
 
 // One correlation of the sample: weighted sums of the complex voxels and of their amplitudes,
