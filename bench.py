@@ -71,7 +71,7 @@ PMC_ROUNDS = ("r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, n
 NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
                      "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
                                "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
-EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid")
+EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes")
 DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
 
 
@@ -85,7 +85,7 @@ def parse(argv=None):
     p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid"])
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes"])
     p.add_argument("--extras", default="auto",
                    help="other workloads timed for a few steps into \"workloads\" of the same JSON line: auto (all of "
                         "them when N = 1, the workload is the headline and the shape is the default), all, none, or a "
@@ -676,7 +676,36 @@ class Wgrid(object):
         }
 
 
-WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid}
+class WgridF32Planes(Wgrid):
+    """The same call with the w-planes in float32 (af_wgrid_plane_precision(AF_WGRID_PLANES_F32)): what a float32
+    image gets -- the reference's single-precision call, africanus/gridding/wgridder/im2vis.py:41-47 -- and what a
+    float64 caller may opt into at epsilon >= 1e-5 (gridding.wgridder.plane_precision("single")); same checker, same
+    accuracy contract.  Not the default for float64 images: adjointness with `dirty` then holds to ~1e-7, and the
+    reference's double-precision test pins 1e-12."""
+
+    def __init__(self, *a):
+        Wgrid.__init__(self, *a)
+        self.label += "; float32 w-planes"
+
+    def predict(self, d_vis, stream, P):
+        lib = self._lib.load()
+        prev = lib.af_wgrid_plane_precision(1)           # per thread
+        try:
+            Wgrid.predict(self, d_vis, stream, P)
+        finally:
+            lib.af_wgrid_plane_precision(prev)
+
+    def roofline(self, kernel_s):
+        r = Wgrid.roofline(self, kernel_s)
+        nvis = float(self.args.rows) * self.args.chans
+        r["kernel"] = "wg_degrid_tiles<%d, float2>" % self.W
+        r["alg_bytes"] = float(self.nplanes) * self.nu * self.nu * 8 + nvis * 16 + nvis * 4 + self.args.rows * 24
+        r["note"] += "; float32 planes: 8 bytes per cell"
+        return r
+
+
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid,
+             "wgrid_f32planes": WgridF32Planes}
 METRIC = "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err"
 
 

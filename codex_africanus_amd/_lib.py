@@ -118,6 +118,7 @@ _SIGNATURES = {
                                            _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
                                            _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_wgrid_padded": (_i64, [_i64]),
+    "af_wgrid_plane_precision": (_int, [_int]),
     "af_wgrid_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _i64, _int]),
     "af_wgrid_planes": (_i64, [ctypes.c_double, ctypes.c_double, ctypes.c_double, _int, _int]),
     "af_wgrid_im2vis_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double,

@@ -6,9 +6,32 @@ import numpy as np
 from ... import _lib
 from ..._device import Call, _is_torch, np_dtype_of
 
+import contextlib
+import threading
+
 LIGHTSPEED = 2.99792458e8
 _NQUAD = 48
 PLANE_BUDGET = 48 << 30      # bytes of w-plane grids kept resident per call (288 GB of HBM per GPU)
+PLANES_F64, PLANES_F32 = 0, 1                                  # include/afhip.h: AF_WGRID_PLANES_*
+_planes = threading.local()
+
+
+@contextlib.contextmanager
+def plane_precision(mode):
+    """``with plane_precision("single"):`` -- ``model`` calls of this thread keep their w-planes in float32 where the
+    requested accuracy allows (epsilon >= 1e-5): half the bytes of every pass of the plane transforms (configs[4]: 39 ->
+    27 ms, l2 error 1.2905e-6 -> 1.2973e-6).  Not the default for float64 images: <R x, y> = <x, R^H y> then holds to
+    ~1e-7 instead of 1e-12 (the reference's adjointness test pins 1e-12 for double precision,
+    africanus/gridding/wgridder/tests/test_wgridder.py:125-188); float32 images always take float32 planes, as the
+    reference's single-precision calls take float grids in ducc0.  ``"double"`` restores the default."""
+    if mode not in ("single", "double"):
+        raise ValueError("plane_precision is 'single' or 'double'")
+    prev = getattr(_planes, "mode", PLANES_F64)
+    _planes.mode = PLANES_F32 if mode == "single" else PLANES_F64
+    try:
+        yield
+    finally:
+        _planes.mode = prev
 
 
 def kernel_parameters(epsilon):
@@ -134,12 +157,18 @@ def _operator(adjoint, uvw, freq, image, vis, freq_bin_idx, freq_bin_counts, nx,
         resident = max(1, min(want, PLANE_BUDGET // (nu * nv * 16)))
         ws_bytes = int(lib.af_wgrid_workspace_bytes(nx, ny, resident, nrow, max([x[2] for x in bands] + [1]), want, W))
         p_ws = c.scratch(ws_bytes)
-        for b, c0, nc, cands, npl in bands:
-            img = ctypes.c_void_p((p_out if adjoint else p_in).value + 8 * b * nx * ny)
-            _lib.call(entry, p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,
-                      p_in if adjoint else img, nx, ny, float(cell), float(celly), p_cu, p_cv, p_qt,
-                      p_qw, W, beta, float(min(cands)), float(max(cands)), float(max_nm1), int(bool(do_wstacking)), p_wgt,
-                      p_mask, img if adjoint else p_out, p_ws, max(ws_bytes, 256), c.stream)
+        # float32 planes: the reference's single-precision call (float32 image), or the caller's plane_precision("single")
+        single = (not adjoint) and (np_dtype_of(image) == np.float32 or getattr(_planes, "mode", PLANES_F64) == PLANES_F32)
+        prev = lib.af_wgrid_plane_precision(PLANES_F32 if single else PLANES_F64)        # per thread
+        try:
+            for b, c0, nc, cands, npl in bands:
+                img = ctypes.c_void_p((p_out if adjoint else p_in).value + 8 * b * nx * ny)
+                _lib.call(entry, p_uvw, ctypes.c_void_p(p_fr.value + 8 * c0), nrow, nc, c0, nchan,
+                          p_in if adjoint else img, nx, ny, float(cell), float(celly), p_cu, p_cv, p_qt,
+                          p_qw, W, beta, float(min(cands)), float(max(cands)), float(max_nm1), int(bool(do_wstacking)),
+                          p_wgt, p_mask, img if adjoint else p_out, p_ws, max(ws_bytes, 256), c.stream)
+        finally:
+            lib.af_wgrid_plane_precision(prev)
         native = np.float64 if adjoint else np.complex128
         return c.result(h, cast=None if out_dtype == native else out_dtype)
 

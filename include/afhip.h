@@ -448,6 +448,14 @@ int64_t af_wgrid_padded(int64_t n);
 size_t af_wgrid_workspace_bytes(int64_t nx, int64_t ny, int64_t planes, int64_t nrow, int64_t nchan_max,
                                 int64_t nplanes_total, int kernel_width);
 int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking);
+/* Precision of the w-planes of the calling THREAD's following af_wgrid_im2vis_f64 calls; returns the previous mode.
+ * AF_WGRID_PLANES_F32: float32 planes (float32 FFTs, fp64 sums) when kernel_width <= 7, i.e. a requested accuracy of
+ * 1e-5 or coarser -- what the reference's single-precision calls get from ducc0 (float32 image:
+ * africanus/gridding/wgridder/im2vis.py:41-47; its tests then ask l2 <= max(epsilon, 3e-7) and adjointness to 1e-4,
+ * gridding/wgridder/tests/test_wgridder.py:55-108,125-188).  Default AF_WGRID_PLANES_F64 (adjointness to 1e-12). */
+#define AF_WGRID_PLANES_F64 0
+#define AF_WGRID_PLANES_F32 1
+int af_wgrid_plane_precision(int mode);
 int af_wgrid_im2vis_f64(const double *uvw, const double *freq, int64_t nrow, int64_t nchan_band, int64_t chan0,
                         int64_t nchan_total, const double *image, int64_t nx, int64_t ny, double cellx, double celly,
                         const double *corr_u, const double *corr_v, const double *quad_t, const double *quad_w,

@@ -107,7 +107,7 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
     assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
     w = r["workloads"]
-    assert set(w) == {"dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid"}
+    assert set(w) == {"dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes"}
     for name, e in w.items():
         assert "error" not in e, (name, e)
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0

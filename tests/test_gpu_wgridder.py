@@ -235,6 +235,49 @@ def test_dirty_is_the_adjoint_of_model(nrow, nchan, tiled):
         assert _l2error(img[0], ref) <= 1e-9
 
 
+@pytest.mark.parametrize("nrow, nchan, tiled", [(700, 4, False), (9000, 16, True)])
+def test_float32_planes_for_single_precision_images_and_on_request(nrow, nchan, tiled):
+    """float32 w-planes (float32 FFTs, fp64 sums; csrc/af_wgridder.hip): taken by float32 images -- the reference's
+    single-precision call, whose tests ask l2 <= max(epsilon, 3e-7) and adjointness to 1e-4
+    (test_wgridder.py:55-108,125-188) -- and by ``plane_precision("single")``; only for epsilon >= 1e-5 (a finer request
+    keeps fp64 planes whatever the mode); float64 images keep fp64 planes and adjointness to rounding by default.
+    Small call = the per-visibility kernel, large call = the sorted tile kernel."""
+    from codex_africanus_amd.gridding.wgridder import dirty, plane_precision
+    nx, ny, nband = 32, 48, 2
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 8.0, nrow, nchan, nband, seed=11)
+    assert (nrow * (nchan // nband) >= 65536) == tiled
+    ref = np.zeros((nrow, nchan), dtype=np.complex128)
+    for b in range(fbi.size):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref[:, ind] = _explicit_degridder(uvw, freq[ind], image[b], cell, cell)
+    base = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+    with plane_precision("single"):
+        opt = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+        fine = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-7)        # W = 9: fp64 planes whatever the mode
+    again = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)           # the mode ended with the block
+    assert _l2error(base, ref) <= 1e-5 and _l2error(opt, ref) <= 1e-5 and _l2error(fine, ref) <= 1e-7
+    assert np.array_equal(again, base) and not np.array_equal(opt, base)
+    assert 1e-9 < _l2error(opt, base) < 3e-6                               # float32 planes were used, and cost ~1e-7..1e-6
+    assert np.array_equal(fine, model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-7))
+    # a float32 image: complex64 result, float32 planes, the single-precision contract
+    img32 = image.astype(np.float32)
+    v32 = model(uvw, freq, img32, fbi, fbc, cell, epsilon=1e-5)
+    assert v32.dtype == np.complex64
+    ref32 = np.zeros_like(ref)
+    for b in range(fbi.size):
+        ind = slice(fbi[b], fbi[b] + fbc[b])
+        ref32[:, ind] = _explicit_degridder(uvw, freq[ind], img32[b].astype(np.float64), cell, cell)
+    assert _l2error(v32, ref32) <= max(1e-5, 3e-7)
+    # adjointness: to rounding for the default, to single precision with float32 planes (reference tolerances 1e-12 / 1e-4)
+    rng = np.random.default_rng(3)
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    img = dirty(uvw, freq, ms, fbi, fbc, nx, ny, cell, epsilon=1e-5)
+    rhs = np.sum(image * img)
+    for vis, tol in ((base, 1e-11), (opt, 1e-5)):
+        lhs = np.vdot(ms, vis).real
+        assert abs(lhs - rhs) <= tol * max(abs(lhs), np.abs(image).sum() * np.abs(img).max()), tol
+
+
 def test_residual_and_hessian_compose_model_and_dirty():
     """test_wgridder.py:191-354: residual = dirty(vis - model(image)) with the weights on the imaging side only;
     hessian = dirty(model(image)); results in the image's dtype; torch inputs give torch outputs."""

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 fused_dde degrid wgrid}"
+WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 fused_dde degrid wgrid wgrid_f32planes}"
 # the line the driver gets: headline + every other single-GPU workload under "workloads"
 python3 bench.py > "$OUT/default_line.json" 2> "$OUT/default_stderr.log"
 for w in $WORKLOADS; do
