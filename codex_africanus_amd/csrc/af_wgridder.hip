@@ -427,14 +427,25 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
                                                        int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
                                                        const int *__restrict__ nchunks, double2 *__restrict__ vis,
-                                                       const WgPoly poly)
+                                                       const WgPoly poly, int xcd_order)
 {
     constexpr int R = WG_TILE + W - 1;
     constexpr int NL = (R * R + 255) / 256;
     __shared__ double2 reg[R * R];
     __shared__ int kred[8];
-    if ((int)blockIdx.x >= *nchunks) return;
-    const int2 ch = chunks[blockIdx.x];
+    // Block -> chunk.  The chunk list is in (tile, w-bucket) order: consecutive chunks share a tile and overlap in their
+    // plane ranges, i.e. re-read the same cells.  Workgroups are dealt round-robin over the 8 XCDs (block i lives on
+    // XCD i % 8), each with its own L2: numbered one to one, eight consecutive chunks would fetch the same cells into
+    // eight L2s.  Each XCD takes a contiguous eighth of the list instead (AFHIP_WGRID_XCD=0: one to one).
+    const int total = *nchunks;
+    int cidx = (int)blockIdx.x;
+    if (xcd_order) {
+        const int per = (total + 7) >> 3;
+        cidx = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= per) return;
+    }
+    if (cidx >= total) return;
+    const int2 ch = chunks[cidx];
     const int tid = threadIdx.x;
     const int nty = (int)((nv + WG_TILE - 1) / WG_TILE);
     const int tu = ch.x / nty, tv = ch.x - tu * nty;
@@ -1329,6 +1340,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // (W <= 7).  Double-precision calls keep fp64 planes: the reference's test pins <R x, y> = <x, R^H y> to 1e-12
     // for them, and `dirty` stays fp64.  AFHIP_WGRID_F32=0 / 1 overrides the mode (measurement hook).
     static const int f32_env = getenv("AFHIP_WGRID_F32") ? atoi(getenv("AFHIP_WGRID_F32")) : -1;
+    const int xcd_env = getenv("AFHIP_WGRID_XCD") ? atoi(getenv("AFHIP_WGRID_XCD")) : 1;      // read per call (A/B)
     const bool single = !adjoint && kernel_width <= 7 && (f32_env >= 0 ? f32_env != 0 : g_plane_precision == AF_WGRID_PLANES_F32);
     for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
@@ -1362,9 +1374,10 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         }
 #define AF_WG_LAUNCH_P(WC, P)                                                                                          \
     if (tiled)                                                                                                         \
-        hipLaunchKernelGGL((wg_degrid_tiles<WC, P>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,   \
-                           nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, \
-                           do_wstacking, vidx, vstart, kb, chunks, nchunks, reinterpret_cast<double2 *>(vis), poly);     \
+        hipLaunchKernelGGL((wg_degrid_tiles<WC, P>), dim3(max_chunks + 8), dim3(256), 0, st, uvw, freq, nchan_band,      \
+                           chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
+                           pk0, pk1, do_wstacking, vidx, vstart, kb, chunks, nchunks, reinterpret_cast<double2 *>(vis),  \
+                           poly, xcd_env);                                                                               \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_degrid_planes<WC, P>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band,       \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
