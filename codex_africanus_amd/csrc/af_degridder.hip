@@ -207,10 +207,20 @@ __global__ __launch_bounds__(256) void degrid_coop_kernel(const double *__restri
                                                           int ncorr, const double2 *__restrict__ coef,
                                                           double scale_factor, int phase_rotate, double ll, double mm,
                                                           double nn, int64_t nrow, int64_t nchan, int64_t npix,
-                                                          const int *__restrict__ perm, double2 *__restrict__ out)
+                                                          const int *__restrict__ perm, double2 *__restrict__ out,
+                                                          int xcd_per)
 {
     const int W = WT ? WT : Wrt;
-    const int64_t vis_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // rows arrive in uv-tile order: neighbouring blocks gather from the same neighbourhood of the grid.  With xcd_per > 0
+    // each XCD (block i lives on XCD i % 8) takes a contiguous eighth of the blocks (xcd_per of them), so that its L2
+    // holds one neighbourhood instead of a share of eight
+    int64_t lb = blockIdx.x;
+    if (xcd_per > 0) {
+        lb = (int64_t)(blockIdx.x & 7) * xcd_per + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= xcd_per) return;
+    }
+    const int64_t vis_raw = lb * 256 + threadIdx.x;
+    if (lb * 256 >= nrow * nchan) return;
     const bool live = vis_raw < nrow * nchan;
     const int64_t vis_idx = live ? vis_raw : nrow * nchan - 1;
     const int64_t p = vis_idx / nchan, c = vis_idx - p * nchan;
@@ -892,15 +902,17 @@ AF_EXPORT int af_degridder_c128(const double *uvw, const double *gridstack, cons
     static const int coop_env = getenv("AFHIP_DEGRID_COOP") ? atoi(getenv("AFHIP_DEGRID_COOP")) : 1;
     const int64_t coop_blocks = af_cdiv(nrow * nchan, 256);
     if (coop_env && kernel_width <= 8 && coop_blocks < (1LL << 31) && npix < (1LL << 30)) {
-        const dim3 cgrid((unsigned)coop_blocks);
+        const int xcd_on = getenv("AFHIP_DEGRID_XCD") ? atoi(getenv("AFHIP_DEGRID_XCD")) : 1;    // read per call (A/B)
+        const int xcd_per = (xcd_on && perm != nullptr && coop_blocks + 8 < (1LL << 31)) ? (int)af_cdiv(coop_blocks, 8) : 0;
+        const dim3 cgrid((unsigned)(xcd_per ? 8 * (int64_t)xcd_per : coop_blocks));
         if (kernel_width == 7)
             hipLaunchKernelGGL((degrid_coop_kernel<7>), cgrid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel,
                                7, (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn, nrow,
-                               nchan, npix, perm, o);
+                               nchan, npix, perm, o, xcd_per);
         else
             hipLaunchKernelGGL((degrid_coop_kernel<0>), cgrid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel,
                                (int)kernel_width, (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll,
-                               mm, nn, nrow, nchan, npix, perm, o);
+                               mm, nn, nrow, nchan, npix, perm, o, xcd_per);
     } else if (kernel_width == 7)
         hipLaunchKernelGGL((degrid_kernel<7>), grid, block, 0, st, uvw, g, wavelengths, chanmap, convolution_kernel, 7,
                            (int)kernel_oversampling, packed, ncorr, cf, scale_factor, phase_rotate, ll, mm, nn, nrow, nchan,
