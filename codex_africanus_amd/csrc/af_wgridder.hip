@@ -158,14 +158,46 @@ template <> __device__ __forceinline__ float2 wg_cell<float2>(double re, double 
 __device__ __forceinline__ double2 wg_wide(double2 v) { return v; }
 __device__ __forceinline__ double2 wg_wide(float2 v) { return make_double2((double)v.x, (double)v.y); }
 
+// exp(2 pi i t) for the plane's element type.  fp64 planes: the library's sincospi.  float32 planes: the result is
+// rounded to float32 anyway, so the phase is reduced in fp64 (t - rint(t), exact) and the rest runs in float32 -- fold to
+// |theta| <= pi / 4 by quarter turns, Taylor polynomials to theta^9 / theta^8 (truncation 2e-9 / 2.5e-8): ~30 float32
+// operations where sincospi takes ~80 fp64 ones (the fill pass is ALU bound: 16.7 M pixels x 16 planes per call).
+template <typename P> struct WgPhase;
+template <> struct WgPhase<double2> {
+    static __device__ __forceinline__ void eval(double t, double &cs, double &sn) { sincospi(2.0 * t, &sn, &cs); }
+};
+template <> struct WgPhase<float2> {
+    static __device__ __forceinline__ void eval(double t, double &cs, double &sn)
+    {
+        const double MAGIC = 6755399441055744.0;                       // 1.5 * 2^52
+        const float r = (float)(t - ((t + MAGIC) - MAGIC));            // [-0.5, 0.5] turns
+        const float k = rintf(4.0f * r);                               // quarter turns, -2 .. 2
+        const float th = 6.2831853071795865f * fmaf(k, -0.25f, r);     // |theta| <= pi / 4
+        const float t2 = th * th;
+        float s_ = fmaf(t2, 2.7557319e-06f, -1.9841270e-04f);
+        s_ = fmaf(s_, t2, 8.3333333e-03f);
+        s_ = fmaf(s_, t2, -1.6666667e-01f);
+        s_ = fmaf(s_ * t2, th, th);
+        float c_ = fmaf(t2, 2.4801587e-05f, -1.3888889e-03f);
+        c_ = fmaf(c_, t2, 4.1666667e-02f);
+        c_ = fmaf(c_, t2, -0.5f);
+        c_ = fmaf(c_, t2, 1.0f);
+        const int q = (int)k & 3;                                      // rotate by k quarter turns
+        const float cc = (q & 1) ? -s_ : c_, ss = (q & 1) ? c_ : s_;
+        cs = (double)((q & 2) ? -cc : cc);
+        sn = (double)((q & 2) ? -ss : ss);
+        if (!isfinite(t)) { cs = __builtin_nan(""); sn = cs; }
+    }
+};
+
+// grid: (ceil(nv / 256), nx): a block is 256 consecutive pv of the image row ix
 template <typename P>
 __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ image, const double *__restrict__ A,
                                                     const double *__restrict__ nm1, int64_t nx, int64_t ny, int64_t nv,
                                                     double wk, P *__restrict__ S)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx * nv) return;
-    const int64_t ix = i / nv, pv = i - ix * nv;
+    const int64_t ix = blockIdx.y, pv = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pv >= nv) return;
     int64_t iy = pv + ny / 2;                               // pv = (iy - ny/2) mod nv
     iy = iy >= nv ? iy - nv : iy;
     P out = wg_cell<P>(0.0, 0.0);
@@ -173,10 +205,10 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
         const int64_t j = ix * ny + iy;
         const double v = image[j] * A[j];
         double sn, cs;
-        sincospi(2.0 * wk * nm1[j], &sn, &cs);
+        WgPhase<P>::eval(wk * nm1[j], cs, sn);
         out = wg_cell<P>(v * cs, v * sn);
     }
-    S[i] = out;
+    S[ix * nv + pv] = out;
 }
 // G[pv * nu + pu] = S[ix(pu) * nv + pv] (0 where pu is not a row of the image); 32 x 32 tiles through LDS
 template <typename P>
@@ -1348,7 +1380,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             int rc;
             if (single) {
                 float2 *gk = reinterpret_cast<float2 *>(grid) + (int64_t)(k - pk0) * nu * nv, *Sf = reinterpret_cast<float2 *>(S);
-                hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nx * nv, 256)), dim3(256), 0, st, image, A, nm1,
+                hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, image, A, nm1,
                                    nx, ny, nv, w0 + k * dw, Sf);
                 AF_LAUNCH_CHECK();
                 rc = wg_fft_rows((int)nv, (int)nx, Sf, st, false, true);            // along v, the image's rows only
@@ -1361,7 +1393,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 continue;
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
-            hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nx * nv, 256)), dim3(256), 0, st, image, A, nm1, nx,
+            hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, image, A, nm1, nx,
                                ny, nv, w0 + k * dw, S);
             AF_LAUNCH_CHECK();
             rc = wg_fft_rows((int)nv, (int)nx, S, st);                          // along v, the image's rows only
