@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
     const T *__restrict__ dde1, const T *__restrict__ coh, const T *__restrict__ dde2,
     const T *__restrict__ die1, const T *__restrict__ bvis, const T *__restrict__ die2, int64_t nsrc,
     int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p, int *__restrict__ status,
-    T *__restrict__ out, int nct, int64_t nrb, int group, int ts_max, int stage_reals, int trips_max)
+    T *__restrict__ out, int nct, int64_t nrb, int group, int ts_max, int stage_reals, int trips_max, int die_lds)
 {
     constexpr int RS = TB / CT;                      // rows per cell slot: a thread owns rows rl + k RS, k < CPT
     constexpr int RB = RS * CPT;                     // rows per block
@@ -364,43 +364,46 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
     const int64_t sstride_dde = ntime * nant * nchan * CS;
     const int64_t sstride_coh = ncell * CS;
 
-    if (use_lds) {
+    // staging of per-antenna terms (the block's timesteps x every antenna x the tile's channels) into an LDS stage
+    T *lds = reinterpret_cast<T *>(tile_lds);
+    const int units = tsb * (int)nant * SEG_UNITS;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int64_t seg_stride = nchan * CS;       // reals between antennas of one (source, timestep)
+    // a tile that sticks out of the band copies the band's LAST CT channels instead (never reads past the array;
+    // nchan >= CT is a launch condition) and its lanes find channel f at position f - f0c of the segment
+    const int64_t f0c = f0 + CT <= nchan ? f0 : nchan - CT;
+    const int flc = f < nchan ? (int)(f - f0c) : 0;
+    int o1[CPT], o2[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        o1[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a1[k]) * CT + flc) * CS;
+        o2[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a2[k]) * CT + flc) * CS;
+    }
+    // (timestep tlo, antenna 0, channel f0c) of a (time, antenna, chan, corr) array -> stage st
+    auto stage_copy = [&](const T *src0, int st) {
+        T *dst0 = lds + st * stage_reals;
+        for (int t = 0; t < trips; ++t) {
+            const int ebase = t * TB + wave * 64;    // wave-uniform
+            int u = ebase + lane;
+            u = u < units ? u : units - 1;
+            const int seg = u / SEG_UNITS, k = u - seg * SEG_UNITS;
+            const T *g = src0 + (int64_t)seg * seg_stride + k * UNIT;
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst0 + ebase * UNIT));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    };
+    const int64_t slab0 = tlo * nant * seg_stride + f0c * CS;
+
+    if (use_lds && nsrc > 0) {
         // Three LDS stages: in iteration s the coherencies of source s + 1 are requested into registers, THEN the
         // copy of source s + 2's Jones terms is issued, source s is computed from stage s % 3, and the wait at the end
         // leaves exactly that copy outstanding (every wave issues the same `trips` copy instructions per source --
         // lanes past the end of the block's segment list re-copy the last unit into the stage's padding -- so the
         // count is one immediate per trip count).  One barrier per source.
-        T *lds = reinterpret_cast<T *>(tile_lds);
-        const int units = tsb * (int)nant * SEG_UNITS;
-        const int wave = tid >> 6, lane = tid & 63;
-        const int64_t seg_stride = nchan * CS;       // reals between antennas of one (source, timestep)
-        // a tile that sticks out of the band copies the band's LAST CT channels instead (never reads past the array;
-        // nchan >= CT is a launch condition) and its lanes find channel f at position f - f0c of the segment
-        const int64_t f0c = f0 + CT <= nchan ? f0 : nchan - CT;
-        const int flc = f < nchan ? (int)(f - f0c) : 0;
-        int o1[CPT], o2[CPT];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            o1[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a1[k]) * CT + flc) * CS;
-            o2[k] = (((int)(ti[k] - tlo) * (int)nant + (int)a2[k]) * CT + flc) * CS;
-        }
-        const T *src_t = dde1 + tlo * nant * seg_stride + f0c * CS;
-
-        auto stage_load = [&](int64_t s, int st) {
-            const T *src0 = src_t + s * sstride_dde;
-            T *dst0 = lds + st * stage_reals;
-            for (int t = 0; t < trips; ++t) {
-                const int ebase = t * TB + wave * 64;    // wave-uniform
-                int u = ebase + lane;
-                u = u < units ? u : units - 1;
-                const int seg = u / SEG_UNITS, k = u - seg * SEG_UNITS;
-                const T *g = src0 + (int64_t)seg * seg_stride + k * UNIT;
-                const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst0 + ebase * UNIT));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-            }
-        };
+        const T *src_t = dde1 + slab0;
+        auto stage_load = [&](int64_t s, int st) { stage_copy(src_t + s * sstride_dde, st); };
         // wait until only the youngest `trips` vector-memory operations of this wave (one source's copy) are outstanding
         auto wait_keep_one_copy = [&]() {
             switch (trips) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
             }
             st = st == 2 ? 0 : st + 1;
         }
-    } else {
+    } else if (nsrc > 0) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const T *p1 = dde1 + ((ti[k] * nant + a1[k]) * nchan + fc) * CS;
@@ -473,19 +476,36 @@ __global__ __launch_bounds__(TB) void predict_vis_tile_kernel(
             }
         }
     }
+    // out += base_vis (predict.py:329-339), then out = die1 . out . die2^H (:353-367): the DIE terms of the block's
+    // timesteps go through an LDS stage like the DDE terms (die1 == die2 as every caller passes them: `die_lds`);
+    // every stage is free here (the source loop ended with a barrier)
+    const bool die_staged = die_lds && use_lds;          // block-uniform
+    if (die_staged) stage_copy(die1 + slab0, 0);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        if (!live[k]) continue;
-        if (bvis != nullptr) {
+        if (bvis != nullptr && live[k]) {
             Cx<T> b[NC];
             load_jones<T, NC>(bvis + cell[k] * CS, b);
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[k][c] = cadd(acc[k][c], b[c]);
         }
+    }
+    if (die_staged) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        if (!live[k]) continue;
         if (die1 != nullptr) {
             Cx<T> g1[NC], g2[NC], rr[NC];
-            load_jones<T, NC>(die1 + ((ti[k] * nant + a1[k]) * nchan + f) * CS, g1);
-            load_jones<T, NC>(die2 + ((ti[k] * nant + a2[k]) * nchan + f) * CS, g2);
+            if (die_staged) {
+                load_jones<T, NC>(lds + o1[k], g1);
+                load_jones<T, NC>(lds + o2[k], g2);
+            } else {
+                load_jones<T, NC>(die1 + ((ti[k] * nant + a1[k]) * nchan + f) * CS, g1);
+                load_jones<T, NC>(die2 + ((ti[k] * nant + a2[k]) * nchan + f) * CS, g2);
+            }
             jones_mul3<T, NC, J2X2>(g1, acc[k], g2, rr);
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[k][c] = rr[c];
@@ -819,12 +839,13 @@ int launch_tile(const PArgs &a)
     auto stage_bytes = [&](int ts) { return af_align_up((size_t)ts * per_ts, (size_t)TB * 16); };
     int ts_max = env_int("AFHIP_PREDICT_TILE_TS", 1);
     ts_max = ts_max < 1 ? 1 : ts_max > 2 ? 2 : ts_max;
-    while (ts_max > 1 && 3 * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) --ts_max;
-    if (3 * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) return AF_ENOTSUP;
-    const size_t lds = 3 * stage_bytes(ts_max);
+    const size_t stages = a.nsrc > 0 ? 3 : 1;                             // DIE terms only: one stage, filled once
+    while (ts_max > 1 && stages * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) --ts_max;
+    if (stages * stage_bytes(ts_max) > (size_t)TILE_LDS_BUDGET) return AF_ENOTSUP;
+    const size_t lds = stages * stage_bytes(ts_max);
     const int stage_reals = (int)(stage_bytes(ts_max) / sizeof(T));
     const int trips_max = (int)(stage_bytes(ts_max) / ((size_t)TB * 16));
-    if (trips_max > 4) return AF_ENOTSUP;                                  // the counted waits cover 1..4 trips
+    if (trips_max > 4 && a.nsrc > 0) return AF_ENOTSUP;                    // the source loop's counted waits cover 1..4 trips
     const int nct = (int)af_cdiv(a.nchan, CT);
     const int64_t nrb = af_cdiv(a.nrow, RB);
     // row blocks per XCD turn.  Rows first: the ~64 resident workgroups of an XCD are `group` row blocks x 64 / group chan
@@ -843,7 +864,8 @@ int launch_tile(const PArgs &a)
                        (const I *)a.ant2, a.nrow, (const T *)a.dde1, (const T *)a.coh, (const T *)a.dde2,
                        (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.nsrc, a.ntime, a.nant, a.nchan,
                        a.tmin, a.status, (T *)a.out, nct, nrb, env_int("AFHIP_PREDICT_ROWS_FIRST", 1) ? -group : group, ts_max,
-                       stage_reals, trips_max);
+                       stage_reals, trips_max,
+                       (a.die1 != nullptr && a.die1 == a.die2 && ((uintptr_t)a.die1 & 15) == 0 && env_int("AFHIP_PREDICT_DIE_LDS", 1)) ? 1 : 0);
     AF_LAUNCH_CHECK();
     return AF_OK;
 }
@@ -936,6 +958,21 @@ int launch_presence(const PArgs &a)
         } else {
             rc = coh ? launch_tile<T, I, NC, J2X2, true, CT, 512, 1>(a) : launch_tile<T, I, NC, J2X2, false, CT, 512, 1>(a);
         }
+        if (rc != AF_ENOTSUP) return rc;
+    }
+    // apply_gains (predict.py:623-647) and any call with DIE terms but neither DDE terms nor coherencies: the same kernel
+    // with no sources -- the per-lane gain gathers were what held these calls at 3.3 TB/s
+    if (!ddes && !coh && a.die1 != nullptr && a.die1 == a.die2 && env_int("AFHIP_PREDICT_TILE", 1) != 0 &&
+        env_int("AFHIP_PREDICT_DIE_LDS", 1) != 0 && (a.nchan * NC * 2 * sizeof(T)) % 16 == 0 && ((uintptr_t)a.die1 & 15) == 0 &&
+        a.nchan >= 4 && a.nrow * a.nchan >= ((int64_t)1 << 16)) {
+        constexpr int CT = (NC * 2 * sizeof(T) >= 64) ? 4 : (NC * 2 * sizeof(T) >= 32) ? 8 : 16;
+        // one LDS stage leaves room for wider tiles: 2 CT measured best (3.73 / 3.93 / 3.82 TB/s at CT / 2 CT / 4 CT for
+        // 2x2 complex128, tools/bench_apply_gains.py; AFHIP_APPLY_CT is the measurement hook)
+        const int want = env_int("AFHIP_APPLY_CT", 2 * CT);
+        int rc = AF_ENOTSUP;
+        if (want == 4 * CT && a.nchan >= 4 * CT) rc = launch_tile<T, I, NC, J2X2, false, 4 * CT, 512, 1>(a);
+        else if (want == 2 * CT && a.nchan >= 2 * CT) rc = launch_tile<T, I, NC, J2X2, false, 2 * CT, 512, 1>(a);
+        if (rc == AF_ENOTSUP) rc = launch_tile<T, I, NC, J2X2, false, CT, 512, 1>(a);
         if (rc != AF_ENOTSUP) return rc;
     }
     if (ddes && coh) return launch<T, I, NC, J2X2, true, true>(a);

@@ -66,6 +66,29 @@ def test_tile_kernel_bit_exact_c64_int64_offset_unsorted(corrs):
         assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("corrs", [(2, 2), (2,), (1,)])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_apply_gains_and_die_only_calls_on_the_tile_kernel(shape, corrs, monkeypatch):
+    """apply_gains (africanus/rime/predict.py:623-647) = predict_vis with DIE terms and base_vis only: the same kernel
+    with no sources, the gains of the block's timesteps staged in LDS once (one stage, 2 CT channels wide).  Bit-equal
+    to the oracle; with distinct die1 / die2 arrays (lane kernel) and with AFHIP_PREDICT_DIE_LDS=0 (gathers) too;
+    complex64 and int64 indices."""
+    nrow, nchan, _, nant, rpt = shape
+    rng = np.random.default_rng(nrow + 7 * len(corrs))
+    d = _case(rng, nrow, nchan, 1, nant, rpt, corrs)
+    ref = oracle.predict_vis(d["ti"], d["a1"], d["a2"], None, None, None, d["die"], d["bvis"], d["die"])
+    assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"]), ref)
+    assert_array_equal(rime.predict_vis(d["ti"], d["a1"], d["a2"], None, None, None, d["die"], d["bvis"], d["die"]), ref)
+    other = d["die"][:, ::-1].copy()
+    assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], other),
+                       oracle.predict_vis(d["ti"], d["a1"], d["a2"], None, None, None, d["die"], d["bvis"], other))
+    d32 = _case(rng, nrow, nchan, 1, nant, rpt, corrs, dtype=np.complex64, idx=np.int64, offset=3)
+    assert_array_equal(rime.apply_gains(d32["ti"], d32["a1"], d32["a2"], d32["die"], d32["bvis"], d32["die"]),
+                       oracle.predict_vis(d32["ti"], d32["a1"], d32["a2"], None, None, None, d32["die"], d32["bvis"], d32["die"]))
+    monkeypatch.setenv("AFHIP_PREDICT_DIE_LDS", "0")
+    assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"]), ref)
+
+
 def test_tile_and_lane_kernels_agree_and_distinct_dde_arrays_fall_back(monkeypatch):
     """dde1 is not dde2 (legal, rare): the stage holds ONE array, so the call takes the lane-per-cell kernel; both
     kernels give the oracle's bits.  AFHIP_PREDICT_TILE=0 forces the lane kernel for the A/B."""
