@@ -1013,9 +1013,14 @@ def run_ranks(args):
         out = headline_json(args, res, desc, "RCCL all-reduce over xGMI" if backend == "nccl" else "gloo all-reduce")
         extras = {}
         for name in extras_requested(args, world):
+            # the previous workload's buffers go back to the driver before the next one allocates (a free that lands
+            # inside the timed steps shows as one slow step in five); two warm-up steps
+            import gc
+            gc.collect()
+            torch.cuda.synchronize(dev)
             torch.cuda.empty_cache()
             try:
-                r = measure(args, name, max(1, min(args.extra_steps, args.steps)), 1, 0, 1, dev, dist, min(cpu_s, 1.0))
+                r = measure(args, name, max(1, min(args.extra_steps, args.steps)), 2, 0, 1, dev, dist, min(cpu_s, 1.0))
             except Exception as exc:       # an extra must never cost the headline its line
                 extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
                 continue

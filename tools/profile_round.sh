@@ -13,7 +13,9 @@ WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 fused_dde degrid wgrid wgrid_f32
 python3 bench.py > "$OUT/default_line.json" 2> "$OUT/default_stderr.log"
 for w in $WORKLOADS; do
     mkdir -p "$OUT/$w"
-    ARGS="bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --check-rows 0 --extras none"
+    # 10 timed steps after 2 warm-up steps: the kernel-trace average then covers mostly warm launches (the first launch
+    # of a process is 5-10 % slower: clocks, instruction cache) and agrees with the HIP-event figure of the bench line
+    ARGS="bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --check-rows 0 --extras none"
     python3 bench.py --workload $w --extras none > "$OUT/$w/bench_line.json" 2> "$OUT/$w/bench_stderr.log"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w/stats" -o stats -- python3 $ARGS > "$OUT/$w/stats.log" 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/$w/fetch" -o fetch -- python3 $ARGS > "$OUT/$w/fetch.log" 2>&1
@@ -24,7 +26,7 @@ for w in $WORKLOADS; do
         --kernel-trace --output-format csv -d "$OUT/$w/sq2" -o sq2 -- python3 $ARGS > "$OUT/$w/sq2.log" 2>&1
 done
 # auxiliary benches: kernel-trace stats of each (per-kernel durations of the real launches)
-for t in bench_degridder bench_wgridder bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr bench_predict_tile bench_im_to_vis_f32; do
+for t in bench_degridder bench_wgridder bench_vis_to_im bench_wsclean bench_api_kernels bench_im_to_vis_ncorr bench_predict_tile bench_im_to_vis_f32 bench_apply_gains ab_beam_cube; do
     [ -f tools/$t.py ] || continue
     mkdir -p "$OUT/aux/$t"
     python3 tools/$t.py > "$OUT/aux/$t/result.json" 2> "$OUT/aux/$t/stderr.log"
