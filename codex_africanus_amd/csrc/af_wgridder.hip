@@ -437,6 +437,27 @@ __global__ __launch_bounds__(256) void wg_vis_scatter(WgSort q, int *__restrict_
         if (slot >= 0) idx[slot] = (unsigned)i;
     }
 }
+// The sort in ONE pass over the keys (round 3): the counting pass keeps what its atomics return -- the visibility's rank
+// within its bin -- next to the key; after the scan a second pass only adds the bin's start.  (Count, then scatter with
+// a second round of returning atomics and the keys computed twice: 1.9 + 4.5 ms at configs[4].)
+__global__ __launch_bounds__(256) void wg_vis_rank(WgSort q, int *__restrict__ count, int2 *__restrict__ keyrank)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < q.nvis; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        const int key = i < q.nvis ? wg_vis_key(q, i) : -1;
+        const int rank = wg_run_atomic(count, key, true);
+        if (i < q.nvis) keyrank[i] = make_int2(key, rank);
+    }
+}
+__global__ __launch_bounds__(256) void wg_vis_place(int64_t nvis, const int2 *__restrict__ keyrank, const int *__restrict__ start,
+                                                    unsigned *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvis) return;
+    const int2 kr = keyrank[i];
+    if (kr.x >= 0) idx[start[kr.x] + kr.y] = (unsigned)i;
+}
 // chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them
 __global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int chunk, int2 *__restrict__ chunks,
                               int *__restrict__ nchunks)
@@ -1030,7 +1051,7 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, chunks, stage, grid, A, nm1, total; int nbins, ntiles, gtiles; };
+struct WgWs { size_t hist, perm, key, sums, vcount, vstart, vcursor, vidx, vkr, chunks, stage, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
 // nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
@@ -1054,6 +1075,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.vstart = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vcursor = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vidx = take((size_t)nvis_max * sizeof(unsigned));
+    w.vkr = take((size_t)nvis_max * sizeof(int2));              // (key, rank within the bin) of the one-pass sort
     w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / WG_CHUNK + 1) * sizeof(int2));
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
@@ -1287,7 +1309,10 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
         int64_t blocks = af_cdiv(nvis, 256);
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wg_vis_count, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount);
+        static const int onepass = getenv("AFHIP_WGRID_SORT1") ? atoi(getenv("AFHIP_WGRID_SORT1")) : 1;
+        int2 *keyrank = reinterpret_cast<int2 *>(ws + L.vkr);
+        if (onepass) hipLaunchKernelGGL(wg_vis_rank, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount, keyrank);
+        else hipLaunchKernelGGL(wg_vis_count, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount);
         AF_LAUNCH_CHECK();
         const int nblk = (int)af_cdiv(nbins, 1024);
         int *sums = reinterpret_cast<int *>(ws + L.sums);
@@ -1297,8 +1322,12 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_LAUNCH_CHECK();
         hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)nblk), dim3(256), 0, st, vcount, nbins, sums, vstart, vcursor);
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, st, q, vcursor,
-                           reinterpret_cast<unsigned *>(ws + L.vidx));
+        if (onepass)
+            hipLaunchKernelGGL(wg_vis_place, dim3((unsigned)af_cdiv(nvis, 256)), dim3(256), 0, st, nvis, keyrank, vstart,
+                               reinterpret_cast<unsigned *>(ws + L.vidx));
+        else
+            hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, st, q, vcursor,
+                               reinterpret_cast<unsigned *>(ws + L.vidx));
         AF_LAUNCH_CHECK();
         hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
                            reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
