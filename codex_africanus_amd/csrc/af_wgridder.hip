@@ -1393,12 +1393,12 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
         int64_t blocks = af_cdiv(nvis, 256);
         if (blocks > 16384) blocks = 16384;
-        static const int sort_env = getenv("AFHIP_WGRID_SORT1") ? atoi(getenv("AFHIP_WGRID_SORT1")) : 2;
+        const int sort_env = getenv("AFHIP_WGRID_SORT1") ? atoi(getenv("AFHIP_WGRID_SORT1")) : 2;     // read per call (A/B, tests)
         int2 *keyrank = reinterpret_cast<int2 *>(ws + L.vkr);
         int *sums = reinterpret_cast<int *>(ws + L.sums);
         // two levels, atomics in LDS: a few hundred coarse bins of F = 2^S fine keys each (F counters must fit LDS)
         int S = 0;
-        while (af_cdiv(nbins, 1 << S) > 512 && S < 14) ++S;
+        while (af_cdiv(nbins, 1 << S) > 512 && S < 13) ++S;          // F <= 8192 counters = 32 KB of LDS
         const int C = (int)af_cdiv(nbins, 1 << S), NB = (int)af_cdiv(nvis, WG_VPB);
         if (sort_env >= 2 && C <= 2048) {
             int *keys = reinterpret_cast<int *>(ws + L.vidx);          // the keys live where the final indices go

@@ -278,6 +278,27 @@ def test_float32_planes_for_single_precision_images_and_on_request(nrow, nchan, 
         assert abs(lhs - rhs) <= tol * max(abs(lhs), np.abs(image).sum() * np.abs(img).max()), tol
 
 
+def test_the_three_visibility_sorts_give_the_same_visibilities(monkeypatch):
+    """The sorted tile path orders the (row, chan) visibilities by (tile, w bucket) on the device: two levels with every
+    atomic in LDS (default), rank + place with global atomics (AFHIP_WGRID_SORT1=1), count + scatter (=0).  The order
+    inside a bucket differs, the result of a visibility does not depend on it: bit-equal outputs; both directions."""
+    from codex_africanus_amd.gridding.wgridder import dirty
+    nx, ny, nrow, nchan = 96, 64, 9000, 16
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 6.0, nrow, nchan, 2, seed=21)
+    rng = np.random.default_rng(4)
+    flag = (rng.random((nrow, nchan)) > 0.05).astype(np.uint8)
+    ms = rng.standard_normal((nrow, nchan)) + 1j * rng.standard_normal((nrow, nchan))
+    out = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("AFHIP_WGRID_SORT1", mode)
+        out[mode] = (model(uvw, freq, image, fbi, fbc, cell, flag=flag, epsilon=1e-6),
+                     dirty(uvw, freq, ms, fbi, fbc, nx, ny, cell, flag=flag, epsilon=1e-6))
+    for mode in ("1", "0"):
+        assert np.array_equal(out[mode][0], out["2"][0])
+        # the adjoint adds the visibilities of a cell in sorted order: equal to rounding, not to the bit
+        assert np.abs(out[mode][1] - out["2"][1]).max() <= 1e-12 * np.abs(out["2"][1]).max()
+
+
 def test_residual_and_hessian_compose_model_and_dirty():
     """test_wgridder.py:191-354: residual = dirty(vis - model(image)) with the weights on the imaging side only;
     hessian = dirty(model(image)); results in the image's dtype; torch inputs give torch outputs."""
