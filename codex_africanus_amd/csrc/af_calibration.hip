@@ -24,17 +24,27 @@ __device__ __forceinline__ C2 cadd(C2 a, C2 b) { return C2{__dadd_rn(a.re, b.re)
 __device__ __forceinline__ C2 csub(C2 a, C2 b) { return C2{__dsub_rn(a.re, b.re), __dsub_rn(a.im, b.im)}; }
 __device__ __forceinline__ C2 cconj(C2 a) { return C2{a.re, -a.im}; }
 __device__ __forceinline__ C2 cneg(C2 a) { return C2{-a.re, -a.im}; }
-// CPython's _Py_c_quot, the algorithm numba lowers complex division to
+// CPython's _Py_c_quot, the algorithm numba lowers complex division to:
+//   |b.re| >= |b.im|:  rat = b.im / b.re, den = b.re + b.im rat,  ((a.re + a.im rat) / den, (a.im - a.re rat) / den)
+//   otherwise:         rat = b.re / b.im, den = b.re rat + b.im,  ((a.re rat + a.im) / den, (a.im rat - a.re) / den)
+// As ONE instruction stream (round 3): which branch a lane takes depends on its data, so a wave ran both -- six
+// divisions per quotient, 48 per cell of correct_vis with FULL gains, half of that kernel's instructions.  With
+// (x, y) = the larger / smaller part of b and (p, q) = (a.re, a.im) or swapped, both branches are rat = y / x,
+// den = x + y rat, re = (p + q rat) / den (fp addition commutes bit for bit), and the imaginary numerators are the two
+// orders of one subtraction -- computed both (they differ in the sign of an exact zero) and selected.  Same bits.
 __device__ __forceinline__ C2 cdiv(C2 a, C2 b)
 {
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    if (fabs(b.re) >= fabs(b.im)) {
-        if (b.re == 0.0) return C2{nan, nan};
-        const double rat = __ddiv_rn(b.im, b.re), den = __dadd_rn(b.re, __dmul_rn(b.im, rat));
-        return C2{__ddiv_rn(__dadd_rn(a.re, __dmul_rn(a.im, rat)), den), __ddiv_rn(__dsub_rn(a.im, __dmul_rn(a.re, rat)), den)};
-    }
-    const double rat = __ddiv_rn(b.re, b.im), den = __dadd_rn(__dmul_rn(b.re, rat), b.im);
-    return C2{__ddiv_rn(__dadd_rn(__dmul_rn(a.re, rat), a.im), den), __ddiv_rn(__dsub_rn(__dmul_rn(a.im, rat), a.re), den)};
+    const bool first = fabs(b.re) >= fabs(b.im);
+    const double x = first ? b.re : b.im, y = first ? b.im : b.re;
+    const double p = first ? a.re : a.im, q = first ? a.im : a.re;
+    const double rat = __ddiv_rn(y, x), den = __dadd_rn(x, __dmul_rn(y, rat));
+    const double re = __ddiv_rn(__dadd_rn(p, __dmul_rn(q, rat)), den);
+    // first: a.im - a.re rat = q - p rat;  second: a.im rat - a.re = p rat - q
+    const double pr = __dmul_rn(p, rat);
+    const double im = __ddiv_rn(first ? __dsub_rn(q, pr) : __dsub_rn(pr, q), den);
+    const bool zero = first && b.re == 0.0;
+    return C2{zero ? nan : re, zero ? nan : im};
 }
 
 constexpr int jones_elems(int mode, int ncorr) { return mode == 0 ? ncorr : (mode == 1 ? 2 : 4); }
