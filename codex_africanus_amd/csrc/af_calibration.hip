@@ -6,6 +6,8 @@
 // HBM-bound streaming kernels: one lane per (row, chan) cell, directions summed in registers in the
 // reference's order with the reference's operation order (bit-identical results); the time bin of a row is
 // found by a binary search of the (normalised) bin starts instead of the reference's bin-outer loop.
+#include <stdlib.h>
+
 #include "af_common.h"
 
 namespace {
@@ -117,7 +119,11 @@ __device__ __forceinline__ void jones_term(const C2 *__restrict__ g, const C2 *_
 // 64 / 32-byte segment per record and instruction) and the wave transposes through a private LDS region: slot
 // 64 k + lane on the way in, an XOR-swizzled slot on the way out so that both directions are free of bank conflicts.
 // `rec` is the lane's record index (units of J*16 bytes); every lane of the wave must call.
-template <int J>
+// RJ = units of 16 bytes per `rec` (the record a `rec` index counts): J when a call fetches one direction's record,
+// J / ndir when it fetches the ndir adjacent records of a cell in one go (J = ndir x the layout's elements: all
+// directions of a (time, antenna, chan) cell are contiguous, so each load instruction then covers whole cache lines --
+// with two directions of FULL gains 8 cells x 128 bytes = 1 KB contiguous instead of 16 half-used lines).
+template <int J, int RJ = J>
 __device__ __forceinline__ void gather_gain(const C2 *__restrict__ jones, int rec, C2 (&g)[J], double2 *lds_wave)
 {
     if constexpr (J == 1) {
@@ -130,15 +136,15 @@ __device__ __forceinline__ void gather_gain(const C2 *__restrict__ jones, int re
         for (int k = 0; k < J; ++k) {
             const int c = k * CPI + lane / J, h = lane % J;
             const int rec_c = __shfl(rec, c, 64);
-            const int hs = J == 4 ? (h ^ ((c >> 1) & 3)) : h;
-            lds_wave[k * 64 + lane] = src[(int64_t)rec_c * J + hs];
+            const int hs = J >= 4 ? (h ^ ((c >> 1) & (J - 1))) : h;
+            lds_wave[k * 64 + lane] = src[(int64_t)rec_c * RJ + hs];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int slot = J == 4 ? (j ^ ((lane >> 1) & 3)) : j;
+            const int slot = J >= 4 ? (j ^ ((lane >> 1) & (J - 1))) : j;
             const double2 v = lds_wave[lane * J + slot];
             g[j] = C2{v.x, v.y};
         }
@@ -149,7 +155,8 @@ __device__ __forceinline__ void gather_gain(const C2 *__restrict__ jones, int re
 
 // OP 0 corrupt, 1 residual, 2 correct, 3 compute-and-corrupt (model per time bin, phase computed here);
 // grid: ceil(nrow*nchan / 256)
-template <int OP, int MODE, int NCORR>
+// NDIRT = 2: the call has exactly two directions and fetches both records of a gain in one cooperative gather
+template <int OP, int MODE, int NCORR, int NDIRT = 0>
 __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
                                                     const int64_t *__restrict__ ant2, const C2 *__restrict__ jones,
                                                     const C2 *__restrict__ vis, const unsigned char *__restrict__ flag,
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                                                     const double *__restrict__ lm = nullptr)
 {
     constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
-    __shared__ double2 lds_gain[4][J > 1 ? 64 * J : 1];
+    constexpr int JT = NDIRT > 0 ? NDIRT * J : J;       // 16-byte units per gather
+    __shared__ double2 lds_gain[4][JT > 1 ? 64 * JT : 1];
     double2 *lds_wave = lds_gain[threadIdx.x >> 6];
     const int64_t cell_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = cell_raw < nrow * nchan;      // out-of-range lanes still take part in the wave's gathers
@@ -199,17 +207,36 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                 for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
             }
         }
-        for (int64_t s = 0; s < ndir; ++s) {
-            C2 m[V];
-            if (active) {
-#pragma unroll
-                for (int c = 0; c < V; ++c) m[c] = model[(cell * ndir + s) * V + c];
-            }
+        if constexpr (NDIRT > 0) {
+            C2 ga[JT], gb[JT];
             if (any_active) {
-                gather_gain<J>(jones, rec1 + (int)s, g1, lds_wave);
-                gather_gain<J>(jones, rec2 + (int)s, g2, lds_wave);
+                gather_gain<JT, J>(jones, rec1, ga, lds_wave);
+                gather_gain<JT, J>(jones, rec2, gb, lds_wave);
             }
-            if (active) jones_term<MODE, NCORR, OP == 0 ? +1 : -1>(g1, m, g2, acc);
+#pragma unroll
+            for (int s = 0; s < NDIRT; ++s) {
+                C2 m[V];
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < V; ++c) m[c] = model[(cell * NDIRT + s) * V + c];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) { g1[j] = ga[s * J + j]; g2[j] = gb[s * J + j]; }
+                    jones_term<MODE, NCORR, OP == 0 ? +1 : -1>(g1, m, g2, acc);
+                }
+            }
+        } else {
+            for (int64_t s = 0; s < ndir; ++s) {
+                C2 m[V];
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < V; ++c) m[c] = model[(cell * ndir + s) * V + c];
+                }
+                if (any_active) {
+                    gather_gain<J>(jones, rec1 + (int)s, g1, lds_wave);
+                    gather_gain<J>(jones, rec2 + (int)s, g2, lds_wave);
+                }
+                if (active) jones_term<MODE, NCORR, OP == 0 ? +1 : -1>(g1, m, g2, acc);
+            }
         }
     } else if constexpr (OP == 3) {
         // compute_and_corrupt_vis.py:14-22: source_vis = model[t,nu,s] * exp(1j * real_phase) / n, n = sqrt(1 - l^2 - m^2)
@@ -310,9 +337,20 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     const C2 *jn = reinterpret_cast<const C2 *>(jones), *vs = reinterpret_cast<const C2 *>(vis);
     const C2 *md = reinterpret_cast<const C2 *>(model);
     C2 *o = reinterpret_cast<C2 *>(out);
+    // two directions (corrupt / residual): both records of a gain per gather (AFHIP_CALIB_PAIR=0: one per direction)
+    const bool pair = (OP == 0 || OP == 1) && ndir == 2 && !(getenv("AFHIP_CALIB_PAIR") && atoi(getenv("AFHIP_CALIB_PAIR")) == 0);
 #define AF_CALIB_LAUNCH(M, N)                                                                                          \
-    hipLaunchKernelGGL((calib_kernel<OP, M, N>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow, nant, \
-                       nchan, ndir, o, uvw, freq, lm)
+    do {                                                                                                               \
+        if constexpr (OP == 0 || OP == 1) {                                                                            \
+            if (pair) {                                                                                                \
+                hipLaunchKernelGGL((calib_kernel<OP, M, N, 2>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md,  \
+                                   nrow, nant, nchan, ndir, o, uvw, freq, lm);                                         \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((calib_kernel<OP, M, N>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow,     \
+                           nant, nchan, ndir, o, uvw, freq, lm);                                                       \
+    } while (0)
     if (mode == 0 && ncorr == 1) AF_CALIB_LAUNCH(0, 1);
     else if (mode == 0) AF_CALIB_LAUNCH(0, 2);
     else if (mode == 1) AF_CALIB_LAUNCH(1, 2);

@@ -54,6 +54,32 @@ def test_calibration_utils_random_against_oracle(seed):
     assert_array_equal(correct_vis(tbi, tbc, ant1, ant2, j1, data, flag), oracle.correct_vis(tbi, tbc, ant1, ant2, j1, data, flag))
 
 
+@pytest.mark.parametrize("layout", range(4))
+def test_two_directions_fetch_both_gain_records_per_gather(layout, monkeypatch):
+    """With exactly two directions corrupt_vis / residual_vis fetch both records of a gain in one cooperative gather (whole
+    cache lines per load instruction; csrc/af_calibration.hip `calib_kernel<..., 2>`): bit-equal to the oracle and to the
+    one-record-per-direction form (AFHIP_CALIB_PAIR=0) in all four (visibility, gain) layouts, more than one wave per
+    block, flags, rows outside every bin."""
+    rng = np.random.default_rng(40 + layout)
+    ntime, nant, nchan, ndir = 3, 9, 37, 2
+    corr, jcorr = [((1,), (1,)), ((2,), (2,)), ((2, 2), (2,)), ((2, 2), (2, 2))][layout]
+    a1, a2 = np.triu_indices(nant, 1)
+    nbl = a1.shape[0]
+    nrow = ntime * nbl + 2
+    tbi, tbc = (np.arange(ntime) * nbl).astype(np.int64), np.full(ntime, nbl, np.int64)
+    ant1 = np.concatenate([np.tile(a1, ntime), [0, 1]]).astype(np.int64)
+    ant2 = np.concatenate([np.tile(a2, ntime), [1, 2]]).astype(np.int64)
+    rc = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    jones, model, data = rc(ntime, nant, nchan, ndir, *jcorr) + 1.0, rc(nrow, nchan, ndir, *corr), rc(nrow, nchan, *corr)
+    flag = rng.random(data.shape) < 0.2
+    ref_c = oracle.corrupt_vis(tbi, tbc, ant1, ant2, jones, model)
+    ref_r = oracle.residual_vis(tbi, tbc, ant1, ant2, jones, data, flag, model)
+    for pair in ("1", "0"):
+        monkeypatch.setenv("AFHIP_CALIB_PAIR", pair)
+        assert_array_equal(corrupt_vis(tbi, tbc, ant1, ant2, jones, model), ref_c)
+        assert_array_equal(residual_vis(tbi, tbc, ant1, ant2, jones, data, flag, model), ref_r)
+
+
 def test_calibration_round_trip_and_errors(g9):
     """correct_vis undoes a direction-independent corrupt_vis (calibration/utils/tests/test_utils.py:117-164);
     the reference's argument errors"""
