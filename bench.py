@@ -101,6 +101,9 @@ def parse(argv=None):
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
                    help="torch.distributed backend; nccl = RCCL over xGMI.  auto = nccl, or gloo when "
                         "AFHIP_BENCH_DEVICE puts the ranks on one device (the N > 1 code path on a one-GPU box)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="N = 1: still create the process group (world size 1) and all-reduce the chi^2 vector every step -- "
+                        "on a one-GPU box this loads librccl, builds a communicator and runs the collective on the device")
     p.add_argument("--launch-timeout", type=int, default=3600, help="self-launched ranks: seconds before they are killed")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=2.0,
@@ -197,6 +200,25 @@ class Dft(object):
     def reference_rows(self, rows):
         import oracle
         return oracle.im_to_vis(self.image, self.uvw[rows], self.lm, self.freq, omp=True), rows
+
+    def end_to_end(self):
+        """The drop-in call as a reference user makes it: numpy in -> numpy out, `dft.im_to_vis(image, uvw, lm, frequency)`
+        (upload, transform, 64 B per visibility back over PCIe into a fresh array).  SURVEY 8(d): reported separately,
+        never `value`.  Best of two calls after one warm call."""
+        from codex_africanus_amd import dft
+        a = self.args
+        best = None
+        for k in range(3):
+            t0 = time.perf_counter()
+            vis = dft.im_to_vis(self.image, self.uvw, self.lm, self.freq)
+            dt = time.perf_counter() - t0
+            if k:
+                best = dt if best is None else min(best, dt)
+        assert vis.shape == (a.rows, a.chans, 4)
+        del vis
+        return {"ms": best * 1e3, "value": a.rows * a.chans / best / 1e6, "unit": "Mvis/s",
+                "call": "codex_africanus_amd.dft.im_to_vis(numpy arrays) -> numpy array: H2D + kernels + D2H of %.2f GB"
+                        % (a.rows * a.chans * 64 / 1e9)}
 
     def roofline(self, kernel_s):
         a = self.args
@@ -405,6 +427,22 @@ class FusedDde(object):
                        self.MH, self.NUD, P(v["ext"]), P(v["fmap"]), P(v["pa"]), self.ntime, self.NANT, P(v["pe"]),
                        P(v["asc"]), None, None, self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws),
                        self.ws_bytes, stream)
+
+    def front_end_check(self, d_vis, rank, world, dev):
+        """The row-shard front-end a multi-GPU job goes through -- sharding.fused_predict_shard with this rank's rows
+        and timesteps (bounds given) -- on the arrays of the benchmark: its visibilities must equal the direct C-ABI
+        call's (d_vis) in every bit.  One extra predict before the timed region."""
+        import torch
+        from codex_africanus_amd import sharding
+        v, a = self.dv, self.args
+        ti = torch.from_numpy(self.h["time_index"]).to(dev)
+        vis, _, bounds = sharding.fused_predict_shard(
+            rank, world, ti, v["a1"], v["a2"], v["lm"], v["uvw"], v["freq"], v["X"], v["beam"], v["ext"], v["fmap"],
+            v["pa"], v["pe"], v["asc"], bounds=(rank * a.rows, (rank + 1) * a.rows))
+        same = bool(torch.equal(vis.reshape(d_vis.shape), d_vis))
+        if not same:
+            raise SystemExit("rank %d: sharding.fused_predict_shard differs from the C-ABI call" % rank)
+        return "sharding.fused_predict_shard(rank %d of %d, rows %s) == af_fused_predict_c128: bit-equal" % (rank, world, bounds)
 
     def _chain(self, rows, dde=None, tinv=None):
         """The reference chain on `rows` (only their timesteps' Jones terms are built)."""
@@ -794,12 +832,13 @@ def check_rows(wl, d_vis, nrow, n, dev):
     return float(np.abs(got - ref.reshape(got.shape)).max())
 
 
-def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
+def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, collective=None):
     """Times `steps` steps of one workload on this rank's device (all ranks call it together).  Returns the result
-    dict on rank 0, None elsewhere."""
+    dict on rank 0, None elsewhere.  `collective`: all-reduce the chi^2 vector (default: when world > 1)."""
     import torch
-    from codex_africanus_amd import _lib
+    from codex_africanus_amd import _lib, sharding
     lib = _lib.load()
+    collective = world > 1 if collective is None else collective
     wargs = argparse.Namespace(**vars(args))
     wargs.workload = workload
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -821,9 +860,10 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
         wl.predict(d_vis, stream, P)
         if have_chi2:
             _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
-            if world > 1:
-                dist.all_reduce(d_chi2, op=dist.ReduceOp.SUM)
+            if collective:
+                sharding.allreduce_chi2(d_chi2)       # RCCL over xGMI (gloo in the one-device tests)
 
+    front_end = wl.front_end_check(d_vis, rank, world, dev) if hasattr(wl, "front_end_check") else None
     for _ in range(warmup):
         step()
     ev = Events(_lib, steps)
@@ -860,6 +900,10 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds):
         "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
         "corrs": ncorr, "fp64_max_abs_err": max_err, "roofline": roofline_entry(wl, wargs, workload, kernel_s),
     }
+    if front_end is not None:
+        res["front_end"] = front_end
+    if hasattr(wl, "end_to_end") and world == 1:
+        res["end_to_end"] = wl.end_to_end()
     if cpu_seconds > 0 and world == 1:
         res["cpu_baseline"] = wl.cpu_baseline(cpu_seconds)
     return res
@@ -886,7 +930,50 @@ def headline_json(args, res, world_desc, backend_desc):
     }
     if "cpu_baseline" in res:
         out["cpu_baseline"] = res["cpu_baseline"]
+    if "front_end" in res:
+        out["config"]["front_end"] = res["front_end"]
     return out
+
+
+def compact_summary(out, res, extras):
+    """Per-workload numbers where the driver's record keeps them (its `parsed` copy keeps the scalar
+    entries of "config", "roofline" and "cpu_baseline" and a 2 000-character tail of the line; the long "workloads"
+    block falls outside both).  Three copies of the same few numbers: scalar keys `<workload>_<field>` inside
+    "roofline", the same table as lists under roofline["others"] ([ms_per_step, kernel_ms, frac, max_abs_err,
+    Mvis/s]), and -- as the LAST key of the line, i.e. inside the tail -- "summary"."""
+    roof, table = out["roofline"], {}
+    for name, e in extras.items():
+        if "error" in e:
+            table[name] = None
+            roof["%s_error" % name] = e["error"][:120]
+            continue
+        r = e["roofline"]
+        table[name] = [round(e["ms_per_step"], 4), round(e["kernel_ms"], 4), round(r["frac"], 4), e["fp64_max_abs_err"],
+                       round(e["value"], 2)]
+        roof["%s_ms_per_step" % name] = e["ms_per_step"]
+        roof["%s_kernel_ms" % name] = e["kernel_ms"]
+        roof["%s_frac" % name] = r["frac"]
+        roof["%s_bound" % name] = r["bound"]
+        roof["%s_max_abs_err" % name] = e["fp64_max_abs_err"]
+        for k, v in e.get("variants", {}).items():
+            roof["%s_%s" % (name, k)] = v
+    if table:
+        roof["others"] = table
+        roof["others_columns"] = "ms_per_step, kernel_ms, roofline frac, max_abs_err, Mvis/s"
+    e2e = res.get("end_to_end")
+    if e2e:
+        out["end_to_end"] = e2e
+        out["config"]["end_to_end_ms"] = e2e["ms"]
+        out["config"]["end_to_end_mvis_s"] = e2e["value"]
+        roof["end_to_end_ms"] = e2e["ms"]
+        roof["end_to_end_mvis_s"] = e2e["value"]
+    if table or e2e:
+        out["summary"] = {"headline": [round(out["ms_per_step"], 4), round(roof["kernel_ms"], 4), round(roof["frac"], 4),
+                                       out["fp64_max_abs_err"], round(out["value"], 2)],
+                          "columns": "ms_per_step, kernel_ms, roofline frac, max_abs_err, Mvis/s",
+                          "end_to_end_ms": None if not e2e else round(e2e["ms"], 3),
+                          "end_to_end_mvis_s": None if not e2e else round(e2e["value"], 2)}
+        out["summary"].update(table)
 
 
 def extras_requested(args, world):
@@ -948,27 +1035,79 @@ def require_devices(n, what):
     return have
 
 
+def supervise(procs, logs, timeout):
+    """Waits for rank processes started with Popen (rank 0's stdout a pipe, `logs[r]` the file rank r > 0 writes to or
+    None).  The first rank that exits non-zero ends the job: the others -- blocked in the rendezvous or the all-reduce
+    it never joins -- are terminated and reaped.  Returns (exit code, rank 0's stdout, message)."""
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    def rank_log(r):
+        if logs[r] is None:
+            return ""
+        logs[r].seek(0)
+        return logs[r].read().decode("utf-8", "replace")[-2000:]
+
+    deadline = time.time() + timeout
+    failed, message = None, ""
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            stop_all()
+            break
+        if time.time() > deadline:
+            stop_all()
+            reader.join(timeout=10)
+            return 1, b"".join(chunks), "the ranks did not finish within %d s; stopped" % timeout
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    if failed is None:
+        bad = [(r, c) for r, c in enumerate(codes) if c]
+        failed = bad[0] if bad else None
+    if failed is not None:
+        message = "rank %d exited with code %d; exit codes of all ranks %s\n%s" % (failed[0], failed[1], codes, rank_log(failed[0]))
+        return (failed[1] if failed[1] > 0 else 1), b"".join(chunks), message
+    return 0, b"".join(chunks), ""
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher: start the N ranks (children of this GPU-free process), relay
     rank 0's JSON line, fail if any rank fails."""
+    import tempfile
     require_devices(args.gpus, "self-launched ranks")
     envs = rank_environments(args.gpus, free_port(), os.environ)
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
-    procs = []
+    procs, logs = [], []
     for r, e in enumerate(envs):
-        procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    try:
-        out0, _ = procs[0].communicate(timeout=args.launch_timeout)
-        codes = [procs[0].returncode] + [p.wait(timeout=60) for p in procs[1:]]
-    except subprocess.TimeoutExpired:        # a rank that never met the rendezvous must not hang the driver
-        for p in procs:
-            p.kill()
-        sys.stderr.write("bench.py: the ranks did not finish within %d s; killed\n" % args.launch_timeout)
-        return 1
+        # rank 0's stdout carries the JSON line; the other ranks' output is kept (a rank that dies says why)
+        log = None if r == 0 else tempfile.TemporaryFile()
+        logs.append(log)
+        procs.append(subprocess.Popen(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else log,
+                                      stderr=None if r == 0 else subprocess.STDOUT))
+    code, out0, message = supervise(procs, logs, args.launch_timeout)
     text = out0.decode("utf-8", "replace")
+    if code:
+        sys.stderr.write("bench.py: %s\n%s\n" % (message, text[-2000:]))
+        return code
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
-    if any(codes) or len(lines) != 1:
-        sys.stderr.write("bench.py: rank exit codes %s; rank 0 printed %d JSON line(s)\n%s\n" % (codes, len(lines), text[-2000:]))
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON line(s)\n%s\n" % (len(lines), text[-2000:]))
         return 1
     sys.stdout.write(lines[0] + "\n")
     sys.stdout.flush()
@@ -992,8 +1131,14 @@ def run_ranks(args):
     backend = args.backend
     if backend == "auto":
         backend = "gloo" if "AFHIP_BENCH_DEVICE" in os.environ else "nccl"
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if grouped:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                       # --force-dist without a launcher: this process is the whole job
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         else:
@@ -1004,13 +1149,18 @@ def run_ranks(args):
         dist.all_reduce(warm)
         torch.cuda.synchronize(dev)
     cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
-    res = measure(args, args.workload, args.steps, args.warmup, rank, world, dev, dist, cpu_s)
+    res = measure(args, args.workload, args.steps, args.warmup, rank, world, dev, dist, cpu_s, collective=grouped)
     if rank == 0:
         launcher = ("self-launched" if os.environ.get("AFHIP_BENCH_SELF_LAUNCHED") else "external launcher") if world > 1 else "single process"
         desc = "ranks: one process per GPU (%s), %d of %d device(s) visible in use%s" % (
             launcher, 1 if "AFHIP_BENCH_DEVICE" in os.environ else world, have,
             ", all ranks on device %s" % os.environ["AFHIP_BENCH_DEVICE"] if "AFHIP_BENCH_DEVICE" in os.environ and world > 1 else "")
         out = headline_json(args, res, desc, "RCCL all-reduce over xGMI" if backend == "nccl" else "gloo all-reduce")
+        if grouped and world == 1:
+            out["config"]["collective"] = ("world-size-1 process group (--force-dist), backend %s: chi2 all-reduced by "
+                                           "sharding.allreduce_chi2 every step" % backend)
+            if backend == "nccl":
+                out["config"]["rccl_loaded"] = any("librccl" in ln for ln in open("/proc/self/maps"))
         extras = {}
         for name in extras_requested(args, world):
             # the previous workload's buffers go back to the driver before the next one allocates (a free that lands
@@ -1041,9 +1191,10 @@ def run_ranks(args):
                                                 if k in r["cpu_baseline"]}
         if extras:
             out["workloads"] = extras
+        compact_summary(out, res, extras)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
@@ -1103,6 +1254,10 @@ def run_threads(args):
     staging = torch.zeros((n, nchan), dtype=torch.float64, device=dev0)
     total = torch.zeros(nchan, dtype=torch.float64, device=dev0)
     reduce_stream = torch.cuda.Stream(device=dev0)
+    with torch.cuda.device(dev0):
+        reduced = torch.cuda.Event()
+        reduced.record(reduce_stream)
+    history = []
     evs = []
     for w in workers:                    # a HIP event belongs to the device that is current when it is created
         with torch.cuda.device(w.dev):
@@ -1120,6 +1275,7 @@ def run_threads(args):
         if step_no is not None:
             evs[k].disarm()
         with torch.cuda.stream(w.stream):
+            w.stream.wait_event(reduced)                       # the previous step's sum has read staging[k]
             staging[k].copy_(w.d_chi2, non_blocking=True)      # xGMI peer copy (nchan doubles)
             w.done.record(w.stream)
         return k
@@ -1132,6 +1288,8 @@ def run_threads(args):
             reduce_stream.wait_event(w.done)
         with torch.cuda.stream(reduce_stream):
             torch.sum(staging, dim=0, out=total)
+            history.append(total.clone())                      # every step's reduced vector is checked below
+            reduced.record(reduce_stream)
         return len(done)
 
     def sync_all():
@@ -1159,6 +1317,9 @@ def run_threads(args):
     chi2_check = sum(w.d_chi2.cpu().numpy() for w in workers)
     if not np.allclose(chi2_sum, chi2_check, rtol=1e-12, atol=0):
         raise SystemExit("chi^2 reduced across devices differs from the sum of the partials")
+    for k, h in enumerate(history):          # identical inputs every step: every step's reduction must be the same vector
+        if not np.array_equal(h.cpu().numpy(), chi2_sum):
+            raise SystemExit("step %d reduced a different chi^2 vector than the last step (staging overwritten early?)" % k)
     w0 = workers[0]
     with torch.cuda.device(dev0):
         max_err = check_rows(w0.wl, w0.d_vis, nrow, args.check_rows, dev0) if args.check_rows > 0 else None

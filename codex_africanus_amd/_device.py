@@ -135,6 +135,7 @@ class _DeferredStatus(object):
         self._buf = None
         self._free = []
         self._pending = []          # (slot, event, message)
+        self._carry = []            # messages of flagged calls drained to make room, not yet reported
 
     def _ensure(self):
         if self._buf is None:
@@ -147,7 +148,9 @@ class _DeferredStatus(object):
         with self._lock:
             self._ensure()
             if not self._free:
-                self._drain_locked(wait=True)
+                # every slot is in flight (more than SLOTS device-mode calls enqueued before the GPU retired one):
+                # wait for them, and KEEP what they report -- poll() raises it first
+                self._carry.extend(self._drain_locked(wait=True))
             slot = self._free.pop()
         word = ws_tensor[offset_bytes:offset_bytes + 4].view(torch.int32)
         self._buf[slot:slot + 1].copy_(word, non_blocking=True)
@@ -172,10 +175,11 @@ class _DeferredStatus(object):
         return bad
 
     def poll(self, wait=False):
-        if not self._pending:
+        if not self._pending and not self._carry:
             return
         with self._lock:
-            bad = self._drain_locked(wait)
+            bad = self._carry + self._drain_locked(wait)
+            self._carry = []
         if bad:
             raise ValueError("; ".join(bad) + " (reported by an earlier device-mode call; its rows are NaN)")
 

@@ -199,3 +199,72 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
             chan_blocks.append(acc)
         row_blocks.append(_cat(chan_blocks, 1))
     return _cat(row_blocks, 0)
+
+
+def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
+                      beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
+                      point_errors=None, antenna_scaling=None,
+                      die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
+                      feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
+                      corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, streams=None, chunks=None):
+    """
+    Chunked fused predict from source-level inputs, block for block what ``rime.dask.fused_predict_vis`` computes (the
+    reference graph of africanus/rime/examples/predict.py:404-525 with the chunk rules of
+    africanus/rime/dask_predict.py:478-524) on numpy arrays or torch ROCm tensors.
+
+    ``chunks``: dict with any of "source", "row", "time", "chan".  Row chunk k is paired with time chunk k of
+    ``parallactic_angles`` / ``point_errors`` / ``feed_rotation`` / ``die{1,2}_jones`` (counts must agree; every block
+    normalises ``time_index`` by its own minimum, africanus/rime/predict.py:597); the antenna axis and the beam cube
+    are never chunked.  Source chunks are summed (serial chain when ``streams=True``); ``base_vis`` and the DIEs are
+    applied to that sum.  The row layout's plan is made once per row chunk and re-used for its source and channel blocks.
+    """
+    from .rime.fused import fused_predict_vis as _fused, cached_plan
+    chunks = chunks or {}
+    if (die1_jones is None) != (die2_jones is None):
+        raise ValueError("Both die1_jones and die2_jones must be present or absent")
+    nrow, nsrc, nchan = int(uvw.shape[0]), int(lm.shape[0]), int(frequency.shape[0])
+    per_time = [a for a in (parallactic_angles, point_errors, feed_rotation, die1_jones, die2_jones) if a is not None]
+    ntime = int(per_time[0].shape[0]) if per_time else None
+    row_chunks = normalize_chunks(chunks.get("row"), nrow, "row")
+    chan_chunks = normalize_chunks(chunks.get("chan"), nchan, "chan")
+    src_chunks = normalize_chunks(chunks.get("source"), nsrc, "source")
+    if ntime is not None:
+        time_chunks = normalize_chunks(chunks.get("time"), ntime, "time")
+        if len(time_chunks) != len(row_chunks):
+            raise ValueError("Number of row chunks (%s) does not equal number of time chunks (%s)."
+                             % (row_chunks, time_chunks))
+        tb = _bounds(time_chunks)
+    else:
+        tb = [(0, 0)] * len(row_chunks)
+    if "ant" in chunks or "antenna" in chunks:
+        na = int(per_time[0].shape[1]) if per_time else None
+        if na is not None and normalize_chunks(chunks.get("ant", chunks.get("antenna")), na, "ant") != (na,):
+            raise ValueError("Subdivision of antenna dimension into multiple chunks is not supported.")
+    flat = brightness is not None and len(brightness.shape) == 3
+    cut = lambda a, *sl: None if a is None else a[sl]
+    row_blocks = []
+    for (r0, r1), (t0, t1) in zip(_bounds(row_chunks), tb):
+        ti, a1, a2, uv = time_index[r0:r1], antenna1[r0:r1], antenna2[r0:r1], uvw[r0:r1]
+        plan = None
+        if beam is not None:
+            plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]))
+        chan_blocks = []
+        for (c0, c1) in _bounds(chan_chunks):
+            acc = None
+            for (s0, s1) in _bounds(src_chunks):
+                b = None if brightness is None else (brightness[s0:s1] if flat else brightness[s0:s1, c0:c1])
+                part = _fused(ti, a1, a2, lm[s0:s1], uv, frequency[c0:c1], b, beam, beam_lm_extents, beam_freq_map,
+                              cut(parallactic_angles, slice(t0, t1)),
+                              cut(point_errors, slice(t0, t1), slice(None), slice(c0, c1)),
+                              cut(antenna_scaling, slice(None), slice(c0, c1)), None, None, None, convention,
+                              cut(feed_rotation, slice(t0, t1)), cut(gauss_shape, slice(s0, s1)),
+                              cut(stokes, slice(s0, s1)), cut(spi, slice(s0, s1)), cut(ref_freq, slice(s0, s1)),
+                              corr_schema, spectral_base, plan)
+                acc = part if acc is None else acc + part
+            if die1_jones is not None or base_vis is not None:
+                bv = acc if base_vis is None else base_vis[r0:r1, c0:c1] + acc
+                acc = _predict_vis(ti, a1, a2, None, None, None, cut(die1_jones, slice(t0, t1), slice(None), slice(c0, c1)),
+                                   bv, cut(die2_jones, slice(t0, t1), slice(None), slice(c0, c1)))
+            chan_blocks.append(acc)
+        row_blocks.append(_cat(chan_blocks, 1))
+    return _cat(row_blocks, 0)

@@ -192,3 +192,131 @@ def predict_vis(time_index, antenna1, antenna2, dde1_jones=None, source_coh=None
         die2_jones, None if die2_jones is None else g_ix, block_ids, ("row",),
         align_arrays=False, adjust_chunks={"row": row_chunks},
         meta=np.empty((0,) * len(v_ix), dtype=out_dtype), dtype=out_dtype)
+
+
+# ---------------------------------------------------------------------------- fused predict from source-level inputs
+def _fused_block(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, extents, freq_map, pa, pe,
+                 ascale, feed_rot, gauss_shape, stokes, spi, ref_freq, running, block_id=None, convention="fourier",
+                 corr_schema=None, spectral_base=0):
+    """One (source chunk, row chunk, chan chunk) block: every contracted axis (lm / uvw components, antennas, the
+    beam cube's axes) arrives as nested one-element lists; ``running`` is the previous link of a ``streams=True``
+    chain (its length-1 source axis still on)."""
+    from .fused import fused_predict_vis as _np_fused, cached_plan
+    u = lambda x: None if x is None else _first(x)
+    pa_ = u(pa)
+    with placement.block(block_id):
+        plan = None if beam is None else cached_plan(time_index, antenna1, antenna2, pa_.shape[1])
+        vis = _np_fused(time_index, antenna1, antenna2, u(lm), u(uvw), frequency, u(brightness), u(beam), u(extents),
+                        u(freq_map), pa_, u(pe), u(ascale), None, None, None, convention, u(feed_rot), u(gauss_shape),
+                        u(stokes), u(spi), u(ref_freq), corr_schema, spectral_base, plan)
+    if running is not None:
+        vis = vis + running[0]
+    return vis[None, ...]
+
+
+def _single_chunk(arr, axes, message):
+    if arr is not None and any(len(arr.chunks[ax]) != 1 for ax in axes):
+        raise ValueError(message)
+
+
+def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
+                      beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
+                      point_errors=None, antenna_scaling=None,
+                      die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
+                      feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
+                      corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, streams=None):
+    """
+    dask front-end of :func:`codex_africanus_amd.rime.fused_predict_vis`: the graph the reference builds from
+    source-level inputs (africanus/rime/examples/predict.py:404-525: ``rime.dask.phase_delay`` -> ``da.einsum`` ->
+    ``rime.dask.beam_cube_dde`` [-> feed rotation einsum] -> ``rime.dask.predict_vis``) as ONE blockwise call whose
+    block is one fused device call: neither the (source, row, chan, 2, 2) coherencies nor the (source, time, ant, chan,
+    2, 2) beam terms ever exist.  The chunk contract is the reference's: row chunks of ``time_index`` / ``antenna1`` /
+    ``antenna2`` / ``uvw`` / ``base_vis`` agree; every per-time array (``parallactic_angles``, ``point_errors``,
+    ``feed_rotation``, ``die{1,2}_jones``) has as many time chunks as there are row chunks, row chunk k indexing into
+    time chunk k (every block normalises ``time_index`` by its own minimum, africanus/rime/predict.py:597); the antenna
+    axis, the beam cube, its extents and its frequency map are single chunks (africanus/rime/dask_predict.py:478-524,
+    africanus/rime/dask.py:177-185); source chunks are summed -- by a serial chain when ``streams=True``, else by
+    ``sum(axis=0)`` -- and ``base_vis`` / the DIEs are applied after that sum (africanus/rime/dask_predict.py:372-439).
+    Row block k runs on GPU k % n_devices (``placement``); the row layout's plan is cached per row chunk.
+    """
+    _need_dask()
+    if (die1_jones is None) != (die2_jones is None):
+        raise ValueError("Both die1_jones and die2_jones must be present or absent")
+    beam_args = (beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
+    have_beam = beam is not None
+    if any((a is None) != (not have_beam) for a in beam_args):
+        raise ValueError("beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors and "
+                         "antenna_scaling must all be present or all absent")
+    model = stokes is not None or spi is not None or ref_freq is not None
+    if model and (brightness is not None or stokes is None or spi is None or ref_freq is None):
+        raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
+    if not model and brightness is None:
+        raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
+    if feed_rotation is not None and not have_beam:
+        raise ValueError("feed_rotation multiplies the beam term: pass the beam arguments as well")
+    row_chunks = time_index.chunks[0]
+    for name, a in (("antenna1", antenna1), ("antenna2", antenna2), ("uvw", uvw), ("base_vis", base_vis)):
+        if a is not None and a.chunks[0] != row_chunks:
+            raise ValueError("%s row chunks %s do not match time_index row chunks %s" % (name, a.chunks[0], row_chunks))
+    _single_chunk(beam, range(beam.ndim) if have_beam else (), "Beam chunking unsupported")
+    _single_chunk(beam_freq_map, (0,), "Beam frequency map chunking unsupported")
+    _single_chunk(beam_lm_extents, (0, 1), "Chunking of beam_lm_extents unsupported")
+    for name, a, ant_axis in (("parallactic_angles", parallactic_angles, 1), ("point_errors", point_errors, 1),
+                              ("feed_rotation", feed_rotation, 1), ("die1_jones", die1_jones, 1),
+                              ("die2_jones", die2_jones, 1), ("antenna_scaling", antenna_scaling, 0)):
+        if a is None:
+            continue
+        if len(a.chunks[ant_axis]) != 1:
+            raise ValueError("Subdivision of antenna dimension into multiple chunks is not supported.")
+        if name != "antenna_scaling" and len(a.chunks[0]) != len(row_chunks):
+            raise ValueError("Number of row chunks (%s) does not equal number of time chunks (%s)."
+                             % (row_chunks, a.chunks[0]))
+    src_chunks = lm.chunks[0]
+    for name, a in (("brightness", brightness), ("gauss_shape", gauss_shape), ("stokes", stokes), ("spi", spi),
+                    ("ref_freq", ref_freq)):
+        if a is not None and a.chunks[0] != src_chunks:
+            raise ValueError("%s source chunks %s do not match lm source chunks %s" % (name, a.chunks[0], src_chunks))
+    chan_chunks = frequency.chunks[0]
+    flat = brightness is not None and brightness.ndim == 3
+    for name, a, ax in (("brightness", None if flat else brightness, 1), ("point_errors", point_errors, 2),
+                        ("antenna_scaling", antenna_scaling, 1), ("die1_jones", die1_jones, 2),
+                        ("die2_jones", die2_jones, 2), ("base_vis", base_vis, 1)):
+        if a is not None and a.chunks[ax] != chan_chunks:
+            raise ValueError("%s chan chunks %s do not match frequency chunks %s" % (name, a.chunks[ax], chan_chunks))
+
+    out_ix = ("src", "row", "chan", "corr-1", "corr-2")
+    ix = lambda a, names: None if a is None else names
+    block_ids = _row_block_ids(len(row_chunks))
+    b_ix = ("src", "corr-1", "corr-2") if flat else ("src", "chan", "corr-1", "corr-2")
+    new_axes = {"corr-1": 2, "corr-2": 2} if brightness is None else None
+    dtype = np.complex128
+
+    def blocks(src_sel, running):
+        sel = lambda a: None if a is None else a.blocks[src_sel]
+        lm_, b_, gs_, st_, sp_, rf_ = (sel(a) for a in (lm, brightness, gauss_shape, stokes, spi, ref_freq))
+        return da.blockwise(
+            _fused_block, out_ix, time_index, ("row",), antenna1, ("row",), antenna2, ("row",),
+            lm_, ("src", "lmc"), uvw, ("row", "uvwc"), frequency, ("chan",), b_, ix(b_, b_ix),
+            beam, ix(beam, ("bl", "bm", "bf", "bc-1", "bc-2")), beam_lm_extents, ix(beam_lm_extents, ("e1", "e2")),
+            beam_freq_map, ix(beam_freq_map, ("bf",)), parallactic_angles, ix(parallactic_angles, ("row", "ant")),
+            point_errors, ix(point_errors, ("row", "ant", "chan", "pec")),
+            antenna_scaling, ix(antenna_scaling, ("ant", "chan", "asc")),
+            feed_rotation, ix(feed_rotation, ("row", "ant", "fr-1", "fr-2")), gs_, ix(gs_, ("src", "gsc")),
+            st_, ix(st_, ("src", "pol")), sp_, ix(sp_, ("src", "spi", "pol")), rf_, ix(rf_, ("src",)),
+            running, ix(running, out_ix), block_ids, ("row",),
+            align_arrays=False, adjust_chunks={"row": row_chunks, "src": 1}, new_axes=new_axes,
+            convention=convention, corr_schema=tuple(tuple(r) for r in corr_schema), spectral_base=spectral_base,
+            meta=np.empty((0,) * 5, dtype=dtype), dtype=dtype)
+
+    if streams is True:
+        running = None
+        for k in range(len(src_chunks)):
+            running = blocks(slice(k, k + 1), running)
+        summed = running[0]
+    else:
+        summed = blocks(slice(None), None).sum(axis=0)
+    if die1_jones is None and base_vis is None:
+        return summed
+    # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
+    return predict_vis(time_index, antenna1, antenna2, None, None, None, die1_jones,
+                       summed if base_vis is None else base_vis + summed, die2_jones)

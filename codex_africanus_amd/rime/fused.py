@@ -11,8 +11,11 @@ or ``ddes`` (130 GB with 64 antennas): the form in which BASELINE configs 2-4 ar
 The reference's own counterpart is the experimental fused RIME
 (africanus/experimental/rime/fused/core.py:88-120).
 """
+import collections
 import ctypes
+import hashlib
 import os
+import threading
 
 import numpy as np
 
@@ -86,6 +89,40 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True):
         _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
                   ctypes.byref(n_items))
     return FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h)
+
+
+_plan_cache = collections.OrderedDict()
+_plan_lock = threading.Lock()
+
+
+def cached_plan(time_index, antenna1, antenna2, nant, grouped=True):
+    """:func:`fused_plan` memoised on the CONTENTS of the three index arrays (a 16-byte digest: ~1 ms per 1e6 rows):
+    what the row-chunk front-ends call (``rime.dask.fused_predict_vis``, ``chunked.fused_predict_vis``,
+    ``sharding.fused_predict_shard``), where the same row chunk comes back for every channel block, every source chunk
+    and every imaging cycle, each time as a fresh array.  ``AFHIP_PLAN_CACHE`` = number of plans kept (default 16,
+    least recently used first out; 0 = no cache)."""
+    limit = int(os.environ.get("AFHIP_PLAN_CACHE", "16"))
+    if limit <= 0:
+        return fused_plan(time_index, antenna1, antenna2, nant, grouped)
+    h = hashlib.blake2b(digest_size=16)
+    n = 0
+    for a in (time_index, antenna1, antenna2):
+        a = np.ascontiguousarray(_host(a))
+        n = int(a.shape[0])
+        h.update(a.dtype.str.encode())
+        h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")
+    key = (n, int(nant), bool(grouped), h.digest())
+    with _plan_lock:
+        plan = _plan_cache.get(key)
+        if plan is not None:
+            _plan_cache.move_to_end(key)
+            return plan
+    plan = fused_plan(time_index, antenna1, antenna2, nant, grouped)
+    with _plan_lock:
+        _plan_cache[key] = plan
+        while len(_plan_cache) > limit:
+            _plan_cache.popitem(last=False)
+    return plan
 
 
 def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,

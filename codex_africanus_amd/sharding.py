@@ -46,9 +46,11 @@ def time_slice(time_index, start, stop):
 
 def allreduce_chi2(chi2, group=None):
     """Sum the per-channel chi-squared vector over all ranks, in place (RCCL/gloo all-reduce of
-    nchan float64 values: latency bound).  No-op without an initialised process group."""
+    nchan float64 values: latency bound).  No-op without an initialised process group; with one -- also a group
+    of ONE rank -- the collective runs (a world-size-1 ``nccl`` group still builds an RCCL communicator and launches
+    the reduction on the device, which is how the one-GPU test box exercises the path: tests/test_gpu_rccl.py)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(chi2, op=dist.ReduceOp.SUM, group=group)
     return chi2
 
@@ -58,7 +60,7 @@ def allreduce_image(image, group=None):
     row-sharded ``vis_to_im`` (the reference sums row-chunk images, africanus/dft/dask.py:90).
     No-op without an initialised process group."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
     return image
 
@@ -120,4 +122,51 @@ def predict_shard(rank, world_size, image, uvw, lm, frequency, data=None, conven
     c2 = None
     if data is not None:
         c2 = allreduce_chi2(chi2(vis, data), group=group)
+    return vis, c2, (start, stop)
+
+
+def fused_predict_shard(rank, world_size, time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
+                        beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
+                        point_errors=None, antenna_scaling=None, die1_jones=None, base_vis=None, die2_jones=None,
+                        data=None, weight=None, group=None, bounds=None, **kwargs):
+    """
+    One rank's part of the row-sharded FUSED predict (BASELINE configs[3]: 8e6 rows x 64 chan x 1000 sources over 8
+    GPUs, the only predict that exists at that size): the rank's rows are a contiguous block that starts and ends on
+    timestep boundaries (``shard_bounds(nrow, world_size, time_index)``: the reference's rule that a time never
+    straddles two row chunks, africanus/rime/dask_predict.py:494-499), its slice of every (time, ant, ...) array is
+    ``time_slice`` of those rows, sources / frequency / beam cube are replicated.  One ``fused_predict_vis`` call on
+    the rank's device, then -- if ``data`` (the observed visibilities of the SAME rows as passed in) is given -- the
+    per-channel chi-squared of the shard, all-reduced over the ranks (RCCL over xGMI / gloo): the path's only collective.
+
+    Arrays are FULL-length (every rank sees all rows; the rank's block is sliced here) unless ``bounds=(start, stop)``
+    is given: then ``time_index`` / ``antenna1`` / ``antenna2`` / ``uvw`` / ``base_vis`` / ``data`` / ``weight`` hold
+    only this rank's rows -- rows [start, stop) of the job -- and the per-time arrays only this rank's timesteps, which
+    is how a job that cannot hold 8e6 rows in one place feeds its ranks.  Further keyword arguments go to
+    ``fused_predict_vis`` (``feed_rotation`` -- sliced like the other per-time arrays -- ``gauss_shape``, ``stokes``,
+    ``spi``, ``ref_freq``, ``corr_schema``, ``convention``...).  Returns (vis_shard, chi2 or None, (start, stop)).
+    """
+    from .rime.fused import fused_predict_vis, cached_plan, _host
+    feed_rotation = kwargs.pop("feed_rotation", None)
+    if bounds is None:
+        ti_h = np.asarray(_host(time_index))
+        start, stop = shard_bounds(ti_h.shape[0], world_size, ti_h)[rank]
+        t0, t1 = time_slice(ti_h, start, stop)
+        tmin = int(ti_h.min()) if ti_h.size else 0
+        t0, t1 = t0 - tmin, t1 - tmin                 # time_index may carry an offset; the per-time arrays start at 0
+        rows, times = slice(start, stop), slice(t0, t1)
+    else:
+        start, stop = (int(b) for b in bounds)
+        rows, times = slice(None), slice(None)
+    cut = lambda a, *sl: None if a is None else a[sl]
+    ti, a1, a2 = time_index[rows], antenna1[rows], antenna2[rows]
+    plan = None
+    if beam is not None and stop > start:
+        plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]))
+    vis = fused_predict_vis(ti, a1, a2, lm, uvw[rows], frequency, brightness, beam, beam_lm_extents, beam_freq_map,
+                            cut(parallactic_angles, times), cut(point_errors, times), antenna_scaling,
+                            cut(die1_jones, times), cut(base_vis, rows), cut(die2_jones, times),
+                            feed_rotation=cut(feed_rotation, times), plan=plan, **kwargs)
+    c2 = None
+    if data is not None:
+        c2 = allreduce_chi2(chi2(vis, data[rows], cut(weight, rows)), group=group)
     return vis, c2, (start, stop)

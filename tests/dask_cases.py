@@ -106,11 +106,65 @@ def main():
         assert np.array_equal(ph, rime.phase_delay(g1["lm"], g1["uvw"], g1["frequency"]))
     producers_and_calibration()
     wgridder_cases()
+    nfused = fused_cases()
     stats = _lib.pool_stats(0)
-    print("predict_vis cases: %d; placement devices %s policy %s; pool hits %d misses %d"
-          % (ncase, placement.devices(), placement.get_policy(), stats["hits"], stats["misses"]))
+    print("predict_vis cases: %d; fused predict cases: %d; placement devices %s policy %s; pool hits %d misses %d"
+          % (ncase, nfused, placement.devices(), placement.get_policy(), stats["hits"], stats["misses"]))
     _lib.shutdown()
     print("DASK_CASES_OK")
+
+
+def fused_cases():
+    """rime.dask.fused_predict_vis (one fused device call per block) against G14: the REFERENCE's dask graph
+    phase_delay -> einsum -> beam_cube_dde [-> feed rotation] -> predict_vis of africanus/rime/examples/predict.py:404-525
+    on the same chunkings, and the reference's chunk errors (africanus/rime/dask_predict.py:478-524)"""
+    from fused_cases import CASES, CHUNKINGS, NANT, case_arrays, scale_of
+    g14 = load("g14_fused_dask.npz")
+
+    def dask_args(name, ck, override=None):
+        s, r, t, c = CHUNKINGS[ck]
+        if override:
+            s, r, t, c = (override.get(k, v) for k, v in zip("srtc", (s, r, t, c)))
+        a = case_arrays(g14, name, ck)
+        ch = {"time_index": (r,), "antenna1": (r,), "antenna2": (r,), "lm": (s, 2), "uvw": (r, 3), "frequency": (c,),
+              "brightness": (s, c, 2, 2), "stokes": (s, 4), "spi": (s, 2, 4), "ref_freq": (s,), "gauss_shape": (s, 3),
+              "beam": a["beam"].shape if "beam" in a else None, "beam_lm_extents": (2, 2), "beam_freq_map": (4,),
+              "parallactic_angles": (t, NANT), "point_errors": (t, NANT, c, 2), "antenna_scaling": (NANT, c, 2),
+              "feed_rotation": (t, NANT, 2, 2), "die1_jones": (t, NANT, c, 2, 2), "die2_jones": (t, NANT, c, 2, 2),
+              "base_vis": (r, c, 2, 2)}
+        return {k: da.from_array(v, chunks=ch[k]) for k, v in a.items()}
+
+    n = 0
+    with dask.config.set(scheduler="threads", num_workers=6):
+        for name in CASES:
+            for ck in CHUNKINGS:
+                ref = g14["vis_%s_%s" % (name, ck)]
+                for streams in (None, True):
+                    vis = rdask.fused_predict_vis(streams=streams, **dask_args(name, ck))
+                    assert vis.shape == ref.shape and vis.dtype == ref.dtype and vis.chunks[0] == CHUNKINGS[ck][1], (name, ck)
+                    assert vis.chunks[1] == CHUNKINGS[ck][3]
+                    out = vis.compute()
+                    assert np.abs(out - ref).max() <= 1e-9 * scale_of(g14, name), (name, ck, streams)
+                    n += 1
+        # many row blocks computed concurrently, each placed by its block id, plans cached per row chunk
+        many = dask_args("beam_feed", "one", {"r": (10,) * 6, "t": (1,) * 6})
+        out = rdask.fused_predict_vis(**many).compute()
+        assert np.abs(out - g14["vis_beam_feed_one"]).max() <= 1e-9 * scale_of(g14, "beam_feed")
+    raises(ValueError, "does not equal number of time chunks",
+           lambda: rdask.fused_predict_vis(**dask_args("beam", "rows3", {"t": (3, 3)})))
+    raises(ValueError, "Subdivision of antenna dimension", lambda: rdask.fused_predict_vis(
+        **dict(dask_args("beam", "one"), parallactic_angles=da.from_array(g14["parallactic_angles"], chunks=(6, (2, 3))))))
+    raises(ValueError, "Beam chunking unsupported", lambda: rdask.fused_predict_vis(
+        **dict(dask_args("beam", "one"), beam=da.from_array(g14["beam"], chunks=(5, 9, 4, 2, 2)))))
+    raises(ValueError, "row chunks", lambda: rdask.fused_predict_vis(
+        **dict(dask_args("beam", "rows3"), uvw=da.from_array(g14["uvw"], chunks=(30, 3)))))
+    raises(ValueError, "chan chunks", lambda: rdask.fused_predict_vis(
+        **dict(dask_args("beam", "one"), frequency=da.from_array(g14["frequency"], chunks=(3,)))))
+    raises(ValueError, "source chunks", lambda: rdask.fused_predict_vis(
+        **dict(dask_args("beam", "one"), lm=da.from_array(g14["lm"], chunks=(3, 2)))))
+    raises(ValueError, "Both die1_jones and die2_jones",
+           lambda: rdask.fused_predict_vis(**dict(dask_args("beam_die", "one"), die2_jones=None)))
+    return n
 
 
 def producers_and_calibration():

@@ -87,3 +87,28 @@ def test_cpu_sample_sizing(bench):
     assert s["probe_s"] >= 0.5 and abs(s["per_row_s"] - 1e-3) < 1e-9 and s["probe_rows"] >= 500
     assert s["seconds"] >= 2.0 and s["rows"] % 8 == 0 and s["rows"] >= 8000
     assert s["rows"] < 40000                                      # bounded: not minutes of CPU work
+
+
+def test_a_rank_that_dies_early_ends_the_job(bench):
+    """the launcher waited on rank 0 only, so a rank that exited early (device missing, import error) left
+    rank 0 blocked in the rendezvous until the timeout.  Now the first non-zero exit stops and reaps the others."""
+    import tempfile
+    import time
+    log = tempfile.TemporaryFile()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"], stdout=subprocess.PIPE),
+             subprocess.Popen([sys.executable, "-c", "import sys; print('no such device'); sys.exit(7)"], stdout=log,
+                              stderr=subprocess.STDOUT)]
+    code, out0, message = bench.supervise(procs, [None, log], 100)
+    assert code == 7 and time.time() - t0 < 30
+    assert "rank 1 exited with code 7" in message and "no such device" in message
+    assert all(p.returncode is not None for p in procs)                  # reaped, no zombies
+    # the good case: both exit 0, rank 0's output is relayed
+    procs = [subprocess.Popen([sys.executable, "-c", "print('{\"ok\": 1}')"], stdout=subprocess.PIPE),
+             subprocess.Popen([sys.executable, "-c", "pass"], stdout=subprocess.DEVNULL)]
+    code, out0, message = bench.supervise(procs, [None, None], 100)
+    assert code == 0 and out0.decode().strip() == '{"ok": 1}' and message == ""
+    # the timeout
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"], stdout=subprocess.PIPE)]
+    code, out0, message = bench.supervise(procs, [None], 1)
+    assert code == 1 and "did not finish" in message and procs[0].returncode is not None

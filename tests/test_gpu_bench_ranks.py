@@ -115,3 +115,46 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
     assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
+
+
+def test_the_driver_visible_keys_of_the_default_line():
+    """every single-GPU workload's numbers inside "roofline" (scalar keys + "others"), the
+    numpy-in -> numpy-out rate as "end_to_end", and the same table as the LAST key of the line ("summary", inside the
+    2 000-character tail the driver keeps)."""
+    rc, lines, out, err = _run(["--rows", "20000", "--sources", "100", "--steps", "2", "--warmup", "1", "--npix", "1024",
+                                "--extras", "all", "--extra-steps", "2", "--cpu-seconds", "0.2", "--check-rows", "32"],
+                               _clean_env())
+    assert rc == 0, (out[-2000:], err[-4000:])
+    line = lines[0]
+    r = json.loads(line)
+    roof = r["roofline"]
+    names = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes")
+    assert set(roof["others"]) == set(names)
+    for n in names:
+        ms, kernel_ms, frac, err_, value = roof["others"][n]
+        assert ms > 0 and kernel_ms > 0 and 0 < frac < 1.5 and value > 0
+        assert roof["%s_ms_per_step" % n] == r["workloads"][n]["ms_per_step"]
+        assert roof["%s_kernel_ms" % n] > 0 and roof["%s_frac" % n] > 0 and roof["%s_bound" % n] in ("hbm", "mfma")
+    e = r["end_to_end"]
+    assert e["ms"] > 0 and abs(e["value"] - 20000 * 64 / (e["ms"] * 1e-3) / 1e6) <= 1e-6 * e["value"]
+    assert r["config"]["end_to_end_ms"] == e["ms"] and roof["end_to_end_mvis_s"] == e["value"]
+    assert e["value"] < r["value"]                              # PCIe-inclusive: never the headline
+    assert list(r)[-1] == "summary" and len(json.dumps(r["summary"])) < 1500
+    assert line.rstrip().endswith(json.dumps(r["summary"]) + "}")
+    assert set(names) <= set(r["summary"]) and r["summary"]["headline"][0] == round(r["ms_per_step"], 4)
+
+
+@pytest.mark.parametrize("executor", ["ranks", "threads"])
+def test_fused_dde_rows_over_two_ranks(executor):
+    """BASELINE configs[3]'s shape of job -- the FUSED predict (the only predict that exists at 1000 sources), rows
+    sharded over the ranks, chi^2 all-reduced -- in both executors, two ranks aliased onto device 0.  The ranks
+    executor also proves sharding.fused_predict_shard bit-equal to the C-ABI call on each rank's rows."""
+    extra = ["--executor", executor, "--workload", "fused_dde", "--gpus", "2", "--steps", "2", "--warmup", "1",
+             "--rows", "20160", "--sources", "60", "--no-cpu-baseline"]
+    rc, lines, out, err = _run(extra, _clean_env(AFHIP_BENCH_DEVICE="0"))
+    assert rc == 0, (out[-2000:], err[-4000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rows_total"] == 40320 and "configs[2]" in r["config"]["workload"]
+    assert r["fp64_max_abs_err"] < 1e-8 and r["roofline"]["kernel"] == "fused_predict_kernel"
+    if executor == "ranks":
+        assert "bit-equal" in r["config"]["front_end"] and "rank 0 of 2" in r["config"]["front_end"]

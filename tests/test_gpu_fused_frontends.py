@@ -1,0 +1,182 @@
+"""
+Row-chunk -> GPU front-ends of the FUSED predict (the only predict that exists at BASELINE configs[2] / [3] sizes):
+``chunked.fused_predict_vis``, the block function of ``rime.dask.fused_predict_vis`` under the blockwise calling
+convention, and ``sharding.fused_predict_shard``.  Expected values: G14 (tests/golden/g14_fused_dask.npz), the
+REFERENCE's own dask graph -- ``rime.dask.phase_delay`` -> ``da.einsum`` -> ``rime.dask.beam_cube_dde`` [-> feed
+rotation] -> ``rime.dask.predict_vis`` (africanus/rime/examples/predict.py:404-525, chunk rules of
+africanus/rime/dask_predict.py:478-524) -- computed by real dask on three chunkings.  Tolerance 1e-9 relative to the
+per-visibility sum of |term| magnitudes (polynomial phasor and a different association of the 2 x 2 products; the
+north-star tolerance is 1e-8); row chunking alone changes no bit.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+from blockwise_emulator import Chunked, blockwise
+from conftest import load_golden
+from codex_africanus_amd import chunked, sharding, rime
+from codex_africanus_amd.rime import dask as rdask
+from fused_cases import CASES, CHUNKINGS, NANT, case_arrays, scale_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g14():
+    return load_golden("g14_fused_dask.npz")
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("ck", list(CHUNKINGS))
+def test_chunked_fused_predict_equals_the_reference_dask_graph(g14, name, ck):
+    s, r, t, c = CHUNKINGS[ck]
+    a = case_arrays(g14, name, ck)
+    out = chunked.fused_predict_vis(chunks={"source": s, "row": r, "time": t, "chan": c}, **a)
+    ref = g14["vis_%s_%s" % (name, ck)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.abs(out - ref).max() <= 1e-9 * scale_of(g14, name)
+    # the plain call on the same arrays
+    one = rime.fused_predict_vis(**a)
+    assert np.abs(one - g14["vis_%s_one" % name]).max() <= 1e-9 * scale_of(g14, name)
+    if ck == "rows3":                  # rows chunked on timestep boundaries, nothing else: not a bit changes
+        assert_array_equal(out, one)
+
+
+def _emulated(g14, name, ck, streams=None, executor=None):
+    """The graph of rime.dask.fused_predict_vis with the block calls made through the blockwise emulator."""
+    s, r, t, c = CHUNKINGS[ck]
+    a = case_arrays(g14, name, ck)
+    one = lambda n: (int(n),)
+    C = lambda x, *ch: None if x is None else Chunked(x, ch)
+    ix = lambda x, names: None if x is None else names
+    out_ix = ("src", "row", "chan", "corr-1", "corr-2")
+    idx = [C(a[k], r) for k in ("time_index", "antenna1", "antenna2")]
+    ids = Chunked(np.arange(len(r), dtype=np.int64), ((1,) * len(r),))
+    beam, ext, fmap = a.get("beam"), a.get("beam_lm_extents"), a.get("beam_freq_map")
+    pa, pe, asc, fr = a.get("parallactic_angles"), a.get("point_errors"), a.get("antenna_scaling"), a.get("feed_rotation")
+    edges = np.concatenate([[0], np.cumsum(s)])
+
+    def blocks(lo, hi, src_chunks, running):
+        sel = lambda x: None if x is None else x[lo:hi]
+        b, gs, st, sp, rf = (sel(a.get(k)) for k in ("brightness", "gauss_shape", "stokes", "spi", "ref_freq"))
+        return blockwise(
+            rdask._fused_block, out_ix, idx[0], ("row",), idx[1], ("row",), idx[2], ("row",),
+            C(a["lm"][lo:hi], src_chunks, one(2)), ("src", "lmc"), C(a["uvw"], r, one(3)), ("row", "uvwc"),
+            C(a["frequency"], c), ("chan",), C(b, src_chunks, c, one(2), one(2)), ix(b, ("src", "chan", "corr-1", "corr-2")),
+            C(beam, *[one(n) for n in (beam.shape if beam is not None else ())]), ix(beam, ("bl", "bm", "bf", "bc-1", "bc-2")),
+            C(ext, one(2), one(2)), ix(ext, ("e1", "e2")), C(fmap, one(len(fmap)) if fmap is not None else None), ix(fmap, ("bf",)),
+            C(pa, t, one(NANT)), ix(pa, ("row", "ant")), C(pe, t, one(NANT), c, one(2)), ix(pe, ("row", "ant", "chan", "pec")),
+            C(asc, one(NANT), c, one(2)), ix(asc, ("ant", "chan", "asc")),
+            C(fr, t, one(NANT), one(2), one(2)), ix(fr, ("row", "ant", "fr-1", "fr-2")),
+            C(gs, src_chunks, one(3)), ix(gs, ("src", "gsc")), C(st, src_chunks, one(4)), ix(st, ("src", "pol")),
+            C(sp, src_chunks, one(2), one(4)), ix(sp, ("src", "spi", "pol")), C(rf, src_chunks), ix(rf, ("src",)),
+            None if running is None else Chunked(running, (one(1), r, c, one(2), one(2))), ix(running, out_ix),
+            ids, ("row",), executor=executor, convention="fourier",
+            corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0)
+
+    if streams:
+        running = None
+        for k in range(len(s)):
+            running = blocks(int(edges[k]), int(edges[k + 1]), one(edges[k + 1] - edges[k]), running)
+        summed = running[0]
+    else:
+        per_chunk = blocks(0, int(edges[-1]), s, None)
+        assert per_chunk.shape[0] == len(s)
+        summed = per_chunk.sum(axis=0)
+    if a.get("die1_jones") is None:
+        return summed
+    g_ix, v_ix = ("row", "ant", "chan", "c1", "c2"), ("row", "chan", "c1", "c2")
+    die = Chunked(a["die1_jones"], (t, one(NANT), c, one(2), one(2)))
+    return blockwise(rdask._die_block, v_ix, idx[0], ("row",), idx[1], ("row",), idx[2], ("row",), die, g_ix,
+                     Chunked(a["base_vis"] + summed, (r, c, one(2), one(2))), v_ix, die, g_ix, ids, ("row",),
+                     executor=executor)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_dask_block_function_under_the_blockwise_convention(g14, name):
+    ck = "rows3u_src2_chan2"
+    ref = g14["vis_%s_%s" % (name, ck)]
+    for streams in (None, True):
+        out = _emulated(g14, name, ck, streams)
+        assert out.shape == ref.shape
+        assert np.abs(out - ref).max() <= 1e-9 * scale_of(g14, name)
+    # and equal to the dask-free chunked front-end, bit for bit (same blocks, same sums)
+    s, r, t, c = CHUNKINGS[ck]
+    a = case_arrays(g14, name, ck)
+    assert_array_equal(_emulated(g14, name, ck), chunked.fused_predict_vis(chunks={"source": s, "row": r, "time": t, "chan": c}, **a))
+
+
+def test_dask_blocks_on_a_thread_pool(g14):
+    with ThreadPoolExecutor(6) as ex:
+        for _ in range(3):
+            out = _emulated(g14, "beam_feed_model", "rows3u_src2_chan2", executor=ex)
+            assert_array_equal(out, _emulated(g14, "beam_feed_model", "rows3u_src2_chan2"))
+
+
+def test_plan_cache_serves_repeated_row_chunks(g14):
+    from codex_africanus_amd.rime import fused
+    a = case_arrays(g14, "beam", "one")
+    fused._plan_cache.clear()
+    p1 = fused.cached_plan(a["time_index"], a["antenna1"], a["antenna2"], NANT)
+    p2 = fused.cached_plan(a["time_index"].copy(), a["antenna1"].copy(), a["antenna2"].copy(), NANT)
+    assert p1 is p2 and len(fused._plan_cache) == 1
+    p3 = fused.cached_plan(a["time_index"][:20], a["antenna1"][:20], a["antenna2"][:20], NANT)
+    assert p3 is not p1 and p3.nrow == 20 and len(fused._plan_cache) == 2
+    # int64 indices of equal value are a different key but an equal plan
+    p4 = fused.cached_plan(a["time_index"].astype(np.int64), a["antenna1"], a["antenna2"], NANT)
+    assert_array_equal(p4.items, p1.items)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("name", ["beam_feed", "beam_die", "nobeam"])
+def test_fused_predict_shard_rows_over_ranks(g14, name, world):
+    """Every rank's shard (ranks run one after the other on the one device here; no process group -> the all-reduce
+    is the identity, so the partial chi^2 vectors are summed by hand): the shards tile the rows on timestep boundaries,
+    the concatenated visibilities equal the unsharded call bit for bit, the chi^2 partials sum to the whole."""
+    import torch
+    dev = torch.device("cuda:0")
+    a = case_arrays(g14, name, "one")
+    t = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    da_ = {k: t(v) for k, v in a.items()}
+    da_["time_index"] = da_["time_index"] + 5                 # an offset the shards must not trip over
+    full = rime.fused_predict_vis(**da_)
+    data = full + 0.01
+    pieces, chi2, covered = [], 0.0, []
+    for rank in range(world):
+        vis, c2, (lo, hi) = sharding.fused_predict_shard(rank, world, data=data, **da_)
+        assert vis.shape[0] == hi - lo
+        assert lo % 10 == 0 and hi % 10 == 0                  # 10 baselines per timestep: whole timesteps only
+        pieces.append(vis)
+        chi2 = chi2 + c2
+        covered.append((lo, hi))
+    assert covered[0][0] == 0 and covered[-1][1] == full.shape[0]
+    assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
+    assert torch.equal(torch.cat(pieces), full)
+    want = sharding.chi2(full, data)
+    assert torch.allclose(chi2, want, rtol=1e-12, atol=0)
+    ref = g14["vis_%s_one" % name]
+    assert np.abs(full.cpu().numpy() - ref).max() <= 1e-9 * scale_of(g14, name)
+    # a rank that holds only its own rows and timesteps (bounds given): same bits
+    lo, hi = covered[-1]
+    if hi > lo:
+        t0, t1 = sharding.time_slice(a["time_index"], lo, hi)
+        loc = dict(da_)
+        for k in ("time_index", "antenna1", "antenna2", "uvw", "base_vis"):
+            loc[k] = None if loc.get(k) is None else loc[k][lo:hi]
+        for k in ("parallactic_angles", "point_errors", "feed_rotation", "die1_jones", "die2_jones"):
+            loc[k] = None if loc.get(k) is None else loc[k][t0:t1]
+        vis, c2, b = sharding.fused_predict_shard(world - 1, world, data=data[lo:hi], bounds=(lo, hi), **loc)
+        assert b == (lo, hi) and torch.equal(vis, pieces[-1])
+
+
+def test_chunk_errors_of_the_reference(g14):
+    a = case_arrays(g14, "beam_die", "one")
+    with pytest.raises(ValueError, match="does not equal number of time chunks"):
+        chunked.fused_predict_vis(chunks={"row": (20, 20, 20), "time": (3, 3)}, **a)
+    with pytest.raises(ValueError, match="Subdivision of antenna dimension"):
+        chunked.fused_predict_vis(chunks={"ant": (2, 3)}, **a)
+    b = dict(a, die2_jones=None)
+    with pytest.raises(ValueError, match="Both die1_jones and die2_jones"):
+        chunked.fused_predict_vis(**b)

@@ -150,6 +150,26 @@ def test_index_guard_device_mode(big):
     pkg.check_status()
 
 
+def test_index_errors_survive_a_full_slot_table():
+    """with every status slot in flight, watch() drained the table to make room and threw the drained calls'
+    reports away.  More flagged calls than slots, no poll in between: every one of them is reported."""
+    import torch
+    from codex_africanus_amd import _device
+    dev = torch.device("cuda:0")
+    d = _device._DeferredStatus()
+    d.SLOTS = 4
+    ws = torch.zeros(64, dtype=torch.uint8, device=dev)
+    ws[8:12].view(torch.int32).fill_(3)
+    for k in range(11):
+        d.watch(ws, 8, lambda flags, k=k: "call %d flags %d" % (k, flags))
+    with pytest.raises(ValueError) as e:
+        d.poll(wait=True)
+    for k in range(11):
+        assert "call %d flags 3" % k in str(e.value)
+    d.poll(wait=True)                                         # reported once
+    assert sorted(d._free) == [0, 1, 2, 3] and not d._pending and not d._carry
+
+
 def test_index_guard_through_the_c_abi():
     """Host wrapper bypassed: the status word at workspace + 8 and the NaN rows, dies-only call."""
     import ctypes
