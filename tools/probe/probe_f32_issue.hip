@@ -1,3 +1,4 @@
+// build + run (gfx950 box): hipcc --offload-arch=gfx950 -O3 -o probe_f32_issue probe_f32_issue.hip && ./probe_f32_issue
 // Issue cost of float32 VALU forms from one wave and from two waves of a SIMD: v_fma_f32, v_pk_fma_f32, v_pk_mul_f32,
 // v_mul_f32 + v_fmac_f32 pairs (the rotation recurrence of dft_f32_kernel<..., CHAIN>), 64 independent instructions
 // per iteration on 16 destination registers.  Cycles by s_memtime (wave 0 alone is the oldest wave and keeps its

@@ -1,3 +1,4 @@
+// build + run (gfx950 box): hipcc --offload-arch=gfx950 -O3 -o probe_glds probe_glds.hip && ./probe_glds
 // where does global_load_lds_dwordx4 put its bytes?  (LDS destination base offsets 0, 16, 48, 1024; 64 lanes)
 #include <hip/hip_runtime.h>
 #include <stdio.h>

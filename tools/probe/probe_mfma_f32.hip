@@ -1,3 +1,4 @@
+// build + run (gfx950 box): hipcc --offload-arch=gfx950 -O3 -o probe_mfma_f32 probe_mfma_f32.hip && ./probe_mfma_f32
 // v_mfma_f32_4x4x1_16b_f32: lane layout of A / B / D and the CBSZ / ABID broadcast of A, and whether fp64 VALU work
 // overlaps with a stream of these MFMAs (separate pipes?).
 #include <hip/hip_runtime.h>
