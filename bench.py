@@ -1318,7 +1318,7 @@ def run_threads(args):
     if not np.allclose(chi2_sum, chi2_check, rtol=1e-12, atol=0):
         raise SystemExit("chi^2 reduced across devices differs from the sum of the partials")
     for k, h in enumerate(history):          # identical inputs every step: every step's reduction must be the same vector
-        if not np.array_equal(h.cpu().numpy(), chi2_sum):
+        if not np.allclose(h.cpu().numpy(), chi2_sum, rtol=1e-12, atol=0):     # (to the order of the chi^2 kernel's atomics)
             raise SystemExit("step %d reduced a different chi^2 vector than the last step (staging overwritten early?)" % k)
     w0 = workers[0]
     with torch.cuda.device(dev0):

@@ -37,6 +37,8 @@ def test_chunked_fused_predict_equals_the_reference_dask_graph(g14, name, ck):
     ref = g14["vis_%s_%s" % (name, ck)]
     assert out.shape == ref.shape and out.dtype == ref.dtype
     assert np.abs(out - ref).max() <= 1e-9 * scale_of(g14, name)
+    if name == "beam_localtime" and ck != "one":
+        return                         # a chunk-local time index only means something chunk by chunk
     # the plain call on the same arrays
     one = rime.fused_predict_vis(**a)
     assert np.abs(one - g14["vis_%s_one" % name]).max() <= 1e-9 * scale_of(g14, name)

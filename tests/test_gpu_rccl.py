@@ -36,7 +36,8 @@ data = vis + 0.01
 vis, c2, (lo, hi) = sharding.predict_shard(0, 1, t(real_image(d)), t(d["uvw"]), t(d["lm"]), t(d["frequency"]), data=data)
 torch.cuda.synchronize(dev)
 local = sharding.chi2(vis, data)
-assert (lo, hi) == (0, 3000) and torch.equal(c2, local), "a sum over one rank is the rank's own vector"
+# (two runs of the chi^2 kernel agree to the order of its atomic adds)
+assert (lo, hi) == (0, 3000) and torch.allclose(c2, local, rtol=1e-12, atol=0), "a sum over one rank is the rank's own vector"
 x = torch.arange(64, dtype=torch.float64, device=dev)
 y = sharding.allreduce_chi2(x.clone())
 assert torch.equal(x, y)
