@@ -247,7 +247,7 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         ti, a1, a2, uv = time_index[r0:r1], antenna1[r0:r1], antenna2[r0:r1], uvw[r0:r1]
         plan = None
         if beam is not None:
-            plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]))
+            plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]), uvw=None if gauss_shape is not None else uv)
         chan_blocks = []
         for (c0, c1) in _bounds(chan_chunks):
             acc = None

@@ -1,0 +1,482 @@
+// Fused RIME predict with per-antenna beam-cube DDEs for ANTENNA-DECOMPOSABLE uvw, as one complex GEMM per
+// (timestep, channel) on the matrix cores.
+//
+// The reference's chain  phase_delay -> einsum -> beam_cube_dde -> predict_vis
+// (africanus/rime/examples/predict.py:107-134,404-472,525; africanus/rime/phase.py:28-61;
+// africanus/rime/fast_beam_cubes.py:57-240; africanus/rime/predict.py:199-212) evaluates
+//
+//     V_pq(t,nu) = sum_s  E_p(s,t,nu) . ( K_pq(s,nu) X_s(nu) ) . E_q(s,t,nu)^H ,   K_pq = exp(i C nu (l,m,n).uvw_pq).
+//
+// In every real Measurement Set the baseline coordinates are differences of per-antenna coordinates,
+// uvw_pq = uvw_p - uvw_q (per timestep); then the phasor factorises, K_pq = k_p conj(k_q) with
+// k_a = exp(i C nu (l,m,n).uvw_a), and with A_a = k_a E_a (2 x 2 per (antenna, source)), G_a = A_a X_s:
+//
+//     V_pq = sum_s G_ps A_qs^H        i.e.   M = G H^H ,   G, H : (2 nant) x (2 nsrc) complex,
+//
+// a dense complex matrix product per (timestep, channel): M = N = 2 nant (128 at 64 antennas), K = 2 nsrc -- the case
+// the north star reserves the matrix cores for ("MFMA used only if the source x chan accumulation is reformulated as a
+// genuine dense GEMM").  Per (row, chan, source) that is 64 flop (8 complex MACs) on the needed half of M, against the
+// ~126 flop the lane-per-row kernel executes (phasor per (row, source), M = G E^H, acc += K M), and the phasor is
+// evaluated per (antenna, source) instead of per (row, source): 31.5 x fewer at 64 antennas.
+//
+// One workgroup (8 waves) owns one (timestep, channel):
+//   waves 4-7 (sampling)  per batch of ST sources: voxel geometry and antenna phasor of one (source, antenna) term per
+//             lane, then four sampling rounds (four lanes of a quad = the four correlations of one term: the sampler of
+//             af_fused_predict.hip, bilinear on the channel's pre-interpolated beam plane), E [. R], A = k E, G = A X
+//             -> LDS, as MFMA operand panels  H[s][k][col]  (k = re0, re1, im0, im1 of A's row; col = 2 antenna + row)
+//             and  G[s][k][row]  (k = re0, re1, im0, im1, -re0, -re1), double-buffered, one barrier per batch;
+//   waves 0-3 (matrix)    the upper block triangle of M in 16 x 16 tiles (8 antennas x 8 antennas x 2 x 2), tile i on
+//             wave i % 4, real and imaginary accumulators; per source and tile two v_mfma_f64_16x16x4:
+//                 Cr += [Gr0 Gr1 Gi0 Gi1] . [Hr0 Hr1 Hi0 Hi1]^T      Ci += [Gi0 Gi1 -Gr0 -Gr1] . [Hr0 Hr1 Hi0 Hi1]^T
+//             (Re and Im of sum_k G_k conj(H_k)); epilogue: tile element (p,i,q,j) -> row(t,p,q) of the output through
+//             the plan's row map; an off-diagonal tile also serves row(t,q,p) with the conjugate transpose.
+// fp64 MFMA and fp64 VALU share one pipe on gfx950, so the matrix cores buy no rate; what the
+// formulation buys is the flop count (36 of the 64 tiles of M at 64 antennas: 73 flop per (row, chan, source) instead of
+// ~126) and a pure-FMA instruction stream.
+//
+// Rows that are not antenna-decomposable (BASELINE's random uvw), Gaussian shapes (they depend on the baseline) and
+// more than 64 antennas stay on af_fused_predict_c128.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+#include <vector>
+
+#include "af_fused_device.h"
+
+namespace {
+
+constexpr int G_THREADS = 512;       // 4 matrix waves + 4 sampling waves
+constexpr int G_SAMPLERS = 256;      // sampling lanes
+constexpr int COL_PAD = 16;          // doubles of padding per operand plane (planes of one source on different banks)
+constexpr int H_PLANES = 4, G_PLANES = 6;
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// grid: (nsteps, channels of the plane group); block 512.  NB = 8-antenna blocks (nant <= 8 NB); ST = sources per batch.
+// Dynamic LDS: 2 buffers x ST x (4 + 6) planes x CS doubles, then per-antenna constants (6 doubles), feed rotations
+// (4 double2), antenna coordinates in table units (4 doubles) and the phasor table.
+template <bool FEED, int NB, int ST>
+__global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
+    const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
+    const double *__restrict__ f4, const double2 *__restrict__ brightness, const double *__restrict__ vrec,
+    int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
+    const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
+    const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
+    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0)
+{
+    constexpr int NA = NB * 8;              // padded antennas
+    constexpr int NC = NA * 2;              // rows / columns of M
+    constexpr int CS = NC + COL_PAD;        // doubles per operand plane
+    constexpr int SRC_DOUBLES = (H_PLANES + G_PLANES) * CS;   // one source: H planes then G planes
+    constexpr int BUF_DOUBLES = ST * SRC_DOUBLES;
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int TPW = (NTILE + 3) / 4;    // tiles per matrix wave
+    extern __shared__ double ldsd[];
+    double *ldsA = ldsd + 2 * BUF_DOUBLES;                 // (sin pa, cos pa, pe_l, pe_m, as_l, as_m) per antenna
+    double *ldsU = ldsA + 6 * NA;                          // (u, v, w, 0) FT per antenna: table units per unit of (l, m, n)
+    double2 *ldsR = reinterpret_cast<double2 *>(ldsU + 4 * NA);   // feed rotations
+    double2 *ldsT = ldsR + 4 * NA;                         // phasor table
+    const int tid = threadIdx.x;
+    const bool matrix_wave = tid < G_THREADS - G_SAMPLERS;
+    const int ptid = tid - (G_THREADS - G_SAMPLERS);
+    const int64_t f = f0 + blockIdx.y;
+    const int t = blockIdx.x;
+
+    // ---- block set-up ------------------------------------------------------------------------------
+    fine_table_init(ldsT, tid, G_THREADS);
+    const double FT = f4[f] * (PH_TABLE / 4.0);
+    for (int a = tid; a < NA; a += G_THREADS) {
+        double sp = 0.0, cp = 1.0, pl = 0.0, pm = 0.0, sl_ = 1.0, sm_ = 1.0, u = 0.0, v = 0.0, w = 0.0;
+        if (a < nant) {
+            sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
+            const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
+            const double *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
+            pl = pe[0]; pm = pe[1]; sl_ = as[0]; sm_ = as[1];
+            const double *x = ant_uvw + ((int64_t)t * nant + a) * 3;
+            u = __dmul_rn(x[0], FT); v = __dmul_rn(x[1], FT); w = __dmul_rn(x[2], FT);
+        }
+        ldsA[6 * a + 0] = sp; ldsA[6 * a + 1] = cp; ldsA[6 * a + 2] = pl; ldsA[6 * a + 3] = pm;
+        ldsA[6 * a + 4] = sl_; ldsA[6 * a + 5] = sm_;
+        ldsU[4 * a + 0] = u; ldsU[4 * a + 1] = v; ldsU[4 * a + 2] = w; ldsU[4 * a + 3] = 0.0;
+    }
+    if constexpr (FEED)
+        for (int i = tid; i < 4 * nant; i += G_THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
+    // padded antennas (nant < NA) never get written by the samplers: their operand columns must read as zero
+    if (nant < NA)
+        for (int i = tid; i < 2 * BUF_DOUBLES; i += G_THREADS) ldsd[i] = 0.0;
+    __syncthreads();
+    const int nbatch = (nsrc + ST - 1) / ST;
+
+    if (!matrix_wave) {
+        // =================================== sampling waves =========================================
+        FusedGrid grid;
+        {
+            const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+            grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
+            grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
+            grid.stride_m = VREC * 8u;
+            grid.stride_l = (unsigned)beam_mh * grid.stride_m;
+        }
+        const double fscale = freq_data[3 * f + 0];
+        const int e_corr = ptid & 3;               // this lane's correlation: (i, j) = (e_corr >> 1, e_corr & 1)
+        const int ei = e_corr >> 1, ej = e_corr & 1;
+        const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
+        const unsigned corr_off = e_corr * 32u;
+        constexpr int NTASK = ST * NA;             // (source, antenna) terms per batch
+        __builtin_amdgcn_s_setprio(3);
+        for (int b = 0; b < nbatch; ++b) {
+            const int s0 = b * ST;
+            double *H = ldsd + (b & 1) * BUF_DOUBLES;
+            if (only_stage != 2) {
+                for (int task0 = 0; task0 < NTASK; task0 += G_SAMPLERS) {
+                    // ---- this lane's own term: geometry and antenna phasor ----------------------------
+                    const int task = task0 + ptid;
+                    int e_sl = task / NA, e_ant = task - e_sl * NA;
+                    const bool have_task = task < NTASK && e_ant < nant;
+                    if (!have_task) e_sl = e_ant = 0;
+                    const bool have = have_task && s0 + e_sl < nsrc;
+                    const int own_info = e_sl | (e_ant << 11) | ((int)have_task << 30) | (int)((unsigned)have << 31);
+                    const double *sp = lmn + 4 * (have ? s0 + e_sl : 0);
+                    const double2 lm2 = *reinterpret_cast<const double2 *>(sp);
+                    const double nn = sp[2];
+                    FusedVoxels gx;
+                    fused_voxels(grid, lm2.x, lm2.y, ldsA[6 * e_ant + 0], ldsA[6 * e_ant + 1], ldsA[6 * e_ant + 2],
+                                 ldsA[6 * e_ant + 3], ldsA[6 * e_ant + 4], ldsA[6 * e_ant + 5], fscale, gx);
+                    // k_a = exp(i C nu (l u_a + m v_a + n w_a)): phase_delay's phasor of the ANTENNA (rime/phase.py:45-61)
+                    const C2 kph = table_phasor(ldsT, fma(nn, ldsU[4 * e_ant + 2],
+                                                          fma(lm2.y, ldsU[4 * e_ant + 1], __dmul_rn(lm2.x, ldsU[4 * e_ant + 0]))));
+                    auto round = [&](auto lane_c) {
+                        constexpr int QL = decltype(lane_c)::value;
+                        const int info = quad_bcast<QL>(own_info);
+                        const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
+                        const bool r_task = (info >> 30) & 1, r_have = info < 0;
+                        // G[i][j] = A[i][0] X[0][j] + A[i][1] X[1][j]: this lane needs column j of X
+                        const double2 *bp = brightness + ((int64_t)(r_have ? s0 + r_sl : 0) * nchan + f) * 4;
+                        const double2 b0 = bp[ej], b1 = bp[2 + ej];
+                        double2 v[4];
+                        double ab[4], wt[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
+                            wt[k] = quad_bcast<QL>(gx.wt[k]);
+                            const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
+                            v[k] = *reinterpret_cast<const double2 *>(r);
+                            ab[k] = r[2];
+                        }
+                        C2 kk;
+                        kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
+                        double2 e2 = beam_reduce1(v, ab, wt);
+                        if (!r_have) e2 = make_double2(0.0, 0.0);
+                        C2 e;
+                        e.re = e2.x; e.im = e2.y;
+                        if constexpr (FEED) {
+                            // E <- E . R(t, antenna)  ("stafij,tajk->stafik", rime/examples/predict.py:472)
+                            C2 E0, E1;
+                            E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
+                            E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
+                            const double2 r0 = ldsR[4 * r_ant + ej], r1 = ldsR[4 * r_ant + 2 + ej];
+                            C2 R0, R1;
+                            R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
+                            e = cmul(E0, R0);
+                            cmac(e, E1, R1);
+                        }
+                        const C2 A = cmul(kk, e);          // A[i][j] = k E[i][j]
+                        C2 A0, A1, B0, B1;
+                        A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
+                        A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
+                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                        C2 Gv = cmul(A0, B0);
+                        cmac(Gv, A1, B1);
+                        if (r_task) {
+                            double *hs = H + r_sl * SRC_DOUBLES + 2 * r_ant + ei;
+                            double *gs = hs + H_PLANES * CS;
+                            hs[ej * CS] = A.re; hs[(2 + ej) * CS] = A.im;
+                            gs[ej * CS] = Gv.re; gs[(2 + ej) * CS] = Gv.im; gs[(4 + ej) * CS] = -Gv.re;
+                        }
+                    };
+                    round(std::integral_constant<int, 0>{});
+                    round(std::integral_constant<int, 1>{});
+                    round(std::integral_constant<int, 2>{});
+                    round(std::integral_constant<int, 3>{});
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ======================================= matrix waves ===========================================
+    const int wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, c16 = lane & 15;
+    int offA[TPW], offB[TPW];                   // doubles from the start of a source's planes
+    v4d cr[TPW], ci[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        // wave-uniform tile coordinates of tile j * 4 + wave in the row-major upper block triangle
+        int pb = 0, qb = 0;
+        {
+            int ii = j * 4 + wave < NTILE ? j * 4 + wave : 0;
+            while (ii >= NB - pb) { ii -= NB - pb; ++pb; }
+            qb = pb + ii;
+        }
+        offA[j] = H_PLANES * CS + kq * CS + pb * 16 + c16;
+        offB[j] = kq * CS + qb * 16 + c16;
+        cr[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        ci[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int b = 0; b < nbatch; ++b) {
+        __syncthreads();
+        if (only_stage == 1) continue;
+        const double *P = ldsd + (b & 1) * BUF_DOUBLES;
+#pragma unroll
+        for (int sl = 0; sl < ST; ++sl) {
+            const double *S = P + sl * SRC_DOUBLES;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (j * 4 + wave < NTILE) {      // wave-uniform
+                    const double a0 = S[offA[j]], a1 = S[offA[j] + 2 * CS], bb = S[offB[j]];
+                    cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, cr[j], 0, 0, 0);
+                    ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, ci[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (only_stage == 1) return;
+    // ---- epilogue: tile element (row, col) = ((p, i), (q, j)) -> the output row of baseline (p, q) ----
+    const int32_t *rm = rowmap + (int64_t)t * NA * NA;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int i = j * 4 + wave;
+        if (i >= NTILE) continue;
+        int pb = 0, qb = 0;
+        {
+            int ii = i;
+            while (ii >= NB - pb) { ii -= NB - pb; ++pb; }
+            qb = pb + ii;
+        }
+        const int q = qb * 8 + (c16 >> 1), jj = c16 & 1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = kq + 4 * reg;
+            const int p = pb * 8 + (row >> 1), ii = row & 1;
+            const double re = cr[j][reg], im = ci[j][reg];
+            const int r1 = rm[p * NA + q];
+            if (r1 >= 0) out[((int64_t)r1 * nchan + f) * 4 + ii * 2 + jj] = make_double2(re, im);
+            if (pb != qb) {
+                const int r2 = rm[q * NA + p];      // the same antennas the other way round: V_qp = V_pq^H
+                if (r2 >= 0) out[((int64_t)r2 * nchan + f) * 4 + jj * 2 + ii] = make_double2(re, -im);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Host-side planner (HOST pointers): is uvw antenna-decomposable, and if so with which antenna coordinates?
+//   Per timestep (time_index - min): the baselines of the step form a graph on the antennas; a breadth-first walk of
+//   every connected component integrates uvw along a spanning tree (x_root = 0, x_q = x_p - uvw_pq), two Gauss-Seidel
+//   sweeps of the normal equations (x_p <- mean of what its baselines imply) pull that towards the least-squares
+//   solution, and the component's mean is removed (small coordinates -> small phase arguments).  The plan is accepted
+//   when  max_rows |x_p - x_q - uvw_pq|_inf <= tol  [metres]: a residual delta changes a source's phase by at most
+//   2 pi nu / c |(l, m, n)| delta  (1.8e-10 rad at tol = 1e-10 m, 1.7 GHz, 0.05 rad from the phase centre).
+//   ant_uvw_host (nsteps, nant, 3) and rowmap_host (nsteps, nap, nap), nap = 8 ceil(nant / 8): row of baseline
+//   (antenna1 = p, antenna2 = q) of the step, or -1.  Not decomposable (decomposable = 0; arrays unspecified) also when
+//   a (step, p, q) occurs twice -- the row map could hold only one of them.
+AF_EXPORT int af_fused_plan_antennas(const int64_t *time_index_host, const int32_t *antenna1_host,
+                                     const int32_t *antenna2_host, const double *uvw_host, int64_t nrow, int64_t nant,
+                                     double tol, int64_t nsteps, double *ant_uvw_host, int32_t *rowmap_host,
+                                     double *max_residual, int *decomposable)
+{
+    AF_REQUIRE(decomposable != nullptr && max_residual != nullptr, "af_fused_plan_antennas: result pointer is NULL");
+    *decomposable = 0;
+    *max_residual = 0.0;
+    if (nrow == 0) { *decomposable = 1; return AF_OK; }
+    AF_REQUIRE(time_index_host && antenna1_host && antenna2_host && uvw_host && ant_uvw_host && rowmap_host,
+               "af_fused_plan_antennas: NULL array");
+    AF_REQUIRE(nant >= 1 && nant <= 64 && nrow < (1LL << 31) && nsteps >= 1, "af_fused_plan_antennas: bad extents");
+    int64_t tmin = time_index_host[0], tmax = tmin;
+    for (int64_t r = 1; r < nrow; ++r) {
+        tmin = time_index_host[r] < tmin ? time_index_host[r] : tmin;
+        tmax = time_index_host[r] > tmax ? time_index_host[r] : tmax;
+    }
+    AF_REQUIRE(tmax - tmin + 1 == nsteps, "af_fused_plan_antennas: nsteps %lld, time_index spans %lld", (long long)nsteps,
+               (long long)(tmax - tmin + 1));
+    const int64_t nap = 8 * ((nant + 7) / 8);
+    for (int64_t i = 0; i < nsteps * nap * nap; ++i) rowmap_host[i] = -1;
+    for (int64_t i = 0; i < nsteps * nant * 3; ++i) ant_uvw_host[i] = 0.0;
+    // rows by step (counting sort) and the row map
+    std::vector<int64_t> first((size_t)nsteps + 1, 0);
+    for (int64_t r = 0; r < nrow; ++r) ++first[(size_t)(time_index_host[r] - tmin) + 1];
+    for (int64_t s = 0; s < nsteps; ++s) first[(size_t)s + 1] += first[(size_t)s];
+    std::vector<int32_t> order((size_t)nrow);
+    {
+        std::vector<int64_t> at(first.begin(), first.end() - 1);
+        for (int64_t r = 0; r < nrow; ++r) order[(size_t)at[(size_t)(time_index_host[r] - tmin)]++] = (int32_t)r;
+    }
+    for (int64_t r = 0; r < nrow; ++r) {
+        const int32_t p = antenna1_host[r], q = antenna2_host[r];
+        AF_REQUIRE(p >= 0 && p < nant && q >= 0 && q < nant, "af_fused_plan_antennas: antenna index out of range");
+        int32_t &slot = rowmap_host[((time_index_host[r] - tmin) * nap + p) * nap + q];
+        if (slot != -1) return AF_OK;             // the same baseline twice in one step
+        slot = (int32_t)r;
+    }
+    double worst = 0.0;
+    std::vector<int> comp((size_t)nant), queue;
+    std::vector<std::vector<int32_t>> adj((size_t)nant);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        double *x = ant_uvw_host + s * nant * 3;
+        for (auto &a : adj) a.clear();
+        for (int64_t k = first[(size_t)s]; k < first[(size_t)s + 1]; ++k) {
+            const int32_t r = order[(size_t)k];
+            adj[(size_t)antenna1_host[r]].push_back(r);
+            if (antenna2_host[r] != antenna1_host[r]) adj[(size_t)antenna2_host[r]].push_back(r);
+        }
+        std::fill(comp.begin(), comp.end(), -1);
+        int ncomp = 0;
+        for (int root = 0; root < (int)nant; ++root) {
+            if (comp[(size_t)root] >= 0 || adj[(size_t)root].empty()) continue;
+            comp[(size_t)root] = ncomp;
+            queue.assign(1, root);
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int p = queue[h];
+                for (int32_t r : adj[(size_t)p]) {
+                    const int a1 = antenna1_host[r], a2 = antenna2_host[r];
+                    const int o = a1 == p ? a2 : a1;
+                    if (comp[(size_t)o] >= 0) continue;
+                    comp[(size_t)o] = ncomp;
+                    for (int c = 0; c < 3; ++c)      // uvw_r = x_a1 - x_a2
+                        x[3 * o + c] = a1 == p ? x[3 * p + c] - uvw_host[3 * (int64_t)r + c] : x[3 * p + c] + uvw_host[3 * (int64_t)r + c];
+                    queue.push_back(o);
+                }
+            }
+            ++ncomp;
+        }
+        for (int sweep = 0; sweep < 2; ++sweep)
+            for (int p = 0; p < (int)nant; ++p) {
+                double acc[3] = {0.0, 0.0, 0.0};
+                int n = 0;
+                for (int32_t r : adj[(size_t)p]) {
+                    const int a1 = antenna1_host[r], a2 = antenna2_host[r];
+                    if (a1 == a2) continue;
+                    const int o = a1 == p ? a2 : a1;
+                    for (int c = 0; c < 3; ++c)
+                        acc[c] += a1 == p ? x[3 * o + c] + uvw_host[3 * (int64_t)r + c] : x[3 * o + c] - uvw_host[3 * (int64_t)r + c];
+                    ++n;
+                }
+                if (n)
+                    for (int c = 0; c < 3; ++c) x[3 * p + c] = acc[c] / n;
+            }
+        for (int k = 0; k < ncomp; ++k) {          // remove every component's mean
+            double mean[3] = {0.0, 0.0, 0.0};
+            int n = 0;
+            for (int p = 0; p < (int)nant; ++p)
+                if (comp[(size_t)p] == k) { for (int c = 0; c < 3; ++c) mean[c] += x[3 * p + c]; ++n; }
+            for (int p = 0; p < (int)nant; ++p)
+                if (comp[(size_t)p] == k) for (int c = 0; c < 3; ++c) x[3 * p + c] -= mean[c] / n;
+        }
+        for (int64_t k = first[(size_t)s]; k < first[(size_t)s + 1]; ++k) {
+            const int32_t r = order[(size_t)k];
+            const int a1 = antenna1_host[r], a2 = antenna2_host[r];
+            for (int c = 0; c < 3; ++c) {
+                const double d = fabs(x[3 * a1 + c] - x[3 * a2 + c] - uvw_host[3 * (int64_t)r + c]);
+                if (!(d <= worst)) worst = d;       // NaN sticks
+            }
+        }
+    }
+    *max_residual = worst;
+    *decomposable = worst <= tol ? 1 : 0;
+    return AF_OK;
+}
+
+// The antenna-decomposed form of af_fused_predict_c128: same arguments, with the plan of af_fused_plan_antennas
+// (DEVICE copies: ant_uvw (nsteps, nant, 3), rowmap (nsteps, nap, nap)) in place of uvw, antenna1 / antenna2 and the
+// items; nsteps <= ntime; every row of `out` that the row map names is written, nothing else is touched.  Same workspace
+// as af_fused_predict_c128 (af_fused_predict_workspace_bytes).  nant <= 64; no gauss_shape.
+AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
+                                             const double *lm, const double *frequency, const double *brightness,
+                                             int64_t nsrc, int64_t nchan, const double *beam, int64_t beam_lw,
+                                             int64_t beam_mh, int64_t beam_nud, const double *beam_lm_extents,
+                                             const double *beam_freq_map, const double *parallactic_angles, int64_t ntime,
+                                             int64_t nant, const double *point_errors, const double *antenna_scaling,
+                                             const double *feed_rotation, int convention, double *out, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
+               "convention not in ('fourier', 'casa')");
+    AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
+    AF_REQUIRE(nsteps >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
+               "af_fused_predict_antennas_c128: negative extent");
+    AF_REQUIRE(nant <= 64, "af_fused_predict_antennas_c128: more than 64 antennas (use af_fused_predict_c128)");
+    AF_REQUIRE(nsteps <= ntime, "af_fused_predict_antennas_c128: %lld steps but %lld timesteps of per-antenna terms",
+               (long long)nsteps, (long long)ntime);
+    AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nsteps < (1LL << 31), "af_fused_predict_antennas_c128: too large");
+    hipStream_t st_ = af_stream(stream);
+    if (nrow == 0 || nchan == 0 || nsteps == 0) return AF_OK;
+    AF_REQUIRE(out != nullptr, "af_fused_predict_antennas_c128: out is NULL");
+    if (nsrc == 0) {
+        AF_HIP(hipMemsetAsync(out, 0, sizeof(double) * 2 * 4 * (size_t)(nrow * nchan), st_));
+        return AF_OK;
+    }
+    AF_REQUIRE(ant_uvw && rowmap && lm && frequency && brightness && beam && beam_lm_extents && beam_freq_map &&
+                   parallactic_angles && point_errors && antenna_scaling,
+               "af_fused_predict_antennas_c128: NULL array");
+    const FusedWs W = fused_ws(nsrc, nchan, beam_lw, beam_mh, beam_nud);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= W.total,
+               "af_fused_predict_antennas_c128: workspace too small (%zu < %zu)", workspace_bytes, W.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_fused_predict_antennas_c128: workspace must be 256-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    double *lmn = reinterpret_cast<double *>(ws + W.lmn), *f4 = reinterpret_cast<double *>(ws + W.f4);
+    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *planes = reinterpret_cast<double *>(ws + W.planes);
+    hipLaunchKernelGGL(fused_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st_, lm, nsrc, lmn);
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fused_prep_freq, dim3((unsigned)af_cdiv(nchan, 64)), dim3(64), 0, st_, frequency, nchan,
+                       convention, f4);
+    AF_LAUNCH_CHECK();
+    int rc = af_freq_grid_interp_f64(frequency, nchan, beam_freq_map, beam_nud, freq_data, stream);
+    if (rc != AF_OK) return rc;
+    const int64_t ncell = beam_lw * beam_mh;
+    AF_REQUIRE(ncell < (1LL << 25), "af_fused_predict_antennas_c128: beam cube too large (fewer than 2^25 cells per plane)");
+    static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
+    const bool feed = feed_rotation != nullptr;
+    const int nb = (int)((nant + 7) / 8);
+    auto launch = [&](auto kernel, int NBc, int STc) -> int {
+        const int na = NBc * 8, cs = na * 2 + COL_PAD;
+        const size_t lds_bytes = (size_t)2 * STc * (H_PLANES + G_PLANES) * cs * sizeof(double) + (size_t)na * 6 * sizeof(double) +
+                                 (size_t)na * 4 * sizeof(double) + (size_t)na * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
+        AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_antennas_c128: %zu bytes of LDS needed", lds_bytes);
+        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+        for (int64_t f0 = 0; f0 < nchan; f0 += PLANE_GROUP) {
+            const int64_t nf = nchan - f0 < PLANE_GROUP ? nchan - f0 : PLANE_GROUP;
+            int64_t blocks = af_cdiv(ncell * 4, 256);
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(beam_plane_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, st_,
+                               reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes);
+            AF_LAUNCH_CHECK();
+            if (f0 == 0) af_prof_begin(st_);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nsteps, (unsigned)nf), dim3(G_THREADS), lds_bytes, st_, ant_uvw, rowmap,
+                               lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw, beam_mh, beam_nud,
+                               beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
+                               reinterpret_cast<const double2 *>(feed_rotation), (int)nsrc, nchan, ntime, (int)nant,
+                               reinterpret_cast<double2 *>(out), only_stage, f0);
+            if (f0 == 0) af_prof_end(st_);
+            AF_LAUNCH_CHECK();
+        }
+        return AF_OK;
+    };
+    // sources per batch: about one super-round of the 256 sampling lanes (ST x 8 NB terms), two buffers within ~100 KB
+#define AF_GEMM_PICK(NBC, STC) (feed ? launch(fused_gemm_kernel<true, NBC, STC>, NBC, STC) : launch(fused_gemm_kernel<false, NBC, STC>, NBC, STC))
+    switch (nb) {
+    case 1: return AF_GEMM_PICK(1, 16);
+    case 2: return AF_GEMM_PICK(2, 8);
+    case 3: return AF_GEMM_PICK(3, 8);
+    case 4: return AF_GEMM_PICK(4, 8);
+    case 5: return AF_GEMM_PICK(5, 4);
+    case 6: return AF_GEMM_PICK(6, 4);
+    case 7: return AF_GEMM_PICK(7, 4);
+    default: return AF_GEMM_PICK(8, 4);
+    }
+#undef AF_GEMM_PICK
+}

@@ -107,3 +107,38 @@ AF_EXPORT int af_fused_predict_model_c128(const double *stokes, const double *sp
                                  point_errors, antenna_scaling, feed_rotation, gauss_shape, convention, out, ws + W.rest, rest,
                                  stream);
 }
+
+// The sky-model form of af_fused_predict_antennas_c128 (antenna-decomposable uvw: csrc/af_fused_gemm.hip): brightness =
+// convert(spectral_model(...)) on the device, then the GEMM-form predict.  Workspace: af_fused_predict_model_workspace_bytes.
+AF_EXPORT int af_fused_predict_antennas_model_c128(const double *stokes, const double *spi, const double *ref_freq,
+                                                   const int *base, int64_t nspi, int64_t npol, const int *src1_host,
+                                                   const int *src2_host, const int *op_host, const double *ant_uvw,
+                                                   const int32_t *rowmap, int64_t nsteps, int64_t nrow, const double *lm,
+                                                   const double *frequency, int64_t nsrc, int64_t nchan, const double *beam,
+                                                   int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                                                   const double *beam_lm_extents, const double *beam_freq_map,
+                                                   const double *parallactic_angles, int64_t ntime, int64_t nant,
+                                                   const double *point_errors, const double *antenna_scaling,
+                                                   const double *feed_rotation, int convention, double *out, void *workspace,
+                                                   size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(nsrc >= 0 && nchan >= 0 && nspi >= 0 && npol >= 1 && npol <= 12,
+               "af_fused_predict_antennas_model_c128: bad extents");
+    const size_t rest = af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud);
+    const ModelWs W = model_ws(nsrc, nchan, npol, 4, rest);
+    AF_REQUIRE(workspace != nullptr && workspace_bytes >= W.total,
+               "af_fused_predict_antennas_model_c128: workspace too small (%zu < %zu)", workspace_bytes, W.total);
+    AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_fused_predict_antennas_model_c128: workspace must be 256-byte aligned");
+    char *ws = static_cast<char *>(workspace);
+    double *brightness = reinterpret_cast<double *>(ws + W.image);
+    if (nsrc > 0 && nchan > 0) {
+        AF_REQUIRE(stokes && spi && ref_freq && base && frequency, "af_fused_predict_antennas_model_c128: NULL array");
+        int rc = model_image(stokes, spi, ref_freq, frequency, base, nsrc, nspi, npol, nchan, src1_host, src2_host, op_host, 4,
+                             1, reinterpret_cast<double *>(ws + W.spec), brightness, stream);
+        if (rc != AF_OK) return rc;
+    }
+    return af_fused_predict_antennas_c128(ant_uvw, rowmap, nsteps, nrow, lm, frequency, brightness, nsrc, nchan, beam, beam_lw,
+                                          beam_mh, beam_nud, beam_lm_extents, beam_freq_map, parallactic_angles, ntime, nant,
+                                          point_errors, antenna_scaling, feed_rotation, convention, out, ws + W.rest, rest,
+                                          stream);
+}

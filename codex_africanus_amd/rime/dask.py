@@ -205,8 +205,10 @@ def _fused_block(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
     u = lambda x: None if x is None else _first(x)
     pa_ = u(pa)
     with placement.block(block_id):
-        plan = None if beam is None else cached_plan(time_index, antenna1, antenna2, pa_.shape[1])
-        vis = _np_fused(time_index, antenna1, antenna2, u(lm), u(uvw), frequency, u(brightness), u(beam), u(extents),
+        uvw_ = u(uvw)
+        plan = None if beam is None else cached_plan(time_index, antenna1, antenna2, pa_.shape[1],
+                                                      uvw=None if gauss_shape is not None else uvw_)
+        vis = _np_fused(time_index, antenna1, antenna2, u(lm), uvw_, frequency, u(brightness), u(beam), u(extents),
                         u(freq_map), pa_, u(pe), u(ascale), None, None, None, convention, u(feed_rot), u(gauss_shape),
                         u(stokes), u(spi), u(ref_freq), corr_schema, spectral_base, plan)
     if running is not None:

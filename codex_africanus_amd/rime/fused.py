@@ -37,7 +37,15 @@ class FusedPlan(object):
         self.items, self.groups = items, groups
         self.antenna1, self.antenna2 = antenna1, antenna2
         self.n_items = int(items.shape[0]) if nrow else 0
+        # antenna decomposition of uvw (fused_plan(..., uvw=...)): per-antenna coordinates (nsteps, nant, 3), the row of
+        # every (step, antenna1, antenna2) (nsteps, nap, nap) and the largest |x_p - x_q - uvw_pq| [m]; None = the rows
+        # are not (known to be) antenna-decomposable and the call runs on the lane-per-row kernel
+        self.ant_uvw = self.rowmap = self.residual = None
         self._dev = {}
+
+    @property
+    def decomposable(self):
+        return self.ant_uvw is not None
 
     def device(self, arr, call):
         """`arr` (one of this plan's arrays) for the call: the numpy array in host mode, a cached tensor in device mode"""
@@ -51,13 +59,25 @@ class FusedPlan(object):
         return t
 
 
-def fused_plan(time_index, antenna1, antenna2, nant, grouped=True):
+DECOMPOSE_TOL = 1e-10      # metres: see fused_plan
+
+
+def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, decompose_tol=None):
     """
     Plan of a row layout for :func:`fused_predict_vis` with DDEs (host side, O(row)): runs of consecutive rows with
     equal ``time_index`` become workgroup items.  ``grouped`` (default): rows are dealt in 2 x 2 blocks of baselines that
     share their antennas' Jones terms (``af_fused_plan_groups``: 5 instead of 8 LDS reads per (row, source); up to ~230
     antennas); otherwise plain row ranges (``af_fused_plan_rows``).  ``nant`` = the antenna extent
     of the per-antenna arrays (parallactic_angles.shape[1]).
+
+    ``uvw`` (row, 3), optional: the plan then also tests whether the rows are ANTENNA-DECOMPOSABLE,
+    ``uvw_pq = uvw_p - uvw_q`` per timestep -- true of every real Measurement Set, not of uvw drawn at random per row --
+    by solving for per-antenna coordinates (``af_fused_plan_antennas``) and accepting them when
+    ``max |uvw_p - uvw_q - uvw_pq| <= decompose_tol`` metres (default 1e-10: a phase error below
+    ``2 pi nu / c |lmn| 1e-10`` = 2e-10 rad at 1.7 GHz, 0.05 rad off axis).  A decomposable plan (``plan.decomposable``;
+    at most 64 antennas, every (time, antenna1, antenna2) at most once) sends the call to the GEMM form of the predict,
+    ``V(t, nu) = G H^H`` on the matrix cores (csrc/af_fused_gemm.hip: about half the arithmetic of the general kernel);
+    such a plan is bound to these ``uvw``.  ``AFHIP_FUSED_GEMM=0`` switches the test off.
     """
     ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
     a1h = np.ascontiguousarray(_host(antenna1), dtype=np.int32)
@@ -88,36 +108,55 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True):
         items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
         _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
                   ctypes.byref(n_items))
-    return FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h)
+    plan = FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h)
+    if uvw is not None and nrow and nant <= 64 and os.environ.get("AFHIP_FUSED_GEMM", "1") != "0":
+        uvw_h = np.ascontiguousarray(_host(uvw), dtype=np.float64)
+        if uvw_h.shape != (nrow, 3):
+            raise ValueError("uvw must have shape (row, 3)")
+        nap = 8 * ((nant + 7) // 8)
+        ant_uvw = np.zeros((nsteps, nant, 3), dtype=np.float64)
+        rowmap = np.zeros((nsteps, nap, nap), dtype=np.int32)
+        resid, ok = ctypes.c_double(0.0), ctypes.c_int(0)
+        tol = DECOMPOSE_TOL if decompose_tol is None else float(decompose_tol)
+        _lib.call("af_fused_plan_antennas", tip, a1h.ctypes.data_as(ctypes.c_void_p), a2h.ctypes.data_as(ctypes.c_void_p),
+                  uvw_h.ctypes.data_as(ctypes.c_void_p), nrow, nant, tol, nsteps, ant_uvw.ctypes.data_as(ctypes.c_void_p),
+                  rowmap.ctypes.data_as(ctypes.c_void_p), ctypes.byref(resid), ctypes.byref(ok))
+        plan.residual = resid.value
+        if ok.value:
+            plan.ant_uvw, plan.rowmap = ant_uvw, rowmap
+    return plan
 
 
 _plan_cache = collections.OrderedDict()
 _plan_lock = threading.Lock()
 
 
-def cached_plan(time_index, antenna1, antenna2, nant, grouped=True):
+def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
     """:func:`fused_plan` memoised on the CONTENTS of the three index arrays (a 16-byte digest: ~1 ms per 1e6 rows):
     what the row-chunk front-ends call (``rime.dask.fused_predict_vis``, ``chunked.fused_predict_vis``,
     ``sharding.fused_predict_shard``), where the same row chunk comes back for every channel block, every source chunk
     and every imaging cycle, each time as a fresh array.  ``AFHIP_PLAN_CACHE`` = number of plans kept (default 16,
-    least recently used first out; 0 = no cache)."""
+    least recently used first out; 0 = no cache).  With ``uvw`` the plan carries the antenna decomposition (see
+    :func:`fused_plan`) and the digest covers ``uvw`` as well."""
     limit = int(os.environ.get("AFHIP_PLAN_CACHE", "16"))
     if limit <= 0:
-        return fused_plan(time_index, antenna1, antenna2, nant, grouped)
+        return fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
     h = hashlib.blake2b(digest_size=16)
     n = 0
-    for a in (time_index, antenna1, antenna2):
+    for a in (time_index, antenna1, antenna2, uvw):
+        if a is None:
+            continue
         a = np.ascontiguousarray(_host(a))
         n = int(a.shape[0])
         h.update(a.dtype.str.encode())
         h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")
-    key = (n, int(nant), bool(grouped), h.digest())
+    key = (n, int(nant), bool(grouped), uvw is not None, h.digest())
     with _plan_lock:
         plan = _plan_cache.get(key)
         if plan is not None:
             _plan_cache.move_to_end(key)
             return plan
-    plan = fused_plan(time_index, antenna1, antenna2, nant, grouped)
+    plan = fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
     with _plan_lock:
         _plan_cache[key] = plan
         while len(_plan_cache) > limit:
@@ -256,15 +295,23 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             if tuple(antenna_scaling.shape) != (nant, nchan, 2):
                 raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
             if plan is None:
-                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True)
+                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True,
+                                  uvw=None if gauss_shape is not None else uvw)
             if plan.nrow != nrow or plan.nant != nant or plan.nsteps > ntime:
                 raise ValueError("plan was made for %d rows, %d antennas, %d timesteps; the call has %d, %d, %d"
                                  % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
-            n_items = ctypes.c_int64(plan.n_items)
-            p_items = c.inp(plan.device(plan.items, c), np.int32)
-            p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
-            a1h, a2h = plan.antenna1, plan.antenna2
-            p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
+            # antenna-decomposable rows: the GEMM form (Gaussian shapes depend on the baseline: general kernel)
+            gemm = plan.decomposable and gauss_shape is None and nrow > 0 and \
+                os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
+            if gemm:
+                p_au = c.inp(plan.device(plan.ant_uvw, c), np.float64)
+                p_rm = c.inp(plan.device(plan.rowmap, c), np.int32)
+            else:
+                n_items = ctypes.c_int64(plan.n_items)
+                p_items = c.inp(plan.device(plan.items, c), np.int32)
+                p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
+                a1h, a2h = plan.antenna1, plan.antenna2
+                p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
             p_beam, p_ext, p_map = c.inp(beam, np.complex128), c.inp(beam_lm_extents, np.float64), \
                 c.inp(beam_freq_map, np.float64)
             p_pa, p_pe, p_as = c.inp(parallactic_angles, np.float64), c.inp(point_errors, np.float64), \
@@ -273,7 +320,21 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
             p_fr_rot = c.inp(feed_rotation, np.complex128)
             p_gs = c.inp(gauss_shape, np.float64)
-            if model:
+            if model and gemm:
+                ws_bytes = int(_lib.load().af_fused_predict_model_workspace_bytes(nsrc, nchan, m_npol, beam_lw, beam_mh,
+                                                                                  beam_nud))
+                p_ws = c.scratch(ws_bytes)
+                _lib.call("af_fused_predict_antennas_model_c128", p_st, p_sp, p_rf, p_mb, int(spi.shape[1]), m_npol,
+                          m_tabs[0], m_tabs[1], m_tabs[2], p_au, p_rm, plan.nsteps, nrow, p_lm, p_fr, nsrc, nchan, p_beam,
+                          beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_fr_rot, conv, p_out,
+                          p_ws, max(ws_bytes, 256), c.stream)
+            elif gemm:
+                ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
+                p_ws = c.scratch(ws_bytes)
+                _lib.call("af_fused_predict_antennas_c128", p_au, p_rm, plan.nsteps, nrow, p_lm, p_fr, p_b, nsrc, nchan,
+                          p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_fr_rot, conv,
+                          p_out, p_ws, max(ws_bytes, 256), c.stream)
+            elif model:
                 ws_bytes = int(_lib.load().af_fused_predict_model_workspace_bytes(nsrc, nchan, m_npol, beam_lw, beam_mh,
                                                                                   beam_nud))
                 p_ws = c.scratch(ws_bytes)

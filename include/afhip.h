@@ -297,6 +297,34 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
                           const double *feed_rotation, const double *gauss_shape, int convention,
                           double *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the same predict for ANTENNA-DECOMPOSABLE uvw: one complex GEMM per (timestep, channel) ----------------
+ * When uvw_pq = uvw_p - uvw_q per timestep (every real Measurement Set) the phasor of phase_delay
+ * (africanus/rime/phase.py:45-61) factorises into per-antenna phasors and the chain above becomes
+ *     V_pq(t,nu) = sum_s G_ps A_qs^H,   A_as = k_as E_as,  G_as = A_as X_s,  k_as = exp(i C nu (l,m,n)_s . uvw_a)
+ * i.e. M = G H^H with M (2 nant x 2 nant), K = 2 nsrc: evaluated with v_mfma_f64_16x16x4 on the upper block triangle
+ * (csrc/af_fused_gemm.hip).  Replaces the same reference functions as af_fused_predict_c128; results agree with it
+ * and with the reference chain to the rounding of the phase argument plus 2 pi nu / c |lmn| x the plan's residual.
+ * af_fused_plan_antennas (HOST pointers; O(row)): per timestep a spanning-tree integration of uvw over the baseline
+ *   graph + two Gauss-Seidel sweeps towards the least-squares antenna coordinates, component means removed;
+ *   *decomposable = 1 iff max_rows |x_p - x_q - uvw_pq|_inf <= tol [m] (reported in *max_residual) and no
+ *   (step, antenna1, antenna2) occurs twice.  nsteps = max(time_index) - min(time_index) + 1;
+ *   ant_uvw_host (nsteps, nant, 3) double; rowmap_host (nsteps, nap, nap) int32, nap = 8 ceil(nant / 8): the row of
+ *   baseline (p, q) of the step or -1.  nant <= 64.
+ * af_fused_predict_antennas_c128 (DEVICE pointers): ant_uvw / rowmap = device copies of the plan; the other arguments
+ *   as af_fused_predict_c128 (same workspace size); writes out[row] for every row the map names.  No gauss_shape (it
+ *   depends on the baseline: use af_fused_predict_c128). */
+int af_fused_plan_antennas(const int64_t *time_index_host, const int32_t *antenna1_host, const int32_t *antenna2_host,
+                           const double *uvw_host, int64_t nrow, int64_t nant, double tol, int64_t nsteps,
+                           double *ant_uvw_host, int32_t *rowmap_host, double *max_residual, int *decomposable);
+int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
+                                   const double *lm, const double *frequency, const double *brightness, int64_t nsrc,
+                                   int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                                   const double *beam_lm_extents, const double *beam_freq_map,
+                                   const double *parallactic_angles, int64_t ntime, int64_t nant,
+                                   const double *point_errors, const double *antenna_scaling,
+                                   const double *feed_rotation, int convention, double *out, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
 /* ---- chi-squared ---------------------------------------------------------------
  * chi2_per_chan[nu] = sum_{r,c} weight[r,nu,c] * |data[r,nu,c] - model[r,nu,c]|^2
  * (weight NULL = 1).  model/data (nrow,nchan,ncorr) complex128, weight real float64,
@@ -428,6 +456,17 @@ int af_fused_predict_model_c128(const double *stokes, const double *spi, const d
                                 int64_t nant, const double *point_errors, const double *antenna_scaling,
                                 const double *feed_rotation, const double *gauss_shape, int convention, double *out,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* the same for antenna-decomposable uvw (af_fused_predict_antennas_c128 after the model steps) */
+int af_fused_predict_antennas_model_c128(const double *stokes, const double *spi, const double *ref_freq, const int *base,
+                                         int64_t nspi, int64_t npol, const int *src1_host, const int *src2_host,
+                                         const int *op_host, const double *ant_uvw, const int32_t *rowmap, int64_t nsteps,
+                                         int64_t nrow, const double *lm, const double *frequency, int64_t nsrc,
+                                         int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh,
+                                         int64_t beam_nud, const double *beam_lm_extents, const double *beam_freq_map,
+                                         const double *parallactic_angles, int64_t ntime, int64_t nant,
+                                         const double *point_errors, const double *antenna_scaling,
+                                         const double *feed_rotation, int convention, double *out, void *workspace,
+                                         size_t workspace_bytes, void *stream);
 
 /* wgridder-style degridding, image -> visibilities at a requested accuracy (BASELINE configs[4]):
  * the entry under africanus.gridding.wgridder.model (africanus/gridding/wgridder/im2vis.py:14-61), whose arithmetic is the

@@ -1,0 +1,196 @@
+"""
+The GEMM form of the fused predict (csrc/af_fused_gemm.hip): for antenna-decomposable uvw (uvw_pq = uvw_p - uvw_q per
+timestep -- every real Measurement Set) the chain phase_delay -> einsum -> beam_cube_dde -> predict_vis
+(africanus/rime/examples/predict.py:107-134,404-472,525) is V(t, nu) = G H^H, evaluated with fp64 MFMA.  Checked against
+the CPU oracle chain to 1e-9 of the per-visibility sum of |term| magnitudes (north star: 1e-8), against the general
+kernel on the same rows, and the dispatcher: rows that are not decomposable, repeated baselines, Gaussian shapes and
+more than 64 antennas stay on the general kernel.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd import rime
+from codex_africanus_amd.rime import fused
+from test_gpu_fused import _problem, _oracle_chain, _scale
+
+pytestmark = pytest.mark.gpu
+
+
+def _decomposable(d, nant, seed=0, keep=1.0, swap=0.0, shuffle=False, autos=False):
+    """Replace the problem's uvw by differences of per-(time, antenna) coordinates; optionally drop baselines, swap
+    antenna1 / antenna2 of some rows, shuffle the rows inside every timestep, turn some rows into autocorrelations."""
+    rng = np.random.default_rng(1000 + seed)
+    ti, a1, a2 = d["time_index"].copy(), d["ant1"].copy(), d["ant2"].copy()
+    nrow = ti.shape[0]
+    if autos:
+        sel = rng.random(nrow) < 0.05
+        # an autocorrelation per (time, antenna) at most once: keep the first row of each (time, antenna1)
+        key = ti.astype(np.int64) * nant + a1
+        first = np.zeros(nrow, bool)
+        first[np.unique(key, return_index=True)[1]] = True
+        sel &= first
+        a2[sel] = a1[sel]
+    if swap:
+        sw = rng.random(nrow) < swap
+        a1[sw], a2[sw] = a2[sw].copy(), a1[sw].copy()
+    order = np.arange(nrow)
+    if keep < 1.0:
+        order = order[rng.random(nrow) < keep]
+    if shuffle:
+        order = order[np.lexsort((rng.random(order.shape[0]), ti[order]))]
+    x = rng.uniform(-1, 1, (d["ntime"], nant, 3)) * np.array([3000.0, 3000.0, 300.0])
+    ti, a1, a2 = ti[order], a1[order], a2[order]
+    d = dict(d)
+    d["time_index"], d["ant1"], d["ant2"] = ti, a1, a2
+    d["uvw"] = x[ti, a1] - x[ti, a2]
+    d["ant_xyz"] = x
+    return d
+
+
+def _call(d, **kw):
+    return rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                                  d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"], **kw)
+
+
+@pytest.mark.parametrize("nant, nrow", [(5, 37), (7, 300), (8, 500), (12, 1000), (17, 1500), (24, 2000), (33, 2500),
+                                        (40, 1700), (47, 3000), (50, 3000), (57, 4000), (64, 4100)])
+def test_gemm_form_matches_the_reference_chain(nant, nrow):
+    d = _decomposable(_problem(3, nrow, 6, 23, nant), nant)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable and plan.residual <= 1e-10
+    out = _call(d, plan=plan)
+    ref = _oracle_chain(d, True)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+    # without an explicit plan the call plans for itself, decomposes and takes the same route: same bits
+    assert np.array_equal(_call(d), out)
+
+
+def test_gemm_form_equals_the_general_kernel(monkeypatch):
+    d = _decomposable(_problem(11, 4032, 5, 37, 64), 64)
+    a = _call(d)
+    monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
+    b = _call(d)
+    assert not np.array_equal(a, b)                       # two different kernels ...
+    assert np.abs(a - b).max() < 1e-10 * _scale(d)        # ... one answer
+
+
+@pytest.mark.parametrize("case", ["missing", "swapped", "shuffled", "autos", "all"])
+def test_row_layouts(case):
+    """baselines missing from some timesteps (flagged antennas), rows stored with antenna1 > antenna2 (served by the
+    conjugate transpose of the computed tile), any row order inside a timestep, autocorrelations (diagonal blocks)"""
+    kw = dict(missing=dict(keep=0.7), swapped=dict(swap=0.4), shuffled=dict(shuffle=True), autos=dict(autos=True),
+              all=dict(keep=0.8, swap=0.3, shuffle=True, autos=True))[case]
+    nant = 19
+    d = _decomposable(_problem(5, 1500, 4, 17, nant), nant, seed=2, **kw)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable
+    out = _call(d, plan=plan)
+    ref = _oracle_chain(d, True)
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+
+
+def test_feed_rotation_model_dies_and_convention():
+    nant = 13
+    d = _decomposable(_problem(8, 900, 5, 11, nant), nant, seed=4)
+    rng = d["rng"]
+    fr = oracle.feed_rotation(d["pa"], "linear")
+    out = _call(d, feed_rotation=fr, convention="casa")
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"], "casa")
+    coh = np.einsum("srf,sfij->srfij", phase, d["X"])
+    dde = np.einsum("stafij,tajk->stafik", oracle.beam_cube_dde(d["beam"], d["extents"], d["beam_freq_map"], d["lm"],
+                                                                 d["pa"], d["pe"], d["as"], d["frequency"]), fr)
+    ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, coh, dde, None, None, None)
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+    # DIEs and base_vis ride on top (applied by predict_vis, as in the general route)
+    shp = (d["ntime"], nant, 5, 2, 2)
+    die = 1.0 + 0.1 * rng.standard_normal(shp) + 0.1j * rng.standard_normal(shp)
+    bvis = 0.1 * (rng.standard_normal((900, 5, 2, 2)) + 1j * rng.standard_normal((900, 5, 2, 2)))
+    out = _call(d, die1_jones=die, base_vis=bvis, die2_jones=die)
+    assert np.abs(out - _oracle_chain(d, True, die, bvis)).max() < 2e-9 * _scale(d)
+    # the sky model instead of brightness
+    nsrc = d["lm"].shape[0]
+    stokes = np.stack([rng.lognormal(0, 1, nsrc)] + [0.1 * rng.standard_normal(nsrc) for _ in range(3)], axis=1)
+    spi = rng.uniform(-1.0, 0.2, (nsrc, 2, 4))
+    rf = rng.uniform(0.9e9, 1.5e9, nsrc)
+    out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], None,
+                                 d["beam"], d["extents"], d["beam_freq_map"], d["pa"], d["pe"], d["as"],
+                                 stokes=stokes, spi=spi, ref_freq=rf)
+    st = oracle.spectral_model(stokes, spi, rf, d["frequency"], base=0)
+    I, Q, U, V = (st[..., k] for k in range(4))           # noqa: E741
+    d2 = dict(d, X=np.stack([I + Q, U + 1j * V, U - 1j * V, I - Q], axis=-1).reshape(nsrc, 5, 2, 2))
+    assert np.abs(out - _oracle_chain(d2, True)).max() < 1e-9 * _scale(d2)
+
+
+def test_device_resident_call_and_time_offset():
+    import torch
+    nant = 10
+    d = _decomposable(_problem(9, 700, 4, 9, nant), nant, seed=5)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    plan = fused.fused_plan(d["time_index"] + 11, d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    out = rime.fused_predict_vis(t(d["time_index"] + 11), t(d["ant1"]), t(d["ant2"]), t(d["lm"]), t(d["uvw"]),
+                                 t(d["frequency"]), t(d["X"]), t(d["beam"]), t(d["extents"]), t(d["beam_freq_map"]),
+                                 t(d["pa"]), t(d["pe"]), t(d["as"]), plan=plan)
+    assert plan.decomposable and out.is_cuda
+    assert np.abs(out.cpu().numpy() - _oracle_chain(d, True)).max() < 1e-9 * _scale(d)
+
+
+def test_dispatcher_falls_back():
+    """what must NOT take the GEMM route: uvw drawn per row (BASELINE's recipe), uvw decomposable only to 1e-6 m, the same
+    baseline twice in a timestep, Gaussian shapes, more than 64 antennas -- all give the reference's answer"""
+    nant = 9
+    base = _problem(12, 600, 4, 13, nant)
+    plan = fused.fused_plan(base["time_index"], base["ant1"], base["ant2"], nant, uvw=base["uvw"])
+    assert not plan.decomposable and plan.residual > 1.0
+    assert np.abs(_call(base, plan=plan) - _oracle_chain(base, True)).max() < 1e-9 * _scale(base)
+    d = _decomposable(base, nant, seed=6)
+    noisy = dict(d, uvw=d["uvw"] + 1e-6 * np.random.default_rng(1).standard_normal(d["uvw"].shape))
+    plan = fused.fused_plan(noisy["time_index"], noisy["ant1"], noisy["ant2"], nant, uvw=noisy["uvw"])
+    assert not plan.decomposable and 1e-8 < plan.residual < 1e-4
+    assert fused.fused_plan(noisy["time_index"], noisy["ant1"], noisy["ant2"], nant, uvw=noisy["uvw"],
+                            decompose_tol=1e-4).decomposable
+    assert np.abs(_call(noisy) - _oracle_chain(noisy, True)).max() < 1e-9 * _scale(noisy)
+    dup = dict(d)
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        dup[k] = np.concatenate([d[k], d[k][:5]])
+    plan = fused.fused_plan(dup["time_index"], dup["ant1"], dup["ant2"], nant, uvw=dup["uvw"])
+    assert not plan.decomposable
+    order = np.argsort(dup["time_index"], kind="stable")
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        dup[k] = dup[k][order]
+    assert np.abs(_call(dup) - _oracle_chain(dup, True)).max() < 1e-9 * _scale(dup)
+    gs = np.zeros((13, 3))
+    gs[::2] = [1e-4, 5e-5, 0.3]
+    out = _call(d, gauss_shape=gs)
+    phase = oracle.phase_delay(d["lm"], d["uvw"], d["frequency"]) * oracle.gaussian_shape(d["uvw"], d["frequency"], gs)
+    dde = oracle.beam_cube_dde(d["beam"], d["extents"], d["beam_freq_map"], d["lm"], d["pa"], d["pe"], d["as"], d["frequency"])
+    ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, np.einsum("srf,sfij->srfij", phase, d["X"]), dde,
+                             None, None, None)
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+    big = _decomposable(_problem(13, 2500, 3, 5, 70), 70, seed=7)
+    plan = fused.fused_plan(big["time_index"], big["ant1"], big["ant2"], 70, uvw=big["uvw"])
+    assert not plan.decomposable
+    assert np.abs(_call(big) - _oracle_chain(big, True)).max() < 1e-9 * _scale(big)
+
+
+def test_plan_through_the_c_abi():
+    """af_fused_plan_antennas called directly: residual, antenna coordinates up to a per-timestep shift, row map"""
+    import ctypes
+    from codex_africanus_amd import _lib
+    nant = 6
+    d = _decomposable(_problem(14, 45, 2, 3, nant), nant, seed=8, keep=0.8, swap=0.3)
+    ti = d["time_index"].astype(np.int64)
+    a1, a2 = d["ant1"].astype(np.int32), d["ant2"].astype(np.int32)
+    nsteps = int(ti.max() - ti.min()) + 1
+    au, rm = np.zeros((nsteps, nant, 3)), np.zeros((nsteps, 8, 8), np.int32)
+    res, ok = ctypes.c_double(), ctypes.c_int()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.call("af_fused_plan_antennas", P(ti), P(a1), P(a2), P(d["uvw"]), ti.shape[0], nant, 1e-10, nsteps, P(au), P(rm),
+              ctypes.byref(res), ctypes.byref(ok))
+    assert ok.value == 1 and res.value < 1e-11
+    assert np.abs(au[ti, a1] - au[ti, a2] - d["uvw"]).max() == res.value
+    for r in range(ti.shape[0]):
+        assert rm[ti[r], a1[r], a2[r]] == r
+    assert (rm >= 0).sum() == ti.shape[0]
