@@ -15,6 +15,8 @@ Workloads (--workload), one per BASELINE config a single GPU can run:
     dft_complex  the same transform with complex brightness matrices (= the fused predict without DDEs)
     dft_f32      the same transform for single-precision callers (float32 in, complex64 out; af_im_to_vis_f32)
     fused_dde    fused predict with per-antenna beam-cube DDEs, 64 antennas: BASELINE configs[2]
+    fused_dde_ant  the same with antenna-decomposable uvw (uvw_pq = uvw_p - uvw_q, as in a Measurement Set): one complex
+                 GEMM per (timestep, channel) on the fp64 matrix cores (= fused_dde --uvw antennas)
     degrid       convolutional degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7x7 taps: BASELINE configs[4]
     wgrid        wgridder-style degridding of a 4096^2 image at epsilon 1e-5: BASELINE configs[4] as named
 The default run (N = 1, headline shape) also times every other workload for a few steps and reports them under
@@ -65,13 +67,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz, vector or matrix
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector = fp32-input MFMA peak (64 flop/clk/SIMD)
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth (degridder's gather view)
-PMC_ROUNDS = ("r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, newest first
+PMC_ROUNDS = ("r04", "r03", "r02")    # profiles/<round>_<workload>_pmc_summary.json, newest first
 # the REAL reference (numba 0.54) measured in the build container: im_to_vis 10k x 16 x 100 x 4
 # on one core 0.263 Mvis/s = 38 ns per (row, chan, src); linear in sources -> 0.026 Mvis/s/core at 1000 sources
 NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
                      "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
                                "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
-EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes")
+EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
 DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
 
 
@@ -85,7 +87,12 @@ def parse(argv=None):
     p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes"])
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid",
+                                                         "wgrid_f32planes"])
+    p.add_argument("--uvw", default="random", choices=["random", "antennas"],
+                   help="fused_dde: uvw drawn per row (BASELINE's recipe: not antenna-decomposable, lane-per-row kernel) or "
+                        "differences of per-(time, antenna) coordinates as in a Measurement Set (the GEMM form on the "
+                        "matrix cores); workload fused_dde_ant = fused_dde --uvw antennas")
     p.add_argument("--extras", default="auto",
                    help="other workloads timed for a few steps into \"workloads\" of the same JSON line: auto (all of "
                         "them when N = 1, the workload is the headline and the shape is the default), all, none, or a "
@@ -376,6 +383,12 @@ class FusedDde(object):
         ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
         ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
         time_index = np.repeat(np.arange(ntime, dtype=np.int64), nbl)[:nrow]
+        self.antennas = args.workload == "fused_dde_ant" or getattr(args, "uvw", "random") == "antennas"
+        if self.antennas:
+            # a Measurement Set's uvw: per-(time, antenna) coordinates, baselines are their differences (same extent as
+            # the per-row recipe: |u|, |v| <= 4000 m, |w| <= 400 m)
+            xyz = rng.uniform(-1, 1, (ntime, nant, 3)) * np.array([2000.0, 2000.0, 200.0])
+            uvw = xyz[time_index, ant1] - xyz[time_index, ant2]
         g = np.linspace(-1, 1, self.LW)
         ll, mm = np.meshgrid(g, g, indexing="ij")
         pattern = np.exp(-(ll**2 + mm**2) / 0.5) * np.exp(1j * (0.3 * ll + 0.2 * mm))
@@ -409,6 +422,17 @@ class FusedDde(object):
             _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
                       ctypes.byref(n_items))
         self.n_items, self.ntime, self.nbl = n_items.value, ntime, nbl
+        if self.antennas:
+            nap = 8 * ((nant + 7) // 8)
+            au, rm = np.zeros((ntime, nant, 3)), np.zeros((ntime, nap, nap), np.int32)
+            res, ok = ctypes.c_double(), ctypes.c_int()
+            HP = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+            _lib.call("af_fused_plan_antennas", tip, pa1, pa2, HP(uvw), nrow, nant, 1e-10, ntime, HP(au), HP(rm),
+                      ctypes.byref(res), ctypes.byref(ok))
+            if not ok.value:
+                raise SystemExit("fused_dde_ant: the synthetic uvw did not decompose (residual %g m)" % res.value)
+            self.plan_residual = res.value
+            self.d_au, self.d_rm = t(au), t(rm)
         self.dv = dict(items=t(items), groups=None if groups is None else t(groups), a1=t(ant1), a2=t(ant2), X=t(X), beam=t(beam), ext=t(extents),
                        fmap=t(beam_freq_map), pa=t(pa), pe=t(pe), asc=t(asc), lm=t(lm), uvw=t(uvw), freq=t(freq))
         self.ws_bytes = int(lib.af_fused_predict_workspace_bytes(nsrc, nchan, self.LW, self.MH, self.NUD))
@@ -418,9 +442,17 @@ class FusedDde(object):
         self.ncorr = 4
         self.label = ("fused predict with per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2]), "
                       "parallactic angles %s" % args.pa)
+        if self.antennas:
+            self.label += "; antenna-decomposable uvw (Measurement-Set geometry): GEMM form on the fp64 matrix cores"
 
     def predict(self, d_vis, stream, P):
         a, v = self.args, self.dv
+        if self.antennas:
+            self._lib.call("af_fused_predict_antennas_c128", P(self.d_au), P(self.d_rm), self.ntime, a.rows, P(v["lm"]),
+                           P(v["freq"]), P(v["X"]), a.sources, a.chans, P(v["beam"]), self.LW, self.MH, self.NUD, P(v["ext"]),
+                           P(v["fmap"]), P(v["pa"]), self.ntime, self.NANT, P(v["pe"]), P(v["asc"]), None,
+                           self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws), self.ws_bytes, stream)
+            return
         self._lib.call("af_fused_predict_c128", P(v["items"]), self.n_items, P(v["a1"]), P(v["a2"]),
                        None if v["groups"] is None else P(v["groups"]), a.rows,
                        P(v["lm"]), P(v["uvw"]), P(v["freq"]), P(v["X"]), a.sources, a.chans, P(v["beam"]), self.LW,
@@ -442,7 +474,8 @@ class FusedDde(object):
         same = bool(torch.equal(vis.reshape(d_vis.shape), d_vis))
         if not same:
             raise SystemExit("rank %d: sharding.fused_predict_shard differs from the C-ABI call" % rank)
-        return "sharding.fused_predict_shard(rank %d of %d, rows %s) == af_fused_predict_c128: bit-equal" % (rank, world, bounds)
+        return "sharding.fused_predict_shard(rank %d of %d, rows %s) == the direct C-ABI call (%s): bit-equal" % (
+            rank, world, bounds, "af_fused_predict_antennas_c128" if self.antennas else "af_fused_predict_c128")
 
     def _chain(self, rows, dde=None, tinv=None):
         """The reference chain on `rows` (only their timesteps' Jones terms are built)."""
@@ -482,6 +515,18 @@ class FusedDde(object):
         # occupies its SIMD for 4 cycles, so the pipe's capacity is 256 CU x 4 SIMD x 16 lanes x clock lane-instructions/s
         units = float(nrow) * nchan * nsrc
         terms = float(nsrc) * self.ntime * self.NANT * nchan
+        if self.antennas:
+            # the GEMM form: 8 complex MACs = 64 flop per (row, chan, source) of needed output; executed: 36 of the 64
+            # 16 x 16 tiles of M per (timestep, channel, source), 2 MFMA 16x16x4 (2048 flop each) per tile
+            mfma_flops = 36.0 * 2 * 2048 * nsrc * self.ntime * nchan
+            executed = {"mfma_flop_per_unit": mfma_flops / units, "mfma_tflops": mfma_flops / kernel_s / 1e12,
+                        "mfma_pipe_occupancy_at_2.4GHz": mfma_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
+                        "note": "matrix-core flops actually issued (upper block triangle incl. the diagonal blocks' lower "
+                                "halves and baselines a short last timestep lacks) against the 78.6 TFLOP/s fp64 pipe"}
+            return dict(kernel="fused_gemm_kernel", bound="mfma", alg_flops=units * 64.0, alg_bytes=float(alg_bytes),
+                        channels_in_kernel=nchan, executed=executed,
+                        note="antenna-decomposable uvw: V(t, nu) = G H^H, M = N = 128, K = 2 nsrc per (timestep, channel) on "
+                             "v_mfma_f64_16x16x4; 64 flop per (row, chan, src) (8 complex MACs) against the fp64 pipe")
         fp64_lane_instr = 63.0 * units + (344.0 * 64 / 512) * terms
         cap = 256 * 4 * 16 * 2.4e9
         executed = {"fp64_instructions_per_unit": fp64_lane_instr / units, "flop_equivalent_per_unit": 2 * fp64_lane_instr / units,
@@ -742,7 +787,8 @@ class WgridF32Planes(Wgrid):
         return r
 
 
-WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "degrid": Degrid, "wgrid": Wgrid,
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "fused_dde_ant": FusedDde, "degrid": Degrid,
+             "wgrid": Wgrid,
              "wgrid_f32planes": WgridF32Planes}
 METRIC = "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err"
 
@@ -863,7 +909,9 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
             if collective:
                 sharding.allreduce_chi2(d_chi2)       # RCCL over xGMI (gloo in the one-device tests)
 
-    front_end = wl.front_end_check(d_vis, rank, world, dev) if hasattr(wl, "front_end_check") else None
+    # (AFHIP_FUSED_STAGE runs one stage of the fused kernels for profiling: their output is meaningless)
+    staged = os.environ.get("AFHIP_FUSED_STAGE", "0") != "0"
+    front_end = wl.front_end_check(d_vis, rank, world, dev) if hasattr(wl, "front_end_check") and not staged else None
     for _ in range(warmup):
         step()
     ev = Events(_lib, steps)

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
     int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
     const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
     const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
-    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0)
+    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio)
 {
     constexpr int NA = NB * 8;              // padded antennas
     constexpr int NC = NA * 2;              // rows / columns of M
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
         const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
         const unsigned corr_off = e_corr * 32u;
         constexpr int NTASK = ST * NA;             // (source, antenna) terms per batch
-        __builtin_amdgcn_s_setprio(3);
+        if (sample_prio >= 0) __builtin_amdgcn_s_setprio(3);
         for (int b = 0; b < nbatch; ++b) {
             const int s0 = b * ST;
             double *H = ldsd + (b & 1) * BUF_DOUBLES;
@@ -147,27 +147,42 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
                     // k_a = exp(i C nu (l u_a + m v_a + n w_a)): phase_delay's phasor of the ANTENNA (rime/phase.py:45-61)
                     const C2 kph = table_phasor(ldsT, fma(nn, ldsU[4 * e_ant + 2],
                                                           fma(lm2.y, ldsU[4 * e_ant + 1], __dmul_rn(lm2.x, ldsU[4 * e_ant + 0]))));
-                    auto round = [&](auto lane_c) {
+                    // Four sampling rounds; in round QL the four lanes of a quad take the geometry of quad lane QL and
+                    // sample one correlation each.  ALL four rounds' gathers are issued before the first is consumed: a
+                    // sampling wave is one dependent chain behind the L2 latency, and the registers are there (the
+                    // matrix waves' accumulators set the kernel's allocation).
+                    struct Round {
+                        int info;
+                        double2 b0, b1, v[4];
+                        double ab[4], wt[4];
+                        C2 kk;
+                    };
+                    auto issue = [&](auto lane_c, Round &R) {
                         constexpr int QL = decltype(lane_c)::value;
                         const int info = quad_bcast<QL>(own_info);
-                        const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
-                        const bool r_task = (info >> 30) & 1, r_have = info < 0;
+                        R.info = info;
+                        const int r_sl = info & 2047;
+                        const bool r_have = info < 0;
                         // G[i][j] = A[i][0] X[0][j] + A[i][1] X[1][j]: this lane needs column j of X
                         const double2 *bp = brightness + ((int64_t)(r_have ? s0 + r_sl : 0) * nchan + f) * 4;
-                        const double2 b0 = bp[ej], b1 = bp[2 + ej];
-                        double2 v[4];
-                        double ab[4], wt[4];
+                        R.b0 = bp[ej];
+                        R.b1 = bp[2 + ej];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
-                            wt[k] = quad_bcast<QL>(gx.wt[k]);
+                            R.wt[k] = quad_bcast<QL>(gx.wt[k]);
                             const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
-                            v[k] = *reinterpret_cast<const double2 *>(r);
-                            ab[k] = r[2];
+                            R.v[k] = *reinterpret_cast<const double2 *>(r);
+                            R.ab[k] = r[2];
                         }
-                        C2 kk;
-                        kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
-                        double2 e2 = beam_reduce1(v, ab, wt);
+                        R.kk.re = quad_bcast<QL>(kph.re);
+                        R.kk.im = quad_bcast<QL>(kph.im);
+                    };
+                    auto finish = [&](const Round &R) {
+                        const int info = R.info;
+                        const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
+                        const bool r_task = (info >> 30) & 1, r_have = info < 0;
+                        double2 e2 = beam_reduce1(R.v, R.ab, R.wt);
                         if (!r_have) e2 = make_double2(0.0, 0.0);
                         C2 e;
                         e.re = e2.x; e.im = e2.y;
@@ -182,11 +197,11 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
                             e = cmul(E0, R0);
                             cmac(e, E1, R1);
                         }
-                        const C2 A = cmul(kk, e);          // A[i][j] = k E[i][j]
+                        const C2 A = cmul(R.kk, e);        // A[i][j] = k E[i][j]
                         C2 A0, A1, B0, B1;
                         A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
                         A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
-                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                        B0.re = R.b0.x; B0.im = R.b0.y; B1.re = R.b1.x; B1.im = R.b1.y;
                         C2 Gv = cmul(A0, B0);
                         cmac(Gv, A1, B1);
                         if (r_task) {
@@ -196,10 +211,15 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
                             gs[ej * CS] = Gv.re; gs[(2 + ej) * CS] = Gv.im; gs[(4 + ej) * CS] = -Gv.re;
                         }
                     };
-                    round(std::integral_constant<int, 0>{});
-                    round(std::integral_constant<int, 1>{});
-                    round(std::integral_constant<int, 2>{});
-                    round(std::integral_constant<int, 3>{});
+                    Round R0, R1, R2, R3;
+                    issue(std::integral_constant<int, 0>{}, R0);
+                    issue(std::integral_constant<int, 1>{}, R1);
+                    issue(std::integral_constant<int, 2>{}, R2);
+                    issue(std::integral_constant<int, 3>{}, R3);
+                    finish(R0);
+                    finish(R1);
+                    finish(R2);
+                    finish(R3);
                 }
             }
             __syncthreads();
@@ -439,6 +459,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     const int64_t ncell = beam_lw * beam_mh;
     AF_REQUIRE(ncell < (1LL << 25), "af_fused_predict_antennas_c128: beam cube too large (fewer than 2^25 cells per plane)");
     static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
+    static const int sample_prio = getenv("AFHIP_GEMM_PRIO") ? atoi(getenv("AFHIP_GEMM_PRIO")) : 1;   // A/B hook
     const bool feed = feed_rotation != nullptr;
     const int nb = (int)((nant + 7) / 8);
     auto launch = [&](auto kernel, int NBc, int STc) -> int {
@@ -460,7 +481,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
                                lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw, beam_mh, beam_nud,
                                beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
                                reinterpret_cast<const double2 *>(feed_rotation), (int)nsrc, nchan, ntime, (int)nant,
-                               reinterpret_cast<double2 *>(out), only_stage, f0);
+                               reinterpret_cast<double2 *>(out), only_stage, f0, sample_prio);
             if (f0 == 0) af_prof_end(st_);
             AF_LAUNCH_CHECK();
         }

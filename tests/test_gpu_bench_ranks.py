@@ -107,12 +107,13 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
     assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
     w = r["workloads"]
-    assert set(w) == {"dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes"}
+    assert set(w) == {"dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes"}
     for name, e in w.items():
         assert "error" not in e, (name, e)
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
         assert e["cpu_baseline"]["value"] > 0
     assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
+    assert w["fused_dde_ant"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde_ant"]["roofline"]["kernel"] == "fused_gemm_kernel"
     assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
 
@@ -128,7 +129,7 @@ def test_the_driver_visible_keys_of_the_default_line():
     line = lines[0]
     r = json.loads(line)
     roof = r["roofline"]
-    names = ("dft_complex", "dft_f32", "fused_dde", "degrid", "wgrid", "wgrid_f32planes")
+    names = ("dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
     assert set(roof["others"]) == set(names)
     for n in names:
         ms, kernel_ms, frac, err_, value = roof["others"][n]
@@ -144,17 +145,18 @@ def test_the_driver_visible_keys_of_the_default_line():
     assert set(names) <= set(r["summary"]) and r["summary"]["headline"][0] == round(r["ms_per_step"], 4)
 
 
-@pytest.mark.parametrize("executor", ["ranks", "threads"])
-def test_fused_dde_rows_over_two_ranks(executor):
+@pytest.mark.parametrize("executor, workload", [("ranks", "fused_dde"), ("threads", "fused_dde"), ("ranks", "fused_dde_ant")])
+def test_fused_dde_rows_over_two_ranks(executor, workload):
     """BASELINE configs[3]'s shape of job -- the FUSED predict (the only predict that exists at 1000 sources), rows
     sharded over the ranks, chi^2 all-reduced -- in both executors, two ranks aliased onto device 0.  The ranks
     executor also proves sharding.fused_predict_shard bit-equal to the C-ABI call on each rank's rows."""
-    extra = ["--executor", executor, "--workload", "fused_dde", "--gpus", "2", "--steps", "2", "--warmup", "1",
+    extra = ["--executor", executor, "--workload", workload, "--gpus", "2", "--steps", "2", "--warmup", "1",
              "--rows", "20160", "--sources", "60", "--no-cpu-baseline"]
     rc, lines, out, err = _run(extra, _clean_env(AFHIP_BENCH_DEVICE="0"))
     assert rc == 0, (out[-2000:], err[-4000:])
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rows_total"] == 40320 and "configs[2]" in r["config"]["workload"]
-    assert r["fp64_max_abs_err"] < 1e-8 and r["roofline"]["kernel"] == "fused_predict_kernel"
+    assert r["fp64_max_abs_err"] < 1e-8
+    assert r["roofline"]["kernel"] == ("fused_gemm_kernel" if workload == "fused_dde_ant" else "fused_predict_kernel")
     if executor == "ranks":
         assert "bit-equal" in r["config"]["front_end"] and "rank 0 of 2" in r["config"]["front_end"]
