@@ -41,6 +41,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "af_fused_device.h"
@@ -292,6 +293,277 @@ __global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same product with THREE real matrix products per complex one (the 3M / Karatsuba form): with Gs = Gr + Gi and
+// Hd = Hr - Hi,
+//     P1 = Gr Hr^T,  P2 = Gi Hi^T,  P3 = Gs Hd^T      ->      Re M = P1 + P2,   Im M = P3 - P1 + P2,
+// 3 MFMAs per tile and source PAIR (K = 4 = 2 sources x 2 columns of the Jones row) instead of 4: a quarter of the
+// matrix-core time for one more accumulator per tile (P1, P2, P3: 12 doubles per lane and tile) and two more operand
+// planes per source (Gs, Hd; the negated planes of the 4M form go).  Rounding: every P is a sum of products of the
+// same magnitudes as the direct form's, so the error bound is the direct form's times a small constant.
+// 12 waves: waves 0-7 matrix (tile i on wave i % 8: 5 or 4 tiles at 64 antennas, 9 per SIMD), waves 8-11 sampling.
+// Tile coordinates are compile-time per wave (switch on the wave number): every operand read is one lane base plus an
+// immediate offset.
+constexpr int G3_THREADS = 768, G3_MATRIX = 512, G3_SAMPLERS = 256, G3_PLANES = 6;
+
+constexpr int tri_row(int nb, int i)
+{
+    int pb = 0;
+    while (i >= nb - pb) { i -= nb - pb; ++pb; }
+    return pb;
+}
+constexpr int tri_col(int nb, int i)
+{
+    int pb = 0;
+    while (i >= nb - pb) { i -= nb - pb; ++pb; }
+    return pb + i;
+}
+
+template <typename F, int... Js>
+__device__ __forceinline__ void for_each_const(F &&fn, std::integer_sequence<int, Js...>)
+{
+    (fn(std::integral_constant<int, Js>{}), ...);
+}
+
+template <int NB, int ST, int W>
+__device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, int nbatch, int only_stage, int lane,
+                                             const int32_t *__restrict__ rm, int64_t nchan, int64_t f,
+                                             double2 *__restrict__ out)
+{
+    constexpr int NA = NB * 8, CS = NA * 2 + COL_PAD, SRC = 2 * G3_PLANES * CS, BUF = ST * SRC;
+    constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int CNT = NTILE > W ? (NTILE - W + 7) / 8 : 0;
+    constexpr int CN = CNT > 0 ? CNT : 1;
+    const int kq = lane >> 4, c16 = lane & 15;
+    // K index kq = 2 (source of the pair) + (column of the Jones row): this lane's element of every operand plane
+    const int lane_off = (kq >> 1) * SRC + (kq & 1) * CS + c16;
+    v4d p1[CN], p2[CN], p3[CN];
+#pragma unroll
+    for (int j = 0; j < CN; ++j) p1[j] = p2[j] = p3[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < nbatch; ++b) {
+        __syncthreads();
+        if (only_stage == 1 || CNT == 0) continue;
+        const double *P = ldsd + (b & 1) * BUF + lane_off;
+#pragma unroll
+        for (int s2 = 0; s2 < ST / 2; ++s2) {
+            const double *S = P + 2 * s2 * SRC;
+            for_each_const([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int pb = tri_row(NB, W + 8 * j), qb = tri_col(NB, W + 8 * j);
+                const double *A = S + G3_PLANES * CS + pb * 16, *B = S + qb * 16;
+                p1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], B[0], p1[j], 0, 0, 0);
+                p2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * CS], B[2 * CS], p2[j], 0, 0, 0);
+                p3[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * CS], B[4 * CS], p3[j], 0, 0, 0);
+            }, std::make_integer_sequence<int, CNT>{});
+        }
+    }
+    if (only_stage == 1) return;
+    for_each_const([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int pb = tri_row(NB, W + 8 * j), qb = tri_col(NB, W + 8 * j);
+        // operand rows / columns are antenna SLOTS (the samplers' conflict-free order): slot -> antenna
+        const int qs = qb * 8 + (c16 >> 1), jj = c16 & 1;
+        const int q = (qs % (NA / 4)) * 4 + qs / (NA / 4);
+        int r1[4], r2[4];                 // the tile's row-map entries first (independent loads), then the stores
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ps = pb * 8 + ((kq + 4 * reg) >> 1);
+            const int p = (ps % (NA / 4)) * 4 + ps / (NA / 4);
+            r1[reg] = rm[p * NA + q];
+            r2[reg] = pb != qb ? rm[q * NA + p] : -1;      // the same antennas the other way round: V_qp = V_pq^H
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ii = (kq + 4 * reg) & 1;
+            const double re = p1[j][reg] + p2[j][reg], im = (p3[j][reg] - p1[j][reg]) + p2[j][reg];
+            if (r1[reg] >= 0) out[((int64_t)r1[reg] * nchan + f) * 4 + ii * 2 + jj] = make_double2(re, im);
+            if (r2[reg] >= 0) out[((int64_t)r2[reg] * nchan + f) * 4 + jj * 2 + ii] = make_double2(re, -im);
+        }
+    }, std::make_integer_sequence<int, CNT>{});
+}
+
+template <bool FEED, int NB, int ST>
+__global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
+    const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
+    const double *__restrict__ f4, const double2 *__restrict__ brightness, const double *__restrict__ vrec,
+    int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
+    const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
+    const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
+    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio)
+{
+    static_assert(ST % 2 == 0, "sources are consumed in pairs");
+    constexpr int NA = NB * 8, CS = NA * 2 + COL_PAD, SRC_DOUBLES = 2 * G3_PLANES * CS, BUF_DOUBLES = ST * SRC_DOUBLES;
+    extern __shared__ double ldsd[];
+    double *ldsA = ldsd + 2 * BUF_DOUBLES;
+    double *ldsU = ldsA + 6 * NA;
+    double2 *ldsR = reinterpret_cast<double2 *>(ldsU + 4 * NA);
+    double2 *ldsT = ldsR + 4 * NA;
+    const int tid = threadIdx.x;
+    const int ptid = tid - G3_MATRIX;
+    const int64_t f = f0 + blockIdx.y;
+    const int t = blockIdx.x;
+
+    fine_table_init(ldsT, tid, G3_THREADS);
+    const double FT = f4[f] * (PH_TABLE / 4.0);
+    for (int a = tid; a < NA; a += G3_THREADS) {
+        double sp = 0.0, cp = 1.0, pl = 0.0, pm = 0.0, sl_ = 1.0, sm_ = 1.0, u = 0.0, v = 0.0, w = 0.0;
+        if (a < nant) {
+            sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
+            const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
+            const double *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
+            pl = pe[0]; pm = pe[1]; sl_ = as[0]; sm_ = as[1];
+            const double *x = ant_uvw + ((int64_t)t * nant + a) * 3;
+            u = __dmul_rn(x[0], FT); v = __dmul_rn(x[1], FT); w = __dmul_rn(x[2], FT);
+        }
+        // one plane per constant (consecutive lanes = consecutive antennas read consecutive doubles: no bank conflicts)
+        ldsA[0 * NA + a] = sp; ldsA[1 * NA + a] = cp; ldsA[2 * NA + a] = pl; ldsA[3 * NA + a] = pm;
+        ldsA[4 * NA + a] = sl_; ldsA[5 * NA + a] = sm_;
+        ldsU[0 * NA + a] = u; ldsU[1 * NA + a] = v; ldsU[2 * NA + a] = w;
+    }
+    if constexpr (FEED)
+        for (int i = tid; i < 4 * NA; i += G3_THREADS)
+            ldsR[i] = i < 4 * nant ? feed_rot[(int64_t)t * nant * 4 + i] : make_double2(0.0, 0.0);
+    __syncthreads();
+    const int nbatch = (nsrc + ST - 1) / ST;
+
+    if (tid < G3_MATRIX) {
+        const int32_t *rm = rowmap + (int64_t)t * NA * NA;
+        const int lane = tid & 63;
+        switch (tid >> 6) {
+        case 0: matrix_wave3<NB, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 1: matrix_wave3<NB, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 2: matrix_wave3<NB, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 3: matrix_wave3<NB, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 4: matrix_wave3<NB, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 5: matrix_wave3<NB, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 6: matrix_wave3<NB, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        default: matrix_wave3<NB, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        }
+        return;
+    }
+
+    // =================================== sampling waves (8-11) ======================================
+    FusedGrid grid;
+    {
+        const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+        grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
+        grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
+        grid.stride_m = VREC * 8u;
+        grid.stride_l = (unsigned)beam_mh * grid.stride_m;
+    }
+    const double fscale = freq_data[3 * f + 0];
+    const int e_corr = ptid & 3;
+    const int ei = e_corr >> 1, ej = e_corr & 1;
+    const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
+    const unsigned corr_off = e_corr * 32u;
+    constexpr int NTASK = ST * NA;
+    if (sample_prio >= 0) __builtin_amdgcn_s_setprio(3);
+    for (int b = 0; b < nbatch; ++b) {
+        const int s0 = b * ST;
+        double *H = ldsd + (b & 1) * BUF_DOUBLES;
+        if (only_stage != 2) {
+            for (int task0 = 0; task0 < NTASK; task0 += G3_SAMPLERS) {
+                // every lane owns a term and every term is written (no branch around the stores: the four rounds below
+                // stay one scheduling region): lanes beyond the batch's terms redo an earlier term (same values to the
+                // same place), padded antennas and sources beyond the last write zeros
+                int task = task0 + ptid;
+                if (task >= NTASK) task %= NTASK;
+                const int e_sl = task / NA, e_ant = task - e_sl * NA;
+                const bool have = e_ant < nant && s0 + e_sl < nsrc;
+                const int own_info = e_sl | (e_ant << 11) | (int)((unsigned)have << 31);
+                const double *sp = lmn + 4 * (have ? s0 + e_sl : 0);
+                const double2 lm2 = *reinterpret_cast<const double2 *>(sp);
+                const double nn = sp[2];
+                FusedVoxels gx;
+                fused_voxels(grid, lm2.x, lm2.y, ldsA[0 * NA + e_ant], ldsA[1 * NA + e_ant], ldsA[2 * NA + e_ant],
+                             ldsA[3 * NA + e_ant], ldsA[4 * NA + e_ant], ldsA[5 * NA + e_ant], fscale, gx);
+                const C2 kph = table_phasor(ldsT, fma(nn, ldsU[2 * NA + e_ant],
+                                                      fma(lm2.y, ldsU[1 * NA + e_ant], __dmul_rn(lm2.x, ldsU[0 * NA + e_ant]))));
+                // all four rounds' gathers first (the weights and the phasor are re-broadcast when a round is consumed:
+                // 33 registers per round in flight)
+                struct Round {
+                    int info;
+                    double2 b0, b1, v[4];
+                    double ab[4];
+                };
+                auto issue = [&](auto lane_c, Round &R) {
+                    constexpr int QL = decltype(lane_c)::value;
+                    const int info = quad_bcast<QL>(own_info);
+                    R.info = info;
+                    if constexpr (NA == 64) {
+                        // a wave's 64 lanes are the 64 antennas of ONE source: its brightness matrix comes in by scalar
+                        // loads (no trip through the vector memory pipe, which is what bounds the sampling)
+                        const int us = __builtin_amdgcn_readfirstlane(info < 0 ? s0 + (info & 2047) : 0);
+                        const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
+                        const double2 x0 = bp[0], x1 = bp[1], x2 = bp[2], x3 = bp[3];
+                        R.b0 = ej ? x1 : x0;
+                        R.b1 = ej ? x3 : x2;
+                    } else {
+                        const double2 *bp = brightness + ((int64_t)(info < 0 ? s0 + (info & 2047) : 0) * nchan + f) * 4;
+                        R.b0 = bp[ej];
+                        R.b1 = bp[2 + ej];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
+                        const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
+                        R.v[k] = *reinterpret_cast<const double2 *>(r);
+                        R.ab[k] = r[2];
+                    }
+                };
+                auto finish = [&](auto lane_c, const Round &R) {
+                    constexpr int QL = decltype(lane_c)::value;
+                    const int info = R.info;
+                    const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
+                    const bool r_have = info < 0;
+                    double wt[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
+                    C2 kk;
+                    kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
+                    double2 e2 = beam_reduce1(R.v, R.ab, wt);
+                    if (!r_have) e2 = make_double2(0.0, 0.0);
+                    C2 e;
+                    e.re = e2.x; e.im = e2.y;
+                    if constexpr (FEED) {
+                        C2 E0, E1;
+                        E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
+                        E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
+                        const double2 r0 = ldsR[4 * r_ant + ej], r1 = ldsR[4 * r_ant + 2 + ej];
+                        C2 R0, R1;
+                        R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
+                        e = cmul(E0, R0);
+                        cmac(e, E1, R1);
+                    }
+                    const C2 A = cmul(kk, e);
+                    C2 A0, A1, B0, B1;
+                    A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
+                    A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
+                    B0.re = R.b0.x; B0.im = R.b0.y; B1.re = R.b1.x; B1.im = R.b1.y;
+                    C2 Gv = cmul(A0, B0);
+                    cmac(Gv, A1, B1);
+                    double *hs = H + r_sl * SRC_DOUBLES + 2 * ((r_ant & 3) * (NA / 4) + (r_ant >> 2)) + ei;
+                    double *gs = hs + G3_PLANES * CS;
+                    hs[ej * CS] = A.re; hs[(2 + ej) * CS] = A.im; hs[(4 + ej) * CS] = __dsub_rn(A.re, A.im);
+                    gs[ej * CS] = Gv.re; gs[(2 + ej) * CS] = Gv.im; gs[(4 + ej) * CS] = __dadd_rn(Gv.re, Gv.im);
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
+                Round R0, R1, R2, R3;
+                issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
+                // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
+                // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
+                // stalls they fill)
+                finish(I0{}, R0); finish(I1{}, R1); finish(I2{}, R2); finish(I3{}, R3);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // Host-side planner (HOST pointers): is uvw antenna-decomposable, and if so with which antenna coordinates?
@@ -448,7 +720,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     AF_REQUIRE(((uintptr_t)workspace & 255) == 0, "af_fused_predict_antennas_c128: workspace must be 256-byte aligned");
     char *ws = static_cast<char *>(workspace);
     double *lmn = reinterpret_cast<double *>(ws + W.lmn), *f4 = reinterpret_cast<double *>(ws + W.f4);
-    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *planes = reinterpret_cast<double *>(ws + W.planes);
+    double *freq_data = reinterpret_cast<double *>(ws + W.freq_data), *planes_buf = reinterpret_cast<double *>(ws + W.planes);
     hipLaunchKernelGGL(fused_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st_, lm, nsrc, lmn);
     AF_LAUNCH_CHECK();
     hipLaunchKernelGGL(fused_prep_freq, dim3((unsigned)af_cdiv(nchan, 64)), dim3(64), 0, st_, frequency, nchan,
@@ -462,9 +734,11 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     static const int sample_prio = getenv("AFHIP_GEMM_PRIO") ? atoi(getenv("AFHIP_GEMM_PRIO")) : 1;   // A/B hook
     const bool feed = feed_rotation != nullptr;
     const int nb = (int)((nant + 7) / 8);
-    auto launch = [&](auto kernel, int NBc, int STc) -> int {
+    // AFHIP_GEMM_3M=0: the four-product form (8 waves); default: the three-product form (12 waves)
+    static const int use_3m = getenv("AFHIP_GEMM_3M") ? atoi(getenv("AFHIP_GEMM_3M")) : 1;
+    auto launch = [&](auto kernel, int NBc, int STc, int planes, int threads) -> int {
         const int na = NBc * 8, cs = na * 2 + COL_PAD;
-        const size_t lds_bytes = (size_t)2 * STc * (H_PLANES + G_PLANES) * cs * sizeof(double) + (size_t)na * 6 * sizeof(double) +
+        const size_t lds_bytes = (size_t)2 * STc * planes * cs * sizeof(double) + (size_t)na * 6 * sizeof(double) +
                                  (size_t)na * 4 * sizeof(double) + (size_t)na * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
         AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_antennas_c128: %zu bytes of LDS needed", lds_bytes);
         AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -474,11 +748,11 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
             int64_t blocks = af_cdiv(ncell * 4, 256);
             if (blocks > 1024) blocks = 1024;
             hipLaunchKernelGGL(beam_plane_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, st_,
-                               reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes);
+                               reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes_buf);
             AF_LAUNCH_CHECK();
             if (f0 == 0) af_prof_begin(st_);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)nsteps, (unsigned)nf), dim3(G_THREADS), lds_bytes, st_, ant_uvw, rowmap,
-                               lmn, f4, reinterpret_cast<const double2 *>(brightness), planes, beam_lw, beam_mh, beam_nud,
+            hipLaunchKernelGGL(kernel, dim3((unsigned)nsteps, (unsigned)nf), dim3(threads), lds_bytes, st_, ant_uvw, rowmap,
+                               lmn, f4, reinterpret_cast<const double2 *>(brightness), planes_buf, beam_lw, beam_mh, beam_nud,
                                beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
                                reinterpret_cast<const double2 *>(feed_rotation), (int)nsrc, nchan, ntime, (int)nant,
                                reinterpret_cast<double2 *>(out), only_stage, f0, sample_prio);
@@ -487,13 +761,17 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
         }
         return AF_OK;
     };
-    // sources per batch: about one super-round of the 256 sampling lanes (ST x 8 NB terms), two buffers within ~100 KB
-#define AF_GEMM_PICK(NBC, STC) (feed ? launch(fused_gemm_kernel<true, NBC, STC>, NBC, STC) : launch(fused_gemm_kernel<false, NBC, STC>, NBC, STC))
+    // sources per batch: about one super-round of the 256 sampling lanes (ST x 8 NB terms), two buffers within ~110 KB
+#define AF_GEMM_PICK(NBC, STC)                                                                                          \
+    (use_3m ? (feed ? launch(fused_gemm3_kernel<true, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS)                     \
+                    : launch(fused_gemm3_kernel<false, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS))                   \
+            : (feed ? launch(fused_gemm_kernel<true, NBC, STC>, NBC, STC, H_PLANES + G_PLANES, G_THREADS)                 \
+                    : launch(fused_gemm_kernel<false, NBC, STC>, NBC, STC, H_PLANES + G_PLANES, G_THREADS)))
     switch (nb) {
     case 1: return AF_GEMM_PICK(1, 16);
     case 2: return AF_GEMM_PICK(2, 8);
     case 3: return AF_GEMM_PICK(3, 8);
-    case 4: return AF_GEMM_PICK(4, 8);
+    case 4: return AF_GEMM_PICK(4, 6);
     case 5: return AF_GEMM_PICK(5, 4);
     case 6: return AF_GEMM_PICK(6, 4);
     case 7: return AF_GEMM_PICK(7, 4);
