@@ -84,6 +84,45 @@ def test_fused_dde_full_size_c3():
     assert bool(torch.isfinite(power).all()) and bool((power > 0).all())
 
 
+def test_fused_dde_full_size_c3_antenna_decomposable():
+    """BASELINE configs[2] with a Measurement Set's uvw (differences of per-antenna coordinates): the GEMM form on the
+    matrix cores (csrc/af_fused_gemm.hip).  Same checks: rows of three timesteps against the oracle chain < 1e-8 absolute
+    and < 1e-9 relative; a timestep-aligned row shard through the reference-shaped entry point (which plans, decomposes
+    and dispatches for itself) equals the full call bit for bit; x2 brightness exact; and the general kernel on the same
+    rows agrees to 1e-10 relative."""
+    import os
+    import torch
+    from codex_africanus_amd import rime
+    from codex_africanus_amd.rime import fused
+    wl, vis, args = _workload("fused_dde_ant")
+    h = wl.h
+    nrow, nbl = args.rows, wl.nbl
+    assert wl.antennas and wl.plan_residual < 1e-10
+    rows = np.concatenate([np.arange(0, nbl, 211), 250 * nbl + np.arange(5, nbl, 199),
+                           np.arange((wl.ntime - 1) * nbl, nrow, 7)[:12]])
+    ref, rows = wl.reference_rows(rows)
+    got = _sample(vis, rows)
+    err = np.abs(got - ref.reshape(got.shape)).max()
+    scale = np.abs(h["X"]).sum(axis=0).max()
+    assert err < 1e-8 and err < 1e-9 * scale, err
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dv = wl.dv
+    a, b = 100 * nbl, 137 * nbl
+    call = lambda X, **kw: rime.fused_predict_vis(T(h["time_index"][a:b]), dv["a1"][a:b], dv["a2"][a:b], dv["lm"],
+                                                  dv["uvw"][a:b], dv["freq"], X, dv["beam"], dv["ext"], dv["fmap"],
+                                                  dv["pa"][100:137], dv["pe"][100:137], dv["asc"], **kw)
+    plan = fused.fused_plan(h["time_index"][a:b], h["ant1"][a:b], h["ant2"][a:b], 64, uvw=h["uvw"][a:b])
+    assert plan.decomposable
+    part = call(dv["X"], plan=plan)
+    # (the shard's antenna coordinates are solved from the shard's rows: the same per-timestep solution as the full plan's)
+    assert torch.equal(part.reshape(b - a, 64, 4), vis[a:b])
+    assert torch.equal(call(dv["X"] * 2.0, plan=plan).reshape(b - a, 64, 4), vis[a:b] * 2.0)
+    general = fused.fused_plan(h["time_index"][a:b], h["ant1"][a:b], h["ant2"][a:b], 64)       # no uvw: lane-per-row kernel
+    assert not general.decomposable
+    other = call(dv["X"], plan=general).reshape(b - a, 64, 4)
+    assert float((other - vis[a:b]).abs().max()) < 1e-10 * scale
+
+
 def test_degrid_full_size_c5():
     """BASELINE configs[4]: 4096^2 grid, 1e6 rows x 64 chan, 7 x 7 taps.  Sampled rows against the oracle degridder
     (to rounding: the sums run column-first), x2 grid exact, a row shard equals the full call bit for bit (the
