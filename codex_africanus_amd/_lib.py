@@ -98,6 +98,7 @@ _SIGNATURES = {
     "af_feed_rotation_f32": (_int, [_vp, _i64, _int, _vp, _vp]),
     "af_gaussian_shape_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "af_calibration_workspace_bytes": (_sz, [_i64]),
+    "af_correct_vis_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "af_corrupt_vis_c128": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp,
                                    _sz, _vp]),
     "af_residual_vis_c128": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int,

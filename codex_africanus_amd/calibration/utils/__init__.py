@@ -183,7 +183,9 @@ def correct_vis(time_bin_indices, time_bin_counts, antenna1, antenna2, jones, vi
         p_j, p_v = c.inp(jones, np.complex128), c.inp(vis, np.complex128)
         p_f = c.inp(flag, np.uint8)
         p_out, h = c.out(tuple(int(s) for s in vis.shape), np.complex128)
-        ws = int(_lib.load().af_calibration_workspace_bytes(nrow))
+        # FULL gains: room for the per-(time, antenna, chan) inverse gains (inverted once instead of once per baseline)
+        ws = int(_lib.load().af_correct_vis_workspace_bytes(nrow, ntime, nant, nchan)) if mode == 2 else \
+            int(_lib.load().af_calibration_workspace_bytes(nrow))
         p_ws = c.scratch(ws)
         _lib.call("af_correct_vis_c128", p_tbi, p_tbc, ntime, p_a1, p_a2, p_j, p_v, p_f, nrow, nant, nchan,
                   int(jones.shape[3]), mode, ncorr, p_out, p_ws, max(ws, 256), c.stream)

@@ -153,10 +153,68 @@ __device__ __forceinline__ void gather_gain(const C2 *__restrict__ jones, int re
     }
 }
 
+// The lane-per-cell arrays (visibilities, model, result: V x 16 bytes per cell, cells of a wave contiguous) have the same
+// problem in a milder form: read or written lane by lane, a 16-byte instruction touches 32 (V = 4) or 64 (two directions
+// of model) half-used lines.  They go through the same transpose: coalesced on the memory side (consecutive lanes =
+// consecutive 16 bytes), record-per-lane on the register side.  Loads are gather_gain with rec = the cell number.
+template <int V>
+__device__ __forceinline__ void coop_store(C2 *__restrict__ out, int64_t wave_cell0, int64_t ncells, const C2 (&acc)[V],
+                                           double2 *lds_wave)
+{
+    const int lane = threadIdx.x & 63;
+    if constexpr (V == 1) {
+        if (wave_cell0 + lane < ncells) out[wave_cell0 + lane] = acc[0];
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int slot = V >= 4 ? (j ^ ((lane >> 1) & (V - 1))) : j;
+            lds_wave[lane * V + slot] = make_double2(acc[j].re, acc[j].im);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int CPI = 64 / V;
+        double2 *dst = reinterpret_cast<double2 *>(out);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int c = k * CPI + lane / V, h = lane % V;
+            const int hs = V >= 4 ? (h ^ ((c >> 1) & (V - 1))) : h;
+            // slot hs of cell c's record holds element hs ^ swizzle(c) = h: consecutive lanes store consecutive 16 bytes
+            const double2 v = lds_wave[c * V + hs];
+            if (wave_cell0 + c < ncells) dst[(wave_cell0 + c) * V + h] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Inverse gains of correct_vis with FULL (2 x 2) gains, once per (time, antenna, chan) instead of once per baseline
+// and cell (each antenna's matrix is inverted for every one of its 63 baselines otherwise -- eight complex divisions,
+// half of that kernel's instructions): ainv = G^-1 (correct_vis.py:70-77) and binv = (G^H)^-1 (:79-89), exactly the
+// reference's operations on exactly its operands, so the main kernel's products see the same bits.
+__global__ __launch_bounds__(256) void calib_inverse_kernel(const C2 *__restrict__ jones, int64_t nrec, C2 *__restrict__ ainv,
+                                                            C2 *__restrict__ binv)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrec) return;
+    const C2 *g = jones + r * 4;
+    const C2 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+    const C2 det1 = csub(cmul(g0, g3), cmul(g1, g2));
+    C2 *a = ainv + r * 4, *b = binv + r * 4;
+    a[0] = cdiv(g3, det1); a[1] = cdiv(cneg(g1), det1);
+    a[2] = cdiv(cneg(g2), det1); a[3] = cdiv(g0, det1);
+    const C2 c0 = cconj(g0), c1 = cconj(g1), c2 = cconj(g2), c3 = cconj(g3);
+    const C2 det2 = csub(cmul(c0, c3), cmul(c1, c2));
+    b[0] = cdiv(c3, det2); b[1] = cdiv(cneg(c2), det2);
+    b[2] = cdiv(cneg(c1), det2); b[3] = cdiv(c0, det2);
+}
+
 // OP 0 corrupt, 1 residual, 2 correct, 3 compute-and-corrupt (model per time bin, phase computed here);
 // grid: ceil(nrow*nchan / 256)
 // NDIRT = 2: the call has exactly two directions and fetches both records of a gain in one cooperative gather
-template <int OP, int MODE, int NCORR, int NDIRT = 0>
+// COOP: visibilities / model / result through the cooperative transposes (cells x directions < 2^31);
+// ainv / binv: the tables of calib_inverse_kernel (OP 2, FULL gains) or NULL
+template <int OP, int MODE, int NCORR, int NDIRT = 0, bool COOP = false>
 __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
                                                     const int64_t *__restrict__ ant2, const C2 *__restrict__ jones,
                                                     const C2 *__restrict__ vis, const unsigned char *__restrict__ flag,
@@ -164,11 +222,14 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                                                     int64_t nchan, int64_t ndir, C2 *__restrict__ out,
                                                     const double *__restrict__ uvw = nullptr,
                                                     const double *__restrict__ freq = nullptr,
-                                                    const double *__restrict__ lm = nullptr)
+                                                    const double *__restrict__ lm = nullptr,
+                                                    const C2 *__restrict__ ainv = nullptr,
+                                                    const C2 *__restrict__ binv = nullptr)
 {
     constexpr int J = jones_elems(MODE, NCORR), V = vis_elems(MODE, NCORR);
     constexpr int JT = NDIRT > 0 ? NDIRT * J : J;       // 16-byte units per gather
-    __shared__ double2 lds_gain[4][JT > 1 ? 64 * JT : 1];
+    constexpr int LT = COOP ? (NDIRT > 0 ? (NDIRT * V > JT ? NDIRT * V : JT) : (V > JT ? V : JT)) : JT;
+    __shared__ double2 lds_gain[4][LT > 1 ? 64 * LT : 1];
     double2 *lds_wave = lds_gain[threadIdx.x >> 6];
     const int64_t cell_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool in_range = cell_raw < nrow * nchan;      // out-of-range lanes still take part in the wave's gathers
@@ -180,9 +241,14 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
     for (int c = 0; c < V; ++c) acc[c] = C2{0.0, 0.0};
     bool active = t >= 0;
     if ((OP == 1 || OP == 2) && active) {
+        if constexpr (V == 4) {
+            active = *reinterpret_cast<const unsigned *>(flag + cell * 4) == 0u;      // the cell's four flags in one word
+        } else {
 #pragma unroll
-        for (int c = 0; c < V; ++c) active = active && flag[cell * V + c] == 0;
+            for (int c = 0; c < V; ++c) active = active && flag[cell * V + c] == 0;
+        }
     }
+    const int64_t wave_cell0 = cell_raw - (threadIdx.x & 63);
     // record indices of the two gains of direction 0 (inactive lanes: record 0, fetched and ignored)
     int rec1 = 0, rec2 = 0;
     if (active) {
@@ -202,13 +268,22 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
     C2 g1[J], g2[J];
     if constexpr (OP == 0 || OP == 1) {
         if constexpr (OP == 1) {
-            if (active) {
+            if constexpr (COOP) {
+                C2 vv[V];
+                gather_gain<V>(vis, (int)cell, vv, lds_wave);
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < V; ++c) acc[c] = vv[c];
+                }
+            } else if (active) {
 #pragma unroll
                 for (int c = 0; c < V; ++c) acc[c] = vis[cell * V + c];
             }
         }
         if constexpr (NDIRT > 0) {
             C2 ga[JT], gb[JT];
+            C2 mm[COOP ? NDIRT * V : 1];
+            if constexpr (COOP) gather_gain<NDIRT * V>(model, (int)cell, mm, lds_wave);   // both directions of the cell
             if (any_active) {
                 gather_gain<JT, J>(jones, rec1, ga, lds_wave);
                 gather_gain<JT, J>(jones, rec2, gb, lds_wave);
@@ -218,7 +293,10 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
                 C2 m[V];
                 if (active) {
 #pragma unroll
-                    for (int c = 0; c < V; ++c) m[c] = model[(cell * NDIRT + s) * V + c];
+                    for (int c = 0; c < V; ++c) {
+                        if constexpr (COOP) m[c] = mm[s * V + c];
+                        else m[c] = model[(cell * NDIRT + s) * V + c];
+                    }
 #pragma unroll
                     for (int j = 0; j < J; ++j) { g1[j] = ga[s * J + j]; g2[j] = gb[s * J + j]; }
                     jones_term<MODE, NCORR, OP == 0 ? +1 : -1>(g1, m, g2, acc);
@@ -227,7 +305,9 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
         } else {
             for (int64_t s = 0; s < ndir; ++s) {
                 C2 m[V];
-                if (active) {
+                if constexpr (COOP) {
+                    gather_gain<V>(model, (int)(cell * ndir + s), m, lds_wave);
+                } else if (active) {
 #pragma unroll
                     for (int c = 0; c < V; ++c) m[c] = model[(cell * ndir + s) * V + c];
                 }
@@ -264,13 +344,16 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
             }
         }
     } else {
+        const bool tables = MODE == 2 && ainv != nullptr;      // kernel-uniform
         if (any_active) {
-            gather_gain<J>(jones, rec1, g1, lds_wave);
-            gather_gain<J>(jones, rec2, g2, lds_wave);
+            gather_gain<J>(tables ? ainv : jones, rec1, g1, lds_wave);
+            gather_gain<J>(tables ? binv : jones, rec2, g2, lds_wave);
         }
+        C2 vv[V];
+        if constexpr (COOP) gather_gain<V>(vis, (int)cell, vv, lds_wave);
         if (active) {
             const C2 *a1j = g1, *a2j = g2;
-            const C2 *b = vis + cell * V;
+            const C2 *b = COOP ? vv : vis + cell * V;
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int c = 0; c < NCORR; ++c) acc[c] = cdiv(b[c], cmul(a1j[c], cconj(a2j[c])));
@@ -278,13 +361,19 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = cdiv(b[c], cmul(a1j[c >> 1], cconj(a2j[c & 1])));
             } else {
-                const C2 det1 = csub(cmul(a1j[0], a1j[3]), cmul(a1j[1], a1j[2]));
-                const C2 a00 = cdiv(a1j[3], det1), a01 = cdiv(cneg(a1j[1]), det1);
-                const C2 a10 = cdiv(cneg(a1j[2]), det1), a11 = cdiv(a1j[0], det1);
-                const C2 c0 = cconj(a2j[0]), c1 = cconj(a2j[1]), c2 = cconj(a2j[2]), c3 = cconj(a2j[3]);
-                const C2 det2 = csub(cmul(c0, c3), cmul(c1, c2));
-                const C2 b00 = cdiv(c3, det2), b01 = cdiv(cneg(c2), det2);
-                const C2 b10 = cdiv(cneg(c1), det2), b11 = cdiv(c0, det2);
+                C2 a00, a01, a10, a11, b00, b01, b10, b11;
+                if (tables) {
+                    a00 = a1j[0]; a01 = a1j[1]; a10 = a1j[2]; a11 = a1j[3];
+                    b00 = a2j[0]; b01 = a2j[1]; b10 = a2j[2]; b11 = a2j[3];
+                } else {
+                    const C2 det1 = csub(cmul(a1j[0], a1j[3]), cmul(a1j[1], a1j[2]));
+                    a00 = cdiv(a1j[3], det1); a01 = cdiv(cneg(a1j[1]), det1);
+                    a10 = cdiv(cneg(a1j[2]), det1); a11 = cdiv(a1j[0], det1);
+                    const C2 c0 = cconj(a2j[0]), c1 = cconj(a2j[1]), c2 = cconj(a2j[2]), c3 = cconj(a2j[3]);
+                    const C2 det2 = csub(cmul(c0, c3), cmul(c1, c2));
+                    b00 = cdiv(c3, det2); b01 = cdiv(cneg(c2), det2);
+                    b10 = cdiv(cneg(c1), det2); b11 = cdiv(c0, det2);
+                }
                 C2 t1 = cmul(a00, b[0]), t2 = cmul(a01, b[2]), t3 = cmul(a00, b[1]), t4 = cmul(a01, b[3]);
                 acc[0] = cadd(cadd(cadd(cmul(t1, b00), cmul(t2, b00)), cmul(t3, b10)), cmul(t4, b10));
                 acc[1] = cadd(cadd(cadd(cmul(t1, b01), cmul(t2, b01)), cmul(t3, b11)), cmul(t4, b11));
@@ -294,9 +383,13 @@ __global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowb
             }
         }
     }
-    if (!in_range) return;
+    if constexpr (COOP) {
+        coop_store<V>(out, wave_cell0, nrow * nchan, acc, lds_wave);
+    } else {
+        if (!in_range) return;
 #pragma unroll
-    for (int c = 0; c < V; ++c) out[cell * V + c] = acc[c];
+        for (int c = 0; c < V; ++c) out[cell * V + c] = acc[c];
+    }
 }
 
 template <int OP>
@@ -323,6 +416,11 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     const size_t need = 256 + (size_t)nrow * sizeof(int);
     AF_REQUIRE(workspace != nullptr && workspace_bytes >= need, "%s: workspace too small (%zu < %zu)", who,
                workspace_bytes, need);
+    // correct_vis with FULL gains: room for the two tables of inverse gains (af_correct_vis_workspace_bytes)?
+    const size_t tab_off = af_align_up(need, 256);
+    const size_t nrec = (size_t)ntime * (size_t)nant * (size_t)nchan;
+    const bool tables = OP == 2 && mode == 2 && nrec > 0 && workspace_bytes >= tab_off + 2 * nrec * 4 * sizeof(C2) &&
+                        !(getenv("AFHIP_CALIB_TABLES") && atoi(getenv("AFHIP_CALIB_TABLES")) == 0);
     hipStream_t st = af_stream(stream);
     int64_t *mn = static_cast<int64_t *>(workspace);
     int *rowbin = reinterpret_cast<int *>(static_cast<char *>(workspace) + 256);
@@ -337,25 +435,43 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
     const C2 *jn = reinterpret_cast<const C2 *>(jones), *vs = reinterpret_cast<const C2 *>(vis);
     const C2 *md = reinterpret_cast<const C2 *>(model);
     C2 *o = reinterpret_cast<C2 *>(out);
+    C2 *ainv = nullptr, *binv = nullptr;
+    if (tables) {
+        ainv = reinterpret_cast<C2 *>(static_cast<char *>(workspace) + tab_off);
+        binv = ainv + nrec * 4;
+        hipLaunchKernelGGL(calib_inverse_kernel, dim3((unsigned)af_cdiv((int64_t)nrec, 256)), dim3(256), 0, st, jn,
+                           (int64_t)nrec, ainv, binv);
+        AF_LAUNCH_CHECK();
+    }
+    // lane-per-cell arrays through the cooperative transposes: 2 x 2 visibilities, record numbers within 31 bits
+    // (AFHIP_CALIB_COOP=0: the direct form, for A/B runs)
+    const bool coop = OP != 3 && (mode != 0 || ncorr == 2) && (double)cells * (double)(ndir > 0 ? ndir : 1) < 2147483648.0 &&
+                      !(getenv("AFHIP_CALIB_COOP") && atoi(getenv("AFHIP_CALIB_COOP")) == 0);
     // two directions (corrupt / residual): both records of a gain per gather (AFHIP_CALIB_PAIR=0: one per direction)
     const bool pair = (OP == 0 || OP == 1) && ndir == 2 && !(getenv("AFHIP_CALIB_PAIR") && atoi(getenv("AFHIP_CALIB_PAIR")) == 0);
+#define AF_CALIB_GO(M, N, D, C)                                                                                        \
+    hipLaunchKernelGGL((calib_kernel<OP, M, N, D, C>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow,     \
+                       nant, nchan, ndir, o, uvw, freq, lm, ainv, binv)
 #define AF_CALIB_LAUNCH(M, N)                                                                                          \
     do {                                                                                                               \
         if constexpr (OP == 0 || OP == 1) {                                                                            \
             if (pair) {                                                                                                \
-                hipLaunchKernelGGL((calib_kernel<OP, M, N, 2>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md,  \
-                                   nrow, nant, nchan, ndir, o, uvw, freq, lm);                                         \
+                if (coop && (M != 0 || N == 2)) AF_CALIB_GO(M, N, 2, true);                                            \
+                else AF_CALIB_GO(M, N, 2, false);                                                                      \
                 break;                                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((calib_kernel<OP, M, N>), grid, block, 0, st, rowbin, ant1, ant2, jn, vs, flag, md, nrow,     \
-                           nant, nchan, ndir, o, uvw, freq, lm);                                                       \
+        if constexpr (OP != 3 && (M != 0 || N == 2)) {                                                                 \
+            if (coop) { AF_CALIB_GO(M, N, 0, true); break; }                                                           \
+        }                                                                                                              \
+        AF_CALIB_GO(M, N, 0, false);                                                                                   \
     } while (0)
     if (mode == 0 && ncorr == 1) AF_CALIB_LAUNCH(0, 1);
     else if (mode == 0) AF_CALIB_LAUNCH(0, 2);
     else if (mode == 1) AF_CALIB_LAUNCH(1, 2);
     else AF_CALIB_LAUNCH(2, 2);
 #undef AF_CALIB_LAUNCH
+#undef AF_CALIB_GO
     AF_LAUNCH_CHECK();
     return AF_OK;
 }
@@ -363,6 +479,14 @@ int run(const int64_t *tbin_idx, const int64_t *tbin_counts, int64_t ntime, cons
 }  // namespace
 
 AF_EXPORT size_t af_calibration_workspace_bytes(int64_t nrow) { return nrow < 0 ? 0 : 256 + (size_t)nrow * sizeof(int); }
+
+// correct_vis with FULL gains: the base workspace plus two tables of inverse gains, 2 x (time x ant x chan) x 64 bytes.
+// With only af_calibration_workspace_bytes(nrow) the call still works (every cell then inverts its two gains itself).
+AF_EXPORT size_t af_correct_vis_workspace_bytes(int64_t nrow, int64_t ntime, int64_t nant, int64_t nchan)
+{
+    if (nrow < 0 || ntime < 0 || nant < 0 || nchan < 0) return 0;
+    return af_align_up(256 + (size_t)nrow * sizeof(int), 256) + 2 * (size_t)ntime * (size_t)nant * (size_t)nchan * 64;
+}
 
 AF_EXPORT int af_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
                                   const int64_t *antenna1, const int64_t *antenna2, const double *jones,

@@ -360,6 +360,10 @@ int af_gaussian_shape_f64(const double *uvw, const double *frequency, const doub
  *   Rows outside every bin and (row, chan) cells with any flagged correlation are 0 in the output of
  *   residual / correct.  correct_vis needs ndir == 1.  workspace: af_calibration_workspace_bytes(nrow). */
 size_t af_calibration_workspace_bytes(int64_t nrow);
+/* af_correct_vis_c128 with FULL gains: with this (larger) workspace the call first inverts every (time, antenna, chan)
+ * gain once -- G^-1 and (G^H)^-1 of africanus/calibration/utils/correct_vis.py:70-89, the reference's operations on
+ * the reference's operands, so results do not change by a bit -- instead of once per baseline and cell. */
+size_t af_correct_vis_workspace_bytes(int64_t nrow, int64_t ntime, int64_t nant, int64_t nchan);
 int af_corrupt_vis_c128(const int64_t *time_bin_indices, const int64_t *time_bin_counts, int64_t ntime,
                         const int64_t *antenna1, const int64_t *antenna2, const double *jones,
                         const double *model, int64_t nrow, int64_t nant, int64_t nchan, int64_t ndir, int mode,
