@@ -228,28 +228,36 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     elif brightness is None:
         raise ValueError("pass either brightness or all of stokes, spi and ref_freq")
     if gauss_shape is not None and not have_beam:
-        # Gaussian sources without a beam: the phase x shape x brightness sum is what the fused kernel's accumulating
-        # stage evaluates once its Jones terms are the identity -- a 2 x 2 x 2 cube of identity matrices sampled
-        # anywhere gives E = 1 (bilinear weights sum to one; the amplitude-preserving normalisation of
-        # africanus/rime/fast_beam_cubes.py:227-235 maps 1 to 1 and the zero off-diagonals to 0), so G = E X = X and
-        # V = sum_s shape K X_s, the einsum("srf,srf,sfij->srfij") + source sum of africanus/rime/examples/predict.py:107-134.
-        # (The direct-transform kernels cannot carry the shape: their per-source operand is a (chan, corr) pixel, the
-        # shape depends on the row.)  Costs the full Jones algebra of the fused kernel: see DESIGN.md 3.3.
-        ti_h = np.asarray(_host(time_index))
-        nant_i = int(max(int(np.asarray(_host(antenna1)).max(initial=0)), int(np.asarray(_host(antenna2)).max(initial=0)))) + 1
-        ntime_i = int(ti_h.max() - ti_h.min()) + 1 if ti_h.size else 1
-        fr_h = np.asarray(_host(frequency), dtype=np.float64)
-        ident = np.zeros((2, 2, 2, 2, 2), dtype=np.complex128)
-        ident[..., 0, 0] = ident[..., 1, 1] = 1.0
-        beam = ident
-        beam_lm_extents = np.array([[-2.0, 2.0], [-2.0, 2.0]])
-        lo, hi = (float(fr_h.min()), float(fr_h.max())) if fr_h.size else (1.0, 2.0)
-        beam_freq_map = np.array([0.5 * lo, 2.0 * hi + 1.0])          # every channel inside the cube: no lm scaling
-        parallactic_angles = np.zeros((ntime_i, nant_i))
-        point_errors = np.zeros((ntime_i, nant_i, nchan, 2))
-        antenna_scaling = np.ones((nant_i, nchan, 2))
-        beam_args = (beam, beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
-        have_beam = True
+        # Gaussian sources without a beam: sum_s shape K X_s -- the einsum("srf,srf,sfij->srfij") + source sum of
+        # africanus/rime/examples/predict.py:107-134 -- by the direct transform whose phasor carries the envelope
+        # (csrc/af_gauss_dft.hip).  (Until round 4 this ran through the beam kernel with a cube of identity matrices.)
+        if tuple(gauss_shape.shape) != (nsrc, 3):
+            raise ValueError("gauss_shape must have shape (source, 3)")
+        if model:
+            from ..model.spectral import spectral_model
+            from ..model.coherency import convert
+            brightness = convert(spectral_model(stokes, spi, ref_freq, frequency, base=spectral_base),
+                                 ["I", "Q", "U", "V"], [list(r) for r in corr_schema])
+        bshape = tuple(int(x) for x in brightness.shape)
+        if bshape not in ((nsrc, 2, 2), (nsrc, nchan, 2, 2)):
+            raise ValueError("brightness must have shape (source, chan, 2, 2) or (source, 2, 2)")
+        with Call(lm, uvw, frequency, brightness, gauss_shape) as c:
+            if bshape == (nsrc, 2, 2):
+                if _is_torch(brightness):
+                    brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
+                else:
+                    brightness = np.broadcast_to(np.asarray(brightness)[:, None], (nsrc, nchan, 2, 2))
+            p_lm, p_uvw, p_fr = c.inp(lm, np.float64), c.inp(uvw, np.float64), c.inp(frequency, np.float64)
+            p_b, p_gs = c.inp(brightness, np.complex128), c.inp(gauss_shape, np.float64)
+            p_out, h = c.out((nrow, nchan, 2, 2), np.complex128)
+            ws_bytes = int(_lib.load().af_gauss_predict_workspace_bytes(nsrc, nchan))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_gauss_predict_c128", p_lm, p_uvw, p_fr, p_b, p_gs, nsrc, nrow, nchan,
+                      _lib.CONVENTION[convention], p_out, p_ws, max(ws_bytes, 256), c.stream)
+            vis = c.result(h)
+        if die1_jones is None and base_vis is None:
+            return vis
+        return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
     bshape = tuple(int(s) for s in brightness.shape) if brightness is not None else (nsrc, nchan, 2, 2)
     if bshape == (nsrc, 2, 2):
         flat_spectrum = True

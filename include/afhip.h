@@ -325,6 +325,18 @@ int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap,
                                    const double *feed_rotation, int convention, double *out, void *workspace,
                                    size_t workspace_bytes, void *stream);
 
+/* ---- Gaussian (and point) sources without direction-dependent terms ----------------------------------------
+ * out[r,nu] = sum_s shape(r,s,nu) K(r,s,nu) X_s(nu): the reference's phase_delay (africanus/rime/phase.py:11-63) x
+ * gaussian shape (africanus/model/shape/gaussian_shape.py:11-62) x brightness, summed over the sources
+ * (africanus/rime/examples/predict.py:107-134; africanus/rime/predict.py:229-246), as one direct transform whose phasor
+ * carries the envelope (csrc/af_gauss_dft.hip).  lm (nsrc,2), uvw (nrow,3), frequency (nchan), brightness
+ * (nsrc,nchan,2,2) complex128, gauss_shape (nsrc,3) = (major, minor, orientation) [rad] or NULL (point sources only);
+ * out (nrow,nchan,2,2) complex128.  Any channel spacing (uniform tiles take the recurrences). */
+size_t af_gauss_predict_workspace_bytes(int64_t nsrc, int64_t nchan);
+int af_gauss_predict_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
+                          const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
+                          double *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- chi-squared ---------------------------------------------------------------
  * chi2_per_chan[nu] = sum_{r,c} weight[r,nu,c] * |data[r,nu,c] - model[r,nu,c]|^2
  * (weight NULL = 1).  model/data (nrow,nchan,ncorr) complex128, weight real float64,
