@@ -554,6 +554,10 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
                 using I3 = std::integral_constant<int, 3>;
                 Round R0, R1, R2, R3;
                 issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
+                // (a lane sampling all four correlations of its own term -- no quads, a third fewer instructions -- was
+                // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
+                // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
+                // its instruction count: coherent gathers, --pa common, take 65 ms)
                 // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
                 // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
                 // stalls they fill)
