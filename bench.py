@@ -523,7 +523,7 @@ class FusedDde(object):
                         "mfma_pipe_occupancy_at_2.4GHz": mfma_flops / kernel_s / 1e12 / FP64_PEAK_TFLOPS,
                         "note": "matrix-core flops actually issued (upper block triangle incl. the diagonal blocks' lower "
                                 "halves and baselines a short last timestep lacks) against the 78.6 TFLOP/s fp64 pipe"}
-            return dict(kernel="fused_gemm_kernel", bound="mfma", alg_flops=units * 64.0, alg_bytes=float(alg_bytes),
+            return dict(kernel="fused_gemm3_kernel", bound="mfma", alg_flops=units * 64.0, alg_bytes=float(alg_bytes),
                         channels_in_kernel=nchan, executed=executed,
                         note="antenna-decomposable uvw: V(t, nu) = G H^H, M = N = 128, K = 2 nsrc per (timestep, channel) on "
                              "v_mfma_f64_16x16x4; 64 flop per (row, chan, src) (8 complex MACs) against the fp64 pipe")

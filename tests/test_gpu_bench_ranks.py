@@ -113,7 +113,7 @@ def test_default_line_carries_the_other_single_gpu_configs():
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
         assert e["cpu_baseline"]["value"] > 0
     assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
-    assert w["fused_dde_ant"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde_ant"]["roofline"]["kernel"] == "fused_gemm_kernel"
+    assert w["fused_dde_ant"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde_ant"]["roofline"]["kernel"] == "fused_gemm3_kernel"
     assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
 
@@ -157,6 +157,6 @@ def test_fused_dde_rows_over_two_ranks(executor, workload):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rows_total"] == 40320 and "configs[2]" in r["config"]["workload"]
     assert r["fp64_max_abs_err"] < 1e-8
-    assert r["roofline"]["kernel"] == ("fused_gemm_kernel" if workload == "fused_dde_ant" else "fused_predict_kernel")
+    assert r["roofline"]["kernel"] == ("fused_gemm3_kernel" if workload == "fused_dde_ant" else "fused_predict_kernel")
     if executor == "ranks":
         assert "bit-equal" in r["config"]["front_end"] and "rank 0 of 2" in r["config"]["front_end"]

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
 DOMINANT = {"dft": "dft_mfma_kernel", "dft_complex": "dft_mfma_kernel", "dft_f32": "dft_f32_kernel", "fused_dde": "fused_predict_kernel",
+            "fused_dde_ant": "fused_gemm3_kernel",
             "degrid": "degrid_coop_kernel", "wgrid": "wg_degrid_tiles", "wgrid_f32planes": "wg_degrid_tiles"}
 
 
@@ -26,7 +27,7 @@ def find(base, suffix):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     dl = os.path.join(SRC, "default_line.json")
     if os.path.exists(dl):
         lines = [x for x in open(dl).read().splitlines() if x.startswith("{")]
