@@ -273,6 +273,12 @@ int af_beam_cube_dde_c64(const float *beam, int64_t beam_lw, int64_t beam_mh, in
  * DIE terms / base_vis are applied afterwards with af_predict_vis_c128 (source_coh = out).
  * Limits (AF_EINVAL beyond them): nant <= 664 (one time step's Jones of a source in LDS), beam cube < 2^25 voxels
  * (32-bit byte offsets into its 128-byte voxel records), nchan <= 65535. */
+/* dtype note: af_fused_predict_* and af_wsclean_predict_f64 exist in float64 / complex128 only.  float32 callers of the
+ * fused predict or of wsclean_predict (the reference computes in the input precision: africanus/util/type_inference.py:24-26,
+ * africanus/rime/wsclean_predict.py:11-84) are served by widening the inputs and rounding the complex128 result ONCE to
+ * complex64 in the binding: the dtype contract holds, the values are at least as accurate as the reference's float32
+ * loop.  Native float32 entries exist for phase_delay, predict_vis, beam_cube_dde, feed_rotation, convert, im_to_vis and
+ * vis_to_im. */
 int af_fused_plan_rows(const int64_t *time_index_host, int64_t nrow, int32_t *items_host,
                        int64_t max_items, int64_t *nitems);
 size_t af_fused_predict_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh,
