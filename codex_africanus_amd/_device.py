@@ -264,14 +264,19 @@ class Call(object):
             else:
                 t = torch.from_numpy(np.ascontiguousarray(a)).to(self.torch_device)
             td = _torch_dtype(dtype)
-            if t.dtype != td:
+            if t.dtype == torch.bool and td == torch.uint8:
+                t = t.contiguous().view(torch.uint8)        # flags: same bytes (True is 1), no conversion pass
+            elif t.dtype != td:
                 t = t.to(td)
             t = t.contiguous()
             self._keep.append(t)
             self._keep.append(a)    # keeps id(a) unique for the lifetime of the call
             self._inputs[key] = t.data_ptr()
             return ctypes.c_void_p(t.data_ptr())
-        arr = np.ascontiguousarray(a, dtype=dtype)
+        if dtype == np.uint8 and getattr(a, "dtype", None) == np.bool_:
+            arr = np.ascontiguousarray(a).view(np.uint8)    # flags: same bytes, no conversion pass
+        else:
+            arr = np.ascontiguousarray(a, dtype=dtype)
         buf = _OwnedBuffer(arr.nbytes)
         self._owned.append(buf)
         self._keep.append(arr)

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void calib_inverse_kernel(const C2 *__restrict
 // COOP: visibilities / model / result through the cooperative transposes (cells x directions < 2^31);
 // ainv / binv: the tables of calib_inverse_kernel (OP 2, FULL gains) or NULL
 template <int OP, int MODE, int NCORR, int NDIRT = 0, bool COOP = false>
-__global__ __launch_bounds__(256) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
+// (corrupt_vis with cooperative IO sat at 129 registers: one over four waves per SIMD.  Capped there: 4.42 -> 4.54 TB/s;
+// the same cap makes residual_vis spill: 4.2 -> 3.4 TB/s)
+__global__ __launch_bounds__(256, OP == 0 ? 4 : 1) void calib_kernel(const int *__restrict__ rowbin, const int64_t *__restrict__ ant1,
                                                     const int64_t *__restrict__ ant2, const C2 *__restrict__ jones,
                                                     const C2 *__restrict__ vis, const unsigned char *__restrict__ flag,
                                                     const C2 *__restrict__ model, int64_t nrow, int64_t nant,

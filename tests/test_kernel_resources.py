@@ -95,3 +95,31 @@ def test_wave_specialised_fused_kernel_fits_three_waves_per_simd(tmp_path):
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         assert scratch == 0 and vgprs + agprs <= 168, (name, scratch, vgprs, agprs)
     assert seen == 16, seen     # (NP in {64, 128, run-time} + the unrolled ST = 8 at NP = 64) x FEED x grouped / row plan
+
+
+def test_gemm_form_of_the_fused_predict_fits_three_waves_per_simd(tmp_path):
+    """The 12-wave GEMM-form kernel (8 matrix waves with up to five 16 x 16 tiles x three accumulators, 4 sampling waves
+    with four rounds of gathers in flight) lives on 168 registers; the default (3M) instantiations may keep at most a
+    couple of values in scratch outside the matrix loop (the 64-antenna one keeps none)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+           "--cuda-device-only", "-c", os.path.join(CSRC, "af_fused_gemm.hip"), "-o", str(tmp_path / "k.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    text = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        m = re.search(r"fused_gemm3_kernelILb([01])ELi(\d+)ELi(\d+)E", name)
+        if not m:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs + agprs <= 168 and scratch <= 32 and lds == 0, (name, scratch, vgprs, agprs, lds)   # LDS is dynamic
+        if m.group(2) == "8" and m.group(1) == "0":
+            assert scratch == 0, (name, scratch)          # BASELINE configs[2]'s instantiation
+    assert seen == 16, seen     # 8 antenna-block counts x FEED

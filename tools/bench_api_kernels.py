@@ -96,20 +96,26 @@ tbc = torch.full((ntime_c,), nbl_c, device=dev, dtype=torch.int64)
 tbc[-1] = nrow_c - (ntime_c - 1) * nbl_c
 a1c = torch.randint(0, nant_c, (nrow_c,), device=dev, dtype=torch.int64)
 a2c = torch.randint(0, nant_c, (nrow_c,), device=dev, dtype=torch.int64)
+# Measurement-Set order (antenna1 < antenna2 enumerated per timestep): consecutive rows share antenna1
+_p, _q = np.triu_indices(nant_c, 1)
+a1m = torch.from_numpy(np.tile(_p, ntime_c)[:nrow_c].astype(np.int64)).to(dev)
+a2m = torch.from_numpy(np.tile(_q, ntime_c)[:nrow_c].astype(np.int64)).to(dev)
 jn = rc(ntime_c, nant_c, 64, 2, 2, 2)
 md = rc(nrow_c, 64, 2, 2, 2)
-dt = timeit(lambda: corrupt_vis(tbi, tbc, a1c, a2c, jn, md), reps=3)
-b = md.numel() * 16 + nrow_c * 64 * 64
-out["corrupt_vis FULL (1e6 rows x 64 chan x 2 dir)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 vs = rc(nrow_c, 64, 2, 2)
 flg = torch.rand(nrow_c, 64, 2, 2, device=dev) < 0.01
-dt = timeit(lambda: residual_vis(tbi, tbc, a1c, a2c, jn, vs, flg, md), reps=3)
-b = md.numel() * 16 + 2 * nrow_c * 64 * 64 + flg.numel()
-out["residual_vis FULL (1e6 rows x 64 chan x 2 dir)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 j1 = jn[:, :, :, :1].contiguous()
-dt = timeit(lambda: correct_vis(tbi, tbc, a1c, a2c, j1, vs, flg), reps=3)
-b = 2 * nrow_c * 64 * 64 + flg.numel()
-out["correct_vis FULL (1e6 rows x 64 chan)"] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+for tag, A1, A2 in ((" (random antenna pairs)", a1c, a2c), (", Measurement-Set row order", a1m, a2m)):
+    dt = timeit(lambda: corrupt_vis(tbi, tbc, A1, A2, jn, md), reps=3)
+    b = md.numel() * 16 + nrow_c * 64 * 64
+    key = "" if "random" in tag else tag
+    out["corrupt_vis FULL (1e6 rows x 64 chan x 2 dir)" + key] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+    dt = timeit(lambda: residual_vis(tbi, tbc, A1, A2, jn, vs, flg, md), reps=3)
+    b = md.numel() * 16 + 2 * nrow_c * 64 * 64 + flg.numel()
+    out["residual_vis FULL (1e6 rows x 64 chan x 2 dir)" + key] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
+    dt = timeit(lambda: correct_vis(tbi, tbc, A1, A2, j1, vs, flg), reps=3)
+    b = 2 * nrow_c * 64 * 64 + flg.numel()
+    out["correct_vis FULL (1e6 rows x 64 chan)" + key] = dict(ms=dt * 1e3, GBs=b / dt / 1e9, bytes=b)
 # Stokes <-> correlation conversion at the C2 visibility shape
 del jn, md, vs, flg, j1
 from codex_africanus_amd.model.coherency import convert
