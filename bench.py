@@ -204,6 +204,13 @@ class Dft(object):
                        P(self.d_freq), a.sources, a.rows, a.chans, 4, self._lib.CONVENTION["fourier"], self.mode,
                        P(d_vis), P(self.d_ws), self.ws_bytes, stream)
 
+    def predict_chi2(self, d_vis, d_data, d_chi2, stream, P):
+        """the step's transform AND its chi^2 in one call: summed in the transform's epilogue (af_im_to_vis_chi2_f64)"""
+        a = self.args
+        self._lib.call("af_im_to_vis_chi2_f64", P(self.d_image), int(self.cplx), P(self.d_uvw), P(self.d_lm),
+                       P(self.d_freq), a.sources, a.rows, a.chans, 4, self._lib.CONVENTION["fourier"], self.mode,
+                       P(d_vis), P(d_data), None, P(d_chi2), P(self.d_ws), self.ws_bytes, stream)
+
     def reference_rows(self, rows):
         import oracle
         return oracle.im_to_vis(self.image, self.uvw[rows], self.lm, self.freq, omp=True), rows
@@ -902,10 +909,16 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         d_data = d_vis.clone()
         d_data += 0.01
 
+    fused_chi2 = have_chi2 and hasattr(wl, "predict_chi2") and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0"
+
     def step():
-        wl.predict(d_vis, stream, P)
+        if fused_chi2:
+            wl.predict_chi2(d_vis, d_data, d_chi2, stream, P)
+        else:
+            wl.predict(d_vis, stream, P)
         if have_chi2:
-            _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
+            if not fused_chi2:
+                _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(d_chi2), stream)
             if collective:
                 sharding.allreduce_chi2(d_chi2)       # RCCL over xGMI (gloo in the one-device tests)
 
@@ -940,11 +953,19 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         reported = int(round(float(one.item())))
     kernel_s = ev.collect()
+    if have_chi2:        # the step's chi^2 against a separate pass over the final visibilities (checker)
+        ref_chi2 = torch.zeros_like(d_chi2)
+        _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(ref_chi2), stream)
+        if collective:
+            dist.all_reduce(ref_chi2, op=dist.ReduceOp.SUM)
+        if not torch.allclose(d_chi2, ref_chi2, rtol=1e-10, atol=0):
+            raise SystemExit("rank %d: the step's chi^2 differs from a separate pass over its visibilities" % rank)
     if rank != 0:
         return None
     max_err = check_rows(wl, d_vis, nrow, args.check_rows, dev) if args.check_rows > 0 else None
     res = {
-        "label": wl.label, "has_chi2": have_chi2, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
+        "label": wl.label + ("; chi^2 summed in the transform's epilogue (af_im_to_vis_chi2_f64)" if fused_chi2 else ""),
+        "has_chi2": have_chi2, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
         "corrs": ncorr, "fp64_max_abs_err": max_err, "roofline": roofline_entry(wl, wargs, workload, kernel_s),
     }
@@ -1298,6 +1319,7 @@ def run_threads(args):
             torch.cuda.synchronize(w.dev)
         workers.append(w)
     ncorr = workers[0].wl.ncorr
+    fused_chi2 = hasattr(workers[0].wl, "predict_chi2") and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0"
     dev0 = workers[0].dev
     staging = torch.zeros((n, nchan), dtype=torch.float64, device=dev0)
     total = torch.zeros(nchan, dtype=torch.float64, device=dev0)
@@ -1318,8 +1340,11 @@ def run_threads(args):
             placed[k] = placement.activate()[0]
         if step_no is not None:
             evs[k].arm(step_no)
-        w.wl.predict(w.d_vis, w.sp, P)
-        _lib.call("af_chi2_c128", P(w.d_vis), P(w.d_data), None, nrow, nchan, ncorr, P(w.d_chi2), w.sp)
+        if fused_chi2:
+            w.wl.predict_chi2(w.d_vis, w.d_data, w.d_chi2, w.sp, P)
+        else:
+            w.wl.predict(w.d_vis, w.sp, P)
+            _lib.call("af_chi2_c128", P(w.d_vis), P(w.d_data), None, nrow, nchan, ncorr, P(w.d_chi2), w.sp)
         if step_no is not None:
             evs[k].disarm()
         with torch.cuda.stream(w.stream):

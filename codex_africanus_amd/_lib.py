@@ -68,6 +68,8 @@ _SIGNATURES = {
     "af_im_to_vis_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "af_im_to_vis_f64": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz,
                                 _vp]),
+    "af_im_to_vis_chi2_f64": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp,
+                                     _sz, _vp]),
     "af_im_to_vis_f32_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "af_im_to_vis_f32": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _sz,
                                 _vp]),

@@ -13,13 +13,27 @@ namespace {
 
 // grid: blocks over row ranges; block: 256 lanes striding the (chan*corr) columns of a row.
 // Four rows per step with independent partial sums keep 8 x 16-byte loads in flight per lane.
+// `skip`: device flags of af_im_to_vis_chi2_f64 -- (1, 1, 0) means the transform's epilogue has already summed chi^2
+// (one channel spacing: the MFMA kernels ran; no special column was rewritten afterwards): nothing to do here
+__device__ __forceinline__ bool chi2_done_elsewhere(const int *__restrict__ skip)
+{
+    return skip != nullptr && skip[0] == 1 && skip[1] == 1 && skip[2] == 0;
+}
+__global__ void chi2_zero_unless_done(const int *__restrict__ skip, double *__restrict__ chi2, int64_t nchan)
+{
+    if (chi2_done_elsewhere(skip)) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nchan) chi2[i] = 0.0;
+}
+
 template <bool HAS_WEIGHT>
 __global__ __launch_bounds__(256) void chi2_kernel(const double2 *__restrict__ model,
                                                    const double2 *__restrict__ data,
                                                    const double *__restrict__ weight, int64_t nrow,
                                                    int64_t nchan, int64_t ncorr, int64_t rows_per_block,
-                                                   double *__restrict__ chi2)
+                                                   double *__restrict__ chi2, const int *__restrict__ skip = nullptr)
 {
+    if (chi2_done_elsewhere(skip)) return;
     const int64_t ncol = nchan * ncorr;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < nrow) ? r0 + rows_per_block : nrow;
@@ -68,8 +82,10 @@ template <bool HAS_WEIGHT>
 __global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restrict__ model,
                                                         const double2 *__restrict__ data,
                                                         const double *__restrict__ weight, int64_t ncell,
-                                                        int64_t ncol, int64_t ncorr, double *__restrict__ chi2)
+                                                        int64_t ncol, int64_t ncorr, double *__restrict__ chi2,
+                                                        const int *__restrict__ skip = nullptr)
 {
+    if (chi2_done_elsewhere(skip)) return;
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t col = i % ncol;
@@ -114,16 +130,17 @@ __global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restric
 
 }  // namespace
 
-AF_EXPORT int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
-                           int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream)
+// shared by af_chi2_c128 (skip = NULL) and the fallback pass of af_im_to_vis_chi2_f64 (skip = its device flags)
+int af_chi2_launch(const double *model, const double *data, const double *weight, int64_t nrow, int64_t nchan, int64_t ncorr,
+                   double *chi2_per_chan, const int *skip, hipStream_t st)
 {
-    AF_REQUIRE(nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_chi2_c128: negative extent");
-    if (nchan == 0) return AF_OK;
-    AF_REQUIRE(chi2_per_chan != nullptr, "af_chi2_c128: chi2_per_chan is NULL");
-    hipStream_t st = af_stream(stream);
-    AF_HIP(hipMemsetAsync(chi2_per_chan, 0, sizeof(double) * (size_t)nchan, st));
+    if (skip == nullptr) {
+        AF_HIP(hipMemsetAsync(chi2_per_chan, 0, sizeof(double) * (size_t)nchan, st));
+    } else {
+        hipLaunchKernelGGL(chi2_zero_unless_done, dim3((unsigned)af_cdiv(nchan, 256)), dim3(256), 0, st, skip, chi2_per_chan, nchan);
+        AF_LAUNCH_CHECK();
+    }
     if (nrow == 0 || ncorr == 0) return AF_OK;
-    AF_REQUIRE(model && data, "af_chi2_c128: NULL array");
     const int64_t ncol = nchan * ncorr, ncell = nrow * ncol;
     {   // flat sweep when a grid of whole 256-lane blocks can keep one column per lane
         int64_t grid = 2048;
@@ -132,11 +149,11 @@ AF_EXPORT int af_chi2_c128(const double *model, const double *data, const double
             if (weight)
                 hipLaunchKernelGGL(chi2_flat_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st,
                                    reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data),
-                                   weight, ncell, ncol, ncorr, chi2_per_chan);
+                                   weight, ncell, ncol, ncorr, chi2_per_chan, skip);
             else
                 hipLaunchKernelGGL(chi2_flat_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st,
                                    reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data),
-                                   weight, ncell, ncol, ncorr, chi2_per_chan);
+                                   weight, ncell, ncol, ncorr, chi2_per_chan, skip);
             AF_LAUNCH_CHECK();
             return AF_OK;
         }
@@ -148,11 +165,21 @@ AF_EXPORT int af_chi2_c128(const double *model, const double *data, const double
     if (weight)
         hipLaunchKernelGGL(chi2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st,
                            reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data), weight,
-                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan);
+                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan, skip);
     else
         hipLaunchKernelGGL(chi2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
                            reinterpret_cast<const double2 *>(model), reinterpret_cast<const double2 *>(data), weight,
-                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan);
+                           nrow, nchan, ncorr, rows_per_block, chi2_per_chan, skip);
     AF_LAUNCH_CHECK();
     return AF_OK;
+}
+
+AF_EXPORT int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
+                           int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream)
+{
+    AF_REQUIRE(nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_chi2_c128: negative extent");
+    if (nchan == 0) return AF_OK;
+    AF_REQUIRE(chi2_per_chan != nullptr, "af_chi2_c128: chi2_per_chan is NULL");
+    AF_REQUIRE((model && data) || nrow == 0 || ncorr == 0, "af_chi2_c128: NULL array");
+    return af_chi2_launch(model, data, weight, nrow, nchan, ncorr, chi2_per_chan, nullptr, af_stream(stream));
 }

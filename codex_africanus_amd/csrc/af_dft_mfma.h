@@ -15,7 +15,14 @@ size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_i
 //   lmn     (nsrc,4)  cleaned (l, m, n, 0) of dft_prep_src         srcbad (nsrc) non-finite sources
 //   tilef   [1] = channel step in quarter turns per metre           flags  device flags, [2] = any special column
 //   colstate (chan, 4) zero-column / NaN-source overrides of the reference's `if image[s,nu,c]:`
+// chi2 (optional): the kernels' epilogues add  sum_{row, corr} [w] |data - vis|^2  of their rows to chi2[chan]
+// (af_im_to_vis_chi2_f64: the visibilities are still in registers there; a separate pass would read them back).
+struct AfDftChi2 {
+    const double *data;      // (nrow, nchan, 4) complex128
+    const double *weight;    // (nrow, nchan, 4) real, or NULL
+    double *chi2;            // (nchan), zeroed by the caller
+};
 int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw, const double *frequency, const double *lmn,
                     const int *srcbad, const double *tilef, const int *flags, const int *colstate, int sign,
                     double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
-                    hipStream_t st);
+                    hipStream_t st, const AfDftChi2 *chi2 = nullptr);

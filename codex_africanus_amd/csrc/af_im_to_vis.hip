@@ -775,10 +775,46 @@ AF_EXPORT size_t af_im_to_vis_workspace_bytes(int64_t nsrc, int64_t nchan, int64
     return m;
 }
 
+int af_chi2_launch(const double *model, const double *data, const double *weight, int64_t nrow, int64_t nchan, int64_t ncorr,
+                   double *chi2_per_chan, const int *skip, hipStream_t st);   // af_chi2.hip
+
+namespace {
+int im_to_vis_impl(const double *image, int image_is_complex, const double *uvw, const double *lm,
+                   const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr, int convention, int mode,
+                   double *out, void *workspace, size_t workspace_bytes, void *stream, const AfDftChi2 *chi);
+}
+
 AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const double *uvw, const double *lm,
                                const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan,
                                int64_t ncorr, int convention, int mode, double *out, void *workspace,
                                size_t workspace_bytes, void *stream)
+{
+    return im_to_vis_impl(image, image_is_complex, uvw, lm, frequency, nsrc, nrow, nchan, ncorr, convention, mode, out,
+                          workspace, workspace_bytes, stream, nullptr);
+}
+
+// The transform and the per-channel chi^2 of its result against `data` in one call:
+//     out = im_to_vis(...);   chi2[nu] = sum_{row, corr} [weight] |data - out|^2       (af_chi2_c128's quantity)
+// Where the MFMA kernels run (4 correlations, one channel spacing) chi^2 is summed in their epilogue, from the
+// visibilities still in registers; everywhere else (and when the reference's zero-pixel / NaN-source semantics rewrite
+// a column afterwards) the call falls back, on the device, to the separate pass -- same result either way.
+AF_EXPORT int af_im_to_vis_chi2_f64(const double *image, int image_is_complex, const double *uvw, const double *lm,
+                                    const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                                    int convention, int mode, double *out, const double *data, const double *weight,
+                                    double *chi2_per_chan, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(nchan == 0 || chi2_per_chan != nullptr, "af_im_to_vis_chi2_f64: chi2_per_chan is NULL");
+    AF_REQUIRE(data != nullptr || nrow == 0 || nchan == 0 || ncorr == 0, "af_im_to_vis_chi2_f64: data is NULL");
+    AfDftChi2 chi;
+    chi.data = data; chi.weight = weight; chi.chi2 = chi2_per_chan;
+    return im_to_vis_impl(image, image_is_complex, uvw, lm, frequency, nsrc, nrow, nchan, ncorr, convention, mode, out,
+                          workspace, workspace_bytes, stream, &chi);
+}
+
+namespace {
+int im_to_vis_impl(const double *image, int image_is_complex, const double *uvw, const double *lm,
+                   const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr, int convention, int mode,
+                   double *out, void *workspace, size_t workspace_bytes, void *stream, const AfDftChi2 *chi)
 {
     AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
                "convention not in ('fourier', 'casa')");
@@ -791,11 +827,14 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     AF_REQUIRE(nsrc < (1LL << 31), "af_im_to_vis_f64: nsrc too large");
     AF_REQUIRE(ncorr <= 64 * MAXNC, "af_im_to_vis_f64: more than %d correlations", 64 * MAXNC);
     hipStream_t st = af_stream(stream);
-    if (nrow == 0 || nchan == 0 || ncorr == 0) return AF_OK;
+    if (nrow == 0 || nchan == 0 || ncorr == 0) {
+        if (chi && nchan > 0) AF_HIP(hipMemsetAsync(chi->chi2, 0, sizeof(double) * (size_t)nchan, st));
+        return AF_OK;
+    }
     AF_REQUIRE(out != nullptr && uvw != nullptr && frequency != nullptr, "af_im_to_vis_f64: NULL array");
     if (nsrc == 0) {  // np.zeros output (kernels.py:45)
         AF_HIP(hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)(nrow * nchan * ncorr), st));
-        return AF_OK;
+        return chi ? af_chi2_launch(out, chi->data, chi->weight, nrow, nchan, ncorr, chi->chi2, nullptr, st) : AF_OK;
     }
     AF_REQUIRE(image != nullptr && lm != nullptr, "af_im_to_vis_f64: NULL array");
     const bool cplx = image_is_complex != 0;
@@ -853,12 +892,13 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
     a.nrow = nrow; a.nsrc = nsrc; a.nchan = nchan; a.ncorr = ncorr;
     a.mode = mode; a.st = st; a.mfma = mfma;
     if (mfma) {
+        if (chi) AF_HIP(hipMemsetAsync(chi->chi2, 0, sizeof(double) * (size_t)nchan, st));
         int rc = af_dft_mfma_run(image, (int)cplx, uvw, frequency, reinterpret_cast<const double *>(ws + L.lmn),
                                  reinterpret_cast<const int *>(ws + L.srcbad),
                                  reinterpret_cast<const double *>(ws + L.tilef),
                                  reinterpret_cast<const int *>(ws + L.flags),
                                  reinterpret_cast<const int *>(ws + L.colstate), convention, out, nrow, nsrc,
-                                 L.nsrc_pad, nchan, ws + L.total, st);
+                                 L.nsrc_pad, nchan, ws + L.total, st, chi);
         if (rc != AF_OK) return rc;
     }
     a.constant = convention == AF_CONVENTION_FOURIER ? AF_MINUS_TWO_PI_OVER_C : AF_TWO_PI_OVER_C;
@@ -867,5 +907,12 @@ AF_EXPORT int af_im_to_vis_f64(const double *image, int image_is_complex, const 
         int rc = launch_chunk_ct(cplx, ct, L.chunk_nc[chunk], a);
         if (rc != AF_OK) return rc;
     }
+    if (chi) {
+        // the separate pass, unless the MFMA epilogues have done the sum (device flags (1, 1, 0): one channel spacing, no
+        // column rewritten by the zero-pixel / NaN-source pass); without the MFMA path it always runs
+        return af_chi2_launch(out, chi->data, chi->weight, nrow, nchan, ncorr, chi->chi2,
+                              mfma ? reinterpret_cast<const int *>(ws + L.flags) : nullptr, st);
+    }
     return AF_OK;
 }
+}  // namespace

@@ -23,6 +23,8 @@
 //     fp64 MFMA 4x4x4 every 16.4; per step 128 MFMAs + ~220 VALU ops = ~3300 cycles against 3500 measured.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "af_dft_mfma.h"
 #include "af_mfma_phasor.h"
 
@@ -77,11 +79,27 @@ __global__ void mfma_tile_f0(const double *__restrict__ freq, int64_t nchan, int
 }
 
 // grid: (ceil(nrow/64), tiles of the launch); block: 4 waves, wave w on rows 64 bx + 16 w ...
-template <int CT, bool CPLX>
+// x + (x of the lane the DPP control names): 64-lane sums without LDS round trips
+template <int CTRL> __device__ __forceinline__ double chi_dpp_add(double x)
+{
+    const double y = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true),
+                                      __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true));
+    return x + y;
+}
+template <int LANE> __device__ __forceinline__ double chi_readlane(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), LANE), __builtin_amdgcn_readlane(__double2loint(x), LANE));
+}
+
+// CHI2: the epilogue also adds sum [w] |data - vis|^2 over the block's rows and the four correlations to chi2[chan]
+// (the visibilities are in registers there: the separate chi^2 pass re-reads all of them)
+template <int CT, bool CPLX, bool CHI2 = false>
 __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tile_f0,
     const double *__restrict__ tilef, const int *__restrict__ flags, const double *__restrict__ lmn,
-    double *__restrict__ out, int64_t nrow, int nsrc, int nit, int64_t nchan, int64_t c0_first)
+    double *__restrict__ out, int64_t nrow, int nsrc, int nit, int64_t nchan, int64_t c0_first,
+    const double2 *__restrict__ chi_data = nullptr, const double *__restrict__ chi_weight = nullptr,
+    double *__restrict__ chi2 = nullptr)
 {
     if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
     constexpr int STAGE = stage_doubles(CT, CPLX);
@@ -211,12 +229,62 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     // consecutive channels complete the 128-byte lines
     const int orow = 4 * ((lane >> 2) & 3) + (lane >> 4), ocorr = lane & 3;
     const int64_t r = (int64_t)blockIdx.x * 64 + wave * 16 + orow;
-    if (r >= nrow) return;
     const int nvalid = (int)((nchan - c0 < CT) ? (nchan - c0) : CT);  // block-uniform: the band's last tile may be short
-    double2 *__restrict__ o = reinterpret_cast<double2 *>(out) + (r * nchan + c0) * 4 + ocorr;
+    const bool live = r < nrow;
+    if (!CHI2 && !live) return;
+    double2 *__restrict__ o = reinterpret_cast<double2 *>(out) + ((live ? r : 0) * nchan + c0) * 4 + ocorr;
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        if (j < nvalid) o[j * 4] = make_double2(are[j], aim[j]);
+        for (int j = 0; j < CT; ++j) {
+            if (j < nvalid) o[j * 4] = make_double2(are[j], aim[j]);
+        }
+    }
+    if constexpr (CHI2) {
+        // chi^2 of the rows just written.  The accumulators are DEAD here: the sums read the visibilities back (the lane's
+        // own stores, served by L2) four channels at a time, so this part needs ~40 registers and the kernel keeps the main
+        // loop's 128 + 128 (with the differences taken from the accumulators the 32-channel kernel needed 143-160 VGPRs: ONE
+        // wave per SIMD instead of two, 26.9 instead of 20.4 ms).  The pointer goes through an empty asm so that the
+        // compiler does not forward the stored registers into the loads.  64-lane sums: DPP adds inside the 16-lane rows
+        // (v_mov_dpp quad_perm / row_half_mirror / row_mirror: no LDS round trips), four v_readlane across the rows.
+        // Every lane stays to the end (a block barrier); rows beyond the last add nothing.  The stage buffers are free:
+        // the loop's last barrier is behind every wave.
+        const double2 *vis_back = o;
+        asm volatile("" : "+v"(vis_back));
+        const int64_t cell = ((live ? r : 0) * nchan + c0) * 4 + ocorr;
+        const double2 *__restrict__ dat = chi_data + cell;
+        const double *__restrict__ wgt = chi_weight ? chi_weight + cell : nullptr;
+        double *part = smem;                                  // [wave][CT]
+#pragma unroll
+        for (int g = 0; g < CT / 4; ++g) {
+            double2 d[4], m[4];
+            double wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * g + k;
+                const bool on = j < nvalid && live;
+                m[k] = on ? vis_back[j * 4] : make_double2(0.0, 0.0);
+                d[k] = on ? dat[j * 4] : make_double2(0.0, 0.0);
+                wv[k] = (on && wgt) ? wgt[j * 4] : 1.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * g + k;
+                const double dr = d[k].x - m[k].x, di = d[k].y - m[k].y;
+                double a = fma(dr, dr, di * di) * wv[k];
+                a = chi_dpp_add<0xB1>(a);       // quad_perm [1,0,3,2]
+                a = chi_dpp_add<0x4E>(a);       // quad_perm [2,3,0,1]
+                a = chi_dpp_add<0x141>(a);      // row_half_mirror: the other quad of the 8
+                a = chi_dpp_add<0x140>(a);      // row_mirror: the other 8 of the row
+                const double t01 = chi_readlane<0>(a) + chi_readlane<16>(a), t23 = chi_readlane<32>(a) + chi_readlane<48>(a);
+                if (lane == 0) part[wave * CT + j] = t01 + t23;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (tid < nvalid) {
+            const double total = (part[tid] + part[CT + tid]) + (part[2 * CT + tid] + part[3 * CT + tid]);
+            atomicAdd(&chi2[c0 + tid], total);
+        }
     }
 }
 
@@ -280,7 +348,7 @@ template <int CT, bool CPLX>
 int run_tiles(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
               const double *tilef, const int *flags, int sign, double *out, int64_t nrow,
               int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0, int64_t ntile, double *f0, double *rec, bool prof,
-              hipStream_t st)
+              hipStream_t st, const AfDftChi2 *chi = nullptr)
 {
     for (int64_t t = 0; t < ntile; ++t) {
         int64_t blocks = af_cdiv(nit * stage_doubles(CT, CPLX), 256);
@@ -293,8 +361,13 @@ int run_tiles(const double *image, const double *uvw, const double *frequency, c
                        (int)ntile, sign, f0);
     AF_LAUNCH_CHECK();
     if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
-    hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
-                       uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0);
+    if (chi != nullptr)
+        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX, true>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0,
+                           st, uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0,
+                           reinterpret_cast<const double2 *>(chi->data), chi->weight, chi->chi2);
+    else
+        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
+                           uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0);
     if (prof) af_prof_end(st);
     AF_LAUNCH_CHECK();
     return AF_OK;
@@ -317,7 +390,7 @@ namespace {
 template <bool CPLX>
 int run_all(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
             const double *tilef, const int *flags, const int *colstate, int sign, double *out, int64_t nrow, int64_t nsrc,
-            int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st)
+            int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st, const AfDftChi2 *chi)
 {
     const Plan p = make_plan(nsrc_pad, nchan, CPLX);
     char *ws = static_cast<char *>(workspace);
@@ -326,18 +399,18 @@ int run_all(const double *image, const double *uvw, const double *frequency, con
     int rc = AF_OK;
     if (p.nfull > 0 && p.ct == 32)
         rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi);
     else if (p.nfull > 0)
         rc = run_tiles<64, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st);
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi);
     if (rc != AF_OK) return rc;
     double *trec = reinterpret_cast<double *>(ws + p.tail_rec_off);
     if (p.tail_ct == 32)
         rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi);
     else if (p.tail_ct == 16)
         rc = run_tiles<16, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st);
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi);
     if (rc != AF_OK) return rc;
     // grid-stride sweep; its blocks return at once unless a special column exists
     int64_t fix_blocks = af_cdiv(nrow * nchan * 4, 256);
@@ -351,10 +424,10 @@ int run_all(const double *image, const double *uvw, const double *frequency, con
 int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw, const double *frequency,
                     const double *lmn, const int *srcbad, const double *tilef, const int *flags, const int *colstate,
                     int sign, double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
-                    hipStream_t st)
+                    hipStream_t st, const AfDftChi2 *chi2)
 {
     return image_is_complex ? run_all<true>(image, uvw, frequency, lmn, srcbad, tilef, flags, colstate, sign, out, nrow,
-                                            nsrc, nsrc_pad, nchan, workspace, st)
+                                            nsrc, nsrc_pad, nchan, workspace, st, chi2)
                             : run_all<false>(image, uvw, frequency, lmn, srcbad, tilef, flags, colstate, sign, out, nrow,
-                                             nsrc, nsrc_pad, nchan, workspace, st);
+                                             nsrc, nsrc_pad, nchan, workspace, st, chi2);
 }

@@ -110,6 +110,43 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
         return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
 
 
+def im_to_vis_chi2(image, uvw, lm, frequency, data, weight=None, convention="fourier"):
+    """
+    ``vis = im_to_vis(image, uvw, lm, frequency)`` and ``chi2[nu] = sum_{row, corr} [weight] |data - vis|^2`` in ONE
+    device call (``af_im_to_vis_chi2_f64``): the step of the row-sharded predict -- the transform
+    (africanus/dft/kernels.py:14-69), the shard's per-channel chi-squared, then one all-reduce of that vector
+    (``sharding.allreduce_chi2``).  With 4 correlations on a uniformly spaced band the sum is formed in the transform's
+    epilogue from the visibilities still in registers; otherwise by the separate pass (``sharding.chi2``'s kernel).
+    float64 / complex128.  ``data`` (row, chan, corr) complex, ``weight`` the same shape, real, or None.
+    Returns ``(vis, chi2)``: complex128 (row, chan, corr), float64 (chan,).
+    """
+    if convention not in _lib.CONVENTION:
+        raise ValueError("convention not in ('fourier', 'casa')")
+    if len(image.shape) != 3 or len(uvw.shape) != 2 or uvw.shape[1] != 3 or len(lm.shape) != 2 or lm.shape[1] != 2:
+        raise ValueError("image (source, chan, corr), uvw (row, 3), lm (source, 2) expected")
+    nsrc, nchan, ncorr = (int(s) for s in image.shape)
+    nrow = int(uvw.shape[0])
+    if int(lm.shape[0]) != nsrc or tuple(frequency.shape) != (nchan,):
+        raise ValueError("image (source, chan, corr), lm (source, 2) and frequency (chan,) disagree")
+    if tuple(int(x) for x in data.shape) != (nrow, nchan, ncorr):
+        raise ValueError("data must have the shape of the visibilities %s" % ((nrow, nchan, ncorr),))
+    if weight is not None and tuple(int(x) for x in weight.shape) != (nrow, nchan, ncorr):
+        raise ValueError("weight must have the shape of the visibilities %s" % ((nrow, nchan, ncorr),))
+    is_cplx = np_dtype_of(image).kind == "c"
+    with Call(image, uvw, lm, frequency, data, weight) as c:
+        p_img = c.inp(image, np.complex128 if is_cplx else np.float64)
+        p_uvw, p_lm, p_fr = c.inp(uvw, np.float64), c.inp(lm, np.float64), c.inp(frequency, np.float64)
+        p_d, p_w = c.inp(data, np.complex128), c.inp(weight, np.float64)
+        p_out, h = c.out((nrow, nchan, ncorr), np.complex128)
+        p_chi, hc = c.out((nchan,), np.float64)
+        ws_bytes = _lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, int(is_cplx))
+        p_ws = c.scratch(ws_bytes)
+        _lib.call("af_im_to_vis_chi2_f64", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
+                  _lib.CONVENTION[convention], _MODES[get_mode()], p_out, p_d, p_w, p_chi, p_ws, max(int(ws_bytes), 256),
+                  c.stream)
+        return c.result(h), c.result(hc)
+
+
 def vis_to_im(vis, uvw, lm, frequency, flags, convention="fourier", dtype=None):
     """
     Adjoint direct Fourier transform visibilities -> image,

@@ -116,13 +116,13 @@ def predict_shard(rank, world_size, image, uvw, lm, frequency, data=None, conven
     """One rank's part of the row-sharded direct-transform predict: im_to_vis on its row block
     (device resident) and, if ``data`` (the rank's rows) is given, the all-reduced chi-squared.
     Returns (vis_shard, chi2 or None, (start, stop))."""
-    from .dft.kernels import im_to_vis
+    from .dft.kernels import im_to_vis, im_to_vis_chi2
     start, stop = shard_bounds(uvw.shape[0], world_size)[rank]
-    vis = im_to_vis(image, uvw[start:stop], lm, frequency, convention=convention)
-    c2 = None
-    if data is not None:
-        c2 = allreduce_chi2(chi2(vis, data), group=group)
-    return vis, c2, (start, stop)
+    if data is None:
+        return im_to_vis(image, uvw[start:stop], lm, frequency, convention=convention), None, (start, stop)
+    # transform and chi^2 in one device call (summed in the transform's epilogue where the MFMA kernels run)
+    vis, c2 = im_to_vis_chi2(image, uvw[start:stop], lm, frequency, data, convention=convention)
+    return vis, allreduce_chi2(c2, group=group), (start, stop)
 
 
 def fused_predict_shard(rank, world_size, time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,

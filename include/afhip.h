@@ -143,6 +143,16 @@ int af_im_to_vis_f64(const double *image, int image_is_complex, const double *uv
                      const double *lm, const double *frequency, int64_t nsrc, int64_t nrow,
                      int64_t nchan, int64_t ncorr, int convention, int mode, double *out,
                      void *workspace, size_t workspace_bytes, void *stream);
+/* The transform and the per-channel chi^2 of its result in one call (the step of the row-sharded predict, SURVEY 8(e):
+ * predict, then chi2[nu] = sum_{row, corr} [weight] |data - vis|^2, then ONE all-reduce of that vector):
+ * out as af_im_to_vis_f64; data (nrow,nchan,ncorr) complex128; weight (nrow,nchan,ncorr) float64 or NULL;
+ * chi2_per_chan (nchan) float64 = what af_chi2_c128(out, data, weight) gives (to the order of its atomic sums).  Where
+ * the MFMA kernels run the sum is formed in their epilogue from the visibilities still in registers (no second pass over
+ * them); every other case falls back to the separate pass on the device.  Same workspace as af_im_to_vis_f64. */
+int af_im_to_vis_chi2_f64(const double *image, int image_is_complex, const double *uvw, const double *lm,
+                          const double *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
+                          int convention, int mode, double *out, const double *data, const double *weight,
+                          double *chi2_per_chan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* im_to_vis for single-precision callers: float32 image (complex64 when image_is_complex), uvw, lm and frequency ->
  * complex64 out.  The reference runs this case entirely in float32 (result dtype by promotion,
