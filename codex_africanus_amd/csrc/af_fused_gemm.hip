@@ -554,6 +554,11 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
                 using I3 = std::integral_constant<int, 3>;
                 Round R0, R1, R2, R3;
                 issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
+                // (EIGHT sampling waves, two per SIMD, beside four matrix waves on the four-product form -- the only split
+                // of 12 waves x 168 registers that has room for them -- sampled no faster: 68.6 ms alone against 68.7 with
+                // four waves, so a lone wave's dependent-issue latency is not what bounds the stage either; the matrix waves
+                // then hold 9 tiles x 16 accumulators and spill, 125 ms.  That experiment also showed the f64 MFMA's BLGP bit 0
+                // to negate the A operand, as the ISA says: -Gr needs no plane of its own.)
                 // (a lane sampling all four correlations of its own term -- no quads, a third fewer instructions -- was
                 // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
                 // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
