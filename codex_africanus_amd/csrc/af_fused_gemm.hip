@@ -459,6 +459,24 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     const unsigned corr_off = e_corr * 32u;
     constexpr int NTASK = ST * NA;
     if (sample_prio >= 0) __builtin_amdgcn_s_setprio(3);
+    // A lane's source coordinates are fetched ONE super-round ahead: a batch is a chain of dependent memory round trips
+    // (coordinates -> voxel geometry -> gathers) and the first is taken off its critical path.
+    struct Coords {
+        double2 lm;
+        double n;
+    };
+    auto fetch = [&](int b, int task0) {
+        int task = task0 + ptid;
+        if (task >= NTASK) task %= NTASK;
+        const int e_sl = task / NA, e_ant = task - e_sl * NA;
+        const bool have = e_ant < nant && b * ST + e_sl < nsrc && b < nbatch;
+        const double *sp = lmn + 4 * (have ? b * ST + e_sl : 0);
+        Coords c;
+        c.lm = *reinterpret_cast<const double2 *>(sp);
+        c.n = sp[2];
+        return c;
+    };
+    Coords nxt = fetch(0, 0);
     for (int b = 0; b < nbatch; ++b) {
         const int s0 = b * ST;
         double *H = ldsd + (b & 1) * BUF_DOUBLES;
@@ -472,9 +490,19 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
                 const int e_sl = task / NA, e_ant = task - e_sl * NA;
                 const bool have = e_ant < nant && s0 + e_sl < nsrc;
                 const int own_info = e_sl | (e_ant << 11) | (int)((unsigned)have << 31);
-                const double *sp = lmn + 4 * (have ? s0 + e_sl : 0);
-                const double2 lm2 = *reinterpret_cast<const double2 *>(sp);
-                const double nn = sp[2];
+                // 64 antennas: a wave's 64 lanes are ONE source's antennas -- its 2 x 2 complex brightness comes in by ONE
+                // scalar load per batch, here (inside the sampling rounds every round waited out an SMEM round trip --
+                // lgkmcnt is shared with the LDS reads --: the sampling alone ran 65.1 ms with those loads, 51.6 without)
+                double2 xw[4];
+                if constexpr (NA == 64) {
+                    const int us = __builtin_amdgcn_readfirstlane(have ? s0 + e_sl : 0);
+                    const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xw[c] = bp[c];
+                }
+                const double2 lm2 = nxt.lm;
+                const double nn = nxt.n;
+                nxt = task0 + G3_SAMPLERS < NTASK ? fetch(b, task0 + G3_SAMPLERS) : fetch(b + 1, 0);
                 FusedVoxels gx;
                 fused_voxels(grid, lm2.x, lm2.y, ldsA[0 * NA + e_ant], ldsA[1 * NA + e_ant], ldsA[2 * NA + e_ant],
                              ldsA[3 * NA + e_ant], ldsA[4 * NA + e_ant], ldsA[5 * NA + e_ant], fscale, gx);
@@ -484,26 +512,13 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
                 // 33 registers per round in flight)
                 struct Round {
                     int info;
-                    double2 b0, b1, v[4];
+                    double2 v[4];
                     double ab[4];
                 };
                 auto issue = [&](auto lane_c, Round &R) {
                     constexpr int QL = decltype(lane_c)::value;
                     const int info = quad_bcast<QL>(own_info);
                     R.info = info;
-                    if constexpr (NA == 64) {
-                        // a wave's 64 lanes are the 64 antennas of ONE source: its brightness matrix comes in by scalar
-                        // loads (no trip through the vector memory pipe, which is what bounds the sampling)
-                        const int us = __builtin_amdgcn_readfirstlane(info < 0 ? s0 + (info & 2047) : 0);
-                        const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
-                        const double2 x0 = bp[0], x1 = bp[1], x2 = bp[2], x3 = bp[3];
-                        R.b0 = ej ? x1 : x0;
-                        R.b1 = ej ? x3 : x2;
-                    } else {
-                        const double2 *bp = brightness + ((int64_t)(info < 0 ? s0 + (info & 2047) : 0) * nchan + f) * 4;
-                        R.b0 = bp[ej];
-                        R.b1 = bp[2 + ej];
-                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
@@ -540,7 +555,15 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
                     C2 A0, A1, B0, B1;
                     A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
                     A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
-                    B0.re = R.b0.x; B0.im = R.b0.y; B1.re = R.b1.x; B1.im = R.b1.y;
+                    if constexpr (NA == 64) {
+                        // the wave's source: its brightness matrix was loaded at the top of the batch
+                        const double2 b0 = ej ? xw[1] : xw[0], b1 = ej ? xw[3] : xw[2];
+                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                    } else {
+                        const double2 *bp = brightness + ((int64_t)(r_have ? s0 + r_sl : 0) * nchan + f) * 4;
+                        const double2 b0 = bp[ej], b1 = bp[2 + ej];
+                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                    }
                     C2 Gv = cmul(A0, B0);
                     cmac(Gv, A1, B1);
                     double *hs = H + r_sl * SRC_DOUBLES + 2 * ((r_ant & 3) * (NA / 4) + (r_ant >> 2)) + ei;
