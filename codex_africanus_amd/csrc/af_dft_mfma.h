@@ -7,7 +7,7 @@
 bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex);
 
 // bytes of workspace the path needs behind the common prep arrays (256-byte aligned start)
-size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex);
+size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex, bool gauss = false);
 
 // Packs the records and launches the kernels on `st`.  The kernels do the work iff the prep pass
 // found one channel spacing for the whole band (flags[0] == 1 and flags[1] == 1); otherwise they
@@ -26,3 +26,10 @@ int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw
                     const int *srcbad, const double *tilef, const int *flags, const int *colstate, int sign,
                     double *out, int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace,
                     hipStream_t st, const AfDftChi2 *chi2 = nullptr);
+
+// The same kernels with a Gaussian envelope folded into every lane's phasor (Gaussian / point sources without DDEs,
+// af_gauss_predict_c128): brightness (nsrc, nchan, 4) complex128 for the image, gauss (nsrc, 4) = (el, em, er, -) scaled to
+// the kernels' 1/256-turn frequency units; workspace: af_dft_mfma_workspace_bytes(nsrc_pad, nchan, true, true).
+int af_gauss_mfma_run(const double *brightness, const double *gauss, const double *uvw, const double *frequency,
+                      const double *lmn, const int *srcbad, const double *tilef, const int *flags, int sign, double *out,
+                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st);

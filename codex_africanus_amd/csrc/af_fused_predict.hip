@@ -276,11 +276,25 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     auto stage2 = [&](int s0) {
         // ---- stage 2: every source of the batch, this lane's rows ----------------------------------
         const int nb = (nsrc - s0 < st) ? (nsrc - s0) : st;
+        // the batch's source coordinates by scalar loads BEFORE the source loop: one SMEM round trip per batch where a
+        // load at the head of every source's section waited one out per source (lgkmcnt is shared with the LDS reads of
+        // the Jones terms): 177.6 -> 176.8 ms at BASELINE configs[2], same box
+        double Lh[ST > 0 ? ST : 1], Mh[ST > 0 ? ST : 1], Nh[ST > 0 ? ST : 1];
+        if constexpr (ST > 0) {
+#pragma unroll
+            for (int sl = 0; sl < ST; ++sl) {
+                // ST > 0 always walks whole batches: a source beyond the last one has E = G = 0 in LDS (stage 1 writes
+                // zeros for it) and adds exactly nothing; only its coordinates must come from a valid address
+                const int sg = (s0 + sl >= nsrc) ? nsrc - 1 : s0 + sl;
+                Lh[sl] = lmn[4 * sg]; Mh[sl] = lmn[4 * sg + 1]; Nh[sl] = lmn[4 * sg + 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         auto one_source = [&](int sl) {
-            // ST > 0 always walks whole batches: a source beyond the last one has E = G = 0 in LDS (stage 1 writes
-            // zeros for it) and adds exactly nothing; only its coordinates must come from a valid address
             const int sg = (ST > 0 && s0 + sl >= nsrc) ? nsrc - 1 : s0 + sl;
-            const double l = lmn[4 * sg], m = lmn[4 * sg + 1], n = lmn[4 * sg + 2];
+            double l, m, n;
+            if constexpr (ST > 0) { l = Lh[sl]; m = Mh[sl]; n = Nh[sl]; }
+            else { l = lmn[4 * sg]; m = lmn[4 * sg + 1]; n = lmn[4 * sg + 2]; }
             // Gaussian shape factors exp(-(u1^2 + v1^2) (nu gs)^2) of this lane's rows (gaussian_shape.py:52-60);
             // computed ahead of the row loop so that exp's temporaries do not overlap the Jones algebra
             double shape[RPT];

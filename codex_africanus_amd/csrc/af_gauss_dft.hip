@@ -29,6 +29,7 @@
 
 #include <type_traits>
 
+#include "af_dft_mfma.h"
 #include "af_fused_device.h"
 
 namespace {
@@ -36,8 +37,10 @@ namespace {
 constexpr int GD_CT = 8, GD_ROWS = 256, GD_SB = 16;   // channels per tile, rows per block, sources per LDS batch
 
 struct GaussWs {
-    size_t lmn, gauss, tilef, flags, total;
+    size_t lmn, gauss, tilef, flags, gauss_mfma, srcbad, mtilef, mflags, mfma, total;
 };
+// the MFMA-accumulator form (af_im_to_vis_mfma.hip, GAUSS) needs a 16-channel tile at least
+bool gauss_mfma_eligible(int64_t nchan) { return nchan >= 14 && nchan / 32 + 1 <= 65535; }
 GaussWs gauss_ws(int64_t nsrc, int64_t nchan)
 {
     GaussWs w;
@@ -48,8 +51,39 @@ GaussWs gauss_ws(int64_t nsrc, int64_t nchan)
     w.gauss = take((size_t)nsrc * 4 * sizeof(double));
     w.tilef = take((size_t)ntile * 2 * sizeof(double));
     w.flags = take(64 * sizeof(int));
+    w.gauss_mfma = take((size_t)nsrc * 4 * sizeof(double));
+    w.srcbad = take((size_t)nsrc * sizeof(int));
+    w.mtilef = take(4 * sizeof(double));
+    w.mflags = take(64 * sizeof(int));
+    w.mfma = o;
+    if (gauss_mfma_eligible(nchan)) o += af_dft_mfma_workspace_bytes(af_cdiv(nsrc > 0 ? nsrc : 1, 4) * 4, nchan, true, true);
     w.total = o;
     return w;
+}
+
+// The MFMA kernels evaluate a whole tile (tiles start at multiples of 64 channels) as nu[c0] + j d with ONE d for the band:
+// mflags[0] = mflags[1] = every channel within 2 ulp of that; mtilef[1] = d in quarter turns per metre.  One block.
+__global__ void gauss_band_prep(const double *__restrict__ freq, int64_t nchan, int sign, double *__restrict__ mtilef,
+                                int *__restrict__ mflags)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    const double f0 = freq[0], df = nchan > 1 ? (freq[nchan - 1] - f0) / (double)(nchan - 1) : 0.0;
+    bool good = isfinite(f0) && isfinite(df);
+    for (int64_t j = threadIdx.x; j < nchan; j += blockDim.x) {
+        const int64_t c0 = (j / 64) * 64;
+        const double pred = fma((double)(j - c0), df, freq[c0]), f = freq[j];
+        const double tol = 2.0 * 2.220446049250313e-16 * fmax(fabs(f), fabs(pred));
+        if (!(fabs(f - pred) <= tol)) good = false;
+    }
+    if (!good) atomicAnd(&ok, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mflags[0] = ok; mflags[1] = ok; mflags[2] = 0;
+        mtilef[0] = 4.0 * (double)sign * f0 / AF_LIGHTSPEED;
+        mtilef[1] = 4.0 * (double)sign * df / AF_LIGHTSPEED;
+    }
 }
 
 // per tile: (nu_0, d) with d from the tile's own end points; flags[0] &= every channel within 2 ulp of that progression
@@ -77,8 +111,10 @@ __global__ __launch_bounds__(GD_ROWS) void gauss_dft_kernel(const double *__rest
                                                            const double *__restrict__ gp, const double *__restrict__ freq,
                                                            const double *__restrict__ tilef, const int *__restrict__ flags,
                                                            const double2 *__restrict__ brightness, int nsrc, int64_t nrow,
-                                                           int64_t nchan, double sign4_over_c, double2 *__restrict__ out)
+                                                           int64_t nchan, double sign4_over_c, double2 *__restrict__ out,
+                                                           const int *__restrict__ mflags)
 {
+    if (mflags != nullptr && mflags[0] == 1) return;   // the MFMA kernels own this band (gauss_band_prep)
     if ((flags[0] != 0) != UNIFORM) return;       // decided on the device by gauss_prep_freq
     const int64_t tile = blockIdx.y, c0 = tile * GD_CT;
     const int nt = (int)(nchan - c0 < GD_CT ? nchan - c0 : GD_CT);
@@ -164,8 +200,9 @@ __global__ __launch_bounds__(GD_ROWS) void gauss_dft_kernel(const double *__rest
                         }
                     }
                 };
+                // (a falling band has r_0 > 1; beyond e^700 the envelope is 0 on the whole tile, and 0 x inf must not appear)
                 if (extended)
-                    channels(std::true_type{}, exp_neg(a * nu0 * nu0), exp_neg(a * (2.0 * nu0 * dnu + dnu * dnu)),
+                    channels(std::true_type{}, exp_neg(a * nu0 * nu0), exp_neg(fmax(a * (2.0 * nu0 * dnu + dnu * dnu), -700.0)),
                              exp_neg(2.0 * a * dnu * dnu));
                 else
                     channels(std::false_type{}, 1.0, 1.0, 1.0);
@@ -249,16 +286,37 @@ AF_EXPORT int af_gauss_predict_c128(const double *lm, const double *uvw, const d
                        flags);
     AF_LAUNCH_CHECK();
     const double s4c = 4.0 * (double)convention / AF_LIGHTSPEED;
+    // The MFMA-accumulator form: the brightness matrices as the complex image of dft_mfma_kernel, the envelope in the
+    // lane's phasor.  Whether it or the lane = row kernels below do the work is decided on the device (one channel
+    // spacing for the band); AFHIP_GAUSS_MFMA=0 keeps the band on the lane = row kernels (A/B measurements).
+    static const bool mfma_on = !(getenv("AFHIP_GAUSS_MFMA") && atoi(getenv("AFHIP_GAUSS_MFMA")) == 0);
+    const bool mfma = mfma_on && gauss_mfma_eligible(nchan);
+    const int *mflags = nullptr;
+    if (mfma) {
+        double *gpk = reinterpret_cast<double *>(ws + W.gauss_mfma), *mtilef = reinterpret_cast<double *>(ws + W.mtilef);
+        int *srcbad = reinterpret_cast<int *>(ws + W.srcbad), *mf = reinterpret_cast<int *>(ws + W.mflags);
+        // shape parameters per unit of the kernels' frequency (1/256 turns per metre): nu = F c / 256
+        hipLaunchKernelGGL(fused_prep_gauss, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, gauss_shape, nsrc,
+                           gs * (AF_LIGHTSPEED / 256.0), gpk);
+        AF_LAUNCH_CHECK();
+        AF_HIP(hipMemsetAsync(srcbad, 0, (size_t)nsrc * sizeof(int), st));
+        hipLaunchKernelGGL(gauss_band_prep, dim3(1), dim3(256), 0, st, frequency, nchan, convention, mtilef, mf);
+        AF_LAUNCH_CHECK();
+        const int rc = af_gauss_mfma_run(brightness, gpk, uvw, frequency, lmn, srcbad, mtilef, mf, convention, out, nrow, nsrc,
+                                         af_cdiv(nsrc, 4) * 4, nchan, ws + W.mfma, st);
+        if (rc != AF_OK) return rc;
+        mflags = mf;
+    }
     const dim3 grid((unsigned)af_cdiv(nrow, GD_ROWS), (unsigned)ntile);
-    af_prof_begin(st);
+    if (!mfma) af_prof_begin(st);
     hipLaunchKernelGGL(gauss_dft_kernel<true>, grid, dim3(GD_ROWS), 0, st, uvw, lmn, gp, frequency, tilef, flags,
                        reinterpret_cast<const double2 *>(brightness), (int)nsrc, nrow, nchan, s4c,
-                       reinterpret_cast<double2 *>(out));
-    af_prof_end(st);
+                       reinterpret_cast<double2 *>(out), mflags);
+    if (!mfma) af_prof_end(st);
     AF_LAUNCH_CHECK();
     hipLaunchKernelGGL(gauss_dft_kernel<false>, grid, dim3(GD_ROWS), 0, st, uvw, lmn, gp, frequency, tilef, flags,
                        reinterpret_cast<const double2 *>(brightness), (int)nsrc, nrow, nchan, s4c,
-                       reinterpret_cast<double2 *>(out));
+                       reinterpret_cast<double2 *>(out), mflags);
     AF_LAUNCH_CHECK();
     return AF_OK;
 }

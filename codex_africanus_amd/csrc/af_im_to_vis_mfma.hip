@@ -33,26 +33,43 @@ namespace {
 constexpr int THREADS = 256;        // 4 waves x 16 rows
 
 // doubles of one (tile, step) record: header + CT channels x 16 (source k, corr) x 1 (real pixel) or 3 (Re, Im, -Im)
-__host__ __device__ constexpr int stage_doubles(int ct, bool cplx) { return (ct * (cplx ? 3 : 1) + 1) * 16; }
+// (Gaussian sources, af_gauss_mfma_run: a second header row with the NEXT step's shape parameters)
+__host__ __device__ constexpr int stage_doubles(int ct, bool cplx, bool gauss = false)
+{
+    return (ct * (cplx ? 3 : 1) + 1 + (gauss ? 1 : 0)) * 16;
+}
 
 // record of (tile, step): [ (l,m,n,0) x 4 sources of step+1 | CT/2 channel pairs x 16 (source k, corr n) x 2 channels ];
 // complex images: ... x 2 channels x (Re, Im, -Im) -- the -Im copy lets Re(Y I) = ReY ReI + ImY (-ImI) run as
 // two plain MFMAs (the instruction has no operand negation)
 __global__ void mfma_pack_records(const double *__restrict__ image, int cplx, const double *__restrict__ lmn,
                                   const int *__restrict__ srcbad, int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0,
-                                  int CT, double *__restrict__ rec)
+                                  int CT, double *__restrict__ rec, const double *__restrict__ gauss = nullptr)
 {
-    const int64_t per = stage_doubles(CT, cplx != 0);
+    const int64_t per = stage_doubles(CT, cplx != 0, gauss != nullptr);
     const int64_t total = nit * per;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
-        const int64_t it = i / per, idx = i - it * per;
+        const int64_t it = i / per;
+        int64_t idx = i - it * per;
         double v = 0.0;
         if (idx < 16) {  // (l,m,n) of the NEXT step: its set-up runs during this one
             const int64_t s = 4 * (it + 1) + idx / 4;
             if (s < nsrc && (idx & 3) < 3) v = lmn[4 * s + (idx & 3)];
-        } else if (!cplx) {
+            rec[i] = v;
+            continue;
+        }
+        if (gauss != nullptr) {  // second header row: (el, em, er, 0) of the next step's sources
+            idx -= 16;
+            if (idx < 16) {
+                const int64_t s = 4 * (it + 1) + idx / 4;
+                if (s < nsrc && (idx & 3) < 3) v = gauss[4 * s + (idx & 3)];
+                rec[i] = v;
+                continue;
+            }
+        }
+        if (!cplx) {
             const int64_t e = idx - 16, pair = e / 32, r = e - pair * 32;
             const int64_t kn = r >> 1, j = 2 * pair + (r & 1);
             const int64_t s = 4 * it + (kn >> 2), ch = c0 + j;
@@ -93,16 +110,55 @@ template <int LANE> __device__ __forceinline__ double chi_readlane(double x)
 
 // CHI2: the epilogue also adds sum [w] |data - vis|^2 over the block's rows and the four correlations to chi2[chan]
 // (the visibilities are in registers there: the separate chi^2 pass re-reads all of them)
-template <int CT, bool CPLX, bool CHI2 = false>
+// GAUSS (complex pixels = brightness matrices): the lane's phasor carries the source's Gaussian envelope
+//     shape(row, s, nu) = exp(-a nu^2),   a = u1^2 + v1^2,  u1 = (u em - v el) er,  v1 = u el + v em
+// (africanus/model/shape/gaussian_shape.py:45-60) -- on the tile's arithmetic progression nu_j = nu_0 + j d a
+// second-order PRODUCT recurrence e_(j+1) = e_j r_j, r_(j+1) = r_j c with e_0 = exp(-a nu_0^2),
+// r_0 = exp(-a (2 nu_0 d + d^2)), c = exp(-2 a d^2): three exponentials per (row, source, tile), spread over the
+// set-up slices, and four products per channel (e, r, Re, Im).  The phasors themselves keep their three-term recurrence:
+// Y (8 channels, advanced in place) is the recurrence state, Z = e Y the MFMA operand.  The shape parameters of a step's
+// four sources travel in a second header row of the record, pre-scaled so that nu is in the kernel's 1/256-turn units.
+// A point source (a = 0) has e = r = c = 1 exactly.
+struct GaussEnvelope {
+    double el, em, er;     // shape parameters of the lane's source
+    double a;              // u1^2 + v1^2
+    double e0, r0, c;      // recurrence start of the tile
+};
+// the envelope's slices of a step's set-up: 1 quadratic form, 2 e_0, 3 r_0, 6 c (hdr: the record's second header row)
+__device__ __forceinline__ void gauss_setup_slice(GaussEnvelope &G, int slice, const double *hdr4, double u, double v,
+                                                  double q0, double q1, double q2)
+{
+    switch (slice) {
+    case 0: {
+        const double2 h = *reinterpret_cast<const double2 *>(hdr4);
+        G.el = h.x; G.em = h.y; G.er = hdr4[2];
+        break;
+    }
+    case 1: {
+        const double u1 = __dmul_rn(fma(u, G.em, -__dmul_rn(v, G.el)), G.er), v1 = fma(u, G.el, __dmul_rn(v, G.em));
+        G.a = fma(u1, u1, __dmul_rn(v1, v1));
+        break;
+    }
+    case 2: G.e0 = exp_neg(__dmul_rn(G.a, q0)); break;
+    // (a falling band has r_0 > 1; beyond e^700 the envelope is 0 on the whole tile, and 0 x inf must not appear)
+    case 3: G.r0 = exp_neg(fmax(__dmul_rn(G.a, q1), -700.0)); break;
+    case 6: G.c = exp_neg(__dmul_rn(G.a, q2)); break;
+    default: break;
+    }
+}
+
+template <int CT, bool CPLX, bool CHI2 = false, bool GAUSS = false>
 __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     const double *__restrict__ uvw, const double *__restrict__ records, const double *__restrict__ tile_f0,
     const double *__restrict__ tilef, const int *__restrict__ flags, const double *__restrict__ lmn,
     double *__restrict__ out, int64_t nrow, int nsrc, int nit, int64_t nchan, int64_t c0_first,
     const double2 *__restrict__ chi_data = nullptr, const double *__restrict__ chi_weight = nullptr,
-    double *__restrict__ chi2 = nullptr)
+    double *__restrict__ chi2 = nullptr, const double *__restrict__ gauss = nullptr)
 {
+    static_assert(!GAUSS || (CPLX && !CHI2), "the Gaussian variant takes brightness matrices");
     if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
-    constexpr int STAGE = stage_doubles(CT, CPLX);
+    constexpr int STAGE = stage_doubles(CT, CPLX, GAUSS);
+    constexpr int HDR = GAUSS ? 32 : 16;          // doubles of the record's header
     constexpr int UNITS = STAGE / 2;              // 16-byte units of a stage
     __shared__ double smem[2 * STAGE];
     __shared__ double2 ptab[PHASOR_TABLE];   // exp(2 pi i k / 256): af_sincos.h table phasor
@@ -130,13 +186,24 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     constexpr int GP = 4;                         // channel pairs per B register group (8 channels)
     constexpr int NGRP = CT / 2 / GP;
 
-    double yr[2][8], yi[2][8];
+    double yr[2][8], yi[2][8];                    // GAUSS: yr[0] / yi[0] = Y (recurrence state), yr[1] / yi[1] = Z = e Y
     PhasorSetup cur_, nxt_;
+    GaussEnvelope env_;                           // of the NEXT step while a step runs
+    double ee = 1.0, er = 1.0, ec = 1.0;          // envelope recurrence of the current step
+    // exponents per unit of a: nu_0^2, 2 nu_0 d + d^2, 2 d^2 in the kernel's frequency units (block-uniform)
+    const double q0 = F0 * F0, q1 = fma(2.0 * F0, FD, FD * FD), q2 = 2.0 * FD * FD;
     {   // step 0 is set up in one piece from the global (l,m,n)
         cur_.a0 = cur_.a1 = cur_.a2 = 0.0;
         if (k < nsrc) { cur_.a0 = lmn[4 * k]; cur_.a1 = lmn[4 * k + 1]; cur_.a2 = lmn[4 * k + 2]; }
 #pragma unroll
         for (int sl = 1; sl < 8; ++sl) phasor_setup_slice(cur_, sl, nullptr, u, v, w, F0, FD, ptab, yr[0], yi[0]);
+        if constexpr (GAUSS) {
+            env_.el = env_.em = env_.er = 0.0;
+            if (k < nsrc) { env_.el = gauss[4 * k]; env_.em = gauss[4 * k + 1]; env_.er = gauss[4 * k + 2]; }
+#pragma unroll
+            for (int sl = 1; sl < 8; ++sl) gauss_setup_slice(env_, sl, nullptr, u, v, q0, q1, q2);
+            ee = env_.e0; er = env_.r0; ec = env_.c;
+        }
     }
     nxt_ = cur_;
 
@@ -145,7 +212,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         const int cur = it & 1;
         if (it + 1 < nit) mfma_stage_load<UNITS>(rec + (int64_t)(it + 1) * STAGE, smem + (cur ^ 1) * STAGE, wave, lane);
         const double *S = smem + cur * STAGE;     // header: (l,m,n) of step it + 1
-        const double2 *B = reinterpret_cast<const double2 *>(S + 16 + boff);
+        const double2 *B = reinterpret_cast<const double2 *>(S + HDR + boff);
         constexpr int BPG = CPLX ? 12 : GP;       // 16-byte B reads per group of 8 channels
         constexpr int BSTRIDE = CPLX ? 48 : 16;   // double2 units between channel pairs
         double2 bg[2][BPG];
@@ -167,6 +234,25 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         for (int t = 0; t < BPG; ++t) load_b(0, t);
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
+            if constexpr (GAUSS) {
+                // Z of THIS group from Y (the previous group's MFMAs have been issued), then Y moves on in place
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    yr[1][t] = __dmul_rn(yr[0][t], ee);
+                    yi[1][t] = __dmul_rn(yi[0][t], ee);
+                    ee = __dmul_rn(ee, er);
+                    er = __dmul_rn(er, ec);
+                }
+                if (g + 1 < NGRP) {
+                    static_assert(!GAUSS || CT <= MFMA_ANCHOR, "no re-anchoring in the Gaussian variant");
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {      // in place: Y[t] <- k2 Y[t-2] - Y[t-4] over the group boundary
+                        const double r2 = t >= 2 ? yr[0][t - 2] : yr[0][t + 6], r4 = t >= 4 ? yr[0][t - 4] : yr[0][t + 4];
+                        const double i2 = t >= 2 ? yi[0][t - 2] : yi[0][t + 6], i4 = t >= 4 ? yi[0][t - 4] : yi[0][t + 4];
+                        yr[0][t] = fma(cur_.k2, r2, -r4); yi[0][t] = fma(cur_.k2, i2, -i4);
+                    }
+                }
+            } else
             if (g + 1 < NGRP) {  // phasors of the next 8 channels
                 if (((g + 1) * 8) % MFMA_ANCHOR == 0) {
                     const double tr = fma(anr, cur_.ar, -__dmul_rn(ani, cur_.ai));
@@ -181,8 +267,12 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
             // the MFMAs of group NGRP-2 were issued)
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl)
-                if (sl * NGRP / 8 == g) phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, ptab, yr[0], yi[0]);
+                if (sl * NGRP / 8 == g) {
+                    phasor_setup_slice(nxt_, sl, S + 4 * k, u, v, w, F0, FD, ptab, yr[0], yi[0]);
+                    if constexpr (GAUSS) gauss_setup_slice(env_, sl, S + 16 + 4 * k, u, v, q0, q1, q2);
+                }
             __builtin_amdgcn_sched_barrier(0);
+            const int zb = GAUSS ? 1 : (g & 1);   // the MFMAs' A operands: Z (Gaussian) or this group's phasors
             if constexpr (!CPLX) {
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -205,10 +295,10 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
                         const int j = g * 8 + jj;
-                        if (pass == 0) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], pix(g, jj, 0), are[j], 0, 0, 0);
-                        if (pass == 1) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[g & 1][jj], pix(g, jj, 1), aim[j], 0, 0, 0);
-                        if (pass == 2) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], pix(g, jj, 2), are[j], 0, 0, 0);
-                        if (pass == 3) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[g & 1][jj], pix(g, jj, 0), aim[j], 0, 0, 0);
+                        if (pass == 0) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[zb][jj], pix(g, jj, 0), are[j], 0, 0, 0);
+                        if (pass == 1) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yr[zb][jj], pix(g, jj, 1), aim[j], 0, 0, 0);
+                        if (pass == 2) are[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[zb][jj], pix(g, jj, 2), are[j], 0, 0, 0);
+                        if (pass == 3) aim[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(yi[zb][jj], pix(g, jj, 0), aim[j], 0, 0, 0);
                         const int t = pass * 8 + jj;
                         if (g + 1 < NGRP && t < BPG) {
                             load_b(g + 1, t);
@@ -221,6 +311,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         cur_ = nxt_;
+        if constexpr (GAUSS) { ee = env_.e0; er = env_.r0; ec = env_.c; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed in LDS
         __syncthreads();
     }
@@ -326,7 +417,7 @@ int main_ct(bool cplx)
     return cplx ? 64 : 32;
 }
 
-Plan make_plan(int64_t nsrc_pad, int64_t nchan, bool cplx)
+Plan make_plan(int64_t nsrc_pad, int64_t nchan, bool cplx, bool gauss = false)
 {
     Plan p;
     const int ct = main_ct(cplx), half = ct / 2;
@@ -338,8 +429,8 @@ Plan make_plan(int64_t nsrc_pad, int64_t nchan, bool cplx)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = af_align_up(o + bytes, 256); return at; };
     p.f0_off = take((size_t)(p.nfull + 1) * sizeof(double));
-    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(ct, cplx) * sizeof(double));
-    p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct, cplx) : 0) * sizeof(double));
+    p.rec_off = take((size_t)p.nfull * nit * stage_doubles(ct, cplx, gauss) * sizeof(double));
+    p.tail_rec_off = take((size_t)(p.tail_ct ? nit * stage_doubles(p.tail_ct, cplx, gauss) : 0) * sizeof(double));
     p.total = o;
     return p;
 }
@@ -348,25 +439,34 @@ template <int CT, bool CPLX>
 int run_tiles(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
               const double *tilef, const int *flags, int sign, double *out, int64_t nrow,
               int64_t nsrc, int64_t nit, int64_t nchan, int64_t c0, int64_t ntile, double *f0, double *rec, bool prof,
-              hipStream_t st, const AfDftChi2 *chi = nullptr)
+              hipStream_t st, const AfDftChi2 *chi = nullptr, const double *gauss = nullptr)
 {
+    const int64_t per = stage_doubles(CT, CPLX, gauss != nullptr);
     for (int64_t t = 0; t < ntile; ++t) {
-        int64_t blocks = af_cdiv(nit * stage_doubles(CT, CPLX), 256);
+        int64_t blocks = af_cdiv(nit * per, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(mfma_pack_records, dim3((unsigned)blocks), dim3(256), 0, st, image, (int)CPLX, lmn, srcbad, nsrc,
-                           nit, nchan, c0 + t * CT, CT, rec + t * nit * stage_doubles(CT, CPLX));
+                           nit, nchan, c0 + t * CT, CT, rec + t * nit * per, gauss);
         AF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(mfma_tile_f0, dim3((unsigned)af_cdiv(ntile, 64)), dim3(64), 0, st, frequency, nchan, c0, CT,
                        (int)ntile, sign, f0);
     AF_LAUNCH_CHECK();
     if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
-    if (chi != nullptr)
-        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX, true>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0,
+    const dim3 grid((unsigned)af_cdiv(nrow, 64), (unsigned)ntile);
+    if constexpr (CPLX) {
+        if (gauss != nullptr)
+            hipLaunchKernelGGL((dft_mfma_kernel<CT, true, false, true>), grid, dim3(THREADS), 0, st, uvw, rec, f0, tilef, flags,
+                               lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0, nullptr, nullptr, nullptr, gauss);
+    }
+    if (gauss != nullptr) {
+        // (launched above)
+    } else if (chi != nullptr)
+        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX, true>), grid, dim3(THREADS), 0,
                            st, uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0,
                            reinterpret_cast<const double2 *>(chi->data), chi->weight, chi->chi2);
     else
-        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX>), dim3((unsigned)af_cdiv(nrow, 64), (unsigned)ntile), dim3(THREADS), 0, st,
+        hipLaunchKernelGGL((dft_mfma_kernel<CT, CPLX>), grid, dim3(THREADS), 0, st,
                            uvw, rec, f0, tilef, flags, lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0);
     if (prof) af_prof_end(st);
     AF_LAUNCH_CHECK();
@@ -381,37 +481,39 @@ bool af_dft_mfma_eligible(int64_t nchan, int64_t ncorr, bool image_is_complex)
     return ncorr == 4 && nchan >= 14 && nchan / 32 + 1 <= 65535;
 }
 
-size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex)
+size_t af_dft_mfma_workspace_bytes(int64_t nsrc_pad, int64_t nchan, bool image_is_complex, bool gauss)
 {
-    return make_plan(nsrc_pad, nchan, image_is_complex).total;
+    return make_plan(nsrc_pad, nchan, image_is_complex, gauss).total;
 }
 
 namespace {
 template <bool CPLX>
 int run_all(const double *image, const double *uvw, const double *frequency, const double *lmn, const int *srcbad,
             const double *tilef, const int *flags, const int *colstate, int sign, double *out, int64_t nrow, int64_t nsrc,
-            int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st, const AfDftChi2 *chi)
+            int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st, const AfDftChi2 *chi,
+            const double *gauss = nullptr)
 {
-    const Plan p = make_plan(nsrc_pad, nchan, CPLX);
+    const Plan p = make_plan(nsrc_pad, nchan, CPLX, gauss != nullptr);
     char *ws = static_cast<char *>(workspace);
     double *f0 = reinterpret_cast<double *>(ws + p.f0_off);
     const int64_t nit = nsrc_pad / 4;
     int rc = AF_OK;
     if (p.nfull > 0 && p.ct == 32)
         rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi);
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi, gauss);
     else if (p.nfull > 0)
         rc = run_tiles<64, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi);
+                                 0, p.nfull, f0, reinterpret_cast<double *>(ws + p.rec_off), true, st, chi, gauss);
     if (rc != AF_OK) return rc;
     double *trec = reinterpret_cast<double *>(ws + p.tail_rec_off);
     if (p.tail_ct == 32)
         rc = run_tiles<32, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi);
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi, gauss);
     else if (p.tail_ct == 16)
         rc = run_tiles<16, CPLX>(image, uvw, frequency, lmn, srcbad, tilef, flags, sign, out, nrow, nsrc, nit, nchan,
-                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi);
+                                 p.tail_c0, 1, f0 + p.nfull, trec, p.nfull == 0, st, chi, gauss);
     if (rc != AF_OK) return rc;
+    if (gauss != nullptr) return rc;    // brightness matrices: no zero-pixel / NaN-source column semantics
     // grid-stride sweep; its blocks return at once unless a special column exists
     int64_t fix_blocks = af_cdiv(nrow * nchan * 4, 256);
     if (fix_blocks > 2048) fix_blocks = 2048;
@@ -430,4 +532,15 @@ int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw
                                             nsrc, nsrc_pad, nchan, workspace, st, chi2)
                             : run_all<false>(image, uvw, frequency, lmn, srcbad, tilef, flags, colstate, sign, out, nrow,
                                              nsrc, nsrc_pad, nchan, workspace, st, chi2);
+}
+
+// Gaussian (and point) sources without direction-dependent terms on the same kernels (af_gauss_dft.hip): brightness
+// (nsrc, nchan, 4) complex128 takes the place of a complex image, gauss (nsrc, 4) = (el, em, er, -) in the kernel's
+// frequency units (af_gauss_predict_c128 scales them).  Runs iff flags[0] == flags[1] == 1.
+int af_gauss_mfma_run(const double *brightness, const double *gauss, const double *uvw, const double *frequency,
+                      const double *lmn, const int *srcbad, const double *tilef, const int *flags, int sign, double *out,
+                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st)
+{
+    return run_all<true>(brightness, uvw, frequency, lmn, srcbad, tilef, flags, nullptr, sign, out, nrow, nsrc, nsrc_pad, nchan,
+                         workspace, st, nullptr, gauss);
 }

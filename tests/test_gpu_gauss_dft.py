@@ -42,6 +42,40 @@ def test_uniform_bands(nrow, nchan):
     assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-9 * _scale(d)
 
 
+# bands the MFMA-accumulator form owns (>= 14 channels, one spacing): every tile plan of af_im_to_vis_mfma.hip -- one short
+# 64-channel tile, 16- and 32-channel tails, several full tiles -- and source counts on and off the 4-source step
+@pytest.mark.parametrize("nrow, nchan, nsrc", [(130, 14, 1), (64, 33, 4), (257, 48, 5), (100, 80, 19), (65, 100, 7),
+                                               (70, 130, 8), (1, 96, 3)])
+def test_mfma_form_tile_plans(nrow, nchan, nsrc):
+    d = _problem(35, nrow, nchan, nsrc, 7, with_beam=False)
+    sp = _shapes(nsrc, 8)
+    for conv in ("fourier", "casa"):
+        out = rime.fused_predict_vis(d["time_index"], d["ant1"], d["ant2"], d["lm"], d["uvw"], d["frequency"], d["X"],
+                                     gauss_shape=sp, convention=conv)
+        ref = _chain(d, sp, conv)
+        assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-9 * _scale(d)
+
+
+def test_mfma_form_falling_band_with_an_envelope_that_underflows():
+    """On a falling band the envelope's channel ratio r_0 exceeds 1; where exp(-a nu_0^2) is already 0 it may overflow:
+    0 x inf must not appear."""
+    d = _problem(36, 200, 32, 6, 6, with_beam=False)
+    sp = _shapes(6, 3)
+    sp[1] = [5e-2, 4e-2, 0.7]
+    sp[2] = [2e-3, 1e-3, 2.0]
+    freq = d["frequency"][::-1].copy()
+    dd = dict(d, frequency=freq)
+    out = rime.fused_predict_vis(dd["time_index"], dd["ant1"], dd["ant2"], dd["lm"], dd["uvw"], freq, dd["X"], gauss_shape=sp)
+    assert np.isfinite(out).all()
+    assert np.abs(out - _chain(dd, sp)).max() <= 1e-9 * _scale(dd)
+    # the same band in 8-channel pieces runs the lane = row kernels (fewer than 14 channels): same visibilities
+    for c0 in range(0, 32, 8):
+        part = rime.fused_predict_vis(dd["time_index"], dd["ant1"], dd["ant2"], dd["lm"], dd["uvw"], freq[c0:c0 + 8],
+                                      dd["X"][:, c0:c0 + 8], gauss_shape=sp)
+        assert np.isfinite(part).all()
+        assert np.abs(part - out[:, c0:c0 + 8]).max() <= 1e-9 * _scale(dd)
+
+
 def test_non_uniform_band_descending_band_and_casa():
     d = _problem(32, 400, 21, 15, 6, with_beam=False)
     sp = _shapes(15, 2)
