@@ -73,7 +73,7 @@ PMC_ROUNDS = ("r04", "r03", "r02")    # profiles/<round>_<workload>_pmc_summary.
 NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
                      "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
                                "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
-EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
+EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
 DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
 
 
@@ -87,7 +87,7 @@ def parse(argv=None):
     p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid",
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid",
                                                          "wgrid_f32planes"])
     p.add_argument("--uvw", default="random", choices=["random", "antennas"],
                    help="fused_dde: uvw drawn per row (BASELINE's recipe: not antenna-decomposable, lane-per-row kernel) or "
@@ -297,6 +297,74 @@ class Dft(object):
             "sample_rows": s["rows"], "sample_seconds": s["seconds"],
             "numba_calibration": NUMBA_CALIBRATION,
         }
+
+
+class GaussDft(object):
+    """Gaussian and point sources without DDEs (af_gauss_predict_c128): the reference chain phase_delay x gaussian_shape x
+    brightness summed over sources (africanus/rime/examples/predict.py:107-134, model/shape/gaussian_shape.py:21-62),
+    BASELINE configs[1]'s counts, three sources in four extended."""
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        from codex_africanus_amd.testing import synthetic_inputs
+        self.args, self._lib = args, _lib
+        nrow, nchan, nsrc = args.rows, args.chans, args.sources
+        self.ncorr = 4
+        d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
+        rng = np.random.default_rng(1000 + args.seed + rank)
+        uvw = np.empty((nrow, 3))
+        uvw[:, 0] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 1] = rng.uniform(-4000, 4000, nrow)
+        uvw[:, 2] = rng.uniform(-400, 400, nrow)
+        shapes = np.stack([rng.uniform(0, 3e-4, nsrc), rng.uniform(0, 2e-4, nsrc), rng.uniform(0, np.pi, nsrc)], axis=1)
+        shapes[::4] = 0.0                 # point sources in between
+        self.X = np.ascontiguousarray(np.broadcast_to(d["brightness"][:, None, :], (nsrc, nchan, 4)))
+        self.uvw, self.lm, self.freq, self.shapes = uvw, d["lm"], d["frequency"], shapes
+        self.dv = [t(a) for a in (self.lm, self.uvw, self.freq, self.X, self.shapes)]
+        self.ws_bytes = int(lib.af_gauss_predict_workspace_bytes(nsrc, nchan))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.label = "predict of Gaussian + point sources without DDEs (phase_delay x gaussian_shape x brightness, fused)"
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_gauss_predict_c128", P(v[0]), P(v[1]), P(v[2]), P(v[3]), P(v[4]), a.sources, a.rows, a.chans,
+                       self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws), self.ws_bytes, stream)
+
+    def _chain(self, uvw):
+        import oracle
+        ks = oracle.phase_delay(self.lm, uvw, self.freq) * oracle.gaussian_shape(uvw, self.freq, self.shapes)
+        return np.einsum("srf,sfc->rfc", ks, self.X)
+
+    def reference_rows(self, rows):
+        return self._chain(self.uvw[rows]), rows
+
+    def roofline(self, kernel_s):
+        a = self.args
+        nrow, nchan, nsrc = a.rows, a.chans, a.sources
+        mfma = nchan >= 14
+        # per (row, chan, src): the phasor step (2 FMA), the envelope (e, r and the two products: 4 multiplies) and
+        # four complex x complex MACs (16 FMA)
+        alg_flops = float(nrow) * nchan * nsrc * (2 * 2 + 4 + 16 * 2)
+        alg_bytes = float(nrow) * nchan * 64 + nrow * 24.0 + nsrc * nchan * 64.0
+        return dict(kernel="dft_mfma_kernel<64,true,false,true>" if mfma else "gauss_dft_kernel", bound="mfma",
+                    alg_flops=alg_flops, alg_bytes=alg_bytes, channels_in_kernel=nchan,
+                    note="fp64-pipe bound: 40 flop per (row, chan, src) = phasor recurrence + envelope recurrence + 4 complex MACs")
+
+    def cpu_baseline(self, min_seconds):
+        threads = _threads()
+
+        def single(n):
+            self._chain(self.uvw[:n])
+
+        def parallel(n):
+            return _parallel_rows(lambda lo, hi: self._chain(self.uvw[lo:hi]), n, threads)
+
+        s = sized_cpu_sample(single, parallel, min(self.uvw.shape[0], 4096), threads, min_seconds)
+        nchan = self.freq.shape[0]
+        return {"value": s["rows"] * nchan / s["seconds"] / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
+                "sample": "oracle phase_delay (C) x gaussian_shape x einsum over sources (numpy), %d rows x %d chan x %d src in "
+                          "%.2f s on %d threads" % (s["rows"], nchan, self.lm.shape[0], s["seconds"], threads),
+                "single_thread_value": nchan / s["per_row_s"] / 1e6}
 
 
 class DftF32(object):
@@ -799,7 +867,7 @@ class WgridF32Planes(Wgrid):
         return r
 
 
-WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "fused_dde": FusedDde, "fused_dde_ant": FusedDde, "degrid": Degrid,
+WORKLOADS = {"dft": Dft, "dft_complex": Dft, "dft_f32": DftF32, "gauss": GaussDft, "fused_dde": FusedDde, "fused_dde_ant": FusedDde, "degrid": Degrid,
              "wgrid": Wgrid,
              "wgrid_f32planes": WgridF32Planes}
 METRIC = "Mvis/s (rows x chans) for predict_vis at 1e6 rows/64 ch/1000 src; fp64 max-abs err"

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 fused_dde fused_dde_ant degrid wgrid wgrid_f32planes}"
+WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 gauss fused_dde fused_dde_ant degrid wgrid wgrid_f32planes}"
 T="timeout 900"    # a profiler pass that hangs must not take the box with it
 # the line the driver gets: headline + every other single-GPU workload under "workloads"
 python3 bench.py > "$OUT/default_line.json" 2> "$OUT/default_stderr.log"

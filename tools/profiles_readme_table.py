@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 print("| workload | kernel | bench HIP events | kernel-trace avg | HBM traffic (2 FETCH + WRITE) vs algorithmic | clock | LDS conflict ratio |")
 print("|---|---|---|---|---|---|---|")
-for w in ("dft", "dft_complex", "dft_f32", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes"):
+for w in ("dft", "dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes"):
     ps = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (tag, w))
     pb = os.path.join(ROOT, "profiles", "%s_%s_bench_line.json" % (tag, w))
     if not (os.path.exists(ps) and os.path.exists(pb)):
