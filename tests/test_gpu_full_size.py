@@ -166,6 +166,32 @@ def test_im_to_vis_complex_full_size():
     assert torch.equal(dft.im_to_vis(wl.d_image * 4.0, wl.d_uvw[a:b], wl.d_lm, wl.d_freq), part * 4.0)
 
 
+def test_gaussian_sources_full_size():
+    """configs[1]'s counts with Gaussian + point sources and no DDEs (bench workload `gauss`: the MFMA-accumulator form with
+    the envelope in the phasor): sampled rows vs the oracle chain phase_delay x gaussian_shape x brightness < 1e-8, a row
+    shard equals the same rows of the full call bit for bit, x4 brightness is exact, no envelope -> the complex-image
+    transform of the same sources to rounding."""
+    import torch
+    from codex_africanus_amd import rime
+    wl, vis, args = _workload("gauss")
+    nrow = args.rows
+    rows = np.linspace(0, nrow - 1, 48).astype(np.int64)
+    ref, _ = wl.reference_rows(rows)
+    assert np.abs(_sample(vis, rows) - ref).max() < 1e-8
+    lm, uvw, freq, X, shapes = wl.dv
+    a, b = 123457, 654321
+    idx = torch.zeros(b - a, dtype=torch.int32, device=uvw.device)
+    call = lambda Xd, sh: rime.fused_predict_vis(idx, idx, idx, lm, uvw[a:b], freq, Xd.reshape(args.sources, 64, 2, 2),
+                                                 gauss_shape=sh).reshape(b - a, 64, 4)
+    part = call(X, shapes)
+    assert torch.equal(part, vis[a:b])
+    assert torch.equal(call(X * 4.0, shapes), part * 4.0)
+    points = call(X, torch.zeros_like(shapes))
+    assert bool(torch.isfinite(points.real).all())
+    wl.shapes = np.zeros_like(wl.shapes)      # the oracle chain with point sources only, on a few rows
+    assert np.abs(points[:16].cpu().numpy() - wl._chain(wl.uvw[a:a + 16])).max() < 1e-8
+
+
 def test_wgridder_full_size_c5():
     """configs[4] through the wgridder-shaped entry: 4096^2 image, 1e6 rows x 64 channels, epsilon 1e-5 with
     w-stacking.  Sampled rows against the direct transform of the image's non-zero pixels (CPU oracle) within epsilon;
