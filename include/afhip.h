@@ -347,7 +347,10 @@ int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap,
  * (africanus/rime/examples/predict.py:107-134; africanus/rime/predict.py:229-246), as one direct transform whose phasor
  * carries the envelope (csrc/af_gauss_dft.hip).  lm (nsrc,2), uvw (nrow,3), frequency (nchan), brightness
  * (nsrc,nchan,2,2) complex128, gauss_shape (nsrc,3) = (major, minor, orientation) [rad] or NULL (point sources only);
- * out (nrow,nchan,2,2) complex128.  Any channel spacing (uniform tiles take the recurrences). */
+ * out (nrow,nchan,2,2) complex128.  Any channel spacing: bands of >= 14 channels with one spacing run on the
+ * MFMA-accumulator transform kernels (csrc/af_im_to_vis_mfma.hip, the envelope as a product recurrence in the lane's
+ * phasor), uniform 8-channel tiles of other bands take the same recurrences lane = row, the rest one sincos and one
+ * exponential per channel; which, is decided on the device. */
 size_t af_gauss_predict_workspace_bytes(int64_t nsrc, int64_t nchan);
 int af_gauss_predict_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
                           const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,

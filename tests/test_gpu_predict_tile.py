@@ -85,6 +85,13 @@ def test_apply_gains_and_die_only_calls_on_the_tile_kernel(shape, corrs, monkeyp
     d32 = _case(rng, nrow, nchan, 1, nant, rpt, corrs, dtype=np.complex64, idx=np.int64, offset=3)
     assert_array_equal(rime.apply_gains(d32["ti"], d32["a1"], d32["a2"], d32["die"], d32["bvis"], d32["die"]),
                        oracle.predict_vis(d32["ti"], d32["a1"], d32["a2"], None, None, None, d32["die"], d32["bvis"], d32["die"]))
+    # round 4: such calls (DIE terms + base_vis, 32- or 64-byte cells) run lane = cell with cooperative IO
+    # (apply_dies_coop_kernel); AFHIP_APPLY_COOP=0 sends them to the tile kernel as in round 3, and with
+    # AFHIP_PREDICT_DIE_LDS=0 on top to the per-lane gathers: same bits everywhere
+    monkeypatch.setenv("AFHIP_APPLY_COOP", "0")
+    assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"]), ref)
+    assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], other),
+                       oracle.predict_vis(d["ti"], d["a1"], d["a2"], None, None, None, d["die"], d["bvis"], other))
     monkeypatch.setenv("AFHIP_PREDICT_DIE_LDS", "0")
     assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"]), ref)
 

@@ -21,7 +21,8 @@ ntime = int(ti.max().item()) + 1
 rc = lambda *shape: torch.randn(*shape, dtype=torch.complex128, device=dev)
 vis, die = rc(r, c, 2, 2), rc(ntime, a, c, 2, 2)
 b = 2 * vis.numel() * 16
-for env in ({}, {"AFHIP_APPLY_TILE": "0"}):
+# default: lane = cell with cooperative IO (round 4); AFHIP_APPLY_COOP=0: round 3's LDS-staged tile kernel
+for env in ({}, {"AFHIP_APPLY_COOP": "0"}):
     os.environ.update(env)
     ref = rime.apply_gains(ti, a1, a2, die, vis, die)
     for _ in range(3):
