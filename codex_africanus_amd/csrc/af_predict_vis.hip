@@ -905,16 +905,19 @@ int launch_stream(const PArgs &a)
     return AF_OK;
 }
 
-// ---- DIE terms and base_vis only (apply_gains, predict.py:623-647): lane = one (row, chan) cell, cooperative IO ----
-// out = die1[t, p, nu] . base_vis . die2[t, q, nu]^H.  The two gains of a cell and the cell itself are 32- or 64-byte
-// records: all three arrays (and the result) travel through af_coop_io.h's wave transposes, whole cache lines per
-// instruction.  The arithmetic is predict_vis_kernel's, operation for operation (0 + base_vis, then jones_mul3).
-// Measured at C2's counts (2 x 2 complex128, tools/bench_apply_gains.py, same box): see DESIGN 3.2.
-template <typename T, typename I, int NC, bool J2X2>
-__global__ __launch_bounds__(THREADS) void apply_dies_coop_kernel(
+// ---- calls without DDE terms: lane = one (row, chan) cell, cooperative IO ----------------------------------------
+// out = die1[t, p, nu] . (base_vis + sum_s coh[s]) . die2[t, q, nu]^H  with any of the three parts absent:
+// apply_gains (predict.py:623-647: DIE terms + base_vis) and the plain coherency stream (predict.py:229-246).  The
+// cell, its coherencies and its two gains are 32- or 64-byte records: every array (and the result) travels through
+// af_coop_io.h's wave transposes, whole cache lines per instruction, where the lane-per-record loads of
+// predict_vis_kernel touch 32 quarter-used lines per instruction.  The arithmetic is predict_vis_kernel's, operation for
+// operation (sources ascending from 0, + base_vis, then jones_mul3).  Measured: DESIGN 3.2.
+template <typename T, typename I, int NC, bool J2X2, bool HAVE_COH>
+__global__ __launch_bounds__(THREADS) void predict_cell_coop_kernel(
     const I *__restrict__ time_index, const I *__restrict__ ant1, const I *__restrict__ ant2, int64_t nrow,
-    const T *__restrict__ die1, const T *__restrict__ bvis, const T *__restrict__ die2, int64_t ntime, int64_t nant,
-    int64_t nchan, const long long *__restrict__ tmin_p, int *__restrict__ status, T *__restrict__ out)
+    const T *__restrict__ coh, int64_t nsrc, const T *__restrict__ die1, const T *__restrict__ bvis,
+    const T *__restrict__ die2, int64_t ntime, int64_t nant, int64_t nchan, const long long *__restrict__ tmin_p,
+    int *__restrict__ status, T *__restrict__ out)
 {
     constexpr int U = NC * 2 * (int)sizeof(T) / 16;    // 16-byte units per cell
     static_assert(U == 2 || U == 4, "32- or 64-byte cells");
@@ -924,14 +927,7 @@ __global__ __launch_bounds__(THREADS) void apply_dies_coop_kernel(
     const int64_t cell_raw = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     const bool in_range = cell_raw < ncell;             // out-of-range lanes still take part in the wave's transposes
     const int64_t cell = in_range ? cell_raw : ncell - 1;
-    const int64_t r = cell / nchan, f = cell - r * nchan;
-    int64_t ti = (int64_t)time_index[r] - (int64_t)(*tmin_p), a1 = (int64_t)ant1[r], a2 = (int64_t)ant2[r];
-    const bool bad = guard_indices(ti, a1, a2, ntime, nant, status);
-    double2 u1[U], u2[U], ub[U];
-    coop_gather_units<U>(reinterpret_cast<const double2 *>(die1), (int)((ti * nant + a1) * nchan + f), u1, lds_wave);
-    coop_gather_units<U>(reinterpret_cast<const double2 *>(die2), (int)((ti * nant + a2) * nchan + f), u2, lds_wave);
-    coop_gather_units<U>(reinterpret_cast<const double2 *>(bvis), (int)cell, ub, lds_wave);
-    Cx<T> g1[NC], g2[NC], acc[NC], rr[NC];
+    const bool have_dies = die1 != nullptr;             // kernel-uniform
     auto unpack = [](const double2 (&u)[U], Cx<T> (&j)[NC]) {
         if constexpr (sizeof(T) == 8) {
 #pragma unroll
@@ -946,19 +942,45 @@ __global__ __launch_bounds__(THREADS) void apply_dies_coop_kernel(
             }
         }
     };
-    unpack(u1, g1); unpack(u2, g2); unpack(ub, rr);
+    Cx<T> acc[NC], rr[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {                      // out = 0 + base_vis (predict.py:329-339: -0.0 becomes +0.0 there too)
-        Cx<T> z;
-        z.re = z.im = (T)0;
-        acc[c] = cadd(z, rr[c]);
+    for (int c = 0; c < NC; ++c) acc[c].re = acc[c].im = (T)0;
+    double2 ub[U];
+    if constexpr (HAVE_COH) {
+        // sum over sources, ascending (predict.py:229-246)
+        const double2 *p = reinterpret_cast<const double2 *>(coh);
+        for (int64_t s = 0; s < nsrc; ++s) {
+            coop_gather_units<U>(p + s * ncell * U, (int)cell, ub, lds_wave);
+            unpack(ub, rr);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = cadd(acc[c], rr[c]);
+        }
     }
-    jones_mul3<T, NC, J2X2>(g1, acc, g2, rr);
+    if (bvis != nullptr) {                              // out += base_vis (predict.py:329-339)
+        coop_gather_units<U>(reinterpret_cast<const double2 *>(bvis), (int)cell, ub, lds_wave);
+        unpack(ub, rr);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = cadd(acc[c], rr[c]);
+    }
+    bool bad = false;
+    if (have_dies) {                                    // out = die1 . out . die2^H (predict.py:353-367)
+        const int64_t r = cell / nchan, f = cell - r * nchan;
+        int64_t ti = (int64_t)time_index[r] - (int64_t)(*tmin_p), a1 = (int64_t)ant1[r], a2 = (int64_t)ant2[r];
+        bad = guard_indices(ti, a1, a2, ntime, nant, status);
+        double2 u1[U], u2[U];
+        coop_gather_units<U>(reinterpret_cast<const double2 *>(die1), (int)((ti * nant + a1) * nchan + f), u1, lds_wave);
+        coop_gather_units<U>(reinterpret_cast<const double2 *>(die2), (int)((ti * nant + a2) * nchan + f), u2, lds_wave);
+        Cx<T> g1[NC], g2[NC];
+        unpack(u1, g1); unpack(u2, g2);
+        jones_mul3<T, NC, J2X2>(g1, acc, g2, rr);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = rr[c];
+    }
     const T nan = (T)__builtin_nan("");
     double2 uo[U];
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) uo[c] = make_double2(bad ? nan : rr[c].re, bad ? nan : rr[c].im);
+        for (int c = 0; c < NC; ++c) uo[c] = make_double2(bad ? nan : acc[c].re, bad ? nan : acc[c].im);
     } else {
 #pragma unroll
         for (int c = 0; c < NC; c += 2) {
@@ -966,25 +988,34 @@ __global__ __launch_bounds__(THREADS) void apply_dies_coop_kernel(
                 const unsigned re = __float_as_uint((float)(bad ? nan : v.re)), im = __float_as_uint((float)(bad ? nan : v.im));
                 return __longlong_as_double((long long)(((unsigned long long)im << 32) | re));
             };
-            uo[c / 2] = make_double2(pack(rr[c]), pack(rr[c + 1]));
+            uo[c / 2] = make_double2(pack(acc[c]), pack(acc[c + 1]));
         }
     }
     coop_store_units<U>(reinterpret_cast<double2 *>(out), cell_raw - (threadIdx.x & 63), ncell, uo, lds_wave);
 }
 
+// AF_ENOTSUP: cells that are not 32 or 64 bytes, more than 2^31 cells / gain records, small calls, unaligned arrays
 template <typename T, typename I, int NC, bool J2X2>
-int launch_apply_coop(const PArgs &a)
+int launch_cell_coop(const PArgs &a)
 {
     constexpr int CB = NC * 2 * (int)sizeof(T);        // bytes per cell
     if constexpr (CB != 32 && CB != 64) {
         return AF_ENOTSUP;
     } else {
         const int64_t ncell = a.nrow * a.nchan, ngain = a.ntime * a.nant * a.nchan;
-        if (ncell >= (1LL << 31) || ngain >= (1LL << 31) || ncell < (1LL << 16)) return AF_ENOTSUP;
-        if (((uintptr_t)a.die1 | (uintptr_t)a.die2 | (uintptr_t)a.bvis | (uintptr_t)a.out) & 15) return AF_ENOTSUP;
-        hipLaunchKernelGGL((apply_dies_coop_kernel<T, I, NC, J2X2>), dim3((unsigned)af_cdiv(ncell, THREADS)), dim3(THREADS), 0,
-                           a.st, (const I *)a.time_index, (const I *)a.ant1, (const I *)a.ant2, a.nrow, (const T *)a.die1,
-                           (const T *)a.bvis, (const T *)a.die2, a.ntime, a.nant, a.nchan, a.tmin, a.status, (T *)a.out);
+        if (ncell >= (1LL << 31) / (CB / 16) || ngain >= (1LL << 31) / (CB / 16) || ncell < (1LL << 16)) return AF_ENOTSUP;
+        if (((uintptr_t)a.die1 | (uintptr_t)a.die2 | (uintptr_t)a.bvis | (uintptr_t)a.coh | (uintptr_t)a.out) & 15) return AF_ENOTSUP;
+        const dim3 grid((unsigned)af_cdiv(ncell, THREADS));
+        if (a.coh != nullptr)
+            hipLaunchKernelGGL((predict_cell_coop_kernel<T, I, NC, J2X2, true>), grid, dim3(THREADS), 0, a.st,
+                               (const I *)a.time_index, (const I *)a.ant1, (const I *)a.ant2, a.nrow, (const T *)a.coh, a.nsrc,
+                               (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.ntime, a.nant, a.nchan, a.tmin,
+                               a.status, (T *)a.out);
+        else
+            hipLaunchKernelGGL((predict_cell_coop_kernel<T, I, NC, J2X2, false>), grid, dim3(THREADS), 0, a.st,
+                               (const I *)a.time_index, (const I *)a.ant1, (const I *)a.ant2, a.nrow, (const T *)a.coh, a.nsrc,
+                               (const T *)a.die1, (const T *)a.bvis, (const T *)a.die2, a.ntime, a.nant, a.nchan, a.tmin,
+                               a.status, (T *)a.out);
         AF_LAUNCH_CHECK();
         return AF_OK;
     }
@@ -1046,10 +1077,11 @@ int launch_presence(const PArgs &a)
         }
         if (rc != AF_ENOTSUP) return rc;
     }
-    // apply_gains (predict.py:623-647): DIE terms and base_vis, no sources -- lane per cell with cooperative IO (round 4;
-    // AFHIP_APPLY_COOP=0 falls through to round 3's LDS-staged form below)
-    if (!ddes && !coh && a.die1 != nullptr && a.bvis != nullptr && env_int("AFHIP_APPLY_COOP", 1) != 0) {
-        const int rc = launch_apply_coop<T, I, NC, J2X2>(a);
+    // no DDE terms -- apply_gains (predict.py:623-647: DIE terms + base_vis) and the coherency stream with or without
+    // DIE terms / base_vis: lane per cell with cooperative IO (round 4; AFHIP_APPLY_COOP=0 / AFHIP_PREDICT_COOP=0 fall
+    // through to round 3's forms below)
+    if (!ddes && (coh ? env_int("AFHIP_PREDICT_COOP", 1) != 0 : (a.die1 != nullptr && a.bvis != nullptr && env_int("AFHIP_APPLY_COOP", 1) != 0))) {
+        const int rc = launch_cell_coop<T, I, NC, J2X2>(a);
         if (rc != AF_ENOTSUP) return rc;
     }
     // ... and any other call with DIE terms but neither DDE terms nor coherencies: the tile kernel

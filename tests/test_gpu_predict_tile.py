@@ -96,6 +96,30 @@ def test_apply_gains_and_die_only_calls_on_the_tile_kernel(shape, corrs, monkeyp
     assert_array_equal(rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"]), ref)
 
 
+@pytest.mark.parametrize("corrs", [(2, 2), (2,), (1,)])
+@pytest.mark.parametrize("dtype, idx", [(np.complex128, np.int32), (np.complex64, np.int64)])
+def test_coherency_stream_without_dde_terms_lane_per_cell_cooperative(corrs, dtype, idx, monkeypatch):
+    """Calls without DDE terms (round 4, predict_cell_coop_kernel): the coherency stream summed over sources, with and
+    without base_vis / DIE terms (same and distinct arrays), 32- and 64-byte cells through the wave transposes, 16- and
+    8-byte cells on the lane kernel as before; a row count that leaves the last wave partly empty; bit-equal to the oracle
+    and to round 3's kernels (AFHIP_PREDICT_COOP=0)."""
+    rng = np.random.default_rng(5 + len(corrs))
+    nrow, nchan, nsrc, nant = 1111, 61, 5, 9
+    d = _case(rng, nrow, nchan, nsrc, nant, 36, corrs, dtype=dtype, idx=idx, offset=4)
+    other = d["die"][:, ::-1].copy()
+    combos = ((None, None, None), (None, d["bvis"], None), (d["die"], d["bvis"], d["die"]), (d["die"], None, d["die"]),
+              (d["die"], d["bvis"], other))
+    got = []
+    for die1, bvis, die2 in combos:
+        out = rime.predict_vis(d["ti"], d["a1"], d["a2"], None, d["coh"], None, die1, bvis, die2)
+        assert out.dtype == dtype
+        assert_array_equal(out, oracle.predict_vis(d["ti"], d["a1"], d["a2"], None, d["coh"], None, die1, bvis, die2))
+        got.append(out)
+    monkeypatch.setenv("AFHIP_PREDICT_COOP", "0")
+    for (die1, bvis, die2), out in zip(combos, got):
+        assert_array_equal(rime.predict_vis(d["ti"], d["a1"], d["a2"], None, d["coh"], None, die1, bvis, die2), out)
+
+
 def test_tile_and_lane_kernels_agree_and_distinct_dde_arrays_fall_back(monkeypatch):
     """dde1 is not dde2 (legal, rare): the stage holds ONE array, so the call takes the lane-per-cell kernel; both
     kernels give the oracle's bits.  AFHIP_PREDICT_TILE=0 forces the lane kernel for the A/B."""
