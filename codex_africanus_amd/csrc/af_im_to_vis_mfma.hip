@@ -345,21 +345,23 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
         const double2 *__restrict__ dat = chi_data + cell;
         const double *__restrict__ wgt = chi_weight ? chi_weight + cell : nullptr;
         double *part = smem;                                  // [wave][CT]
+        // channels whose loads are in flight together (8: no change, 21.97 against 21.98 ms; 16: 168 VGPRs, one wave per SIMD)
+        constexpr int CG = 4;
 #pragma unroll
-        for (int g = 0; g < CT / 4; ++g) {
-            double2 d[4], m[4];
-            double wv[4];
+        for (int g = 0; g < CT / CG; ++g) {
+            double2 d[CG], m[CG];
+            double wv[CG];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = 4 * g + k;
+            for (int k = 0; k < CG; ++k) {
+                const int j = CG * g + k;
                 const bool on = j < nvalid && live;
                 m[k] = on ? vis_back[j * 4] : make_double2(0.0, 0.0);
                 d[k] = on ? dat[j * 4] : make_double2(0.0, 0.0);
                 wv[k] = (on && wgt) ? wgt[j * 4] : 1.0;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = 4 * g + k;
+            for (int k = 0; k < CG; ++k) {
+                const int j = CG * g + k;
                 const double dr = d[k].x - m[k].x, di = d[k].y - m[k].y;
                 double a = fma(dr, dr, di * di) * wv[k];
                 a = chi_dpp_add<0xB1>(a);       // quad_perm [1,0,3,2]
