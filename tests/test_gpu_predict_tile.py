@@ -120,6 +120,30 @@ def test_coherency_stream_without_dde_terms_lane_per_cell_cooperative(corrs, dty
         assert_array_equal(rime.predict_vis(d["ti"], d["a1"], d["a2"], None, d["coh"], None, die1, bvis, die2), out)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_calls_without_dde_terms_random_shapes_bit_exact(seed):
+    """Random extents above the 65536-cell threshold of the cooperative lane-per-cell kernel: any subset of
+    {coherencies, DIE terms (one array or two), base_vis}, every correlation layout, both precisions and index types,
+    time indices in any order and offset, last wave partly empty -- bit-equal to the oracle."""
+    rng = np.random.default_rng(900 + seed)
+    nchan = int(rng.integers(17, 90))
+    nrow = int(rng.integers(65536 // nchan + 1, 65536 // nchan + 900))
+    nant, nsrc = int(rng.integers(2, 40)), int(rng.integers(1, 4))
+    corrs = [(2, 2), (2,), (1,)][seed % 3]
+    dtype, idx = [(np.complex128, np.int32), (np.complex64, np.int64)][(seed // 3) % 2]
+    d = _case(rng, nrow, nchan, nsrc, nant, int(rng.integers(20, 500)), corrs, dtype=dtype, idx=idx, sort_time=bool(seed % 2),
+              offset=int(rng.integers(0, 9)))
+    have_coh, have_die, have_bv = bool(seed % 4 != 1), bool(seed % 5 != 0), bool(seed % 2 == 0 or seed % 4 == 1)
+    die2 = d["die"][:, ::-1].copy() if seed % 3 == 1 else d["die"]
+    args = (d["ti"], d["a1"], d["a2"], None, d["coh"] if have_coh else None, None, d["die"] if have_die else None,
+            d["bvis"] if have_bv else None, die2 if have_die else None)
+    if not (have_coh or have_die or have_bv):
+        args = args[:7] + (d["bvis"],) + args[8:]
+    out = rime.predict_vis(*args)
+    assert out.dtype == dtype
+    assert_array_equal(out, oracle.predict_vis(*args))
+
+
 def test_tile_and_lane_kernels_agree_and_distinct_dde_arrays_fall_back(monkeypatch):
     """dde1 is not dde2 (legal, rare): the stage holds ONE array, so the call takes the lane-per-cell kernel; both
     kernels give the oracle's bits.  AFHIP_PREDICT_TILE=0 forces the lane kernel for the A/B."""
