@@ -76,6 +76,25 @@ def test_mfma_form_falling_band_with_an_envelope_that_underflows():
         assert np.abs(part - out[:, c0:c0 + 8]).max() <= 1e-9 * _scale(dd)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes(seed):
+    """random rows / channels / sources, rising and falling bands, both conventions, all-point and all-extended lists"""
+    rng = np.random.default_rng(4000 + seed)
+    nrow, nchan, nsrc = int(rng.integers(1, 400)), int(rng.integers(1, 150)), int(rng.integers(1, 40))
+    d = _problem(40 + seed, nrow, nchan, nsrc, int(rng.integers(3, 9)), with_beam=False)
+    sp = _shapes(nsrc, seed)
+    if seed % 5 == 3:
+        sp[:] = 0.0
+    if seed % 5 == 4:
+        sp[::4] = [1e-4, 5e-5, 1.0]
+    freq = d["frequency"][::-1].copy() if seed % 2 else d["frequency"]
+    dd = dict(d, frequency=freq)
+    conv = ("fourier", "casa")[(seed // 2) % 2]
+    out = rime.fused_predict_vis(dd["time_index"], dd["ant1"], dd["ant2"], dd["lm"], dd["uvw"], freq, dd["X"], gauss_shape=sp,
+                                 convention=conv)
+    assert np.abs(out - _chain(dd, sp, conv)).max() <= 1e-9 * _scale(dd), (nrow, nchan, nsrc)
+
+
 def test_non_uniform_band_descending_band_and_casa():
     d = _problem(32, 400, 21, 15, 6, with_beam=False)
     sp = _shapes(15, 2)
