@@ -269,7 +269,9 @@ class Dft(object):
         return dict(kernel=name, bound="mfma", alg_flops=alg_flops, alg_bytes=float(alg_bytes),
                     channels_in_kernel=dom_chans,
                     note="fp64-pipe bound (MFMA f64 and VALU f64 share one 78.6 TFLOP/s pipe on gfx950), not "
-                         "HBM-bound: nsrc phasors per 64-byte visibility; %d flop per (row, chan, src)" % (2 * fma))
+                         "HBM-bound: nsrc phasors per 64-byte visibility; %d flop per (row, chan, src)" % (2 * fma)
+                         + ("; the kernel time includes the step's chi^2 epilogue (reads the observed data, +0.6 ms at the "
+                            "default shape: the transform alone is 3 % higher in frac)" if getattr(self, "fused_chi2", False) and mfma else ""))
 
     def cpu_baseline(self, min_seconds):
         import oracle
