@@ -494,7 +494,8 @@ def test_beam_cube_dde_reference_kat(g4):
 
 # ---------------------------------------------------------------------------- chi^2
 @pytest.mark.parametrize("shape", [(1237, 13, 4), (4099, 64, 4), (3001, 16, 2), (5003, 8, 1), (2050, 64, 2),
-                                   (70000, 64, 4), (3, 5, 4), (1, 1, 1), (777, 3, 2)])
+                                   (70000, 64, 4), (3, 5, 4), (1, 1, 1), (777, 3, 2),
+                                   (9000, 64, 1), (2100, 256, 1), (1100, 512, 2), (40000, 3, 1), (8200, 64, 3)])
 def test_chi2_against_numpy(shape):
     """af_chi2_c128 has no reference counterpart (parity unpinned): checked against numpy -- the row-block and the
     flat-sweep kernels, 1 / 2 / 4 correlations (the lanes of a channel are added up before the atomics)."""
