@@ -332,6 +332,9 @@ class GaussDft(object):
         self._lib.call("af_gauss_predict_c128", P(v[0]), P(v[1]), P(v[2]), P(v[3]), P(v[4]), a.sources, a.rows, a.chans,
                        self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws), self.ws_bytes, stream)
 
+    # (af_gauss_predict_chi2_c128 -- chi^2 in the kernel's epilogue -- is not used for the step: with 64-channel tiles, one
+    # wave per SIMD, the epilogue costs what the separate pass costs: 48.99 + 0.08 against 47.65 + 1.40 ms)
+
     def _chain(self, uvw):
         import oracle
         ks = oracle.phase_delay(self.lm, uvw, self.freq) * oracle.gaussian_shape(uvw, self.freq, self.shapes)
@@ -1040,7 +1043,7 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         return None
     max_err = check_rows(wl, d_vis, nrow, args.check_rows, dev) if args.check_rows > 0 else None
     res = {
-        "label": wl.label + ("; chi^2 summed in the transform's epilogue (af_im_to_vis_chi2_f64)" if fused_chi2 else ""),
+        "label": wl.label + ("; chi^2 summed in the transform's epilogue (the entry's _chi2 form)" if fused_chi2 else ""),
         "has_chi2": have_chi2, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
         "corrs": ncorr, "fp64_max_abs_err": max_err, "roofline": roofline_entry(wl, wargs, workload, kernel_s),

@@ -32,4 +32,5 @@ int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw
 // the kernels' 1/256-turn frequency units; workspace: af_dft_mfma_workspace_bytes(nsrc_pad, nchan, true, true).
 int af_gauss_mfma_run(const double *brightness, const double *gauss, const double *uvw, const double *frequency,
                       const double *lmn, const int *srcbad, const double *tilef, const int *flags, int sign, double *out,
-                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st);
+                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st,
+                      const AfDftChi2 *chi2 = nullptr);

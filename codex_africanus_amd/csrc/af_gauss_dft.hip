@@ -249,19 +249,26 @@ AF_EXPORT size_t af_gauss_predict_workspace_bytes(int64_t nsrc, int64_t nchan)
 // (africanus/rime/examples/predict.py:107-134 + predict_vis with source_coh only, africanus/rime/predict.py:229-246).
 // lm (nsrc,2), uvw (nrow,3), frequency (nchan), brightness (nsrc,nchan,2,2) complex128, gauss_shape (nsrc,3) =
 // (major, minor, orientation) [rad] or NULL (all point sources); out (nrow,nchan,2,2) complex128.  DEVICE pointers.
-AF_EXPORT int af_gauss_predict_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
-                                    const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
-                                    double *out, void *workspace, size_t workspace_bytes, void *stream)
+int af_chi2_launch(const double *model, const double *data, const double *weight, int64_t nrow, int64_t nchan, int64_t ncorr,
+                   double *chi2_per_chan, const int *skip, hipStream_t st);   // af_chi2.hip
+
+namespace {
+int gauss_predict_impl(const double *lm, const double *uvw, const double *frequency, const double *brightness,
+                       const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention, double *out,
+                       void *workspace, size_t workspace_bytes, void *stream, const AfDftChi2 *chi)
 {
     AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
                "convention not in ('fourier', 'casa')");
     AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && nsrc < (1LL << 31), "af_gauss_predict_c128: bad extents");
     hipStream_t st = af_stream(stream);
-    if (nrow == 0 || nchan == 0) return AF_OK;
+    if (nrow == 0 || nchan == 0) {
+        if (chi && nchan > 0) AF_HIP(hipMemsetAsync(chi->chi2, 0, sizeof(double) * (size_t)nchan, st));
+        return AF_OK;
+    }
     AF_REQUIRE(out != nullptr, "af_gauss_predict_c128: out is NULL");
     if (nsrc == 0) {
         AF_HIP(hipMemsetAsync(out, 0, sizeof(double) * 8 * (size_t)(nrow * nchan), st));
-        return AF_OK;
+        return chi ? af_chi2_launch(out, chi->data, chi->weight, nrow, nchan, 4, chi->chi2, nullptr, st) : AF_OK;
     }
     AF_REQUIRE(lm && uvw && frequency && brightness, "af_gauss_predict_c128: NULL array");
     const GaussWs W = gauss_ws(nsrc, nchan);
@@ -302,8 +309,9 @@ AF_EXPORT int af_gauss_predict_c128(const double *lm, const double *uvw, const d
         AF_HIP(hipMemsetAsync(srcbad, 0, (size_t)nsrc * sizeof(int), st));
         hipLaunchKernelGGL(gauss_band_prep, dim3(1), dim3(256), 0, st, frequency, nchan, convention, mtilef, mf);
         AF_LAUNCH_CHECK();
+        if (chi) AF_HIP(hipMemsetAsync(chi->chi2, 0, sizeof(double) * (size_t)nchan, st));
         const int rc = af_gauss_mfma_run(brightness, gpk, uvw, frequency, lmn, srcbad, mtilef, mf, convention, out, nrow, nsrc,
-                                         af_cdiv(nsrc, 4) * 4, nchan, ws + W.mfma, st);
+                                         af_cdiv(nsrc, 4) * 4, nchan, ws + W.mfma, st, chi);
         if (rc != AF_OK) return rc;
         mflags = mf;
     }
@@ -318,5 +326,32 @@ AF_EXPORT int af_gauss_predict_c128(const double *lm, const double *uvw, const d
                        reinterpret_cast<const double2 *>(brightness), (int)nsrc, nrow, nchan, s4c,
                        reinterpret_cast<double2 *>(out), mflags);
     AF_LAUNCH_CHECK();
+    // chi^2: summed in the MFMA kernels' epilogue when they own the band (device flags (1, 1, 0)), else by the separate pass
+    if (chi) return af_chi2_launch(out, chi->data, chi->weight, nrow, nchan, 4, chi->chi2, mflags, st);
     return AF_OK;
+}
+}  // namespace
+
+AF_EXPORT int af_gauss_predict_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
+                                    const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
+                                    double *out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return gauss_predict_impl(lm, uvw, frequency, brightness, gauss_shape, nsrc, nrow, nchan, convention, out, workspace,
+                              workspace_bytes, stream, nullptr);
+}
+
+// The same predict and  chi2[nu] = sum_{row, corr} [weight] |data - out|^2  (af_chi2_c128's quantity) in one call: the step of
+// the row-sharded predict.  On bands the MFMA-accumulator kernels own, chi^2 is summed in their epilogue
+// (af_im_to_vis_chi2_f64's scheme); elsewhere the call falls back, on the device, to the separate pass.
+AF_EXPORT int af_gauss_predict_chi2_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
+                                         const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
+                                         double *out, const double *data, const double *weight, double *chi2_per_chan,
+                                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    AF_REQUIRE(nchan == 0 || chi2_per_chan != nullptr, "af_gauss_predict_chi2_c128: chi2_per_chan is NULL");
+    AF_REQUIRE(data != nullptr || nrow == 0 || nchan == 0, "af_gauss_predict_chi2_c128: data is NULL");
+    AfDftChi2 chi;
+    chi.data = data; chi.weight = weight; chi.chi2 = chi2_per_chan;
+    return gauss_predict_impl(lm, uvw, frequency, brightness, gauss_shape, nsrc, nrow, nchan, convention, out, workspace,
+                              workspace_bytes, stream, &chi);
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(THREADS) void dft_mfma_kernel(
     const double2 *__restrict__ chi_data = nullptr, const double *__restrict__ chi_weight = nullptr,
     double *__restrict__ chi2 = nullptr, const double *__restrict__ gauss = nullptr)
 {
-    static_assert(!GAUSS || (CPLX && !CHI2), "the Gaussian variant takes brightness matrices");
+    static_assert(!GAUSS || CPLX, "the Gaussian variant takes brightness matrices");
     if (flags[0] != 1 || flags[1] != 1) return;  // one channel spacing for the whole band, decided on the device
     constexpr int STAGE = stage_doubles(CT, CPLX, GAUSS);
     constexpr int HDR = GAUSS ? 32 : 16;          // doubles of the record's header
@@ -457,7 +457,11 @@ int run_tiles(const double *image, const double *uvw, const double *frequency, c
     if (prof) af_prof_begin(st);  // measurement hook: the dominant kernel only
     const dim3 grid((unsigned)af_cdiv(nrow, 64), (unsigned)ntile);
     if constexpr (CPLX) {
-        if (gauss != nullptr)
+        if (gauss != nullptr && chi != nullptr)
+            hipLaunchKernelGGL((dft_mfma_kernel<CT, true, true, true>), grid, dim3(THREADS), 0, st, uvw, rec, f0, tilef, flags,
+                               lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0, reinterpret_cast<const double2 *>(chi->data),
+                               chi->weight, chi->chi2, gauss);
+        else if (gauss != nullptr)
             hipLaunchKernelGGL((dft_mfma_kernel<CT, true, false, true>), grid, dim3(THREADS), 0, st, uvw, rec, f0, tilef, flags,
                                lmn, out, nrow, (int)nsrc, (int)nit, nchan, c0, nullptr, nullptr, nullptr, gauss);
     }
@@ -541,8 +545,9 @@ int af_dft_mfma_run(const double *image, int image_is_complex, const double *uvw
 // frequency units (af_gauss_predict_c128 scales them).  Runs iff flags[0] == flags[1] == 1.
 int af_gauss_mfma_run(const double *brightness, const double *gauss, const double *uvw, const double *frequency,
                       const double *lmn, const int *srcbad, const double *tilef, const int *flags, int sign, double *out,
-                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st)
+                      int64_t nrow, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, void *workspace, hipStream_t st,
+                      const AfDftChi2 *chi2)
 {
     return run_all<true>(brightness, uvw, frequency, lmn, srcbad, tilef, flags, nullptr, sign, out, nrow, nsrc, nsrc_pad, nchan,
-                         workspace, st, nullptr, gauss);
+                         workspace, st, chi2, gauss);
 }

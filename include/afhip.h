@@ -355,6 +355,14 @@ size_t af_gauss_predict_workspace_bytes(int64_t nsrc, int64_t nchan);
 int af_gauss_predict_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
                           const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
                           double *out, void *workspace, size_t workspace_bytes, void *stream);
+/* The same predict and chi2[nu] = sum_{row, corr} [weight] |data - out|^2 (af_chi2_c128's quantity; data (nrow,nchan,2,2)
+ * complex128, weight the same shape real or NULL) in ONE call -- the step of the row-sharded predict, SURVEY 8(e): on bands
+ * the MFMA-accumulator kernels own, chi^2 is summed in their epilogue (as af_im_to_vis_chi2_f64 does); elsewhere the call
+ * falls back, on the device, to the separate pass.  No reference counterpart (parity unpinned: checked against numpy). */
+int af_gauss_predict_chi2_c128(const double *lm, const double *uvw, const double *frequency, const double *brightness,
+                               const double *gauss_shape, int64_t nsrc, int64_t nrow, int64_t nchan, int convention,
+                               double *out, const double *data, const double *weight, double *chi2_per_chan,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- chi-squared ---------------------------------------------------------------
  * chi2_per_chan[nu] = sum_{r,c} weight[r,nu,c] * |data[r,nu,c] - model[r,nu,c]|^2

@@ -183,3 +183,40 @@ def test_through_the_c_abi_and_against_the_beam_route():
     assert float((other - out).abs().max()) <= 1e-9 * _scale(d)
     print("gauss direct %.3f ms, identity-beam route %.3f ms" % (ms_direct, ms_beam))
     assert ms_direct < ms_beam
+
+
+@pytest.mark.parametrize("nrow, nchan, uniform, weighted", [(300, 64, True, False), (1000, 80, True, True), (257, 9, True, True),
+                                                            (400, 21, False, False), (64, 33, True, False)])
+def test_predict_and_chi2_in_one_call(nrow, nchan, uniform, weighted):
+    """af_gauss_predict_chi2_c128: visibilities bit-equal to af_gauss_predict_c128, chi^2 = numpy's sum -- in the MFMA
+    kernels' epilogue (uniform bands of >= 14 channels, every tile plan) and through the separate pass (short and
+    non-uniform bands: the fallback is taken on the device)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nsrc = 13
+    d = _problem(50 + nrow, nrow, nchan, nsrc, 7, with_beam=False)
+    sp = _shapes(nsrc, 11)
+    freq = d["frequency"] if uniform else np.sort(np.random.default_rng(1).uniform(0.9e9, 1.7e9, nchan))
+    rng = np.random.default_rng(2)
+    data = rng.standard_normal((nrow, nchan, 2, 2)) + 1j * rng.standard_normal((nrow, nchan, 2, 2))
+    wgt = rng.random((nrow, nchan, 2, 2)) if weighted else None
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lm, uvw, fr, X, gs, dd, ww = t(d["lm"]), t(d["uvw"]), t(freq), t(d["X"]), t(sp), t(data), t(wgt)
+    lib = _lib.load()
+    nb = int(lib.af_gauss_predict_workspace_bytes(nsrc, nchan))
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+    P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    plain = torch.empty((nrow, nchan, 2, 2), dtype=torch.complex128, device=dev)
+    both = torch.empty_like(plain)
+    chi2 = torch.full((nchan,), -1.0, dtype=torch.float64, device=dev)
+    _lib.call("af_gauss_predict_c128", P(lm), P(uvw), P(fr), P(X), P(gs), nsrc, nrow, nchan, -1, P(plain), P(ws), nb, stream)
+    _lib.call("af_gauss_predict_chi2_c128", P(lm), P(uvw), P(fr), P(X), P(gs), nsrc, nrow, nchan, -1, P(both), P(dd), P(ww),
+              P(chi2), P(ws), nb, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, both)
+    v = both.cpu().numpy()
+    want = ((np.abs(data - v) ** 2) * (1.0 if wgt is None else wgt)).sum(axis=(0, 2, 3))
+    np.testing.assert_allclose(chi2.cpu().numpy(), want, rtol=1e-12)
+    dd2 = dict(d, frequency=freq)
+    assert np.abs(v - _chain(dd2, sp)).max() <= 1e-9 * _scale(dd2)
