@@ -176,6 +176,9 @@ class Dft(object):
         from codex_africanus_amd.testing import synthetic_inputs, real_image
         self.args, self._lib, self.lib = args, _lib, lib
         self.cplx = args.workload == "dft_complex"
+        # chi^2 in the transform's epilogue pays where two waves share a SIMD (real images, 32-channel tiles: +0.6 ms in the
+        # kernel for a 1.5 ms pass); with complex pixels (64-channel tiles, one wave per SIMD) it costs what the pass costs
+        self.chi2_in_epilogue = not self.cplx
         nrow, nchan, nsrc = args.rows, args.chans, args.sources
         self.ncorr = 4
         d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
@@ -987,7 +990,8 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         d_data = d_vis.clone()
         d_data += 0.01
 
-    fused_chi2 = have_chi2 and hasattr(wl, "predict_chi2") and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0"
+    fused_chi2 = (have_chi2 and hasattr(wl, "predict_chi2") and getattr(wl, "chi2_in_epilogue", True)
+                  and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0")
     wl.fused_chi2 = fused_chi2          # the dominant kernel then also reads the data: counted in its algorithmic bytes
 
     def step():
@@ -1398,7 +1402,8 @@ def run_threads(args):
             torch.cuda.synchronize(w.dev)
         workers.append(w)
     ncorr = workers[0].wl.ncorr
-    fused_chi2 = hasattr(workers[0].wl, "predict_chi2") and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0"
+    fused_chi2 = (hasattr(workers[0].wl, "predict_chi2") and getattr(workers[0].wl, "chi2_in_epilogue", True)
+                  and os.environ.get("AFHIP_BENCH_FUSED_CHI2", "1") != "0")
     for w in workers:
         w.wl.fused_chi2 = fused_chi2
     dev0 = workers[0].dev
