@@ -220,8 +220,11 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
     if (pv >= nv) return;
     int64_t iy = pv + ny / 2;                               // pv = (iy - ny/2) mod nv
     iy = iy >= nv ? iy - nv : iy;
+    // the zero band of the row (nv - ny of its nv cells) is written ONCE per call (wg_run's memset): the first transform
+    // runs out of place, S_in -> S, so the band survives from plane to plane and this pass writes the image's cells only
+    if (iy >= ny) return;
     P out = wg_cell<P>(0.0, 0.0);
-    if (iy < ny) {
+    {
         const int64_t j = ix * ny + iy;
         const double v = image != nullptr ? image[j] * A[j] : A[j];    // NULL: wg_geometry has folded the image into A
         double sn, cs;
@@ -238,6 +241,10 @@ __global__ __launch_bounds__(256) void wg_transpose_rows(const P *__restrict__ S
     __shared__ P tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
     const int64_t pu0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
+    {   // a block whose 32 columns are all outside the image has nothing to write (block-uniform)
+        const int64_t lo = nx - nx / 2, hi = nu - nx / 2;          // zero band [lo, hi)
+        if (pu0 >= lo && pu0 + 32 <= hi) return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t pu = pu0 + ty + 8 * j, pv = pv0 + tx;
@@ -249,7 +256,11 @@ __global__ __launch_bounds__(256) void wg_transpose_rows(const P *__restrict__ S
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t pv = pv0 + ty + 8 * j, pu = pu0 + tx;
-        if (pv < nv && pu < nu) G[pv * nu + pu] = tile[tx][ty + 8 * j];
+        int64_t ix = pu + nx / 2;
+        ix = ix >= nu ? ix - nu : ix;
+        // columns that are not rows of the image stay zero: written once per call (wg_run's memset), the second transform
+        // runs out of place from this buffer into the plane
+        if (pv < nv && pu < nu && ix < nx) G[pv * nu + pu] = tile[tx][ty + 8 * j];
     }
 }
 
@@ -1152,7 +1163,7 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, grid, A, nm1, total; int nbins, ntiles, gtiles; };
+struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
 // nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
@@ -1182,6 +1193,8 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.vkr = take((size_t)nvis_max * sizeof(int2));              // (key, rank within the bin) of the one-pass sort
     w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / WG_CHUNK + 1) * sizeof(int2));
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
+    w.stage_in = take((size_t)(nx * nv) * 2 * sizeof(double));   // image -> vis: the first transform's input (zero band kept)
+    w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
@@ -1229,7 +1242,7 @@ void wg_make_poly(int W, double beta, WgPoly &P)
 // enqueues `batch` in-place row transforms of length n on `st` with the plan of (device, n, batch, st); the lock covers
 // the plan table and the enqueue (two host threads that share a stream then enqueue one after the other, and stream
 // order keeps the shared work buffer safe)
-int wg_fft_rows(int n, int batch, void *at, hipStream_t st, bool backward = false, bool single = false)
+int wg_fft_rows(int n, int batch, void *at, hipStream_t st, bool backward = false, bool single = false, void *out = nullptr)
 {
     int dev = 0;
     AF_HIP(hipGetDevice(&dev));
@@ -1258,11 +1271,11 @@ int wg_fft_rows(int n, int batch, void *at, hipStream_t st, bool backward = fals
     it->second.tick = ++g_plan_tick;
     hipfftResult fr;
     if (single) {
-        hipfftComplex *d = reinterpret_cast<hipfftComplex *>(at);
-        fr = hipfftExecC2C(it->second.plan, d, d, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
+        hipfftComplex *d = reinterpret_cast<hipfftComplex *>(at), *o = out ? reinterpret_cast<hipfftComplex *>(out) : d;
+        fr = hipfftExecC2C(it->second.plan, d, o, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
     } else {
-        hipfftDoubleComplex *d = reinterpret_cast<hipfftDoubleComplex *>(at);
-        fr = hipfftExecZ2Z(it->second.plan, d, d, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
+        hipfftDoubleComplex *d = reinterpret_cast<hipfftDoubleComplex *>(at), *o = out ? reinterpret_cast<hipfftDoubleComplex *>(out) : d;
+        fr = hipfftExecZ2Z(it->second.plan, d, o, backward ? HIPFFT_BACKWARD : HIPFFT_FORWARD);
     }
     AF_REQUIRE(fr == HIPFFT_SUCCESS, "af_wgrid: hipFFT failed (%d)", (int)fr);
     return AF_OK;
@@ -1536,6 +1549,17 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     static const int f32_env = getenv("AFHIP_WGRID_F32") ? atoi(getenv("AFHIP_WGRID_F32")) : -1;
     const int xcd_env = getenv("AFHIP_WGRID_XCD") ? atoi(getenv("AFHIP_WGRID_XCD")) : 1;      // read per call (A/B)
     const bool single = !adjoint && kernel_width <= 7 && (f32_env >= 0 ? f32_env != 0 : g_plane_precision == AF_WGRID_PLANES_F32);
+    // image -> vis: the first transform's input lives in its own buffer and the transform runs out of place, so the zero
+    // band of the padded rows (half of every row) is written once per call, not once per plane (wg_fill_rows)
+    double2 *S_in = reinterpret_cast<double2 *>(ws + L.stage_in), *T_in = reinterpret_cast<double2 *>(ws + L.col_in);
+    if (!adjoint && nplanes > 0) {
+        const size_t esz = single ? 8 : 16;
+        // zero bands: cells [ny - ny/2, nv - ny/2) of every row of S_in, cells [nx - nx/2, nu - nx/2) of every row of T_in
+        AF_HIP(hipMemset2DAsync(reinterpret_cast<char *>(S_in) + (size_t)(ny - ny / 2) * esz, (size_t)nv * esz, 0,
+                                (size_t)(nv - ny) * esz, (size_t)nx, st));
+        AF_HIP(hipMemset2DAsync(reinterpret_cast<char *>(T_in) + (size_t)(nx - nx / 2) * esz, (size_t)nu * esz, 0,
+                                (size_t)(nu - nx) * esz, (size_t)nv, st));
+    }
     for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
         for (int k = pk0; k < pk1; ++k) {
@@ -1543,27 +1567,27 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             if (single) {
                 float2 *gk = reinterpret_cast<float2 *>(grid) + (int64_t)(k - pk0) * nu * nv, *Sf = reinterpret_cast<float2 *>(S);
                 hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
-                                   nx, ny, nv, w0 + k * dw, Sf);
+                                   nx, ny, nv, w0 + k * dw, reinterpret_cast<float2 *>(S_in));
                 AF_LAUNCH_CHECK();
-                rc = wg_fft_rows((int)nv, (int)nx, Sf, st, false, true);            // along v, the image's rows only
+                rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, true, Sf);      // along v, the image's rows only: S_in -> S
                 if (rc != AF_OK) return rc;
                 hipLaunchKernelGGL((wg_transpose_rows<float2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)),
-                                   dim3(256), 0, st, Sf, nx, nu, nv, gk);
+                                   dim3(256), 0, st, Sf, nx, nu, nv, reinterpret_cast<float2 *>(T_in));
                 AF_LAUNCH_CHECK();
-                rc = wg_fft_rows((int)nu, (int)nv, gk, st, false, true);            // along u, every column
+                rc = wg_fft_rows((int)nu, (int)nv, T_in, st, false, true, gk);      // along u, every column: T_in -> plane
                 if (rc != AF_OK) return rc;
                 continue;
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
             hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1, nx,
-                               ny, nv, w0 + k * dw, S);
+                               ny, nv, w0 + k * dw, S_in);
             AF_LAUNCH_CHECK();
-            rc = wg_fft_rows((int)nv, (int)nx, S, st);                          // along v, the image's rows only
+            rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, false, S);      // along v, the image's rows only: S_in -> S
             if (rc != AF_OK) return rc;
             hipLaunchKernelGGL((wg_transpose_rows<double2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),
-                               0, st, S, nx, nu, nv, gk);
+                               0, st, S, nx, nu, nv, T_in);
             AF_LAUNCH_CHECK();
-            rc = wg_fft_rows((int)nu, (int)nv, gk, st);                          // along u, every column
+            rc = wg_fft_rows((int)nu, (int)nv, T_in, st, false, false, gk);      // along u, every column: T_in -> plane
             if (rc != AF_OK) return rc;
         }
 #define AF_WG_LAUNCH_P(WC, P)                                                                                          \
