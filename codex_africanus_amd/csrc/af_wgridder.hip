@@ -233,6 +233,16 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
     }
     S[ix * nv + pv] = out;
 }
+// cells [lo, hi) of every one of `rows` rows of `width` cells <- 0 (hipMemset2DAsync does this at 0.8 TB/s)
+template <typename P>
+__global__ __launch_bounds__(256) void wg_zero_band(P *__restrict__ X, int64_t rows, int64_t width, int64_t lo, int64_t hi)
+{
+    const int64_t band = hi - lo, total = rows * band, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / band, c = i - r * band;
+        X[r * width + lo + c] = wg_cell<P>(0.0, 0.0);
+    }
+}
 // G[pv * nu + pu] = S[ix(pu) * nv + pv] (0 where pu is not a row of the image); 32 x 32 tiles through LDS
 template <typename P>
 __global__ __launch_bounds__(256) void wg_transpose_rows(const P *__restrict__ S, int64_t nx, int64_t nu, int64_t nv,
@@ -1553,12 +1563,17 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // band of the padded rows (half of every row) is written once per call, not once per plane (wg_fill_rows)
     double2 *S_in = reinterpret_cast<double2 *>(ws + L.stage_in), *T_in = reinterpret_cast<double2 *>(ws + L.col_in);
     if (!adjoint && nplanes > 0) {
-        const size_t esz = single ? 8 : 16;
         // zero bands: cells [ny - ny/2, nv - ny/2) of every row of S_in, cells [nx - nx/2, nu - nx/2) of every row of T_in
-        AF_HIP(hipMemset2DAsync(reinterpret_cast<char *>(S_in) + (size_t)(ny - ny / 2) * esz, (size_t)nv * esz, 0,
-                                (size_t)(nv - ny) * esz, (size_t)nx, st));
-        AF_HIP(hipMemset2DAsync(reinterpret_cast<char *>(T_in) + (size_t)(nx - nx / 2) * esz, (size_t)nu * esz, 0,
-                                (size_t)(nu - nx) * esz, (size_t)nv, st));
+        if (single) {
+            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(S_in), nx, nv,
+                               ny - ny / 2, nv - ny / 2);
+            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(T_in), nv, nu,
+                               nx - nx / 2, nu - nx / 2);
+        } else {
+            hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, S_in, nx, nv, ny - ny / 2, nv - ny / 2);
+            hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, T_in, nv, nu, nx - nx / 2, nu - nx / 2);
+        }
+        AF_LAUNCH_CHECK();
     }
     for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
