@@ -540,25 +540,39 @@ __global__ __launch_bounds__(256) void wg_sort_spread(int64_t nvis, int S, int C
         if (key >= 0) pairs[atomicAdd(&h[key >> S], 1)] = make_int2((int)i, key);
     }
 }
-__global__ __launch_bounds__(256) void wg_sort_fine(const int2 *__restrict__ pairs, const int *__restrict__ offsets, int S, int C,
-                                                    int NB, int nbins, const int *__restrict__ total, int *__restrict__ start,
-                                                    unsigned *__restrict__ idx)
+// (1024 lanes per coarse bin, four pairs in flight per lane: with 256 lanes and one load per trip the two sweeps over a
+// bin's ~125 000 pairs were load-latency bound, 1.19 ms at configs[4] for 0.8 GB of traffic)
+constexpr int WG_FINE_T = 1024;
+__global__ __launch_bounds__(WG_FINE_T) void wg_sort_fine(const int2 *__restrict__ pairs, const int *__restrict__ offsets, int S, int C,
+                                                          int NB, int nbins, const int *__restrict__ total, int *__restrict__ start,
+                                                          unsigned *__restrict__ idx)
 {
-    extern __shared__ int h[];                           // F counters, then the block scan's partial sums
-    __shared__ int part[256];
+    constexpr int NT = WG_FINE_T;
+    extern __shared__ int h[];                           // F counters
+    __shared__ int part[NT];                             // the block scan's partial sums
     const int F = 1 << S, c = blockIdx.x, tid = threadIdx.x;
     const int lo = offsets[(int64_t)c * NB], hi = c + 1 < C ? offsets[(int64_t)(c + 1) * NB] : *total;
-    for (int f = tid; f < F; f += 256) h[f] = 0;
+    for (int f = tid; f < F; f += NT) h[f] = 0;
     __syncthreads();
-    for (int e = lo + tid; e < hi; e += 256) atomicAdd(&h[pairs[e].y & (F - 1)], 1);
+    {
+        int e = lo + tid;
+        for (; e + 3 * NT < hi; e += 4 * NT) {
+            int k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = pairs[e + u * NT].y;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&h[k[u] & (F - 1)], 1);
+        }
+        for (; e < hi; e += NT) atomicAdd(&h[pairs[e].y & (F - 1)], 1);
+    }
     __syncthreads();
     // exclusive scan of h: every lane owns a run of consecutive fine keys
-    const int per = (F + 255) / 256, f0 = tid * per, f1 = f0 + per < F ? f0 + per : F;
+    const int per = (F + NT - 1) / NT, f0 = tid * per < F ? tid * per : F, f1 = f0 + per < F ? f0 + per : F;
     int sum = 0;
     for (int f = f0; f < f1; ++f) sum += h[f];
     part[tid] = sum;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
+    for (int off = 1; off < NT; off <<= 1) {
         const int a = tid >= off ? part[tid - off] : 0;
         __syncthreads();
         part[tid] += a;
@@ -574,9 +588,19 @@ __global__ __launch_bounds__(256) void wg_sort_fine(const int2 *__restrict__ pai
     }
     if (c == C - 1 && tid == 0) start[nbins] = *total;
     __syncthreads();
-    for (int e = lo + tid; e < hi; e += 256) {
-        const int2 p = pairs[e];
-        idx[lo + atomicAdd(&h[p.y & (F - 1)], 1)] = (unsigned)p.x;
+    {
+        int e = lo + tid;
+        for (; e + 3 * NT < hi; e += 4 * NT) {
+            int2 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = pairs[e + u * NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) idx[lo + atomicAdd(&h[p[u].y & (F - 1)], 1)] = (unsigned)p[u].x;
+        }
+        for (; e < hi; e += NT) {
+            const int2 p = pairs[e];
+            idx[lo + atomicAdd(&h[p.y & (F - 1)], 1)] = (unsigned)p.x;
+        }
     }
 }
 
@@ -1458,7 +1482,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             hipLaunchKernelGGL(wg_sort_spread, dim3((unsigned)NB), dim3(256), (size_t)C * sizeof(int), st, nvis, S, C, NB, keys,
                                offs, keyrank);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_sort_fine, dim3((unsigned)C), dim3(256), (size_t)(1 << S) * sizeof(int), st, keyrank, offs, S, C,
+            hipLaunchKernelGGL(wg_sort_fine, dim3((unsigned)C), dim3(WG_FINE_T), (size_t)(1 << S) * sizeof(int), st, keyrank, offs, S, C,
                                NB, nbins, offs + hn, vstart, reinterpret_cast<unsigned *>(ws + L.vidx));
             AF_LAUNCH_CHECK();
             hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
