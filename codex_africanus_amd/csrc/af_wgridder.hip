@@ -793,7 +793,8 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         __syncthreads();
     }
     if (k0 < k1) {
-        double2 acc = vis[o];
+        // the first plane batch adds to the zeros the call has just written: no need to read them back (scattered 16-byte reads)
+        double2 acc = pk0 == 0 ? make_double2(0.0, 0.0) : vis[o];
         acc.x += are;
         acc.y += aim;
         vis[o] = acc;
@@ -1424,7 +1425,8 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     AF_LAUNCH_CHECK();
     // the band's columns start from zero
     if (!adjoint)
-        AF_HIP(hipMemset2DAsync(vis + 2 * chan0, (size_t)nchan_total * 16, 0, (size_t)nchan_band * 16, (size_t)nrow, st));
+        hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<double2 *>(vis), nrow, nchan_total,
+                           chan0, chan0 + nchan_band);
     const int *perm = nullptr;
     // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
