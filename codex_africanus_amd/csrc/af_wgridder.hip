@@ -233,6 +233,132 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
     }
     S[ix * nv + pv] = out;
 }
+// ---- fill + first row transform in one kernel (image -> vis, fp64 planes, ny = 8^L, nv = 2 ny) ------------------------
+// Row ix of the padded plane holds the image row's ny cells at pv = (iy - ny/2) mod nv and zeros elsewhere.  With
+// M = ny, N = 2 M and s[j] = the cell of iy = j:
+//     X[k] = sum_j s[j] W_N^((j - M/2) k) = (-i)^(-k) ... = i^k Spad[k],   W_N = exp(-2 pi i / N),
+// (W_N^(-M k / 2) = exp(+i pi k / 2) = i^k) and the transform of the zero-padded s splits, decimation in frequency with the
+// upper half identically zero, into two M-point transforms without a single addition:
+//     Spad[2 q] = FFT_M(s)[q],      Spad[2 q + 1] = FFT_M(s . tw)[q],   tw[j] = W_N^j.
+// One workgroup per image row: the row's cells are evaluated into LDS (what wg_fill_rows wrote to memory and hipFFT
+// read back, zeros included), lanes [0, M/8) run FFT_M(s), lanes [M/8, M/4) FFT_M(s tw) -- Stockham radix 8, the eight
+// values of a butterfly in registers across the barrier between a pass's reads and its writes, LDS padded by one cell in
+// eight so that the stride-8 writes of the first pass are conflict free -- and the interleaved result goes out in natural
+// order, coalesced.  Twiddles: W_N^k from a table the call builds once (128 KB, L2 resident), powers by products.
+struct WgC { double x, y; };
+__device__ __forceinline__ WgC wg_cmul(WgC a, WgC b) { return WgC{fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)}; }
+__device__ __forceinline__ WgC wg_cadd(WgC a, WgC b) { return WgC{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ WgC wg_csub(WgC a, WgC b) { return WgC{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ WgC wg_mul_mi(WgC a) { return WgC{a.y, -a.x}; }     // a * (-i)
+// forward DFT of 8 values in place: u[k] <- sum_n u[n] exp(-2 pi i n k / 8)
+__device__ __forceinline__ void wg_dft8(WgC (&u)[8])
+{
+    const double h = 0.70710678118654752440;
+    WgC a0 = wg_cadd(u[0], u[4]), a1 = wg_cadd(u[1], u[5]), a2 = wg_cadd(u[2], u[6]), a3 = wg_cadd(u[3], u[7]);
+    WgC b0 = wg_csub(u[0], u[4]), b1 = wg_csub(u[1], u[5]), b2 = wg_csub(u[2], u[6]), b3 = wg_csub(u[3], u[7]);
+    b1 = WgC{(b1.x + b1.y) * h, (b1.y - b1.x) * h};        // * W8
+    b2 = wg_mul_mi(b2);                                     // * W8^2 = -i
+    b3 = WgC{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};       // * W8^3
+    {
+        const WgC s0 = wg_cadd(a0, a2), s1 = wg_csub(a0, a2), s2 = wg_cadd(a1, a3), s3 = wg_mul_mi(wg_csub(a1, a3));
+        u[0] = wg_cadd(s0, s2); u[4] = wg_csub(s0, s2); u[2] = wg_cadd(s1, s3); u[6] = wg_csub(s1, s3);
+    }
+    {
+        const WgC s0 = wg_cadd(b0, b2), s1 = wg_csub(b0, b2), s2 = wg_cadd(b1, b3), s3 = wg_mul_mi(wg_csub(b1, b3));
+        u[1] = wg_cadd(s0, s2); u[5] = wg_csub(s0, s2); u[3] = wg_cadd(s1, s3); u[7] = wg_csub(s1, s3);
+    }
+}
+__global__ void wg_twiddle_table(int64_t N, double2 *__restrict__ tw)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)N, &sn, &cs);
+    tw[k] = make_double2(cs, sn);
+}
+__host__ __device__ constexpr int wg_pad(int a) { return a + (a >> 3); }     // LDS cell of logical cell a
+template <int LOG8>
+__global__ __launch_bounds__(2 << (3 * LOG8 - 3)) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
+                                                                       int64_t ny, double wk, const double2 *__restrict__ tw,
+                                                                       double2 *__restrict__ S)
+{
+    constexpr int M = 1 << (3 * LOG8), N = 2 * M, Q = M / 8, NT = 2 * Q;
+    constexpr int HB = wg_pad(M) + 8;                       // LDS cells between the two halves (+ 8: the halves' banks interleave)
+    extern __shared__ double2 cells[];
+    const int t = threadIdx.x, hf = t / Q, tt = t - hf * Q;
+    const int64_t ix = blockIdx.x;
+    // phase 0: the row's M cells, image(x A) x exp(2 pi i w_k (n - 1))
+#pragma unroll
+    for (int k = 0; k < M / NT; ++k) {
+        const int j = t + k * NT;
+        const int64_t px = ix * ny + j;
+        double sn, cs;
+        sincospi(2.0 * (wk * nm1[px]), &sn, &cs);
+        const double v = A[px];
+        cells[wg_pad(j)] = make_double2(v * cs, v * sn);
+    }
+    __syncthreads();
+    WgC u[8];
+    // pass 0 (Ns = 1): both halves read s; the upper half multiplies by W_N^j first
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double2 c = cells[wg_pad(tt + j * Q)];
+        u[j] = WgC{c.x, c.y};
+    }
+    if (hf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 w = tw[tt + j * Q];
+            u[j] = wg_cmul(u[j], WgC{w.x, w.y});
+        }
+    }
+    wg_dft8(u);
+    __syncthreads();
+    {
+        double2 *o = cells + hf * HB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[wg_pad(tt * 8 + j)] = make_double2(u[j].x, u[j].y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 1; p < LOG8; ++p) {
+        const int Ns = 1 << (3 * p), r = tt & (Ns - 1);
+        double2 *o = cells + hf * HB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double2 c = o[wg_pad(tt + j * Q)];
+            u[j] = WgC{c.x, c.y};
+        }
+        {   // twiddles exp(-2 pi i r j / (8 Ns)) = W_N^(r j N / (8 Ns)): the first from the table, the powers by products
+            const double2 w = tw[r * (N / (8 * Ns))];
+            const WgC w1{w.x, w.y}, w2 = wg_cmul(w1, w1), w3 = wg_cmul(w1, w2), w4 = wg_cmul(w2, w2);
+            u[1] = wg_cmul(u[1], w1); u[2] = wg_cmul(u[2], w2); u[3] = wg_cmul(u[3], w3); u[4] = wg_cmul(u[4], w4);
+            u[5] = wg_cmul(u[5], wg_cmul(w2, w3)); u[6] = wg_cmul(u[6], wg_cmul(w3, w3)); u[7] = wg_cmul(u[7], wg_cmul(w3, w4));
+        }
+        wg_dft8(u);
+        __syncthreads();
+        const int base = (tt - r) * 8 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[wg_pad(base + j * Ns)] = make_double2(u[j].x, u[j].y);
+        __syncthreads();
+    }
+    // X[k] = i^k Spad[k],  Spad[2 q + b] = Y_b[q]: natural order, coalesced
+    double2 *__restrict__ out = S + ix * (int64_t)N;
+#pragma unroll
+    for (int m = 0; m < N / NT; ++m) {
+        const int k = t + m * NT, q = k >> 1, b = k & 1;
+        const double2 y = cells[b * HB + wg_pad(q)];
+        double2 x;
+        switch (k & 3) {             // i^k
+        case 0: x = y; break;
+        case 1: x = make_double2(-y.y, y.x); break;
+        case 2: x = make_double2(-y.x, -y.y); break;
+        default: x = make_double2(y.y, -y.x); break;
+        }
+        out[k] = x;
+    }
+}
+
 // cells [lo, hi) of every one of `rows` rows of `width` cells <- 0 (hipMemset2DAsync does this at 0.8 TB/s)
 template <typename P>
 __global__ __launch_bounds__(256) void wg_zero_band(P *__restrict__ X, int64_t rows, int64_t width, int64_t lo, int64_t hi)
@@ -1198,7 +1324,7 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, grid, A, nm1, total; int nbins, ntiles, gtiles; };
+struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
 // nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
@@ -1230,6 +1356,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.stage_in = take((size_t)(nx * nv) * 2 * sizeof(double));   // image -> vis: the first transform's input (zero band kept)
     w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
+    w.tw = take((size_t)nv * 2 * sizeof(double));                // W_nv^k of the fused fill + first transform
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
@@ -1601,6 +1728,21 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         }
         AF_LAUNCH_CHECK();
     }
+    // fp64 planes of 512- or 4096-pixel rows: fill and first transform in ONE kernel (wg_fill_fft_rows; AFHIP_WGRID_FFT1=0:
+    // wg_fill_rows + hipFFT as for every other size)
+    int fused_first = 0;
+    size_t fused_lds = 0;
+    const double2 *twid = reinterpret_cast<const double2 *>(ws + L.tw);
+    if (!adjoint && !single && nv == 2 * ny && (ny == 512 || ny == 4096) &&
+        !(getenv("AFHIP_WGRID_FFT1") && atoi(getenv("AFHIP_WGRID_FFT1")) == 0)) {
+        fused_first = ny == 4096 ? 4 : 3;
+        fused_lds = (size_t)2 * (wg_pad((int)ny) + 8) * sizeof(double2);
+        if (fused_first == 4)
+            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)fused_lds));
+        hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nv, 256)), dim3(256), 0, st, nv, reinterpret_cast<double2 *>(ws + L.tw));
+        AF_LAUNCH_CHECK();
+    }
     for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
         const int pk1 = pk0 + resident < nplanes ? pk0 + (int)resident : nplanes;
         for (int k = pk0; k < pk1; ++k) {
@@ -1620,11 +1762,19 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 continue;
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
-            hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1, nx,
-                               ny, nv, w0 + k * dw, S_in);
-            AF_LAUNCH_CHECK();
-            rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, false, S);      // along v, the image's rows only: S_in -> S
-            if (rc != AF_OK) return rc;
+            if (fused_first == 4) {
+                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(1024), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                AF_LAUNCH_CHECK();
+            } else if (fused_first == 3) {
+                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(128), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                AF_LAUNCH_CHECK();
+            } else {
+                hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
+                                   nx, ny, nv, w0 + k * dw, S_in);
+                AF_LAUNCH_CHECK();
+                rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, false, S);  // along v, the image's rows only: S_in -> S
+                if (rc != AF_OK) return rc;
+            }
             hipLaunchKernelGGL((wg_transpose_rows<double2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),
                                0, st, S, nx, nu, nv, T_in);
             AF_LAUNCH_CHECK();

@@ -403,3 +403,24 @@ def test_model_with_caller_supplied_w_bounds_and_epsilon_floor():
         model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-16)
     with pytest.raises(ValueError):
         model(uvw, freq, image, fbi, fbc, cell, w_bounds=(1.0, -1.0))
+
+
+@pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512)])
+def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypatch):
+    """fp64 planes of 512- (and 4096-: tests/test_gpu_full_size.py) pixel rows: the fill pass and the transform along v in
+    one kernel (wg_fill_fft_rows: two half-length Stockham transforms of the row, no zero ever stored).  Same visibilities
+    as wg_fill_rows + hipFFT to rounding, and the accuracy contract against the direct transform on a sparse image."""
+    nrow, nchan = 3000, 3
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.0, nrow, nchan, 1, seed=11)
+    image[0][np.random.default_rng(1).random((nx, ny)) < 0.97] = 0.0        # sparse: the direct transform stays cheap
+    monkeypatch.setenv("AFHIP_WGRID_FFT1", "0")
+    ref = model(uvw, freq, image, fbi, fbc, cell, celly=cell * 0.9, epsilon=1e-7)
+    monkeypatch.delenv("AFHIP_WGRID_FFT1")
+    vis = model(uvw, freq, image, fbi, fbc, cell, celly=cell * 0.9, epsilon=1e-7)
+    assert np.abs(vis - ref).max() <= 1e-12 * np.abs(ref).max()
+    nz = np.nonzero(image[0])
+    x, y = (nz[0] - nx / 2) * cell, (nz[1] - ny / 2) * cell * 0.9
+    n = np.sqrt(1.0 - x * x - y * y)
+    src = np.broadcast_to((image[0][nz] / n)[:, None, None], (x.size, nchan, 1)).copy()
+    direct = oracle.im_to_vis(src, uvw * np.array([1.0, 1.0, -1.0]), np.stack([x, y], 1), freq, omp=True)[:, :, 0]
+    assert _l2error(vis, direct) <= 1e-7
