@@ -240,11 +240,10 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
 // (W_N^(-M k / 2) = exp(+i pi k / 2) = i^k) and the transform of the zero-padded s splits, decimation in frequency with the
 // upper half identically zero, into two M-point transforms without a single addition:
 //     Spad[2 q] = FFT_M(s)[q],      Spad[2 q + 1] = FFT_M(s . tw)[q],   tw[j] = W_N^j.
-// One workgroup per image row: the row's cells are evaluated into LDS (what wg_fill_rows wrote to memory and hipFFT
-// read back, zeros included), lanes [0, M/8) run FFT_M(s), lanes [M/8, M/4) FFT_M(s tw) -- Stockham radix 8, the eight
-// values of a butterfly in registers across the barrier between a pass's reads and its writes, LDS padded by one cell in
-// eight so that the stride-8 writes of the first pass are conflict free -- and the interleaved result goes out in natural
-// order, coalesced.  Twiddles: W_N^k from a table the call builds once (128 KB, L2 resident), powers by products.
+// One workgroup per image row, Stockham radix 8, the eight values of a butterfly in registers across the barrier between a
+// pass's reads and its writes, LDS padded by one cell in eight so that the stride-8 writes of the first pass are conflict
+// free; nothing wg_fill_rows wrote to memory and hipFFT read back (zeros included) exists any more.  Twiddles: W_N^k from a
+// table the call builds once (128 KB, L2 resident), powers by products.
 struct WgC { double x, y; };
 __device__ __forceinline__ WgC wg_cmul(WgC a, WgC b) { return WgC{fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)}; }
 __device__ __forceinline__ WgC wg_cadd(WgC a, WgC b) { return WgC{a.x + b.x, a.y + b.y}; }
@@ -277,85 +276,91 @@ __global__ void wg_twiddle_table(int64_t N, double2 *__restrict__ tw)
     tw[k] = make_double2(cs, sn);
 }
 __host__ __device__ constexpr int wg_pad(int a) { return a + (a >> 3); }     // LDS cell of logical cell a
-template <int LOG8>
-__global__ __launch_bounds__(2 << (3 * LOG8 - 3)) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
+// FROM_CELLS: the row's M cells are read from `src` (row-major, M cells per row: the compact transposition of the first
+// transform's output) instead of being evaluated from the image -- the SECOND row transform, whose input rows have the
+// same shape (the image's nx columns at pu = (ix - nx/2) mod nu, zeros between).
+// M / 8 lanes per row, the two half transforms one after the other: a lane's eight first-pass inputs come straight from
+// memory (kept in registers for the second half), its eight last-pass outputs go straight to memory (cells 2 q + half: the
+// two halves complete each other's cache lines in L2), so only the L - 1 exchanges between passes go through LDS --
+// 74 KB for M = 4096, TWO workgroups per CU (with both halves side by side, 148 KB and one workgroup per CU, the kernel
+// only matched hipFFT on the second transform).
+template <int LOG8, bool FROM_CELLS = false>
+__global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
                                                                        int64_t ny, double wk, const double2 *__restrict__ tw,
-                                                                       double2 *__restrict__ S)
+                                                                       double2 *__restrict__ S,
+                                                                       const double2 *__restrict__ src = nullptr)
 {
-    constexpr int M = 1 << (3 * LOG8), N = 2 * M, Q = M / 8, NT = 2 * Q;
-    constexpr int HB = wg_pad(M) + 8;                       // LDS cells between the two halves (+ 8: the halves' banks interleave)
-    extern __shared__ double2 cells[];
-    const int t = threadIdx.x, hf = t / Q, tt = t - hf * Q;
+    constexpr int M = 1 << (3 * LOG8), N = 2 * M, Q = M / 8;
+    extern __shared__ double2 cells[];                      // wg_pad(M) cells
+    const int tt = threadIdx.x;
     const int64_t ix = blockIdx.x;
-    // phase 0: the row's M cells, image(x A) x exp(2 pi i w_k (n - 1))
-#pragma unroll
-    for (int k = 0; k < M / NT; ++k) {
-        const int j = t + k * NT;
-        const int64_t px = ix * ny + j;
-        double sn, cs;
-        sincospi(2.0 * (wk * nm1[px]), &sn, &cs);
-        const double v = A[px];
-        cells[wg_pad(j)] = make_double2(v * cs, v * sn);
-    }
-    __syncthreads();
-    WgC u[8];
-    // pass 0 (Ns = 1): both halves read s; the upper half multiplies by W_N^j first
+    WgC ya[8], yb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const double2 c = cells[wg_pad(tt + j * Q)];
-        u[j] = WgC{c.x, c.y};
-    }
-    if (hf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double2 w = tw[tt + j * Q];
-            u[j] = wg_cmul(u[j], WgC{w.x, w.y});
+        const int n = tt + j * Q;
+        if constexpr (FROM_CELLS) {
+            const double2 c = src[ix * (int64_t)M + n];
+            ya[j] = WgC{c.x, c.y};
+        } else {
+            const int64_t px = ix * ny + n;
+            double sn, cs;
+            sincospi(2.0 * (wk * nm1[px]), &sn, &cs);
+            const double v = A[px];
+            ya[j] = WgC{v * cs, v * sn};
         }
+        const double2 w = tw[n];                            // the upper half transforms s . W_N^n
+        yb[j] = wg_cmul(ya[j], WgC{w.x, w.y});
     }
-    wg_dft8(u);
-    __syncthreads();
-    {
-        double2 *o = cells + hf * HB;
+    // one half transform: u = the eight first-pass inputs of this lane on entry, Y[tt + j Q] on return
+    auto half = [&](WgC (&u)[8], bool wait_first) {
+        wg_dft8(u);                                         // pass 0 (Ns = 1): no twiddles
+        if (wait_first) __syncthreads();                    // the previous half's last LDS reads are done
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[wg_pad(tt * 8 + j)] = make_double2(u[j].x, u[j].y);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 1; p < LOG8; ++p) {
-        const int Ns = 1 << (3 * p), r = tt & (Ns - 1);
-        double2 *o = cells + hf * HB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double2 c = o[wg_pad(tt + j * Q)];
-            u[j] = WgC{c.x, c.y};
-        }
-        {   // twiddles exp(-2 pi i r j / (8 Ns)) = W_N^(r j N / (8 Ns)): the first from the table, the powers by products
-            const double2 w = tw[r * (N / (8 * Ns))];
-            const WgC w1{w.x, w.y}, w2 = wg_cmul(w1, w1), w3 = wg_cmul(w1, w2), w4 = wg_cmul(w2, w2);
-            u[1] = wg_cmul(u[1], w1); u[2] = wg_cmul(u[2], w2); u[3] = wg_cmul(u[3], w3); u[4] = wg_cmul(u[4], w4);
-            u[5] = wg_cmul(u[5], wg_cmul(w2, w3)); u[6] = wg_cmul(u[6], wg_cmul(w3, w3)); u[7] = wg_cmul(u[7], wg_cmul(w3, w4));
-        }
-        wg_dft8(u);
+        for (int j = 0; j < 8; ++j) cells[wg_pad(tt * 8 + j)] = make_double2(u[j].x, u[j].y);
         __syncthreads();
-        const int base = (tt - r) * 8 + r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[wg_pad(base + j * Ns)] = make_double2(u[j].x, u[j].y);
-        __syncthreads();
-    }
-    // X[k] = i^k Spad[k],  Spad[2 q + b] = Y_b[q]: natural order, coalesced
+        for (int p = 1; p < LOG8; ++p) {
+            const int Ns = 1 << (3 * p), r = tt & (Ns - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double2 c = cells[wg_pad(tt + j * Q)];
+                u[j] = WgC{c.x, c.y};
+            }
+            {   // twiddles exp(-2 pi i r j / (8 Ns)) = W_N^(r j N / (8 Ns)): the first from the table, the powers by products
+                const double2 w = tw[r * (N / (8 * Ns))];
+                const WgC w1{w.x, w.y}, w2 = wg_cmul(w1, w1), w3 = wg_cmul(w1, w2), w4 = wg_cmul(w2, w2);
+                u[1] = wg_cmul(u[1], w1); u[2] = wg_cmul(u[2], w2); u[3] = wg_cmul(u[3], w3); u[4] = wg_cmul(u[4], w4);
+                u[5] = wg_cmul(u[5], wg_cmul(w2, w3)); u[6] = wg_cmul(u[6], wg_cmul(w3, w3)); u[7] = wg_cmul(u[7], wg_cmul(w3, w4));
+            }
+            wg_dft8(u);
+            if (p + 1 < LOG8) {
+                __syncthreads();
+                const int base = (tt - r) * 8 + r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cells[wg_pad(base + j * Ns)] = make_double2(u[j].x, u[j].y);
+                __syncthreads();
+            }
+        }
+    };
+    half(ya, false);
+    half(yb, true);
+    // X[k] = i^k Spad[k],  Spad[2 q] = Y_a[q], Spad[2 q + 1] = Y_b[q], q = tt + j Q: a lane stores 32 contiguous bytes per j
+    // (both halves of a cache line leave together: with the halves' stores microseconds apart the lines left L2 half
+    // written)
     double2 *__restrict__ out = S + ix * (int64_t)N;
 #pragma unroll
-    for (int m = 0; m < N / NT; ++m) {
-        const int k = t + m * NT, q = k >> 1, b = k & 1;
-        const double2 y = cells[b * HB + wg_pad(q)];
-        double2 x;
-        switch (k & 3) {             // i^k
-        case 0: x = y; break;
-        case 1: x = make_double2(-y.y, y.x); break;
-        case 2: x = make_double2(-y.x, -y.y); break;
-        default: x = make_double2(y.y, -y.x); break;
+    for (int j = 0; j < 8; ++j) {
+        const int q = tt + j * Q;
+        double2 x0, x1;
+        if (q & 1) {                                        // k = 2 q: i^k = -1;  k + 1: i^k = -i
+            x0 = make_double2(-ya[j].x, -ya[j].y);
+            x1 = make_double2(yb[j].y, -yb[j].x);
+        } else {                                            // k = 2 q: i^k = 1;   k + 1: i^k = i
+            x0 = make_double2(ya[j].x, ya[j].y);
+            x1 = make_double2(-yb[j].y, yb[j].x);
         }
-        out[k] = x;
+        out[2 * q] = x0;
+        out[2 * q + 1] = x1;
     }
 }
 
@@ -367,6 +372,25 @@ __global__ __launch_bounds__(256) void wg_zero_band(P *__restrict__ X, int64_t r
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t r = i / band, c = i - r * band;
         X[r * width + lo + c] = wg_cell<P>(0.0, 0.0);
+    }
+}
+// T[pv * nx + ix] = S[ix * nv + pv]: the plain transposition of the first transform's output, compact (the second
+// transform's fused kernel places the columns itself); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void wg_transpose_compact(const double2 *__restrict__ S, int64_t nx, int64_t nv, double2 *__restrict__ T)
+{
+    __shared__ double2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
+    const int64_t ix0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ix = ix0 + ty + 8 * j, pv = pv0 + tx;
+        if (ix < nx && pv < nv) tile[ty + 8 * j][tx] = S[ix * nv + pv];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t pv = pv0 + ty + 8 * j, ix = ix0 + tx;
+        if (pv < nv && ix < nx) T[pv * nx + ix] = tile[tx][ty + 8 * j];
     }
 }
 // G[pv * nu + pu] = S[ix(pu) * nv + pv] (0 where pu is not a row of the image); 32 x 32 tiles through LDS
@@ -1324,7 +1348,7 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, grid, A, nm1, total; int nbins, ntiles, gtiles; };
+struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, tw2, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
 // nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
@@ -1357,6 +1381,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.stage_in = take((size_t)(nx * nv) * 2 * sizeof(double));   // image -> vis: the first transform's input (zero band kept)
     w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
     w.tw = take((size_t)nv * 2 * sizeof(double));                // W_nv^k of the fused fill + first transform
+    w.tw2 = take((size_t)nu * 2 * sizeof(double));               // W_nu^k of the fused second transform
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
@@ -1715,19 +1740,6 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // image -> vis: the first transform's input lives in its own buffer and the transform runs out of place, so the zero
     // band of the padded rows (half of every row) is written once per call, not once per plane (wg_fill_rows)
     double2 *S_in = reinterpret_cast<double2 *>(ws + L.stage_in), *T_in = reinterpret_cast<double2 *>(ws + L.col_in);
-    if (!adjoint && nplanes > 0) {
-        // zero bands: cells [ny - ny/2, nv - ny/2) of every row of S_in, cells [nx - nx/2, nu - nx/2) of every row of T_in
-        if (single) {
-            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(S_in), nx, nv,
-                               ny - ny / 2, nv - ny / 2);
-            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(T_in), nv, nu,
-                               nx - nx / 2, nu - nx / 2);
-        } else {
-            hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, S_in, nx, nv, ny - ny / 2, nv - ny / 2);
-            hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, T_in, nv, nu, nx - nx / 2, nu - nx / 2);
-        }
-        AF_LAUNCH_CHECK();
-    }
     // fp64 planes of 512- or 4096-pixel rows: fill and first transform in ONE kernel (wg_fill_fft_rows; AFHIP_WGRID_FFT1=0:
     // wg_fill_rows + hipFFT as for every other size)
     int fused_first = 0;
@@ -1736,11 +1748,42 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (!adjoint && !single && nv == 2 * ny && (ny == 512 || ny == 4096) &&
         !(getenv("AFHIP_WGRID_FFT1") && atoi(getenv("AFHIP_WGRID_FFT1")) == 0)) {
         fused_first = ny == 4096 ? 4 : 3;
-        fused_lds = (size_t)2 * (wg_pad((int)ny) + 8) * sizeof(double2);
+        fused_lds = (size_t)wg_pad((int)ny) * sizeof(double2);
         if (fused_first == 4)
             AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)fused_lds));
         hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nv, 256)), dim3(256), 0, st, nv, reinterpret_cast<double2 *>(ws + L.tw));
+        AF_LAUNCH_CHECK();
+    }
+    // ... and the second transform the same way when the image has 512 or 4096 rows (AFHIP_WGRID_FFT2=0: transposition
+    // with zero columns + hipFFT)
+    int fused_second = 0;
+    size_t fused_lds2 = 0;
+    const double2 *twid2 = reinterpret_cast<const double2 *>(ws + L.tw2);
+    if (!adjoint && !single && nu == 2 * nx && (nx == 512 || nx == 4096) &&
+        !(getenv("AFHIP_WGRID_FFT2") && atoi(getenv("AFHIP_WGRID_FFT2")) == 0)) {
+        fused_second = nx == 4096 ? 4 : 3;
+        fused_lds2 = (size_t)wg_pad((int)nx) * sizeof(double2);
+        if (fused_second == 4)
+            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds2));
+        hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nu, 256)), dim3(256), 0, st, nu, reinterpret_cast<double2 *>(ws + L.tw2));
+        AF_LAUNCH_CHECK();
+    }
+    if (!adjoint && nplanes > 0) {
+        // zero bands of the hipFFT routes' input buffers: cells [ny - ny/2, nv - ny/2) of every row of S_in, cells
+        // [nx - nx/2, nu - nx/2) of every row of T_in (the fused kernels never store a zero)
+        if (single) {
+            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(S_in), nx, nv,
+                               ny - ny / 2, nv - ny / 2);
+            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(T_in), nv, nu,
+                               nx - nx / 2, nu - nx / 2);
+        } else {
+            if (!fused_first)
+                hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, S_in, nx, nv, ny - ny / 2, nv - ny / 2);
+            if (!fused_second)
+                hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, T_in, nv, nu, nx - nx / 2, nu - nx / 2);
+        }
         AF_LAUNCH_CHECK();
     }
     for (int pk0 = 0; !adjoint && pk0 < nplanes; pk0 += (int)resident) {
@@ -1763,10 +1806,10 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
             if (fused_first == 4) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(1024), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
                 AF_LAUNCH_CHECK();
             } else if (fused_first == 3) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(128), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
                 AF_LAUNCH_CHECK();
             } else {
                 hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
@@ -1774,6 +1817,19 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 AF_LAUNCH_CHECK();
                 rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, false, S);  // along v, the image's rows only: S_in -> S
                 if (rc != AF_OK) return rc;
+            }
+            if (fused_second) {
+                // compact transposition, then the second transform by the same fused kernel (its rows from T_c)
+                hipLaunchKernelGGL(wg_transpose_compact, dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st, S,
+                                   nx, nv, T_in);
+                if (fused_second == 4)
+                    hipLaunchKernelGGL((wg_fill_fft_rows<4, true>), dim3((unsigned)nv), dim3(512), fused_lds2, st, nullptr, nullptr, nx,
+                                       0.0, twid2, gk, T_in);
+                else
+                    hipLaunchKernelGGL((wg_fill_fft_rows<3, true>), dim3((unsigned)nv), dim3(64), fused_lds2, st, nullptr, nullptr, nx,
+                                       0.0, twid2, gk, T_in);
+                AF_LAUNCH_CHECK();
+                continue;
             }
             hipLaunchKernelGGL((wg_transpose_rows<double2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),
                                0, st, S, nx, nu, nv, T_in);

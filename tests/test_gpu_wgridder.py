@@ -405,7 +405,7 @@ def test_model_with_caller_supplied_w_bounds_and_epsilon_floor():
         model(uvw, freq, image, fbi, fbc, cell, w_bounds=(1.0, -1.0))
 
 
-@pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512)])
+@pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512), (512, 512), (512, 20)])
 def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypatch):
     """fp64 planes of 512- (and 4096-: tests/test_gpu_full_size.py) pixel rows: the fill pass and the transform along v in
     one kernel (wg_fill_fft_rows: two half-length Stockham transforms of the row, no zero ever stored).  Same visibilities
@@ -413,9 +413,11 @@ def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypa
     nrow, nchan = 3000, 3
     cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.0, nrow, nchan, 1, seed=11)
     image[0][np.random.default_rng(1).random((nx, ny)) < 0.97] = 0.0        # sparse: the direct transform stays cheap
-    monkeypatch.setenv("AFHIP_WGRID_FFT1", "0")
+    monkeypatch.setenv("AFHIP_WGRID_FFT1", "0")          # (512 rows: the second transform takes the same kernel,
+    monkeypatch.setenv("AFHIP_WGRID_FFT2", "0")          #  its rows read from a compact transposition)
     ref = model(uvw, freq, image, fbi, fbc, cell, celly=cell * 0.9, epsilon=1e-7)
     monkeypatch.delenv("AFHIP_WGRID_FFT1")
+    monkeypatch.delenv("AFHIP_WGRID_FFT2")
     vis = model(uvw, freq, image, fbi, fbc, cell, celly=cell * 0.9, epsilon=1e-7)
     assert np.abs(vis - ref).max() <= 1e-12 * np.abs(ref).max()
     nz = np.nonzero(image[0])
