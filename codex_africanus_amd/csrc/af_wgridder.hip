@@ -284,11 +284,11 @@ __host__ __device__ constexpr int wg_pad(int a) { return a + (a >> 3); }     // 
 // two halves complete each other's cache lines in L2), so only the L - 1 exchanges between passes go through LDS --
 // 74 KB for M = 4096, TWO workgroups per CU (with both halves side by side, 148 KB and one workgroup per CU, the kernel
 // only matched hipFFT on the second transform).
-template <int LOG8, bool FROM_CELLS = false>
+// P: the planes' element (double2, or float2: fp64 arithmetic, results rounded once on their way out)
+template <int LOG8, bool FROM_CELLS = false, typename P = double2>
 __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
                                                                        int64_t ny, double wk, const double2 *__restrict__ tw,
-                                                                       double2 *__restrict__ S,
-                                                                       const double2 *__restrict__ src = nullptr)
+                                                                       P *__restrict__ S, const P *__restrict__ src = nullptr)
 {
     constexpr int M = 1 << (3 * LOG8), N = 2 * M, Q = M / 8;
     extern __shared__ double2 cells[];                      // wg_pad(M) cells
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const
     for (int j = 0; j < 8; ++j) {
         const int n = tt + j * Q;
         if constexpr (FROM_CELLS) {
-            const double2 c = src[ix * (int64_t)M + n];
+            const double2 c = wg_wide(src[ix * (int64_t)M + n]);
             ya[j] = WgC{c.x, c.y};
         } else {
             const int64_t px = ix * ny + n;
@@ -347,17 +347,17 @@ __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const
     // X[k] = i^k Spad[k],  Spad[2 q] = Y_a[q], Spad[2 q + 1] = Y_b[q], q = tt + j Q: a lane stores 32 contiguous bytes per j
     // (both halves of a cache line leave together: with the halves' stores microseconds apart the lines left L2 half
     // written)
-    double2 *__restrict__ out = S + ix * (int64_t)N;
+    P *__restrict__ out = S + ix * (int64_t)N;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int q = tt + j * Q;
-        double2 x0, x1;
+        P x0, x1;
         if (q & 1) {                                        // k = 2 q: i^k = -1;  k + 1: i^k = -i
-            x0 = make_double2(-ya[j].x, -ya[j].y);
-            x1 = make_double2(yb[j].y, -yb[j].x);
+            x0 = wg_cell<P>(-ya[j].x, -ya[j].y);
+            x1 = wg_cell<P>(yb[j].y, -yb[j].x);
         } else {                                            // k = 2 q: i^k = 1;   k + 1: i^k = i
-            x0 = make_double2(ya[j].x, ya[j].y);
-            x1 = make_double2(-yb[j].y, yb[j].x);
+            x0 = wg_cell<P>(ya[j].x, ya[j].y);
+            x1 = wg_cell<P>(-yb[j].y, yb[j].x);
         }
         out[2 * q] = x0;
         out[2 * q + 1] = x1;
@@ -376,9 +376,10 @@ __global__ __launch_bounds__(256) void wg_zero_band(P *__restrict__ X, int64_t r
 }
 // T[pv * nx + ix] = S[ix * nv + pv]: the plain transposition of the first transform's output, compact (the second
 // transform's fused kernel places the columns itself); 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void wg_transpose_compact(const double2 *__restrict__ S, int64_t nx, int64_t nv, double2 *__restrict__ T)
+template <typename P>
+__global__ __launch_bounds__(256) void wg_transpose_compact(const P *__restrict__ S, int64_t nx, int64_t nv, P *__restrict__ T)
 {
-    __shared__ double2 tile[32][33];
+    __shared__ P tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
     const int64_t ix0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
 #pragma unroll
@@ -1745,13 +1746,16 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     int fused_first = 0;
     size_t fused_lds = 0;
     const double2 *twid = reinterpret_cast<const double2 *>(ws + L.tw);
-    if (!adjoint && !single && nv == 2 * ny && (ny == 512 || ny == 4096) &&
+    if (!adjoint && nv == 2 * ny && (ny == 512 || ny == 4096) &&
         !(getenv("AFHIP_WGRID_FFT1") && atoi(getenv("AFHIP_WGRID_FFT1")) == 0)) {
         fused_first = ny == 4096 ? 4 : 3;
         fused_lds = (size_t)wg_pad((int)ny) * sizeof(double2);
-        if (fused_first == 4)
+        if (fused_first == 4) {
             AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)fused_lds));
+            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, false, float2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+        }
         hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nv, 256)), dim3(256), 0, st, nv, reinterpret_cast<double2 *>(ws + L.tw));
         AF_LAUNCH_CHECK();
     }
@@ -1760,13 +1764,16 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     int fused_second = 0;
     size_t fused_lds2 = 0;
     const double2 *twid2 = reinterpret_cast<const double2 *>(ws + L.tw2);
-    if (!adjoint && !single && nu == 2 * nx && (nx == 512 || nx == 4096) &&
+    if (!adjoint && nu == 2 * nx && (nx == 512 || nx == 4096) &&
         !(getenv("AFHIP_WGRID_FFT2") && atoi(getenv("AFHIP_WGRID_FFT2")) == 0)) {
         fused_second = nx == 4096 ? 4 : 3;
         fused_lds2 = (size_t)wg_pad((int)nx) * sizeof(double2);
-        if (fused_second == 4)
+        if (fused_second == 4) {
             AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds2));
+            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, true, float2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds2));
+        }
         hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nu, 256)), dim3(256), 0, st, nu, reinterpret_cast<double2 *>(ws + L.tw2));
         AF_LAUNCH_CHECK();
     }
@@ -1774,10 +1781,12 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         // zero bands of the hipFFT routes' input buffers: cells [ny - ny/2, nv - ny/2) of every row of S_in, cells
         // [nx - nx/2, nu - nx/2) of every row of T_in (the fused kernels never store a zero)
         if (single) {
-            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(S_in), nx, nv,
-                               ny - ny / 2, nv - ny / 2);
-            hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(T_in), nv, nu,
-                               nx - nx / 2, nu - nx / 2);
+            if (!fused_first)
+                hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(S_in), nx, nv,
+                                   ny - ny / 2, nv - ny / 2);
+            if (!fused_second)
+                hipLaunchKernelGGL((wg_zero_band<float2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<float2 *>(T_in), nv, nu,
+                                   nx - nx / 2, nu - nx / 2);
         } else {
             if (!fused_first)
                 hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, S_in, nx, nv, ny - ny / 2, nv - ny / 2);
@@ -1792,13 +1801,34 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             int rc;
             if (single) {
                 float2 *gk = reinterpret_cast<float2 *>(grid) + (int64_t)(k - pk0) * nu * nv, *Sf = reinterpret_cast<float2 *>(S);
-                hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
-                                   nx, ny, nv, w0 + k * dw, reinterpret_cast<float2 *>(S_in));
-                AF_LAUNCH_CHECK();
-                rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, true, Sf);      // along v, the image's rows only: S_in -> S
-                if (rc != AF_OK) return rc;
+                float2 *Tf = reinterpret_cast<float2 *>(T_in);
+                if (fused_first == 4) {
+                    hipLaunchKernelGGL((wg_fill_fft_rows<4, false, float2>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny,
+                                       w0 + k * dw, twid, Sf, (const float2 *)nullptr);
+                } else if (fused_first == 3) {
+                    hipLaunchKernelGGL((wg_fill_fft_rows<3, false, float2>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny,
+                                       w0 + k * dw, twid, Sf, (const float2 *)nullptr);
+                } else {
+                    hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A,
+                                       nm1, nx, ny, nv, w0 + k * dw, reinterpret_cast<float2 *>(S_in));
+                    AF_LAUNCH_CHECK();
+                    rc = wg_fft_rows((int)nv, (int)nx, S_in, st, false, true, Sf);  // along v, the image's rows only: S_in -> S
+                    if (rc != AF_OK) return rc;
+                }
+                if (fused_second) {
+                    hipLaunchKernelGGL((wg_transpose_compact<float2>), dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),
+                                       0, st, Sf, nx, nv, Tf);
+                    if (fused_second == 4)
+                        hipLaunchKernelGGL((wg_fill_fft_rows<4, true, float2>), dim3((unsigned)nv), dim3(512), fused_lds2, st, nullptr,
+                                           nullptr, nx, 0.0, twid2, gk, (const float2 *)Tf);
+                    else
+                        hipLaunchKernelGGL((wg_fill_fft_rows<3, true, float2>), dim3((unsigned)nv), dim3(64), fused_lds2, st, nullptr,
+                                           nullptr, nx, 0.0, twid2, gk, (const float2 *)Tf);
+                    AF_LAUNCH_CHECK();
+                    continue;
+                }
                 hipLaunchKernelGGL((wg_transpose_rows<float2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)),
-                                   dim3(256), 0, st, Sf, nx, nu, nv, reinterpret_cast<float2 *>(T_in));
+                                   dim3(256), 0, st, Sf, nx, nu, nv, Tf);
                 AF_LAUNCH_CHECK();
                 rc = wg_fft_rows((int)nu, (int)nv, T_in, st, false, true, gk);      // along u, every column: T_in -> plane
                 if (rc != AF_OK) return rc;
@@ -1806,10 +1836,10 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
             if (fused_first == 4) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S, (const double2 *)nullptr);
                 AF_LAUNCH_CHECK();
             } else if (fused_first == 3) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S);
+                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S, (const double2 *)nullptr);
                 AF_LAUNCH_CHECK();
             } else {
                 hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
@@ -1820,14 +1850,14 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             }
             if (fused_second) {
                 // compact transposition, then the second transform by the same fused kernel (its rows from T_c)
-                hipLaunchKernelGGL(wg_transpose_compact, dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st, S,
+                hipLaunchKernelGGL((wg_transpose_compact<double2>), dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st, S,
                                    nx, nv, T_in);
                 if (fused_second == 4)
                     hipLaunchKernelGGL((wg_fill_fft_rows<4, true>), dim3((unsigned)nv), dim3(512), fused_lds2, st, nullptr, nullptr, nx,
-                                       0.0, twid2, gk, T_in);
+                                       0.0, twid2, gk, (const double2 *)T_in);
                 else
                     hipLaunchKernelGGL((wg_fill_fft_rows<3, true>), dim3((unsigned)nv), dim3(64), fused_lds2, st, nullptr, nullptr, nx,
-                                       0.0, twid2, gk, T_in);
+                                       0.0, twid2, gk, (const double2 *)T_in);
                 AF_LAUNCH_CHECK();
                 continue;
             }

@@ -426,3 +426,27 @@ def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypa
     src = np.broadcast_to((image[0][nz] / n)[:, None, None], (x.size, nchan, 1)).copy()
     direct = oracle.im_to_vis(src, uvw * np.array([1.0, 1.0, -1.0]), np.stack([x, y], 1), freq, omp=True)[:, :, 0]
     assert _l2error(vis, direct) <= 1e-7
+
+
+def test_own_row_transforms_with_float32_planes(monkeypatch):
+    """float32 planes of a 512 x 512 image: the own row transforms compute in fp64 and round once on their way out, so they
+    sit CLOSER to the fp64-plane result than hipFFT's float32 transforms do; both meet the contract at epsilon = 1e-5."""
+    from codex_africanus_amd.gridding.wgridder import plane_precision
+    nx = ny = 512
+    nrow, nchan = 3000, 2
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.0, nrow, nchan, 1, seed=5)
+    image[0][np.random.default_rng(2).random((nx, ny)) < 0.97] = 0.0
+    base = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+    with plane_precision("single"):
+        own = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+        monkeypatch.setenv("AFHIP_WGRID_FFT1", "0")
+        monkeypatch.setenv("AFHIP_WGRID_FFT2", "0")
+        lib = model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-5)
+    assert not np.array_equal(own, base) and not np.array_equal(own, lib)
+    assert _l2error(own, base) <= _l2error(lib, base) < 3e-6
+    nz = np.nonzero(image[0])
+    x, y = (nz[0] - nx / 2) * cell, (nz[1] - ny / 2) * cell
+    n = np.sqrt(1.0 - x * x - y * y)
+    src = np.broadcast_to((image[0][nz] / n)[:, None, None], (x.size, nchan, 1)).copy()
+    direct = oracle.im_to_vis(src, uvw * np.array([1.0, 1.0, -1.0]), np.stack([x, y], 1), freq, omp=True)[:, :, 0]
+    assert _l2error(own, direct) <= 1e-5 and _l2error(lib, direct) <= 1e-5
