@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
     }
     S[ix * nv + pv] = out;
 }
-// ---- fill + first row transform in one kernel (image -> vis, fp64 planes, ny = 8^L, nv = 2 ny) ------------------------
+// ---- fill + row transform in one kernel (image -> vis; rows of 512, 1024, 2048 or 4096 image cells, padded to twice that) ----
 // Row ix of the padded plane holds the image row's ny cells at pv = (iy - ny/2) mod nv and zeros elsewhere.  With
 // M = ny, N = 2 M and s[j] = the cell of iy = j:
 //     X[k] = sum_j s[j] W_N^((j - M/2) k) = (-i)^(-k) ... = i^k Spad[k],   W_N = exp(-2 pi i / N),
@@ -284,13 +284,15 @@ __host__ __device__ constexpr int wg_pad(int a) { return a + (a >> 3); }     // 
 // two halves complete each other's cache lines in L2), so only the L - 1 exchanges between passes go through LDS --
 // 74 KB for M = 4096, TWO workgroups per CU (with both halves side by side, 148 KB and one workgroup per CU, the kernel
 // only matched hipFFT on the second transform).
-// P: the planes' element (double2, or float2: fp64 arithmetic, results rounded once on their way out)
-template <int LOG8, bool FROM_CELLS = false, typename P = double2>
-__global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
-                                                                       int64_t ny, double wk, const double2 *__restrict__ tw,
-                                                                       P *__restrict__ S, const P *__restrict__ src = nullptr)
+// P: the planes' element (double2, or float2: fp64 arithmetic, results rounded once on their way out).
+// M = 2^LOGM = R0 8^L (512, 1024, 2048, 4096): when R0 = 2 or 4 the first pass is a twiddle-free radix-R0 pass over the
+// same eight register values (butterflies tt + m Q, m < 8 / R0), the radix-8 passes follow with Ns = R0, 8 R0, ...
+template <int LOGM, bool FROM_CELLS = false, typename P = double2>
+__global__ __launch_bounds__(1 << (LOGM - 3), 4) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
+                                                                      int64_t ny, double wk, const double2 *__restrict__ tw,
+                                                                      P *__restrict__ S, const P *__restrict__ src = nullptr)
 {
-    constexpr int M = 1 << (3 * LOG8), N = 2 * M, Q = M / 8;
+    constexpr int M = 1 << LOGM, N = 2 * M, Q = M / 8, R0 = 1 << (LOGM % 3);
     extern __shared__ double2 cells[];                      // wg_pad(M) cells
     const int tt = threadIdx.x;
     const int64_t ix = blockIdx.x;
@@ -311,16 +313,37 @@ __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const
         const double2 w = tw[n];                            // the upper half transforms s . W_N^n
         yb[j] = wg_cmul(ya[j], WgC{w.x, w.y});
     }
-    // one half transform: u = the eight first-pass inputs of this lane on entry, Y[tt + j Q] on return
+    // one half transform: u = the eight first-pass inputs of this lane (cells tt + j Q) on entry, Y[tt + j Q] on return
     auto half = [&](WgC (&u)[8], bool wait_first) {
-        wg_dft8(u);                                         // pass 0 (Ns = 1): no twiddles
-        if (wait_first) __syncthreads();                    // the previous half's last LDS reads are done
+        if constexpr (R0 == 1) {
+            wg_dft8(u);                                     // first pass (Ns = 1): radix 8, no twiddles
+            if (wait_first) __syncthreads();                // the previous half's last LDS reads are done
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cells[wg_pad(tt * 8 + j)] = make_double2(u[j].x, u[j].y);
+            for (int j = 0; j < 8; ++j) cells[wg_pad(tt * 8 + j)] = make_double2(u[j].x, u[j].y);
+        } else {
+            constexpr int G = 8 / R0;                       // butterflies of this lane; input j of butterfly m is u[m + j G]
+#pragma unroll
+            for (int m = 0; m < G; ++m) {
+                if constexpr (R0 == 2) {
+                    const WgC a = u[m], b = u[m + G];
+                    u[m] = wg_cadd(a, b); u[m + G] = wg_csub(a, b);
+                } else {
+                    const WgC s0 = wg_cadd(u[m], u[m + 2 * G]), s1 = wg_csub(u[m], u[m + 2 * G]);
+                    const WgC s2 = wg_cadd(u[m + G], u[m + 3 * G]), s3 = wg_mul_mi(wg_csub(u[m + G], u[m + 3 * G]));
+                    u[m] = wg_cadd(s0, s2); u[m + G] = wg_cadd(s1, s3); u[m + 2 * G] = wg_csub(s0, s2); u[m + 3 * G] = wg_csub(s1, s3);
+                }
+            }
+            if (wait_first) __syncthreads();
+#pragma unroll
+            for (int m = 0; m < G; ++m)
+#pragma unroll
+                for (int j = 0; j < R0; ++j)
+                    cells[wg_pad((tt + m * Q) * R0 + j)] = make_double2(u[m + j * G].x, u[m + j * G].y);
+        }
         __syncthreads();
 #pragma unroll
-        for (int p = 1; p < LOG8; ++p) {
-            const int Ns = 1 << (3 * p), r = tt & (Ns - 1);
+        for (int Ns = (R0 == 1 ? 8 : R0); Ns < M; Ns *= 8) {
+            const int r = tt & (Ns - 1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const double2 c = cells[wg_pad(tt + j * Q)];
@@ -333,7 +356,7 @@ __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const
                 u[5] = wg_cmul(u[5], wg_cmul(w2, w3)); u[6] = wg_cmul(u[6], wg_cmul(w3, w3)); u[7] = wg_cmul(u[7], wg_cmul(w3, w4));
             }
             wg_dft8(u);
-            if (p + 1 < LOG8) {
+            if (Ns * 8 < M) {
                 __syncthreads();
                 const int base = (tt - r) * 8 + r;
 #pragma unroll
@@ -363,6 +386,33 @@ __global__ __launch_bounds__(1 << (3 * LOG8 - 3), 4) void wg_fill_fft_rows(const
         out[2 * q + 1] = x1;
     }
 }
+
+// host side: launches the row transform for M = 2^logm cells per row (logm in 9..12); rows = grid size
+template <int LOGM, bool FROM_CELLS, typename P>
+int wg_row_fft_launch1(int64_t rows, const double *A, const double *nm1, int64_t ny, double wk, const double2 *tw, P *out,
+                       const P *src, hipStream_t st)
+{
+    const size_t lds = (size_t)wg_pad(1 << LOGM) * sizeof(double2);
+    auto kernel = wg_fill_fft_rows<LOGM, FROM_CELLS, P>;
+    if (lds > 64 * 1024)
+        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)rows), dim3(1 << (LOGM - 3)), lds, st, A, nm1, ny, wk, tw, out, src);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+template <bool FROM_CELLS, typename P>
+int wg_row_fft_launch(int logm, int64_t rows, const double *A, const double *nm1, int64_t ny, double wk, const double2 *tw, P *out,
+                      const P *src, hipStream_t st)
+{
+    switch (logm) {
+    case 9: return wg_row_fft_launch1<9, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    case 10: return wg_row_fft_launch1<10, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    case 11: return wg_row_fft_launch1<11, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    default: return wg_row_fft_launch1<12, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    }
+}
+// log2(n) when n is 512, 1024, 2048 or 4096 (the sizes the own row transform serves), else 0
+inline int wg_row_fft_logm(int64_t n) { return n == 512 ? 9 : n == 1024 ? 10 : n == 2048 ? 11 : n == 4096 ? 12 : 0; }
 
 // cells [lo, hi) of every one of `rows` rows of `width` cells <- 0 (hipMemset2DAsync does this at 0.8 TB/s)
 template <typename P>
@@ -1741,39 +1791,21 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // image -> vis: the first transform's input lives in its own buffer and the transform runs out of place, so the zero
     // band of the padded rows (half of every row) is written once per call, not once per plane (wg_fill_rows)
     double2 *S_in = reinterpret_cast<double2 *>(ws + L.stage_in), *T_in = reinterpret_cast<double2 *>(ws + L.col_in);
-    // fp64 planes of 512- or 4096-pixel rows: fill and first transform in ONE kernel (wg_fill_fft_rows; AFHIP_WGRID_FFT1=0:
-    // wg_fill_rows + hipFFT as for every other size)
+    // rows of 512, 1024, 2048 or 4096 image cells: fill and first transform in ONE kernel (wg_fill_fft_rows;
+    // AFHIP_WGRID_FFT1=0: wg_fill_rows + hipFFT as for every other size) ...
     int fused_first = 0;
-    size_t fused_lds = 0;
     const double2 *twid = reinterpret_cast<const double2 *>(ws + L.tw);
-    if (!adjoint && nv == 2 * ny && (ny == 512 || ny == 4096) &&
-        !(getenv("AFHIP_WGRID_FFT1") && atoi(getenv("AFHIP_WGRID_FFT1")) == 0)) {
-        fused_first = ny == 4096 ? 4 : 3;
-        fused_lds = (size_t)wg_pad((int)ny) * sizeof(double2);
-        if (fused_first == 4) {
-            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)fused_lds));
-            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, false, float2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-        }
+    if (!adjoint && nv == 2 * ny && wg_row_fft_logm(ny) && !(getenv("AFHIP_WGRID_FFT1") && atoi(getenv("AFHIP_WGRID_FFT1")) == 0)) {
+        fused_first = wg_row_fft_logm(ny);
         hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nv, 256)), dim3(256), 0, st, nv, reinterpret_cast<double2 *>(ws + L.tw));
         AF_LAUNCH_CHECK();
     }
-    // ... and the second transform the same way when the image has 512 or 4096 rows (AFHIP_WGRID_FFT2=0: transposition
+    // ... and the second transform the same way when the image has that many rows (AFHIP_WGRID_FFT2=0: transposition
     // with zero columns + hipFFT)
     int fused_second = 0;
-    size_t fused_lds2 = 0;
     const double2 *twid2 = reinterpret_cast<const double2 *>(ws + L.tw2);
-    if (!adjoint && nu == 2 * nx && (nx == 512 || nx == 4096) &&
-        !(getenv("AFHIP_WGRID_FFT2") && atoi(getenv("AFHIP_WGRID_FFT2")) == 0)) {
-        fused_second = nx == 4096 ? 4 : 3;
-        fused_lds2 = (size_t)wg_pad((int)nx) * sizeof(double2);
-        if (fused_second == 4) {
-            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds2));
-            AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_fill_fft_rows<4, true, float2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds2));
-        }
+    if (!adjoint && nu == 2 * nx && wg_row_fft_logm(nx) && !(getenv("AFHIP_WGRID_FFT2") && atoi(getenv("AFHIP_WGRID_FFT2")) == 0)) {
+        fused_second = wg_row_fft_logm(nx);
         hipLaunchKernelGGL(wg_twiddle_table, dim3((unsigned)af_cdiv(nu, 256)), dim3(256), 0, st, nu, reinterpret_cast<double2 *>(ws + L.tw2));
         AF_LAUNCH_CHECK();
     }
@@ -1802,12 +1834,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             if (single) {
                 float2 *gk = reinterpret_cast<float2 *>(grid) + (int64_t)(k - pk0) * nu * nv, *Sf = reinterpret_cast<float2 *>(S);
                 float2 *Tf = reinterpret_cast<float2 *>(T_in);
-                if (fused_first == 4) {
-                    hipLaunchKernelGGL((wg_fill_fft_rows<4, false, float2>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny,
-                                       w0 + k * dw, twid, Sf, (const float2 *)nullptr);
-                } else if (fused_first == 3) {
-                    hipLaunchKernelGGL((wg_fill_fft_rows<3, false, float2>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny,
-                                       w0 + k * dw, twid, Sf, (const float2 *)nullptr);
+                if (fused_first) {
+                    rc = wg_row_fft_launch<false, float2>(fused_first, nx, A, nm1, ny, w0 + k * dw, twid, Sf, nullptr, st);
+                    if (rc != AF_OK) return rc;
                 } else {
                     hipLaunchKernelGGL((wg_fill_rows<float2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A,
                                        nm1, nx, ny, nv, w0 + k * dw, reinterpret_cast<float2 *>(S_in));
@@ -1818,13 +1847,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 if (fused_second) {
                     hipLaunchKernelGGL((wg_transpose_compact<float2>), dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),
                                        0, st, Sf, nx, nv, Tf);
-                    if (fused_second == 4)
-                        hipLaunchKernelGGL((wg_fill_fft_rows<4, true, float2>), dim3((unsigned)nv), dim3(512), fused_lds2, st, nullptr,
-                                           nullptr, nx, 0.0, twid2, gk, (const float2 *)Tf);
-                    else
-                        hipLaunchKernelGGL((wg_fill_fft_rows<3, true, float2>), dim3((unsigned)nv), dim3(64), fused_lds2, st, nullptr,
-                                           nullptr, nx, 0.0, twid2, gk, (const float2 *)Tf);
                     AF_LAUNCH_CHECK();
+                    rc = wg_row_fft_launch<true, float2>(fused_second, nv, nullptr, nullptr, nx, 0.0, twid2, gk, Tf, st);
+                    if (rc != AF_OK) return rc;
                     continue;
                 }
                 hipLaunchKernelGGL((wg_transpose_rows<float2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)),
@@ -1835,12 +1860,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 continue;
             }
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
-            if (fused_first == 4) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<4>), dim3((unsigned)nx), dim3(512), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S, (const double2 *)nullptr);
-                AF_LAUNCH_CHECK();
-            } else if (fused_first == 3) {
-                hipLaunchKernelGGL((wg_fill_fft_rows<3>), dim3((unsigned)nx), dim3(64), fused_lds, st, A, nm1, ny, w0 + k * dw, twid, S, (const double2 *)nullptr);
-                AF_LAUNCH_CHECK();
+            if (fused_first) {
+                rc = wg_row_fft_launch<false, double2>(fused_first, nx, A, nm1, ny, w0 + k * dw, twid, S, nullptr, st);
+                if (rc != AF_OK) return rc;
             } else {
                 hipLaunchKernelGGL((wg_fill_rows<double2>), dim3((unsigned)af_cdiv(nv, 256), (unsigned)nx), dim3(256), 0, st, nullptr, A, nm1,
                                    nx, ny, nv, w0 + k * dw, S_in);
@@ -1852,13 +1874,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                 // compact transposition, then the second transform by the same fused kernel (its rows from T_c)
                 hipLaunchKernelGGL((wg_transpose_compact<double2>), dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st, S,
                                    nx, nv, T_in);
-                if (fused_second == 4)
-                    hipLaunchKernelGGL((wg_fill_fft_rows<4, true>), dim3((unsigned)nv), dim3(512), fused_lds2, st, nullptr, nullptr, nx,
-                                       0.0, twid2, gk, (const double2 *)T_in);
-                else
-                    hipLaunchKernelGGL((wg_fill_fft_rows<3, true>), dim3((unsigned)nv), dim3(64), fused_lds2, st, nullptr, nullptr, nx,
-                                       0.0, twid2, gk, (const double2 *)T_in);
                 AF_LAUNCH_CHECK();
+                rc = wg_row_fft_launch<true, double2>(fused_second, nv, nullptr, nullptr, nx, 0.0, twid2, gk, T_in, st);
+                if (rc != AF_OK) return rc;
                 continue;
             }
             hipLaunchKernelGGL((wg_transpose_rows<double2>), dim3((unsigned)af_cdiv(nu, 32), (unsigned)af_cdiv(nv, 32)), dim3(256),

@@ -405,14 +405,16 @@ def test_model_with_caller_supplied_w_bounds_and_epsilon_floor():
         model(uvw, freq, image, fbi, fbc, cell, w_bounds=(1.0, -1.0))
 
 
-@pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512), (512, 512), (512, 20)])
+@pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512), (512, 512), (512, 20), (16, 1024), (2048, 16), (16, 2048),
+                                    (1024, 2048)])
 def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypatch):
-    """fp64 planes of 512- (and 4096-: tests/test_gpu_full_size.py) pixel rows: the fill pass and the transform along v in
+    """rows of 512, 1024, 2048 (and 4096: tests/test_gpu_full_size.py) image cells -- radix 8 throughout, or a radix-2 / radix-4
+    first pass: the fill pass and the transform along v in
     one kernel (wg_fill_fft_rows: two half-length Stockham transforms of the row, no zero ever stored).  Same visibilities
     as wg_fill_rows + hipFFT to rounding, and the accuracy contract against the direct transform on a sparse image."""
     nrow, nchan = 3000, 3
-    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.0, nrow, nchan, 1, seed=11)
-    image[0][np.random.default_rng(1).random((nx, ny)) < 0.97] = 0.0        # sparse: the direct transform stays cheap
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 3.0 * nx / max(nx, ny, 512), nrow, nchan, 1, seed=11)   # <= 3 degrees across the longer side
+    image[0][np.random.default_rng(1).random((nx, ny)) < 1.0 - 800.0 / (nx * ny)] = 0.0   # sparse: the direct transform stays cheap
     monkeypatch.setenv("AFHIP_WGRID_FFT1", "0")          # (512 rows: the second transform takes the same kernel,
     monkeypatch.setenv("AFHIP_WGRID_FFT2", "0")          #  its rows read from a compact transposition)
     ref = model(uvw, freq, image, fbi, fbc, cell, celly=cell * 0.9, epsilon=1e-7)
