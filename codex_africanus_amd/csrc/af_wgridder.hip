@@ -18,9 +18,13 @@
 //     psi(dw), and adds them to its sum.  Plane spacing dw = 1 / (2 sigma max|n - 1|).
 // The planes are built in batches of as many grids as the workspace holds; per batch ONE pass over the visibilities
 // takes every visibility through its own planes.  All work is enqueued on the caller's stream.
-// Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: 43 ms, the transpose 62 ms;
-// profiles/r02_aux_bench_wgridder*):
-//   * planes: pruned 2-D transform (wg_fill_rows -> hipFFT rows -> wg_transpose_rows -> hipFFT rows), v-major;
+// Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: image -> vis 22.8 ms in round 4 (43 ms in
+// round 2), the transpose 62 ms; profiles/r04_wgrid_*):
+//   * planes, image -> vis: pruned 2-D transform, v-major.  Rows of 512 / 1024 / 2048 / 4096 image cells: the own row
+//     transform (wg_fill_fft_rows: a padded row = two half-length Stockham transforms of its non-zero cells; the fill pass
+//     is the first transform's input stage) -> wg_transpose_compact -> the same kernel.  Other sizes: wg_fill_rows ->
+//     hipFFT rows -> wg_transpose_rows -> hipFFT rows, out of place from buffers whose zero bands are written once per call;
+//   * planes, vis -> image: hipFFT rows in place around wg_transpose_*;
 //   * visibilities: counting sort by (32 x 32 tile, w-plane) on the device, chunks of <= 256 of one tile, the tile's
 //     cells of every plane staged through LDS (wg_degrid_tiles); small calls gather from memory (wg_degrid_planes);
 //   * tap weights of all kernels from one function (wg_taps: per-tap polynomials for W <= 10).

@@ -522,7 +522,9 @@ int af_fused_predict_antennas_model_c128(const double *stokes, const double *spi
  * (af_wgrid_padded: the smallest even 2-3-5-7-smooth size >= 2 n); quad_t / quad_w (48): Gauss-Legendre nodes / weights on (0, 1); kernel_width W and beta: the
  * exponential-of-semicircle kernel exp(beta (sqrt(1 - (2t/W)^2) - 1)); [wl_min, wl_max]: range of w nu / c over the
  * band (HOST scalars, they size the w-plane loop); max_abs_nm1: largest |n - 1| of the image.  All device work is
- * enqueued on `stream`; uses hipFFT (plans cached per device and size, released by af_shutdown). */
+ * enqueued on `stream`; the plane transforms of image rows / columns of 512, 1024, 2048 or 4096 cells are own kernels
+ * (csrc/af_wgridder.hip, wg_fill_fft_rows), every other size uses hipFFT (plans cached per device and size, released by
+ * af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);
 /* Workspace of both directions.  planes: w-plane grids resident at a time (>= 1; af_wgrid_planes() of them = a single
  * pass over the visibilities); nchan_max / nplanes_total: the most channels / w-planes of a band the workspace will serve;
