@@ -226,6 +226,15 @@ def test_wgridder_full_size_c5():
     assert np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= eps
     twice = model(d_uvw, d_freq, d_img * 2.0, np.array([0]), np.array([nchan]), cell, epsilon=eps)
     assert torch.equal(twice, vis * 2.0)
+    # the own row transforms (4096-cell rows: four radix-8 passes) against the hipFFT route on the same call
+    import os
+    os.environ["AFHIP_WGRID_FFT1"] = os.environ["AFHIP_WGRID_FFT2"] = "0"
+    try:
+        lib = model(d_uvw, d_freq, d_img, np.array([0]), np.array([nchan]), cell, epsilon=eps)
+    finally:
+        del os.environ["AFHIP_WGRID_FFT1"], os.environ["AFHIP_WGRID_FFT2"]
+    assert not torch.equal(lib, vis)
+    assert float((lib - vis).abs().max()) <= 1e-12 * float(vis.abs().max())
 
 
 def test_wgridder_dirty_full_size_c5():
