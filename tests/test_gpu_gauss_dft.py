@@ -220,3 +220,19 @@ def test_predict_and_chi2_in_one_call(nrow, nchan, uniform, weighted):
     np.testing.assert_allclose(chi2.cpu().numpy(), want, rtol=1e-12)
     dd2 = dict(d, frequency=freq)
     assert np.abs(v - _chain(dd2, sp)).max() <= 1e-9 * _scale(dd2)
+
+
+@pytest.mark.parametrize("band", ["rising40", "falling33", "rising80"])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_mfma_form_against_the_reference_itself(band, conv):
+    """G15: the REFERENCE's own phase_delay x gaussian x brightness -> predict_vis on bands of 40 / 33 (falling) / 80 uniformly
+    spaced channels, i.e. on the MFMA-accumulator form (one short tile; a falling band; a full tile and a 16-channel tail),
+    generated by tests/golden/make_golden_gauss.py under the real numba.  1e-9 of the summed |brightness|."""
+    from conftest import load_golden
+    g = load_golden("g15_gauss.npz")
+    freq, X = g["frequency_" + band], g["brightness_" + band]
+    out = rime.fused_predict_vis(g["time_index"], g["antenna1"], g["antenna2"], g["lm"], g["uvw"], freq, X,
+                                 gauss_shape=g["shape_params"], convention=conv)
+    ref = g["vis_%s_%s" % (band, conv)]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.abs(out - ref).max() <= 1e-9 * float(g["scale_" + band])

@@ -516,3 +516,21 @@ def test_convert_reference_kat():
     assert np.all(oracle.convert(circ, ["RR", "RL", "LR", "LL"], ["I", "Q", "U", "V"]) == x)
     v = oracle.convert(np.asarray([I]), ["I"], ["XX", "XY", "YX", "YY"], implicit_stokes=True)
     assert v[0] == I and v[-1] == I
+
+
+@pytest.mark.parametrize("band", ["rising40", "falling33", "rising80"])
+@pytest.mark.parametrize("conv", ["fourier", "casa"])
+def test_gaussian_predict_chain_against_the_reference(band, conv):
+    """G15 (tests/golden/make_golden_gauss.py): the reference's phase_delay x gaussian shape x brightness summed by
+    predict_vis, africanus/rime/examples/predict.py:107-134 -- the oracle chain the Gaussian kernels are checked against
+    reproduces it to rounding (the einsum's summation order is numpy's)."""
+    from conftest import load_golden
+    g = load_golden("g15_gauss.npz")
+    freq, X = g["frequency_" + band], g["brightness_" + band]
+    phase = oracle.phase_delay(g["lm"], g["uvw"], freq, conv)
+    shape = oracle.gaussian_shape(g["uvw"], freq, g["shape_params"])
+    coh = np.einsum("srf,srf,sfij->srfij", phase, shape, X)
+    vis = oracle.predict_vis(g["time_index"], g["antenna1"], g["antenna2"], None, coh, None, None, None, None)
+    ref = g["vis_%s_%s" % (band, conv)]
+    assert vis.shape == ref.shape
+    assert np.abs(vis - ref).max() <= 1e-13 * float(g["scale_" + band])
