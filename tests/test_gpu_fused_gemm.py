@@ -194,3 +194,32 @@ def test_plan_through_the_c_abi():
     for r in range(ti.shape[0]):
         assert rm[ti[r], a1[r], a2[r]] == r
     assert (rm >= 0).sum() == ti.shape[0]
+
+
+@pytest.mark.parametrize("case", ["beam", "beam_die", "beam_feed"])
+def test_gemm_form_against_the_reference_itself(case):
+    """G16 (tests/golden/make_golden_gemm.py): the REFERENCE's phase_delay -> einsum -> beam_cube_dde [-> feed rotation] ->
+    predict_vis [+ DIE terms, base_vis] under the real numba, on G14's sky / beam / per-antenna terms with a Measurement
+    Set's uvw (differences of antenna coordinates): the rows the dispatcher sends to the GEMM form."""
+    from conftest import load_golden
+    from fused_cases import linear_feed_rotation
+    g, h = load_golden("g14_fused_dask.npz"), load_golden("g16_fused_gemm.npz")
+    nant = g["parallactic_angles"].shape[1]
+    plan = fused.fused_plan(g["time_index"], g["antenna1"], g["antenna2"], nant, uvw=h["uvw"])
+    assert plan.decomposable
+    kw = {}
+    if case == "beam_die":
+        kw = dict(die1_jones=g["die"], base_vis=g["base_vis"], die2_jones=g["die"])
+    if case == "beam_feed":
+        kw = dict(feed_rotation=linear_feed_rotation(g["parallactic_angles"]))
+    out = rime.fused_predict_vis(g["time_index"], g["antenna1"], g["antenna2"], g["lm"], h["uvw"], g["frequency"], g["brightness"],
+                                 g["beam"], g["beam_lm_extents"], g["beam_freq_map"], g["parallactic_angles"], g["point_errors"],
+                                 g["antenna_scaling"], plan=plan, **kw)
+    ref = h["vis_" + case]
+    scale = max(float(h["scale"]), float(np.abs(ref).max()))
+    assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-9 * scale
+    # the general kernel on the same rows (planner told not to decompose) agrees as well
+    gen = rime.fused_predict_vis(g["time_index"], g["antenna1"], g["antenna2"], g["lm"], h["uvw"], g["frequency"], g["brightness"],
+                                 g["beam"], g["beam_lm_extents"], g["beam_freq_map"], g["parallactic_angles"], g["point_errors"],
+                                 g["antenna_scaling"], plan=fused.fused_plan(g["time_index"], g["antenna1"], g["antenna2"], nant), **kw)
+    assert np.abs(gen - ref).max() <= 1e-9 * scale
