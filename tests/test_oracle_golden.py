@@ -534,3 +534,22 @@ def test_gaussian_predict_chain_against_the_reference(band, conv):
     ref = g["vis_%s_%s" % (band, conv)]
     assert vis.shape == ref.shape
     assert np.abs(vis - ref).max() <= 1e-13 * float(g["scale_" + band])
+
+
+@pytest.mark.parametrize("case", ["beam", "beam_die", "beam_feed"])
+def test_fused_chain_on_measurement_set_uvw_against_the_reference(case):
+    """G16 (tests/golden/make_golden_gemm.py): the oracle chain phase_delay -> einsum -> beam_cube_dde [-> feed rotation] ->
+    predict_vis reproduces the reference's on antenna-decomposable uvw (what the GEMM-form tests compare with)."""
+    from conftest import load_golden
+    from fused_cases import linear_feed_rotation, oracle_fused_predict_vis
+    g, h = load_golden("g14_fused_dask.npz"), load_golden("g16_fused_gemm.npz")
+    kw = {}
+    if case == "beam_die":
+        kw = dict(die1_jones=g["die"], base_vis=g["base_vis"], die2_jones=g["die"])
+    if case == "beam_feed":
+        kw = dict(feed_rotation=linear_feed_rotation(g["parallactic_angles"]))
+    vis = oracle_fused_predict_vis(g["time_index"], g["antenna1"], g["antenna2"], g["lm"], h["uvw"], g["frequency"], g["brightness"],
+                                   g["beam"], g["beam_lm_extents"], g["beam_freq_map"], g["parallactic_angles"],
+                                   g["point_errors"], g["antenna_scaling"], **kw)
+    ref = h["vis_" + case]
+    assert vis.shape == ref.shape and np.abs(vis - ref).max() <= 1e-12 * max(float(h["scale"]), float(np.abs(ref).max()))
