@@ -11,7 +11,10 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libafhip.so")
+# AFHIP_LIB: another build of the same library (an experimental or the profiling build, tools/ab_lib.sh,
+# tools/profile_gemm_stage.sh) -- chosen per process, nothing is overwritten in place
+LIB_PATH = os.path.abspath(os.environ["AFHIP_LIB"]) if os.environ.get("AFHIP_LIB") else \
+    os.path.join(_HERE, "lib", "libafhip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 AF_OK, AF_EINVAL, AF_ENOMEM, AF_ENOTSUP, AF_EHIP_BASE = 0, 1, 2, 3, 1000
@@ -21,6 +24,7 @@ AF_DFT_CLAMP_N = 0x100
 AF_DFT_VALU_ONLY = 0x200
 AF_JONES_DIAG, AF_JONES_2X2 = 1, 2
 AF_STATUS_TIME_INDEX, AF_STATUS_ANTENNA = 1, 2
+AF_STATUS_PLAN_INDEX, AF_STATUS_PLAN_UVW = 4, 8
 AF_PREDICT_VIS_STATUS_OFFSET = 8
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -121,6 +125,8 @@ _SIGNATURES = {
     "af_gauss_predict_chi2_c128": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "af_fused_plan_antennas": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, _i64, _vp, _vp,
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "af_fused_plan_check": (_int, [_vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _i64, _vp,
+                                   _vp]),
     "af_fused_predict_antennas_c128": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                                               _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_fused_predict_antennas_model_c128": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp,
@@ -164,6 +170,8 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into codex_africanus_amd/lib/libafhip.so."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "afhip.h"))
+    if os.environ.get("AFHIP_LIB"):
+        return LIB_PATH             # somebody else's build: used as it is
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:

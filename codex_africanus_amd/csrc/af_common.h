@@ -39,6 +39,16 @@ int af_hip_fail(hipError_t e, const char *what, const char *file, int line);
 void af_prof_begin(hipStream_t st);
 void af_prof_end(hipStream_t st);
 
+// Stage hooks of the fused kernels (tools/profile_fused.sh, tools/profile_gemm_stage.sh: run ONE stage of a kernel, whose
+// output is then meaningless) exist only in the profiling build (make HOOKS=1 -> ../lib/prof/libafhip.so, selected with
+// AFHIP_LIB): the shipped library compiles them to their defaults and a stray environment variable changes nothing.
+#ifdef AFHIP_STAGE_HOOKS
+#include <stdlib.h>
+#define AF_STAGE_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define AF_STAGE_ENV(name, dflt) (dflt)
+#endif
+
 static inline hipStream_t af_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t af_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -48,259 +48,17 @@
 
 namespace {
 
-constexpr int G_THREADS = 512;       // 4 matrix waves + 4 sampling waves
-constexpr int G_SAMPLERS = 256;      // sampling lanes
 constexpr int COL_PAD = 16;          // doubles of padding per operand plane (planes of one source on different banks)
-constexpr int H_PLANES = 4, G_PLANES = 6;
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// grid: (nsteps, channels of the plane group); block 512.  NB = 8-antenna blocks (nant <= 8 NB); ST = sources per batch.
-// Dynamic LDS: 2 buffers x ST x (4 + 6) planes x CS doubles, then per-antenna constants (6 doubles), feed rotations
-// (4 double2), antenna coordinates in table units (4 doubles) and the phasor table.
-template <bool FEED, int NB, int ST>
-__global__ __launch_bounds__(G_THREADS) void fused_gemm_kernel(
-    const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
-    const double *__restrict__ f4, const double2 *__restrict__ brightness, const double *__restrict__ vrec,
-    int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
-    const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
-    const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
-    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio)
-{
-    constexpr int NA = NB * 8;              // padded antennas
-    constexpr int NC = NA * 2;              // rows / columns of M
-    constexpr int CS = NC + COL_PAD;        // doubles per operand plane
-    constexpr int SRC_DOUBLES = (H_PLANES + G_PLANES) * CS;   // one source: H planes then G planes
-    constexpr int BUF_DOUBLES = ST * SRC_DOUBLES;
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int TPW = (NTILE + 3) / 4;    // tiles per matrix wave
-    extern __shared__ double ldsd[];
-    double *ldsA = ldsd + 2 * BUF_DOUBLES;                 // (sin pa, cos pa, pe_l, pe_m, as_l, as_m) per antenna
-    double *ldsU = ldsA + 6 * NA;                          // (u, v, w, 0) FT per antenna: table units per unit of (l, m, n)
-    double2 *ldsR = reinterpret_cast<double2 *>(ldsU + 4 * NA);   // feed rotations
-    double2 *ldsT = ldsR + 4 * NA;                         // phasor table
-    const int tid = threadIdx.x;
-    const bool matrix_wave = tid < G_THREADS - G_SAMPLERS;
-    const int ptid = tid - (G_THREADS - G_SAMPLERS);
-    const int64_t f = f0 + blockIdx.y;
-    const int t = blockIdx.x;
-
-    // ---- block set-up ------------------------------------------------------------------------------
-    fine_table_init(ldsT, tid, G_THREADS);
-    const double FT = f4[f] * (PH_TABLE / 4.0);
-    for (int a = tid; a < NA; a += G_THREADS) {
-        double sp = 0.0, cp = 1.0, pl = 0.0, pm = 0.0, sl_ = 1.0, sm_ = 1.0, u = 0.0, v = 0.0, w = 0.0;
-        if (a < nant) {
-            sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
-            const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
-            const double *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
-            pl = pe[0]; pm = pe[1]; sl_ = as[0]; sm_ = as[1];
-            const double *x = ant_uvw + ((int64_t)t * nant + a) * 3;
-            u = __dmul_rn(x[0], FT); v = __dmul_rn(x[1], FT); w = __dmul_rn(x[2], FT);
-        }
-        ldsA[6 * a + 0] = sp; ldsA[6 * a + 1] = cp; ldsA[6 * a + 2] = pl; ldsA[6 * a + 3] = pm;
-        ldsA[6 * a + 4] = sl_; ldsA[6 * a + 5] = sm_;
-        ldsU[4 * a + 0] = u; ldsU[4 * a + 1] = v; ldsU[4 * a + 2] = w; ldsU[4 * a + 3] = 0.0;
-    }
-    if constexpr (FEED)
-        for (int i = tid; i < 4 * nant; i += G_THREADS) ldsR[i] = feed_rot[(int64_t)t * nant * 4 + i];
-    // padded antennas (nant < NA) never get written by the samplers: their operand columns must read as zero
-    if (nant < NA)
-        for (int i = tid; i < 2 * BUF_DOUBLES; i += G_THREADS) ldsd[i] = 0.0;
-    __syncthreads();
-    const int nbatch = (nsrc + ST - 1) / ST;
-
-    if (!matrix_wave) {
-        // =================================== sampling waves =========================================
-        FusedGrid grid;
-        {
-            const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
-            grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
-            grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
-            grid.stride_m = VREC * 8u;
-            grid.stride_l = (unsigned)beam_mh * grid.stride_m;
-        }
-        const double fscale = freq_data[3 * f + 0];
-        const int e_corr = ptid & 3;               // this lane's correlation: (i, j) = (e_corr >> 1, e_corr & 1)
-        const int ei = e_corr >> 1, ej = e_corr & 1;
-        const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
-        const unsigned corr_off = e_corr * 32u;
-        constexpr int NTASK = ST * NA;             // (source, antenna) terms per batch
-        if (sample_prio >= 0) __builtin_amdgcn_s_setprio(3);
-        for (int b = 0; b < nbatch; ++b) {
-            const int s0 = b * ST;
-            double *H = ldsd + (b & 1) * BUF_DOUBLES;
-            if (only_stage != 2) {
-                for (int task0 = 0; task0 < NTASK; task0 += G_SAMPLERS) {
-                    // ---- this lane's own term: geometry and antenna phasor ----------------------------
-                    const int task = task0 + ptid;
-                    int e_sl = task / NA, e_ant = task - e_sl * NA;
-                    const bool have_task = task < NTASK && e_ant < nant;
-                    if (!have_task) e_sl = e_ant = 0;
-                    const bool have = have_task && s0 + e_sl < nsrc;
-                    const int own_info = e_sl | (e_ant << 11) | ((int)have_task << 30) | (int)((unsigned)have << 31);
-                    const double *sp = lmn + 4 * (have ? s0 + e_sl : 0);
-                    const double2 lm2 = *reinterpret_cast<const double2 *>(sp);
-                    const double nn = sp[2];
-                    FusedVoxels gx;
-                    fused_voxels(grid, lm2.x, lm2.y, ldsA[6 * e_ant + 0], ldsA[6 * e_ant + 1], ldsA[6 * e_ant + 2],
-                                 ldsA[6 * e_ant + 3], ldsA[6 * e_ant + 4], ldsA[6 * e_ant + 5], fscale, gx);
-                    // k_a = exp(i C nu (l u_a + m v_a + n w_a)): phase_delay's phasor of the ANTENNA (rime/phase.py:45-61)
-                    const C2 kph = table_phasor(ldsT, fma(nn, ldsU[4 * e_ant + 2],
-                                                          fma(lm2.y, ldsU[4 * e_ant + 1], __dmul_rn(lm2.x, ldsU[4 * e_ant + 0]))));
-                    // Four sampling rounds; in round QL the four lanes of a quad take the geometry of quad lane QL and
-                    // sample one correlation each.  ALL four rounds' gathers are issued before the first is consumed: a
-                    // sampling wave is one dependent chain behind the L2 latency, and the registers are there (the
-                    // matrix waves' accumulators set the kernel's allocation).
-                    struct Round {
-                        int info;
-                        double2 b0, b1, v[4];
-                        double ab[4], wt[4];
-                        C2 kk;
-                    };
-                    auto issue = [&](auto lane_c, Round &R) {
-                        constexpr int QL = decltype(lane_c)::value;
-                        const int info = quad_bcast<QL>(own_info);
-                        R.info = info;
-                        const int r_sl = info & 2047;
-                        const bool r_have = info < 0;
-                        // G[i][j] = A[i][0] X[0][j] + A[i][1] X[1][j]: this lane needs column j of X
-                        const double2 *bp = brightness + ((int64_t)(r_have ? s0 + r_sl : 0) * nchan + f) * 4;
-                        R.b0 = bp[ej];
-                        R.b1 = bp[2 + ej];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
-                            R.wt[k] = quad_bcast<QL>(gx.wt[k]);
-                            const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
-                            R.v[k] = *reinterpret_cast<const double2 *>(r);
-                            R.ab[k] = r[2];
-                        }
-                        R.kk.re = quad_bcast<QL>(kph.re);
-                        R.kk.im = quad_bcast<QL>(kph.im);
-                    };
-                    auto finish = [&](const Round &R) {
-                        const int info = R.info;
-                        const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
-                        const bool r_task = (info >> 30) & 1, r_have = info < 0;
-                        double2 e2 = beam_reduce1(R.v, R.ab, R.wt);
-                        if (!r_have) e2 = make_double2(0.0, 0.0);
-                        C2 e;
-                        e.re = e2.x; e.im = e2.y;
-                        if constexpr (FEED) {
-                            // E <- E . R(t, antenna)  ("stafij,tajk->stafik", rime/examples/predict.py:472)
-                            C2 E0, E1;
-                            E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
-                            E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
-                            const double2 r0 = ldsR[4 * r_ant + ej], r1 = ldsR[4 * r_ant + 2 + ej];
-                            C2 R0, R1;
-                            R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
-                            e = cmul(E0, R0);
-                            cmac(e, E1, R1);
-                        }
-                        const C2 A = cmul(R.kk, e);        // A[i][j] = k E[i][j]
-                        C2 A0, A1, B0, B1;
-                        A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
-                        A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
-                        B0.re = R.b0.x; B0.im = R.b0.y; B1.re = R.b1.x; B1.im = R.b1.y;
-                        C2 Gv = cmul(A0, B0);
-                        cmac(Gv, A1, B1);
-                        if (r_task) {
-                            double *hs = H + r_sl * SRC_DOUBLES + 2 * r_ant + ei;
-                            double *gs = hs + H_PLANES * CS;
-                            hs[ej * CS] = A.re; hs[(2 + ej) * CS] = A.im;
-                            gs[ej * CS] = Gv.re; gs[(2 + ej) * CS] = Gv.im; gs[(4 + ej) * CS] = -Gv.re;
-                        }
-                    };
-                    Round R0, R1, R2, R3;
-                    issue(std::integral_constant<int, 0>{}, R0);
-                    issue(std::integral_constant<int, 1>{}, R1);
-                    issue(std::integral_constant<int, 2>{}, R2);
-                    issue(std::integral_constant<int, 3>{}, R3);
-                    finish(R0);
-                    finish(R1);
-                    finish(R2);
-                    finish(R3);
-                }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ======================================= matrix waves ===========================================
-    const int wave = tid >> 6, lane = tid & 63;
-    const int kq = lane >> 4, c16 = lane & 15;
-    int offA[TPW], offB[TPW];                   // doubles from the start of a source's planes
-    v4d cr[TPW], ci[TPW];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        // wave-uniform tile coordinates of tile j * 4 + wave in the row-major upper block triangle
-        int pb = 0, qb = 0;
-        {
-            int ii = j * 4 + wave < NTILE ? j * 4 + wave : 0;
-            while (ii >= NB - pb) { ii -= NB - pb; ++pb; }
-            qb = pb + ii;
-        }
-        offA[j] = H_PLANES * CS + kq * CS + pb * 16 + c16;
-        offB[j] = kq * CS + qb * 16 + c16;
-        cr[j] = (v4d){0.0, 0.0, 0.0, 0.0};
-        ci[j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    }
-    for (int b = 0; b < nbatch; ++b) {
-        __syncthreads();
-        if (only_stage == 1) continue;
-        const double *P = ldsd + (b & 1) * BUF_DOUBLES;
-#pragma unroll
-        for (int sl = 0; sl < ST; ++sl) {
-            const double *S = P + sl * SRC_DOUBLES;
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                if (j * 4 + wave < NTILE) {      // wave-uniform
-                    const double a0 = S[offA[j]], a1 = S[offA[j] + 2 * CS], bb = S[offB[j]];
-                    cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, cr[j], 0, 0, 0);
-                    ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, ci[j], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (only_stage == 1) return;
-    // ---- epilogue: tile element (row, col) = ((p, i), (q, j)) -> the output row of baseline (p, q) ----
-    const int32_t *rm = rowmap + (int64_t)t * NA * NA;
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int i = j * 4 + wave;
-        if (i >= NTILE) continue;
-        int pb = 0, qb = 0;
-        {
-            int ii = i;
-            while (ii >= NB - pb) { ii -= NB - pb; ++pb; }
-            qb = pb + ii;
-        }
-        const int q = qb * 8 + (c16 >> 1), jj = c16 & 1;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = kq + 4 * reg;
-            const int p = pb * 8 + (row >> 1), ii = row & 1;
-            const double re = cr[j][reg], im = ci[j][reg];
-            const int r1 = rm[p * NA + q];
-            if (r1 >= 0) out[((int64_t)r1 * nchan + f) * 4 + ii * 2 + jj] = make_double2(re, im);
-            if (pb != qb) {
-                const int r2 = rm[q * NA + p];      // the same antennas the other way round: V_qp = V_pq^H
-                if (r2 >= 0) out[((int64_t)r2 * nchan + f) * 4 + jj * 2 + ii] = make_double2(re, -im);
-            }
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------------
-// The same product with THREE real matrix products per complex one (the 3M / Karatsuba form): with Gs = Gr + Gi and
-// Hd = Hr - Hi,
+// The complex product as THREE real matrix products (the 3M / Karatsuba form): with Gs = Gr + Gi and Hd = Hr - Hi,
 //     P1 = Gr Hr^T,  P2 = Gi Hi^T,  P3 = Gs Hd^T      ->      Re M = P1 + P2,   Im M = P3 - P1 + P2,
-// 3 MFMAs per tile and source PAIR (K = 4 = 2 sources x 2 columns of the Jones row) instead of 4: a quarter of the
-// matrix-core time for one more accumulator per tile (P1, P2, P3: 12 doubles per lane and tile) and two more operand
-// planes per source (Gs, Hd; the negated planes of the 4M form go).  Rounding: every P is a sum of products of the
+// 3 MFMAs per tile and source PAIR (K = 4 = 2 sources x 2 columns of the Jones row) where the direct form needs 4: a
+// quarter of the matrix-core time for one more accumulator per tile (P1, P2, P3: 12 doubles per lane and tile) and two
+// more operand planes per source (Gs, Hd).  (The direct four-product kernel of round 4's first half, 8 waves, was
+// removed in round 5: 1.33 x the MFMA time and the only GEMM kernel that spilled.)  Rounding: every P is a sum of products of the
 // same magnitudes as the direct form's, so the error bound is the direct form's times a small constant.
 // 12 waves: waves 0-7 matrix (tile i on wave i % 8: 5 or 4 tiles at 64 antennas, 9 per SIMD), waves 8-11 sampling.
 // Tile coordinates are compile-time per wave (switch on the wave number): every operand read is one lane base plus an
@@ -714,6 +472,80 @@ AF_EXPORT int af_fused_plan_antennas(const int64_t *time_index_host, const int32
     return AF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Plan guard.  A plan (af_fused_plan_groups / _rows / _antennas) is made from one call's (time_index, antenna1,
+// antenna2 [, uvw]); the predict entries then read the PLAN's arrays, not the call's.  af_fused_plan_check proves on
+// the device, in O(row) and without a host round trip, that a plan belongs to the arrays of THIS call:
+//   * row r of the call has the plan's step (up to the common offset time_index[0] - plan_step[0]) and antennas;
+//   * with ant_uvw: |x_a1 - x_a2 - uvw_r|_inf <= tol  (x = the plan's antenna coordinates of the row's step).
+// A mismatch sets AF_STATUS_PLAN_INDEX / AF_STATUS_PLAN_UVW in *status and fills `out` with NaN (the predict has
+// already run on the same stream: the call returns nothing that looks like a result).
+namespace {
+
+template <typename IT>
+__global__ void plan_check_kernel(const IT *__restrict__ time_index, const IT *__restrict__ antenna1,
+                                  const IT *__restrict__ antenna2, const double *__restrict__ uvw, int64_t nrow,
+                                  const int32_t *__restrict__ plan_step, const int32_t *__restrict__ plan_a1,
+                                  const int32_t *__restrict__ plan_a2, const double *__restrict__ ant_uvw, int64_t nant,
+                                  double tol, int *__restrict__ status)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    int flags = 0;
+    const int64_t shift = (int64_t)time_index[0] - plan_step[0];
+    const int64_t step = plan_step[r];
+    const int a1 = plan_a1[r], a2 = plan_a2[r];
+    if ((int64_t)time_index[r] - shift != step || (int64_t)antenna1[r] != a1 || (int64_t)antenna2[r] != a2)
+        flags |= AF_STATUS_PLAN_INDEX;
+    if (ant_uvw != nullptr && uvw != nullptr) {
+        const double *x1 = ant_uvw + (step * nant + a1) * 3, *x2 = ant_uvw + (step * nant + a2) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (!(fabs(x1[c] - x2[c] - uvw[3 * r + c]) <= tol)) flags |= AF_STATUS_PLAN_UVW;     // NaN fails
+    }
+    if (flags) atomicOr(status, flags);
+}
+
+__global__ void plan_poison_kernel(const int *__restrict__ status, double *__restrict__ out, int64_t n)
+{
+    if (*status == 0) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = nan;
+}
+
+}  // namespace
+
+AF_EXPORT int af_fused_plan_check(const void *time_index, const void *antenna1, const void *antenna2, int index_bytes,
+                                  const double *uvw, int64_t nrow, const int32_t *plan_step, const int32_t *plan_antenna1,
+                                  const int32_t *plan_antenna2, const double *ant_uvw, int64_t nant, double tol,
+                                  double *out, int64_t out_doubles, int32_t *status, void *stream)
+{
+    AF_REQUIRE(index_bytes == 4 || index_bytes == 8, "af_fused_plan_check: index_bytes must be 4 or 8");
+    AF_REQUIRE(status != nullptr, "af_fused_plan_check: status is NULL");
+    AF_REQUIRE(nrow >= 0 && nant >= 0 && out_doubles >= 0, "af_fused_plan_check: negative extent");
+    hipStream_t st_ = af_stream(stream);
+    AF_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st_));
+    if (nrow == 0) return AF_OK;
+    AF_REQUIRE(time_index && antenna1 && antenna2 && plan_step && plan_antenna1 && plan_antenna2,
+               "af_fused_plan_check: NULL array");
+    AF_REQUIRE((ant_uvw == nullptr) || uvw != nullptr, "af_fused_plan_check: ant_uvw without uvw");
+    const unsigned blocks = (unsigned)af_cdiv(nrow, 256);
+    if (index_bytes == 4)
+        hipLaunchKernelGGL(plan_check_kernel<int32_t>, dim3(blocks), dim3(256), 0, st_, (const int32_t *)time_index,
+                           (const int32_t *)antenna1, (const int32_t *)antenna2, uvw, nrow, plan_step, plan_antenna1,
+                           plan_antenna2, ant_uvw, nant, tol, status);
+    else
+        hipLaunchKernelGGL(plan_check_kernel<int64_t>, dim3(blocks), dim3(256), 0, st_, (const int64_t *)time_index,
+                           (const int64_t *)antenna1, (const int64_t *)antenna2, uvw, nrow, plan_step, plan_antenna1,
+                           plan_antenna2, ant_uvw, nant, tol, status);
+    AF_LAUNCH_CHECK();
+    if (out != nullptr && out_doubles > 0) {
+        hipLaunchKernelGGL(plan_poison_kernel, dim3(2048), dim3(256), 0, st_, status, out, out_doubles);
+        AF_LAUNCH_CHECK();
+    }
+    return AF_OK;
+}
+
 // The antenna-decomposed form of af_fused_predict_c128: same arguments, with the plan of af_fused_plan_antennas
 // (DEVICE copies: ant_uvw (nsteps, nant, 3), rowmap (nsteps, nap, nap)) in place of uvw, antenna1 / antenna2 and the
 // items; nsteps <= ntime; every row of `out` that the row map names is written, nothing else is touched.  Same workspace
@@ -762,12 +594,12 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     if (rc != AF_OK) return rc;
     const int64_t ncell = beam_lw * beam_mh;
     AF_REQUIRE(ncell < (1LL << 25), "af_fused_predict_antennas_c128: beam cube too large (fewer than 2^25 cells per plane)");
-    static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
-    static const int sample_prio = getenv("AFHIP_GEMM_PRIO") ? atoi(getenv("AFHIP_GEMM_PRIO")) : 1;   // A/B hook
+    // profiling builds only (make HOOKS=1 -> lib/prof/libafhip.so, -DAFHIP_STAGE_HOOKS): run one stage / change the
+    // sampling waves' priority; the shipped library does not read the environment here
+    static const int only_stage = AF_STAGE_ENV("AFHIP_FUSED_STAGE", 0);
+    static const int sample_prio = AF_STAGE_ENV("AFHIP_GEMM_PRIO", 1);
     const bool feed = feed_rotation != nullptr;
     const int nb = (int)((nant + 7) / 8);
-    // AFHIP_GEMM_3M=0: the four-product form (8 waves); default: the three-product form (12 waves)
-    static const int use_3m = getenv("AFHIP_GEMM_3M") ? atoi(getenv("AFHIP_GEMM_3M")) : 1;
     auto launch = [&](auto kernel, int NBc, int STc, int planes, int threads) -> int {
         const int na = NBc * 8, cs = na * 2 + COL_PAD;
         const size_t lds_bytes = (size_t)2 * STc * planes * cs * sizeof(double) + (size_t)na * 6 * sizeof(double) +
@@ -795,10 +627,8 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     };
     // sources per batch: about one super-round of the 256 sampling lanes (ST x 8 NB terms), two buffers within ~110 KB
 #define AF_GEMM_PICK(NBC, STC)                                                                                          \
-    (use_3m ? (feed ? launch(fused_gemm3_kernel<true, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS)                     \
-                    : launch(fused_gemm3_kernel<false, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS))                   \
-            : (feed ? launch(fused_gemm_kernel<true, NBC, STC>, NBC, STC, H_PLANES + G_PLANES, G_THREADS)                 \
-                    : launch(fused_gemm_kernel<false, NBC, STC>, NBC, STC, H_PLANES + G_PLANES, G_THREADS)))
+    (feed ? launch(fused_gemm3_kernel<true, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS)                              \
+          : launch(fused_gemm3_kernel<false, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS))
     switch (nb) {
     case 1: return AF_GEMM_PICK(1, 16);
     case 2: return AF_GEMM_PICK(2, 8);

@@ -645,7 +645,8 @@ AF_EXPORT int af_fused_predict_c128(const int32_t *items, int64_t nitems, const 
     const bool feed = feed_rotation != nullptr, gauss = gauss_shape != nullptr;
     // measurement hook (tools/profile_fused.sh): AFHIP_FUSED_STAGE=1 / 2 runs only the beam stage / only the
     // accumulation stage (results are then meaningless); unset = the real kernel
-    static const int only_stage = getenv("AFHIP_FUSED_STAGE") ? atoi(getenv("AFHIP_FUSED_STAGE")) : 0;
+    // (profiling builds only: make HOOKS=1, -DAFHIP_STAGE_HOOKS; the shipped library does not read the environment here)
+    static const int only_stage = AF_STAGE_ENV("AFHIP_FUSED_STAGE", 0);
     // channels in groups of PLANE_GROUP: interpolate the group's beam planes, then one launch for its channels (the
     // planes of a group are rewritten by the next group's pass on the same stream, after this group's kernel)
     auto launch = [&](auto kernel, int nthreads) -> int {

@@ -20,7 +20,7 @@ import threading
 import numpy as np
 
 from .. import _lib
-from .._device import Call, _is_torch
+from .._device import Call, _is_torch, np_dtype_of
 from .predict import predict_vis
 
 
@@ -32,15 +32,20 @@ class FusedPlan(object):
     """Row layout of a fused predict with DDEs: how the rows of every timestep are dealt to the lanes of a workgroup.
     Built by :func:`fused_plan`; holds host copies of the plan arrays and uploads them once per device."""
 
-    def __init__(self, nrow, nant, nsteps, items, groups, antenna1, antenna2):
+    def __init__(self, nrow, nant, nsteps, items, groups, antenna1, antenna2, step):
         self.nrow, self.nant, self.nsteps = nrow, nant, nsteps
         self.items, self.groups = items, groups
         self.antenna1, self.antenna2 = antenna1, antenna2
+        self.step = step            # (row,) int32: time_index - min(time_index) -- what af_fused_plan_check compares
         self.n_items = int(items.shape[0]) if nrow else 0
         # antenna decomposition of uvw (fused_plan(..., uvw=...)): per-antenna coordinates (nsteps, nant, 3), the row of
         # every (step, antenna1, antenna2) (nsteps, nap, nap) and the largest |x_p - x_q - uvw_pq| [m]; None = the rows
         # are not (known to be) antenna-decomposable and the call runs on the lane-per-row kernel
         self.ant_uvw = self.rowmap = self.residual = None
+        self.tol = DECOMPOSE_TOL
+        # rows over the baseline slots the GEMM form evaluates (nsteps x upper block triangle of 8-antenna blocks): the
+        # GEMM form pays for every slot, the lane-per-row kernel for every row (fused_predict_vis picks by this)
+        self.fill = 1.0
         self._dev = {}
 
     @property
@@ -108,7 +113,8 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
         items = np.zeros((max(n_items.value, 1), 4), dtype=np.int32)
         _lib.call("af_fused_plan_rows", tip, nrow, items.ctypes.data_as(ctypes.c_void_p), n_items.value,
                   ctypes.byref(n_items))
-    plan = FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h)
+    step = (ti - (ti.min() if nrow else 0)).astype(np.int32)
+    plan = FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h, step)
     if uvw is not None and nrow and nant <= 64 and os.environ.get("AFHIP_FUSED_GEMM", "1") != "0":
         uvw_h = np.ascontiguousarray(_host(uvw), dtype=np.float64)
         if uvw_h.shape != (nrow, 3):
@@ -121,14 +127,38 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
         _lib.call("af_fused_plan_antennas", tip, a1h.ctypes.data_as(ctypes.c_void_p), a2h.ctypes.data_as(ctypes.c_void_p),
                   uvw_h.ctypes.data_as(ctypes.c_void_p), nrow, nant, tol, nsteps, ant_uvw.ctypes.data_as(ctypes.c_void_p),
                   rowmap.ctypes.data_as(ctypes.c_void_p), ctypes.byref(resid), ctypes.byref(ok))
-        plan.residual = resid.value
+        plan.residual, plan.tol = resid.value, tol
+        nb = nap // 8
+        plan.fill = nrow / float(nsteps * (nb * (nb + 1) // 2) * 64)
         if ok.value:
             plan.ant_uvw, plan.rowmap = ant_uvw, rowmap
     return plan
 
 
+# the GEMM form costs ~73 flop per baseline SLOT of the upper block triangle, the lane-per-row kernel ~126 per ROW
+# (csrc/af_fused_gemm.hip header): below this fill (sub-arrays, baseline selections, an antenna axis much larger than
+# the antennas present) the row kernel is the faster one.  A full 64-antenna step has fill 2016 / 2304 = 0.875.
+GEMM_MIN_FILL = 0.5
+
+
 _plan_cache = collections.OrderedDict()
+_plan_ident = collections.OrderedDict()     # identity of device tensors -> plan (see cached_plan)
 _plan_lock = threading.Lock()
+
+
+def _tensor_ident(arrays):
+    """Identity key of a set of device tensors: (data_ptr, shape, dtype, torch's in-place version counter) each, or None
+    when one of them is not a torch tensor.  The cache entry keeps weak references and is a hit only for the SAME tensor
+    objects at the same version: a new tensor that happens to land on a freed address is a different object."""
+    key = []
+    for a in arrays:
+        if a is None:
+            key.append(None)
+            continue
+        if not _is_torch(a):
+            return None
+        key.append((a.data_ptr(), tuple(a.shape), str(a.dtype), a._version))
+    return tuple(key)
 
 
 def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
@@ -137,13 +167,28 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
     ``sharding.fused_predict_shard``), where the same row chunk comes back for every channel block, every source chunk
     and every imaging cycle, each time as a fresh array.  ``AFHIP_PLAN_CACHE`` = number of plans kept (default 16,
     least recently used first out; 0 = no cache).  With ``uvw`` the plan carries the antenna decomposition (see
-    :func:`fused_plan`) and the digest covers ``uvw`` as well."""
+    :func:`fused_plan`) and the digest covers ``uvw`` as well.
+
+    Device tensors are first looked up by IDENTITY -- the same tensor objects at the same in-place version (torch's
+    ``_version``) as a previous call: no device -> host copy, no stream synchronisation, no O(row) host work --, and only
+    on a miss copied to the host and digested.  Either way ``fused_predict_vis(plan=...)`` verifies the plan
+    against the call's arrays on the device, so a wrong hit cannot produce a wrong result."""
     limit = int(os.environ.get("AFHIP_PLAN_CACHE", "16"))
     if limit <= 0:
         return fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
+    arrays = (time_index, antenna1, antenna2, uvw)
+    ident = _tensor_ident(arrays)
+    if ident is not None:
+        ikey = (int(nant), bool(grouped), ident)
+        with _plan_lock:
+            hit = _plan_ident.get(ikey)
+            if hit is not None and all((r is None and a is None) or (r is not None and r() is a)
+                                       for r, a in zip(hit[0], arrays)):
+                _plan_ident.move_to_end(ikey)
+                return hit[1]
     h = hashlib.blake2b(digest_size=16)
     n = 0
-    for a in (time_index, antenna1, antenna2, uvw):
+    for a in arrays:
         if a is None:
             continue
         a = np.ascontiguousarray(_host(a))
@@ -155,12 +200,19 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
         plan = _plan_cache.get(key)
         if plan is not None:
             _plan_cache.move_to_end(key)
-            return plan
-    plan = fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
-    with _plan_lock:
-        _plan_cache[key] = plan
-        while len(_plan_cache) > limit:
-            _plan_cache.popitem(last=False)
+    if plan is None:
+        plan = fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
+        with _plan_lock:
+            _plan_cache[key] = plan
+            while len(_plan_cache) > limit:
+                _plan_cache.popitem(last=False)
+    if ident is not None:
+        import weakref
+        refs = tuple(None if a is None else weakref.ref(a) for a in arrays)
+        with _plan_lock:
+            _plan_ident[ikey] = (refs, plan)
+            while len(_plan_ident) > 4 * limit:
+                _plan_ident.popitem(last=False)
     return plan
 
 
@@ -189,7 +241,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     the call and no (source, chan, 2, 2) array exists on the caller's side.  ``plan``: a :func:`fused_plan` of the
     row layout (time_index, antenna1, antenna2) -- made once and re-used for every call on that layout (every channel
     block, every imaging cycle); without it the plan is rebuilt per call, which costs a device -> host copy of the three
-    index arrays and O(row) host work.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    index arrays and O(row) host work.  A plan made with ``uvw=`` is bound to those ``uvw`` as well.  A plan passed in is
+    VERIFIED against this call's ``time_index`` / ``antenna1`` / ``antenna2`` / ``uvw`` on the device
+    (``af_fused_plan_check``, O(row), no host round trip): on a mismatch the result is NaN and ``ValueError`` is raised
+    -- at once for numpy arguments, at the next call / ``check_status()`` for device tensors.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
     ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
     per-antenna Jones terms on the device.  float64 / complex128 only.
     """
@@ -302,6 +357,7 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 raise ValueError("point_errors must have shape (time, ant, chan, 2)")
             if tuple(antenna_scaling.shape) != (nant, nchan, 2):
                 raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
+            explicit_plan = plan is not None
             if plan is None:
                 plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True,
                                   uvw=None if gauss_shape is not None else uvw)
@@ -310,6 +366,7 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                                  % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
             # antenna-decomposable rows: the GEMM form (Gaussian shapes depend on the baseline: general kernel)
             gemm = plan.decomposable and gauss_shape is None and nrow > 0 and \
+                plan.fill >= float(os.environ.get("AFHIP_GEMM_MIN_FILL", GEMM_MIN_FILL)) and \
                 os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
             if gemm:
                 p_au = c.inp(plan.device(plan.ant_uvw, c), np.float64)
@@ -318,8 +375,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 n_items = ctypes.c_int64(plan.n_items)
                 p_items = c.inp(plan.device(plan.items, c), np.int32)
                 p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
-                a1h, a2h = plan.antenna1, plan.antenna2
-                p_a1, p_a2 = c.inp(a1h, np.int32), c.inp(a2h, np.int32)
+                p_a1 = c.inp(plan.device(plan.antenna1, c), np.int32)
+                p_a2 = c.inp(plan.device(plan.antenna2, c), np.int32)
             p_beam, p_ext, p_map = c.inp(beam, np.complex128), c.inp(beam_lm_extents, np.float64), \
                 c.inp(beam_freq_map, np.float64)
             p_pa, p_pe, p_as = c.inp(parallactic_angles, np.float64), c.inp(point_errors, np.float64), \
@@ -356,11 +413,39 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 _lib.call("af_fused_predict_c128", p_items, n_items.value, p_a1, p_a2, p_groups, nrow, p_lm, p_uvw, p_fr, p_b,
                           nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe,
                           p_as, p_fr_rot, p_gs, conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+            if explicit_plan and nrow:
+                _check_plan(c, plan, gemm, time_index, antenna1, antenna2, p_uvw, nrow, p_out, nrow * nchan * 8)
         vis = c.result(h)
     if die1_jones is None and base_vis is None:
         return vis
     # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
     return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+
+
+def _plan_status_message(flags):
+    what = []
+    if flags & _lib.AF_STATUS_PLAN_INDEX:
+        what.append("time_index / antenna1 / antenna2 differ from the arrays the plan was made from")
+    if flags & _lib.AF_STATUS_PLAN_UVW:
+        what.append("uvw differ from the uvw the plan's antenna decomposition was solved from")
+    return "fused_predict_vis: stale plan: " + " and ".join(what)
+
+
+def _check_plan(c, plan, gemm, time_index, antenna1, antenna2, p_uvw, nrow, p_out, out_doubles):
+    """A caller-supplied plan against the call's own arrays (af_fused_plan_check, after the predict on its stream)."""
+    from .predict import _index_array
+    p_ti, ib = _index_array(c, time_index)
+    if ib == 4 and not (np_dtype_of(antenna1) == np.int32 and np_dtype_of(antenna2) == np.int32):
+        p_ti, ib = c.inp(time_index, np.int64), 8
+    idt = np.int32 if ib == 4 else np.int64
+    p_a1, p_a2 = c.inp(antenna1, idt), c.inp(antenna2, idt)
+    p_ps = c.inp(plan.device(plan.step, c), np.int32)
+    p_pa1, p_pa2 = c.inp(plan.device(plan.antenna1, c), np.int32), c.inp(plan.device(plan.antenna2, c), np.int32)
+    p_au = c.inp(plan.device(plan.ant_uvw, c), np.float64) if gemm else None
+    p_status = c.scratch(256)
+    _lib.call("af_fused_plan_check", p_ti, p_a1, p_a2, ib, p_uvw, nrow, p_ps, p_pa1, p_pa2, p_au, plan.nant,
+              plan.tol, p_out, out_doubles, p_status, c.stream)
+    c.watch_status(0, _plan_status_message)
 
 
 def _model_dft(stokes, spi, ref_freq, uvw, lm, frequency, base, tabs, npol, convention):

@@ -341,6 +341,23 @@ int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap,
                                    const double *feed_rotation, int convention, double *out, void *workspace,
                                    size_t workspace_bytes, void *stream);
 
+/* Plan guard (DEVICE pointers except none; O(row) on the device, no host round trip).  The predict entries above read
+ * the PLAN's arrays (items / groups / antenna1 / antenna2, ant_uvw / rowmap), not the call's own index arrays and uvw: a
+ * plan re-used with other rows or other uvw would silently compute with the old ones (the reference has no plan:
+ * africanus/rime/predict.py:199-212 reads time_index / antenna1 / antenna2 of the call).  af_fused_plan_check, enqueued
+ * AFTER the predict on the same stream, verifies for every row r
+ *     time_index[r] - time_index[0] == plan_step[r] - plan_step[0],  antenna1[r] == plan_antenna1[r],  antenna2 likewise,
+ *     and, with ant_uvw (nsteps, nant, 3) != NULL:  |x_a1 - x_a2 - uvw[r]|_inf <= tol  [m]
+ * (plan_step = time_index - min(time_index) at planning time, int32; index_bytes = 4 / 8: int32 / int64 index arrays).
+ * On a mismatch AF_STATUS_PLAN_INDEX / AF_STATUS_PLAN_UVW is set in *status (int32, DEVICE; zeroed by the call) and `out`
+ * (out_doubles doubles; may be NULL) is filled with NaN. */
+#define AF_STATUS_PLAN_INDEX 4
+#define AF_STATUS_PLAN_UVW 8
+int af_fused_plan_check(const void *time_index, const void *antenna1, const void *antenna2, int index_bytes,
+                        const double *uvw, int64_t nrow, const int32_t *plan_step, const int32_t *plan_antenna1,
+                        const int32_t *plan_antenna2, const double *ant_uvw, int64_t nant, double tol, double *out,
+                        int64_t out_doubles, int32_t *status, void *stream);
+
 /* ---- Gaussian (and point) sources without direction-dependent terms ----------------------------------------
  * out[r,nu] = sum_s shape(r,s,nu) K(r,s,nu) X_s(nu): the reference's phase_delay (africanus/rime/phase.py:11-63) x
  * gaussian shape (africanus/model/shape/gaussian_shape.py:11-62) x brightness, summed over the sources

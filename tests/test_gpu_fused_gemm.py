@@ -17,6 +17,13 @@ from test_gpu_fused import _problem, _oracle_chain, _scale
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _gemm_at_any_fill(monkeypatch):
+    """These tests are about the GEMM form's arithmetic and row layouts at small, sparse shapes: the fill-factor rule that
+    would send most of them to the lane-per-row kernel (fused.GEMM_MIN_FILL) is off except where it is the subject."""
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+
+
 def _decomposable(d, nant, seed=0, keep=1.0, swap=0.0, shuffle=False, autos=False):
     """Replace the problem's uvw by differences of per-(time, antenna) coordinates; optionally drop baselines, swap
     antenna1 / antenna2 of some rows, shuffle the rows inside every timestep, turn some rows into autocorrelations."""
@@ -223,3 +230,94 @@ def test_gemm_form_against_the_reference_itself(case):
                                  g["beam"], g["beam_lm_extents"], g["beam_freq_map"], g["parallactic_angles"], g["point_errors"],
                                  g["antenna_scaling"], plan=fused.fused_plan(g["time_index"], g["antenna1"], g["antenna2"], nant), **kw)
     assert np.abs(gen - ref).max() <= 1e-9 * scale
+
+
+def test_fill_factor_dispatch(monkeypatch):
+    """the GEMM form pays for every baseline slot of the block triangle, the row kernel for every row: a
+    20-antenna sub-array on a 64-antenna axis (190 rows per step against 2304 slots) must take the row kernel"""
+    nant = 64
+    d = _problem(21, 4032, 3, 11, nant)
+    sub = (d["ant1"] < 20) & (d["ant2"] < 20)
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        d[k] = d[k][sub]
+    d = _decomposable(d, nant, seed=9)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable and 0.05 < plan.fill < 0.12
+    monkeypatch.delenv("AFHIP_GEMM_MIN_FILL")
+    out = _call(d, plan=plan)                                   # the default rule: the row kernel
+    monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
+    assert np.array_equal(out, _call(d))
+    monkeypatch.delenv("AFHIP_FUSED_GEMM")
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+    forced = _call(d, plan=plan)                                # the GEMM form on the same plan: other bits, same answer
+    assert not np.array_equal(out, forced)
+    assert np.abs(out - forced).max() < 1e-10 * _scale(d)
+    full = _decomposable(_problem(22, 4032, 2, 5, nant), nant, seed=10)
+    assert fused.fused_plan(full["time_index"], full["ant1"], full["ant2"], nant, uvw=full["uvw"]).fill == 2016 / 2304.0
+
+
+@pytest.mark.parametrize("route", ["gemm", "rows"])
+def test_stale_plan_is_refused(route, monkeypatch):
+    """VERDICT r4 item 7 / ADVICE r4: a plan is bound to the (time_index, antenna1, antenna2, uvw) it was made from; the
+    call verifies a caller-supplied plan on the device and refuses a stale one instead of computing with the old arrays"""
+    import torch
+    import codex_africanus_amd as af
+    if route == "rows":
+        monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
+    nant = 12
+    d = _decomposable(_problem(23, 660, 3, 7, nant), nant, seed=11)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable == (route == "gemm")
+    good = _call(d, plan=plan)
+    assert np.abs(good - _oracle_chain(d, True)).max() < 1e-9 * _scale(d)
+    # the same plan with a time offset on the call's side is the same layout
+    assert np.array_equal(_call(dict(d, time_index=d["time_index"] + 5), plan=plan), good)
+    # other antennas on the same rows
+    other = dict(d, ant1=d["ant2"].copy(), ant2=d["ant1"].copy())
+    with pytest.raises(ValueError, match="stale plan.*antenna"):
+        _call(other, plan=plan)
+    # rows of two timesteps exchanged (same antennas): the steps differ
+    ti2 = d["time_index"].copy()
+    ti2[ti2 == 1] = 7
+    with pytest.raises(ValueError, match="stale plan"):
+        _call(dict(d, time_index=ti2), plan=plan)
+    if route == "gemm":
+        # re-phased uvw (another field): decomposable, but not by THIS plan's antenna coordinates
+        moved = _decomposable(d, nant, seed=12)
+        assert not np.allclose(moved["uvw"], d["uvw"])
+        with pytest.raises(ValueError, match="stale plan.*uvw"):
+            _call(moved, plan=plan)
+        # uvw equal to rounding (1e-12 m): the same plan serves
+        near = dict(d, uvw=d["uvw"] + 1e-12)
+        assert np.abs(_call(near, plan=plan) - good).max() < 1e-10 * _scale(d)
+    # device tensors: nothing synchronises in the call; the result is NaN and the error surfaces at check_status()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(other[k]) for k in ("time_index", "ant1", "ant2", "lm", "uvw", "frequency", "X", "beam", "extents",
+                                  "beam_freq_map", "pa", "pe", "as")]
+    out = rime.fused_predict_vis(*args, plan=plan)
+    with pytest.raises(ValueError, match="stale plan"):
+        af.check_status()
+    assert bool(torch.isnan(out.real).all())
+    args = [t(d[k]) for k in ("time_index", "ant1", "ant2", "lm", "uvw", "frequency", "X", "beam", "extents",
+                              "beam_freq_map", "pa", "pe", "as")]
+    out = rime.fused_predict_vis(*args, plan=plan)
+    af.check_status()
+    assert np.array_equal(out.cpu().numpy(), good)
+
+
+def test_cached_plan_by_tensor_identity():
+    """device-resident index arrays are looked up by identity + torch's version counter before anything is
+    copied to the host; an in-place change is a miss"""
+    import torch
+    nant = 9
+    d = _decomposable(_problem(24, 300, 2, 3, nant), nant, seed=13)
+    dev = torch.device("cuda:0")
+    ti, a1, a2, uvw = (torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in ("time_index", "ant1", "ant2", "uvw"))
+    p1 = fused.cached_plan(ti, a1, a2, nant, uvw=uvw)
+    assert fused.cached_plan(ti, a1, a2, nant, uvw=uvw) is p1
+    assert fused.cached_plan(ti.clone(), a1, a2, nant, uvw=uvw) is p1          # other object, same contents: the digest
+    uvw.mul_(2.0)                                                             # in place: version counter moves
+    p2 = fused.cached_plan(ti, a1, a2, nant, uvw=uvw)
+    assert p2 is not p1 and p2.decomposable
+    assert np.allclose(p2.ant_uvw, 2.0 * p1.ant_uvw)

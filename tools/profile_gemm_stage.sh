@@ -7,6 +7,11 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 STAGE=${1:-0}
 export AFHIP_FUSED_STAGE=$STAGE
+# the stage hook exists only in the profiling build: make -C codex_africanus_amd/csrc HOOKS=1 (before gpurun: it travels)
+if [ "$STAGE" != 0 ]; then
+  export AFHIP_LIB=codex_africanus_amd/lib/prof/libafhip.so
+  [ -f "$AFHIP_LIB" ] || { echo "build the profiling library first: make -C codex_africanus_amd/csrc HOOKS=1"; exit 1; }
+fi
 OUT=gpurun_out/prof_gemm_s$STAGE
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="bench.py --workload fused_dde_ant --steps 2 --warmup 1 --no-cpu-baseline --check-rows 0 --extras none"

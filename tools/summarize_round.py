@@ -27,7 +27,7 @@ def find(base, suffix):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     dl = os.path.join(SRC, "default_line.json")
     if os.path.exists(dl):
         lines = [x for x in open(dl).read().splitlines() if x.startswith("{")]
@@ -46,6 +46,9 @@ def main():
                 d = json.loads(lines[-1])
                 summary["bench_kernel_ms_hip_events"] = d["roofline"]["kernel_ms"]
                 summary["bench_value_Mvis_s"] = d["value"]
+                ex = d["roofline"].get("executed", {})
+                if "mfma_instructions" in ex:
+                    summary["bench_mfma_instructions"] = ex["mfma_instructions"]
         stats = find(os.path.join(base, "stats"), "kernel_stats.csv")
         if stats:
             shutil.copy(stats, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, w)))
@@ -84,6 +87,13 @@ def main():
                     summary["avg_ns_under_pmc_%s" % sub] = sum(dur) / len(dur)
         if "SQ_LDS_BANK_CONFLICT" in summary and summary.get("SQ_LDS_IDX_ACTIVE"):
             summary["lds_conflict_ratio"] = summary["SQ_LDS_BANK_CONFLICT"] / summary["SQ_LDS_IDX_ACTIVE"]
+        if "bench_mfma_instructions" in summary and "SQ_INSTS_MFMA" in summary:
+            # the line's "executed" block must describe the kernel that ran (it counted the removed 4M
+            # kernel's schedule for a round): matrix instructions claimed == matrix instructions counted
+            ratio = summary["bench_mfma_instructions"] / summary["SQ_INSTS_MFMA"]
+            summary["mfma_claimed_over_counted"] = ratio
+            assert abs(ratio - 1.0) < 0.01, "%s: bench line claims %g MFMA per launch, SQ_INSTS_MFMA counted %g" % (
+                w, summary["bench_mfma_instructions"], summary["SQ_INSTS_MFMA"])
         if "GRBM_GUI_ACTIVE" in summary and "avg_ns_under_pmc_sq" in summary:
             summary["clock_GHz"] = summary["GRBM_GUI_ACTIVE"] / 8.0 / summary["avg_ns_under_pmc_sq"]
         json.dump(summary, open(os.path.join(DST, "%s_%s_pmc_summary.json" % (tag, w)), "w"), indent=1)
