@@ -73,14 +73,21 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         dist.barrier()
     elapsed = time.perf_counter() - t0
     reported = 1
+    kernel_s = ev.collect()
+    per_rank = None
     if world > 1:
+        # every rank's own wall time and dominant-kernel time (straggler diagnosis: the job's time is the MAX), then the
+        # max over ranks and the number of ranks that reported
+        mine = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        mine[rank, 0], mine[rank, 1] = elapsed, kernel_s
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank = mine.cpu().numpy()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         one = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         reported = int(round(float(one.item())))
-    kernel_s = ev.collect()
     if have_chi2:        # the step's chi^2 against a separate pass over the final visibilities (checker)
         ref_chi2 = torch.zeros_like(d_chi2)
         _lib.call("af_chi2_c128", P(d_vis), P(d_data), None, nrow, nchan, ncorr, P(ref_chi2), stream)
@@ -99,6 +106,11 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
     }
     if front_end is not None:
         res["front_end"] = front_end
+    if per_rank is not None:
+        k_ms, e_ms = 1e3 * per_rank[:, 1], 1e3 * per_rank[:, 0] / steps
+        res["per_rank"] = {"kernel_ms": [round(float(x), 4) for x in k_ms], "kernel_ms_min": float(k_ms.min()),
+                           "kernel_ms_max": float(k_ms.max()), "ms_per_step": [round(float(x), 4) for x in e_ms],
+                           "ms_per_step_min": float(e_ms.min()), "ms_per_step_max": float(e_ms.max())}
     if hasattr(wl, "end_to_end") and world == 1:
         res["end_to_end"] = wl.end_to_end()
     if cpu_seconds > 0 and world == 1:
@@ -129,6 +141,10 @@ def headline_json(args, res, world_desc, backend_desc):
         out["cpu_baseline"] = res["cpu_baseline"]
     if "front_end" in res:
         out["config"]["front_end"] = res["front_end"]
+    if "per_rank" in res:
+        out["per_rank"] = res["per_rank"]
+        for k in ("kernel_ms_min", "kernel_ms_max", "ms_per_step_min", "ms_per_step_max"):
+            out["config"]["rank_" + k] = res["per_rank"][k]      # scalars: the driver's record keeps them
     return out
 
 

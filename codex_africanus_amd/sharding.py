@@ -112,12 +112,19 @@ def chi2(model, data, weight=None):
     return out
 
 
-def predict_shard(rank, world_size, image, uvw, lm, frequency, data=None, convention="fourier", group=None):
+def predict_shard(rank, world_size, image, uvw, lm, frequency, data=None, convention="fourier", group=None,
+                  time_index=None):
     """One rank's part of the row-sharded direct-transform predict: im_to_vis on its row block
     (device resident) and, if ``data`` (the rank's rows) is given, the all-reduced chi-squared.
+    ``time_index`` (row,), non-decreasing, optional: the block then starts and ends on timestep boundaries
+    (``shard_bounds(nrow, world_size, time_index)``: the reference's rule for row chunks that meet (time, ant, ...) arrays,
+    africanus/rime/dask_predict.py:494-499), so that the same bounds serve the DIE / DDE stages of the job.
     Returns (vis_shard, chi2 or None, (start, stop))."""
     from .dft.kernels import im_to_vis, im_to_vis_chi2
-    start, stop = shard_bounds(uvw.shape[0], world_size)[rank]
+    if time_index is not None:
+        from .rime.fused import _host
+        time_index = np.asarray(_host(time_index))
+    start, stop = shard_bounds(uvw.shape[0], world_size, time_index)[rank]
     if data is None:
         return im_to_vis(image, uvw[start:stop], lm, frequency, convention=convention), None, (start, stop)
     # transform and chi^2 in one device call (summed in the transform's epilogue where the MFMA kernels run)

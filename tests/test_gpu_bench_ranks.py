@@ -161,3 +161,33 @@ def test_fused_dde_rows_over_two_ranks(executor, workload):
     assert r["roofline"]["kernel"] == ("fused_gemm3_kernel" if workload == "fused_dde_ant" else "fused_predict_kernel")
     if executor == "ranks":
         assert "bit-equal" in r["config"]["front_end"] and "rank 0 of 2" in r["config"]["front_end"]
+
+
+@pytest.mark.parametrize("executor, workload", [("ranks", "dft"), ("threads", "dft"), ("ranks", "fused_dde_ant")])
+def test_configs3_eight_ranks_at_the_full_per_rank_shape(executor, workload):
+    """BASELINE configs[3] as the driver will launch it on an 8-GPU node -- `bench.py --gpus 8`, 1e6 rows x 64 chan x 1000
+    src PER RANK, 8e6 rows in all -- with the eight ranks / workers aliased onto the one device of the test box
+    (AFHIP_BENCH_DEVICE=0, gloo instead of RCCL: 8 x (4.1 GB model + 4.1 GB data) fit one 288 GB device).  Everything of
+    the 8-GPU job except the xGMI hop runs: eight shards of the full shape, the chi^2 all-reduce, max-over-ranks timing,
+    and the per-rank kernel times the line carries for straggler diagnosis."""
+    args = ["--gpus", "8", "--executor", executor, "--workload", workload, "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--check-rows", "32", "--launch-timeout", "850"]
+    rc, lines, out, err = _run(args, _clean_env(AFHIP_BENCH_DEVICE="0"))
+    assert rc == 0, (out[-2000:], err[-4000:])
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak"
+    assert r["config"]["rows_per_gpu"] == 1000000 and r["config"]["rows_total"] == 8000000
+    assert r["config"]["chans"] == 64 and r["config"]["sources"] == 1000
+    assert r["fp64_max_abs_err"] < 1e-8
+    assert abs(r["value"] - 8e6 * 64 / (r["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * r["value"]
+    if executor == "ranks":
+        pr = r["per_rank"]
+        assert len(pr["kernel_ms"]) == 8 and len(pr["ms_per_step"]) == 8
+        assert 0 < pr["kernel_ms_min"] <= pr["kernel_ms_max"]
+        assert r["config"]["rank_kernel_ms_min"] == pr["kernel_ms_min"] and r["config"]["rank_kernel_ms_max"] == pr["kernel_ms_max"]
+        # the job's step time is the slowest rank's (max over ranks), never an average
+        assert r["ms_per_step"] >= pr["ms_per_step_max"] * (1 - 1e-9)
+        assert "gloo" in r["config"]["sharding"] and "all ranks on device 0" in r["config"]["executor"]
+    else:
+        assert len(r["per_device_kernel_ms"]) == 8 and r["config"]["physical_devices"] == 1
