@@ -96,6 +96,9 @@ def parse(argv=None):
                    help="fused_dde: parallactic angles iid U(0, pi/6) per (time, antenna) (SURVEY 8(d), the "
                         "reference's own test recipe) or one angle per timestep + 1e-3 rad antenna jitter "
                         "(a real array: coherent beam gathers)")
+    p.add_argument("--antennas", type=int, default=64,
+                   help="fused_dde / fused_dde_ant: antennas of the array (64 = BASELINE configs[2]; the GEMM form runs up to "
+                        "256 in super-tiles, the lane-per-row kernel up to 664)")
     p.add_argument("--npix", type=int, default=DEFAULT_SHAPE["npix"], help="degrid / wgrid: grid size")
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
                    help="torch.distributed backend; nccl = RCCL over xGMI.  auto = nccl, or gloo when "

@@ -20,7 +20,7 @@ NUMBA_CALIBRATION = {"value": 0.026, "unit": "Mvis/s per core at 1000 sources",
                      "source": "SURVEY.md section 6: africanus.dft.im_to_vis under numba on one Xeon core of the build "
                                "container, 38 ns per (row, chan, src); not measurable on the GPU box (no numba there)"}
 EXTRA_WORKLOADS = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
-DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096)
+DEFAULT_SHAPE = dict(rows=1000000, chans=64, sources=1000, mode="auto", pa="random", npix=4096, antennas=64)
 
 
 

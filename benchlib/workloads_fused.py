@@ -20,6 +20,7 @@ class FusedDde(object):
         import torch
         from codex_africanus_amd.testing import synthetic_inputs
         self.args, self._lib = args, _lib
+        self.NANT = int(getattr(args, "antennas", 64))          # instance attribute: 64 unless --antennas says otherwise
         nrow, nchan, nsrc, nant = args.rows, args.chans, args.sources, self.NANT
         d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
         rng = np.random.default_rng(1000 + args.seed + rank)
@@ -91,8 +92,8 @@ class FusedDde(object):
         self.h = dict(time_index=time_index, ant1=ant1, ant2=ant2, X=X, beam=beam, extents=extents,
                       beam_freq_map=beam_freq_map, pa=pa, pe=pe, asc=asc, lm=lm, uvw=uvw, freq=freq)
         self.ncorr = 4
-        self.label = ("fused predict with per-antenna beam-cube DDEs, 64 antennas (BASELINE configs[2]), "
-                      "parallactic angles %s" % args.pa)
+        self.label = ("fused predict with per-antenna beam-cube DDEs, %d antennas (BASELINE configs[2]%s), "
+                      "parallactic angles %s" % (nant, "" if nant == 64 else " at another array size", args.pa))
         if self.antennas:
             self.label += "; antenna-decomposable uvw (Measurement-Set geometry): GEMM form on the fp64 matrix cores"
 
@@ -168,10 +169,11 @@ class FusedDde(object):
         terms = float(nsrc) * self.ntime * self.NANT * nchan
         if self.antennas:
             # the GEMM form: 8 complex MACs = 64 flop per (row, chan, source) of needed output; executed: 36 of the 64
-            # 16 x 16 tiles of M per (timestep, channel), the complex product in the three-product (3M) form: 3 MFMA
+            # (af_fused_gemm_slots / 64 beyond 64 antennas) 16 x 16 tiles of M per (timestep, channel), the complex product in the three-product (3M) form: 3 MFMA
             # 16x16x4 (2048 flop each) per tile and source PAIR = 1.5 per (tile, source).  (Until round 4 this line
             # counted 2 per (tile, source), the removed four-product kernel's schedule: VERDICT r4 "weak" 3.)
-            self.mfma_per_launch = 36.0 * 1.5 * nsrc * self.ntime * nchan     # = SQ_INSTS_MFMA of the PMC pass
+            tiles = self._lib.load().af_fused_gemm_slots(self.NANT) / 64.0    # 36 at 64 antennas, 136 at 128
+            self.mfma_per_launch = tiles * 1.5 * nsrc * self.ntime * nchan    # = SQ_INSTS_MFMA of the PMC pass
             mfma_flops = self.mfma_per_launch * 2048
             executed = {"mfma_instructions": self.mfma_per_launch, "mfma_flop_per_unit": mfma_flops / units,
                         "mfma_tflops": mfma_flops / kernel_s / 1e12,

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "af_gauss_predict_chi2_c128": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "af_fused_plan_antennas": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, _i64, _vp, _vp,
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "af_fused_gemm_slots": (_i64, [_i64]),
     "af_fused_plan_check": (_int, [_vp, _vp, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _i64, ctypes.c_double, _vp, _i64, _vp,
                                    _vp]),
     "af_fused_predict_antennas_c128": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,

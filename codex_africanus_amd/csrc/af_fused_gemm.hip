@@ -65,18 +65,73 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // immediate offset.
 constexpr int G3_THREADS = 768, G3_MATRIX = 512, G3_SAMPLERS = 256, G3_PLANES = 6;
 
-constexpr int tri_row(int nb, int i)
+// ---- super-tiles (round 5: 65 .. 256 antennas) ---------------------------------------------------------------------
+// A workgroup owns one (timestep, channel, SUPER-TILE of M): its eight matrix waves hold at most 5 tiles each (12
+// accumulator doubles per tile and lane: 168 registers at three waves per SIMD), i.e. <= 40 tiles of 8 x 8 antennas.
+//   DIAG<nb>   block rows = block columns = nb consecutive 8-antenna blocks: the upper block triangle, nb (nb + 1) / 2
+//              tiles; every sampled (source, antenna) term serves as a row (G planes) and as a column (H planes).
+//              nant <= 64 is ONE such super-tile (round 4's kernel).
+//   RECT       8 block rows x 4 block columns off the diagonal (32 tiles, matrix wave w = block row w; fewer column blocks
+//              at the end of the array: those tiles are skipped): the 64 row antennas are sampled for their G planes, the
+//              <= 32 column antennas for their H planes -- 96 terms per source.
+// More than 64 antennas: the ceil(nant / 8) blocks are cut into super-blocks of 8 (the last one shorter); every
+// super-block is a DIAG, every pair (i < j) two RECTs (rows = super-block i, columns = the halves of super-block j).
+// 128 antennas: 2 x 64 + 2 x 96 = 320 sampled terms per source for 8128 baselines (64 antennas: 64 for 2016): sampling
+// per baseline costs 1.24 x what it does at 64 antennas, and far less than the lane-per-row kernel's arithmetic.
+// (Round 5's first tiling -- super-blocks of 4 .. 6 blocks, square RECTs of a x a tiles -- sampled 400 terms at 128
+// antennas: 160.6 ms for 1e6 rows x 64 channels x 1000 sources against 206.3 for the lane-per-row kernel.)
+template <bool RECT, int NBR, int NBC, int ST>
+struct Geo {
+    static constexpr int NAR = 8 * NBR, NAC = 8 * NBC;                      // antennas of the G (row) / H (column) panels
+    static constexpr int CSG = 2 * NAR + COL_PAD, CSH = 2 * NAC + COL_PAD;  // doubles per operand plane
+    static constexpr int SRC = G3_PLANES * (CSH + CSG);                     // one source: H planes, then G planes
+    static constexpr int BUF = ST * SRC;                                    // one batch
+    static constexpr int TPS = RECT ? NAR + NAC : NAR;                      // sampled terms (antenna slots) per source
+    static constexpr int BT = ST * TPS;                                     // terms per batch
+    // the 256 sampling lanes take 256 terms a super-round.  A batch that is not a whole number of super-rounds either
+    // pads its last one (DIAG of small arrays: lanes redo earlier terms) or -- RECT: 4 x 96 = 384 terms -- lets
+    // the super-rounds run on across the batch boundary (a flat term stream), which needs a third panel buffer: while
+    // the matrix waves read batch k - 1 the samplers finish batch k and are already writing into batch k + 1.
+    static constexpr bool STRADDLE = RECT && BT % G3_SAMPLERS != 0;
+    static constexpr int DEPTH = STRADDLE ? 3 : 2;
+    static constexpr int SRB = (BT + G3_SAMPLERS - 1) / G3_SAMPLERS;        // super-rounds per batch (not STRADDLE)
+    static constexpr int NTILE = RECT ? NBR * NBC : NBR * (NBR + 1) / 2;
+    static constexpr size_t lds_bytes()
+    {
+        return (size_t)DEPTH * BUF * sizeof(double) + (size_t)TPS * (6 + 4) * sizeof(double) + (size_t)TPS * 4 * sizeof(double2) +
+               PH_TABLE * sizeof(double2);
+    }
+};
+
+struct SuperTile {
+    int row_ant0, col_ant0;   // first antenna of the row / column super-block
+    int nc_act;               // RECT: column blocks actually present (1 .. NBC)
+    int pad_;
+};
+struct SuperTileList {
+    SuperTile e[16];
+};
+
+// Tiles of the upper block triangle in ROW-PAIR order -- row r (nb - r tiles), then row nb - 1 - r (r + 1 tiles), r = 0,
+// 1, ... -- cut into 8 contiguous chunks, one per matrix wave (4 or 5 tiles at nb = 8): consecutive tiles of a wave share
+// their block row, i.e. their A operand (G planes), which is then read from LDS once per row and source pair instead of
+// once per tile (a third fewer operand reads than the round-robin assignment of round 4; no time gained: 96.7 vs 96.8 ms).
+constexpr int pair_tile(int nb, int idx, bool col)
 {
-    int pb = 0;
-    while (i >= nb - pb) { i -= nb - pb; ++pb; }
-    return pb;
+    for (int r = 0; r < (nb + 1) / 2; ++r) {
+        if (idx < nb - r) return col ? r + idx : r;
+        idx -= nb - r;
+        const int r2 = nb - 1 - r;
+        if (r2 != r) {
+            if (idx < nb - r2) return col ? r2 + idx : r2;
+            idx -= nb - r2;
+        }
+    }
+    return 0;
 }
-constexpr int tri_col(int nb, int i)
-{
-    int pb = 0;
-    while (i >= nb - pb) { i -= nb - pb; ++pb; }
-    return pb + i;
-}
+template <bool RECT, int NBR, int NBC> constexpr int tile_row(int idx) { return RECT ? idx / NBC : pair_tile(NBR, idx, false); }
+template <bool RECT, int NBR, int NBC> constexpr int tile_col(int idx) { return RECT ? idx % NBC : pair_tile(NBR, idx, true); }
+constexpr int chunk_lo(int ntile, int c) { return c * ntile / 8; }
 
 template <typename F, int... Js>
 __device__ __forceinline__ void for_each_const(F &&fn, std::integer_sequence<int, Js...>)
@@ -84,52 +139,69 @@ __device__ __forceinline__ void for_each_const(F &&fn, std::integer_sequence<int
     (fn(std::integral_constant<int, Js>{}), ...);
 }
 
-template <int NB, int ST, int W>
+// antenna (inside its panel of 4 q4 antennas) of operand slot `slot`: the samplers' conflict-free slot order.  q4 is a
+// compile-time constant except for the column panel of a RECT super-tile with fewer than NBC column blocks: its 8 nc_act
+// antennas must fill the FIRST nc_act slot blocks (the tiles of the others are skipped).
+__device__ __forceinline__ int slot_antenna(int slot, int q4) { return (slot % q4) * 4 + slot / q4; }
+__device__ __forceinline__ int antenna_slot(int ant, int q4) { return (ant & 3) * q4 + (ant >> 2); }
+
+// (Round 5, measured and removed: every 16 x 16 x 4 step as FOUR v_mfma_f64_4x4x4_4b on row-rotated A operands, so that the
+// fp64 pipe is handed back to the SIMD's sampling wave every 16 cycles instead of every 64.  With the rotations free -- a
+// deliberately wrong kernel that fed all four the same operand -- 96.7 -> 90.0 ms; with them paid for, never better than the
+// plain form: DPP row_ror copies per tile 108.8 ms, per block row 98.3, the rotated operand read from LDS in rotated lane
+// order 106.0.  CBSZ / ABID do not broadcast for f64: tools/probe/probe_mfma_f64_bcast.hip.  Dealing the chunks so that
+// the two matrix waves of every SIMD carry 9 tiles together instead of 8 / 10 (waves w, w + 4, w + 8 share a SIMD:
+// tools/probe/probe_wave_simd.hip) was slower, 102.2 vs 96.5 ms on one box.)
+template <bool RECT, int NBR, int NBC, int ST, int W>
 __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, int nbatch, int only_stage, int lane,
-                                             const int32_t *__restrict__ rm, int64_t nchan, int64_t f,
-                                             double2 *__restrict__ out)
+                                             const int32_t *__restrict__ rm, int nap, const SuperTile tile,
+                                             int64_t nchan, int64_t f, double2 *__restrict__ out)
 {
-    constexpr int NA = NB * 8, CS = NA * 2 + COL_PAD, SRC = 2 * G3_PLANES * CS, BUF = ST * SRC;
-    constexpr int NTILE = NB * (NB + 1) / 2;
-    constexpr int CNT = NTILE > W ? (NTILE - W + 7) / 8 : 0;
+    using G = Geo<RECT, NBR, NBC, ST>;
+    constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
+    constexpr int T0 = chunk_lo(G::NTILE, W), CNT = chunk_lo(G::NTILE, W + 1) - T0;
     constexpr int CN = CNT > 0 ? CNT : 1;
     const int kq = lane >> 4, c16 = lane & 15;
     // K index kq = 2 (source of the pair) + (column of the Jones row): this lane's element of every operand plane
-    const int lane_off = (kq >> 1) * SRC + (kq & 1) * CS + c16;
+    const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
+    const int offA = (kq >> 1) * SRC + G3_PLANES * CSH + (kq & 1) * CSG + c16;
     v4d p1[CN], p2[CN], p3[CN];
 #pragma unroll
     for (int j = 0; j < CN; ++j) p1[j] = p2[j] = p3[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int buf = 0;
     for (int b = 0; b < nbatch; ++b) {
         __syncthreads();
+        const double *P = ldsd + buf * BUF;
+        buf = buf + 1 == G::DEPTH ? 0 : buf + 1;
         if (only_stage == 1 || CNT == 0) continue;
-        const double *P = ldsd + (b & 1) * BUF + lane_off;
 #pragma unroll
         for (int s2 = 0; s2 < ST / 2; ++s2) {
             const double *S = P + 2 * s2 * SRC;
             for_each_const([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int pb = tri_row(NB, W + 8 * j), qb = tri_col(NB, W + 8 * j);
-                const double *A = S + G3_PLANES * CS + pb * 16, *B = S + qb * 16;
+                constexpr int pb = tile_row<RECT, NBR, NBC>(T0 + j), qb = tile_col<RECT, NBR, NBC>(T0 + j);
+                if (RECT && qb >= tile.nc_act) return;           // block-uniform: the column super-block is one block short
+                const double *A = S + offA + pb * 16, *B = S + offB + qb * 16;
                 p1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], B[0], p1[j], 0, 0, 0);
-                p2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * CS], B[2 * CS], p2[j], 0, 0, 0);
-                p3[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * CS], B[4 * CS], p3[j], 0, 0, 0);
+                p2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * CSG], B[2 * CSH], p2[j], 0, 0, 0);
+                p3[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * CSG], B[4 * CSH], p3[j], 0, 0, 0);
             }, std::make_integer_sequence<int, CNT>{});
         }
     }
     if (only_stage == 1) return;
     for_each_const([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int pb = tri_row(NB, W + 8 * j), qb = tri_col(NB, W + 8 * j);
+        constexpr int pb = tile_row<RECT, NBR, NBC>(T0 + j), qb = tile_col<RECT, NBR, NBC>(T0 + j);
+        if (RECT && qb >= tile.nc_act) return;
         // operand rows / columns are antenna SLOTS (the samplers' conflict-free order): slot -> antenna
-        const int qs = qb * 8 + (c16 >> 1), jj = c16 & 1;
-        const int q = (qs % (NA / 4)) * 4 + qs / (NA / 4);
+        const int jj = c16 & 1;
+        const int q = tile.col_ant0 + slot_antenna(qb * 8 + (c16 >> 1), RECT ? 2 * tile.nc_act : G::NAC / 4);
         int r1[4], r2[4];                 // the tile's row-map entries first (independent loads), then the stores
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int ps = pb * 8 + ((kq + 4 * reg) >> 1);
-            const int p = (ps % (NA / 4)) * 4 + ps / (NA / 4);
-            r1[reg] = rm[p * NA + q];
-            r2[reg] = pb != qb ? rm[q * NA + p] : -1;      // the same antennas the other way round: V_qp = V_pq^H
+            const int p = tile.row_ant0 + slot_antenna(pb * 8 + ((kq + 4 * reg) >> 1), G::NAR / 4);
+            r1[reg] = rm[(int64_t)p * nap + q];
+            r2[reg] = (RECT || pb != qb) ? rm[(int64_t)q * nap + p] : -1;   // the same antennas the other way round: V_qp = V_pq^H
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -141,62 +213,73 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
     }, std::make_integer_sequence<int, CNT>{});
 }
 
-template <bool FEED, int NB, int ST>
+// grid: (nsteps, channels of the plane group, super-tiles of this shape); block 768.
+template <bool FEED, bool RECT, int NBR, int NBC, int ST>
 __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
     const double *__restrict__ f4, const double2 *__restrict__ brightness, const double *__restrict__ vrec,
     int64_t beam_lw, int64_t beam_mh, int64_t beam_nud, const double *__restrict__ lm_ext,
     const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
     const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
-    int64_t ntime, int nant, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio)
+    int64_t ntime, int nant, int nap, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio,
+    const SuperTileList tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
-    constexpr int NA = NB * 8, CS = NA * 2 + COL_PAD, SRC_DOUBLES = 2 * G3_PLANES * CS, BUF_DOUBLES = ST * SRC_DOUBLES;
+    using G = Geo<RECT, NBR, NBC, ST>;
+    constexpr int NAR = G::NAR, NAC = G::NAC, CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF, TPS = G::TPS, BT = G::BT;
     extern __shared__ double ldsd[];
-    double *ldsA = ldsd + 2 * BUF_DOUBLES;
-    double *ldsU = ldsA + 6 * NA;
-    double2 *ldsR = reinterpret_cast<double2 *>(ldsU + 4 * NA);
-    double2 *ldsT = ldsR + 4 * NA;
+    double *ldsA = ldsd + G::DEPTH * BUF;                      // six planes of per-slot constants
+    double *ldsU = ldsA + 6 * TPS;                             // (u, v, w) FT per slot, three planes (+ one of padding)
+    double2 *ldsR = reinterpret_cast<double2 *>(ldsU + 4 * TPS);
+    double2 *ldsT = ldsR + 4 * TPS;
     const int tid = threadIdx.x;
     const int ptid = tid - G3_MATRIX;
     const int64_t f = f0 + blockIdx.y;
     const int t = blockIdx.x;
+    const SuperTile tile = tiles.e[blockIdx.z];
+    // antenna of sampling slot a: DIAG -- the super-block's antennas; RECT -- the column super-block's, then the row one's
+    auto slot_ant = [&](int a) { return RECT ? (a < NAC ? tile.col_ant0 + a : tile.row_ant0 + a - NAC) : tile.row_ant0 + a; };
+    auto slot_ok = [&](int a) {
+        const int ant = slot_ant(a);
+        return ant < nant && (!RECT || a >= NAC || a < 8 * tile.nc_act);
+    };
 
     fine_table_init(ldsT, tid, G3_THREADS);
     const double FT = f4[f] * (PH_TABLE / 4.0);
-    for (int a = tid; a < NA; a += G3_THREADS) {
+    for (int a = tid; a < TPS; a += G3_THREADS) {
         double sp = 0.0, cp = 1.0, pl = 0.0, pm = 0.0, sl_ = 1.0, sm_ = 1.0, u = 0.0, v = 0.0, w = 0.0;
-        if (a < nant) {
-            sincos(parangles[(int64_t)t * nant + a], &sp, &cp);
-            const double *pe = point_errors + (((int64_t)t * nant + a) * nchan + f) * 2;
-            const double *as = antenna_scaling + ((int64_t)a * nchan + f) * 2;
+        if (slot_ok(a)) {
+            const int ant = slot_ant(a);
+            sincos(parangles[(int64_t)t * nant + ant], &sp, &cp);
+            const double *pe = point_errors + (((int64_t)t * nant + ant) * nchan + f) * 2;
+            const double *as = antenna_scaling + ((int64_t)ant * nchan + f) * 2;
             pl = pe[0]; pm = pe[1]; sl_ = as[0]; sm_ = as[1];
-            const double *x = ant_uvw + ((int64_t)t * nant + a) * 3;
+            const double *x = ant_uvw + ((int64_t)t * nant + ant) * 3;
             u = __dmul_rn(x[0], FT); v = __dmul_rn(x[1], FT); w = __dmul_rn(x[2], FT);
         }
-        // one plane per constant (consecutive lanes = consecutive antennas read consecutive doubles: no bank conflicts)
-        ldsA[0 * NA + a] = sp; ldsA[1 * NA + a] = cp; ldsA[2 * NA + a] = pl; ldsA[3 * NA + a] = pm;
-        ldsA[4 * NA + a] = sl_; ldsA[5 * NA + a] = sm_;
-        ldsU[0 * NA + a] = u; ldsU[1 * NA + a] = v; ldsU[2 * NA + a] = w;
+        // one plane per constant (consecutive lanes = consecutive slots read consecutive doubles: no bank conflicts)
+        ldsA[0 * TPS + a] = sp; ldsA[1 * TPS + a] = cp; ldsA[2 * TPS + a] = pl; ldsA[3 * TPS + a] = pm;
+        ldsA[4 * TPS + a] = sl_; ldsA[5 * TPS + a] = sm_;
+        ldsU[0 * TPS + a] = u; ldsU[1 * TPS + a] = v; ldsU[2 * TPS + a] = w;
     }
     if constexpr (FEED)
-        for (int i = tid; i < 4 * NA; i += G3_THREADS)
-            ldsR[i] = i < 4 * nant ? feed_rot[(int64_t)t * nant * 4 + i] : make_double2(0.0, 0.0);
+        for (int i = tid; i < 4 * TPS; i += G3_THREADS)
+            ldsR[i] = slot_ok(i >> 2) ? feed_rot[((int64_t)t * nant + slot_ant(i >> 2)) * 4 + (i & 3)] : make_double2(0.0, 0.0);
     __syncthreads();
     const int nbatch = (nsrc + ST - 1) / ST;
 
     if (tid < G3_MATRIX) {
-        const int32_t *rm = rowmap + (int64_t)t * NA * NA;
+        const int32_t *rm = rowmap + (int64_t)t * nap * nap;
         const int lane = tid & 63;
         switch (tid >> 6) {
-        case 0: matrix_wave3<NB, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 1: matrix_wave3<NB, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 2: matrix_wave3<NB, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 3: matrix_wave3<NB, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 4: matrix_wave3<NB, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 5: matrix_wave3<NB, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        case 6: matrix_wave3<NB, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
-        default: matrix_wave3<NB, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nchan, f, out); break;
+        case 0: matrix_wave3<RECT, NBR, NBC, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 1: matrix_wave3<RECT, NBR, NBC, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 2: matrix_wave3<RECT, NBR, NBC, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 3: matrix_wave3<RECT, NBR, NBC, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 4: matrix_wave3<RECT, NBR, NBC, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 5: matrix_wave3<RECT, NBR, NBC, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 6: matrix_wave3<RECT, NBR, NBC, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        default: matrix_wave3<RECT, NBR, NBC, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
         }
         return;
     }
@@ -215,142 +298,196 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     const int ei = e_corr >> 1, ej = e_corr & 1;
     const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
     const unsigned corr_off = e_corr * 32u;
-    constexpr int NTASK = ST * NA;
     if (sample_prio >= 0) __builtin_amdgcn_s_setprio(3);
+    // This lane's term of super-round sr: (panel buffer, source slot of the batch, antenna slot, global source).  Every
+    // lane owns a term and every term is written (no branch around the stores: the four rounds below stay one scheduling
+    // region): lanes beyond the batch's / the stream's terms redo an earlier term (same values to the same place), padded
+    // antennas and sources beyond the last write zeros.
+    struct Term {
+        int buf, e_sl, slot, src;
+    };
+    const int total_terms = nbatch * BT;
+    // batch b, super-round starting at term task0 of the batch (batches of whole super-rounds, or padded ones)
+    auto term_at = [&](int b, int task0) {
+        Term T;
+        int task = task0 + ptid;
+        if (task >= BT) task %= BT;
+        T.e_sl = task / TPS;
+        T.slot = task - T.e_sl * TPS;
+        T.buf = b & 1;
+        T.src = b * ST + T.e_sl;
+        return T;
+    };
+    // super-round sr of the flat term stream (STRADDLE)
+    auto term_flat = [&](int sr) {
+        Term T;
+        int x = sr * G3_SAMPLERS + ptid;
+        if (x >= total_terms) x = total_terms - 1 - (x - total_terms) % BT;      // the stream's tail: a term of the last batch again
+        const int sg = x / TPS;                    // source slot of the padded stream
+        T.slot = x - sg * TPS;
+        const int bb = sg / ST;
+        T.e_sl = sg - bb * ST;
+        T.buf = bb % G::DEPTH;
+        T.src = sg;
+        return T;
+    };
     // A lane's source coordinates are fetched ONE super-round ahead: a batch is a chain of dependent memory round trips
     // (coordinates -> voxel geometry -> gathers) and the first is taken off its critical path.
     struct Coords {
         double2 lm;
         double n;
     };
-    auto fetch = [&](int b, int task0) {
-        int task = task0 + ptid;
-        if (task >= NTASK) task %= NTASK;
-        const int e_sl = task / NA, e_ant = task - e_sl * NA;
-        const bool have = e_ant < nant && b * ST + e_sl < nsrc && b < nbatch;
-        const double *sp = lmn + 4 * (have ? b * ST + e_sl : 0);
+    auto fetch = [&](const Term &T) {
+        const bool have = T.src < nsrc && slot_ok(T.slot);
+        const double *sp = lmn + 4 * (have ? T.src : 0);
         Coords c;
         c.lm = *reinterpret_cast<const double2 *>(sp);
         c.n = sp[2];
         return c;
     };
-    Coords nxt = fetch(0, 0);
-    for (int b = 0; b < nbatch; ++b) {
-        const int s0 = b * ST;
-        double *H = ldsd + (b & 1) * BUF_DOUBLES;
-        if (only_stage != 2) {
-            for (int task0 = 0; task0 < NTASK; task0 += G3_SAMPLERS) {
-                // every lane owns a term and every term is written (no branch around the stores: the four rounds below
-                // stay one scheduling region): lanes beyond the batch's terms redo an earlier term (same values to the
-                // same place), padded antennas and sources beyond the last write zeros
-                int task = task0 + ptid;
-                if (task >= NTASK) task %= NTASK;
-                const int e_sl = task / NA, e_ant = task - e_sl * NA;
-                const bool have = e_ant < nant && s0 + e_sl < nsrc;
-                const int own_info = e_sl | (e_ant << 11) | (int)((unsigned)have << 31);
-                // 64 antennas: a wave's 64 lanes are ONE source's antennas -- its 2 x 2 complex brightness comes in by ONE
-                // scalar load per batch, here (inside the sampling rounds every round waited out an SMEM round trip --
-                // lgkmcnt is shared with the LDS reads --: the sampling alone ran 65.1 ms with those loads, 51.6 without)
-                double2 xw[4];
-                if constexpr (NA == 64) {
-                    const int us = __builtin_amdgcn_readfirstlane(have ? s0 + e_sl : 0);
-                    const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
+    Coords nxt = fetch(G::STRADDLE ? term_flat(0) : term_at(0, 0));
+    auto super_round = [&](const Term &T, const Term &Tn) {
+            const int e_sl = T.e_sl, e_slot = T.slot;
+            const bool have = T.src < nsrc && slot_ok(e_slot);
+            double *H = ldsd + T.buf * BUF;
+            // operand address of this lane's own term and what it writes: its H planes (column antenna), its G planes
+            // (row antenna), or both (DIAG)
+            const bool col_term = !RECT || e_slot < NAC;
+            // (the slots of an absent last column block -- RECT, nc_act = NBC - 1 -- keep their own places behind the real ones)
+            const int h_slot = !RECT ? antenna_slot(e_slot, NAC / 4)
+                                     : (!col_term ? 0 : (e_slot < 8 * tile.nc_act ? antenna_slot(e_slot, 2 * tile.nc_act) : e_slot));
+            const int h_off = e_sl * SRC + 2 * h_slot;
+            const int g_off = e_sl * SRC + G3_PLANES * CSH + 2 * antenna_slot(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, NAR / 4);
+            const int own_info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
+            // TPS == 64: a wave's 64 lanes are ONE source's slots -- its 2 x 2 complex brightness comes in by ONE scalar
+            // load per super-round, here (inside the sampling rounds every round waited out an SMEM round trip --
+            // lgkmcnt is shared with the LDS reads --: the sampling alone ran 65.1 ms with those loads, 51.6 without)
+            double2 xw[4];
+            if constexpr (TPS == 64) {
+                const int us = __builtin_amdgcn_readfirstlane(have ? T.src : 0);
+                const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xw[c] = bp[c];
-                }
-                const double2 lm2 = nxt.lm;
-                const double nn = nxt.n;
-                nxt = task0 + G3_SAMPLERS < NTASK ? fetch(b, task0 + G3_SAMPLERS) : fetch(b + 1, 0);
-                FusedVoxels gx;
-                fused_voxels(grid, lm2.x, lm2.y, ldsA[0 * NA + e_ant], ldsA[1 * NA + e_ant], ldsA[2 * NA + e_ant],
-                             ldsA[3 * NA + e_ant], ldsA[4 * NA + e_ant], ldsA[5 * NA + e_ant], fscale, gx);
-                const C2 kph = table_phasor(ldsT, fma(nn, ldsU[2 * NA + e_ant],
-                                                      fma(lm2.y, ldsU[1 * NA + e_ant], __dmul_rn(lm2.x, ldsU[0 * NA + e_ant]))));
-                // all four rounds' gathers first (the weights and the phasor are re-broadcast when a round is consumed:
-                // 33 registers per round in flight)
-                struct Round {
-                    int info;
-                    double2 v[4];
-                    double ab[4];
-                };
-                auto issue = [&](auto lane_c, Round &R) {
-                    constexpr int QL = decltype(lane_c)::value;
-                    const int info = quad_bcast<QL>(own_info);
-                    R.info = info;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
-                        const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
-                        R.v[k] = *reinterpret_cast<const double2 *>(r);
-                        R.ab[k] = r[2];
-                    }
-                };
-                auto finish = [&](auto lane_c, const Round &R) {
-                    constexpr int QL = decltype(lane_c)::value;
-                    const int info = R.info;
-                    const int r_sl = info & 2047, r_ant = (info >> 11) & 1023;
-                    const bool r_have = info < 0;
-                    double wt[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
-                    C2 kk;
-                    kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
-                    double2 e2 = beam_reduce1(R.v, R.ab, wt);
-                    if (!r_have) e2 = make_double2(0.0, 0.0);
-                    C2 e;
-                    e.re = e2.x; e.im = e2.y;
-                    if constexpr (FEED) {
-                        C2 E0, E1;
-                        E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
-                        E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
-                        const double2 r0 = ldsR[4 * r_ant + ej], r1 = ldsR[4 * r_ant + 2 + ej];
-                        C2 R0, R1;
-                        R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
-                        e = cmul(E0, R0);
-                        cmac(e, E1, R1);
-                    }
-                    const C2 A = cmul(kk, e);
-                    C2 A0, A1, B0, B1;
-                    A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
-                    A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
-                    if constexpr (NA == 64) {
-                        // the wave's source: its brightness matrix was loaded at the top of the batch
-                        const double2 b0 = ej ? xw[1] : xw[0], b1 = ej ? xw[3] : xw[2];
-                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
-                    } else {
-                        const double2 *bp = brightness + ((int64_t)(r_have ? s0 + r_sl : 0) * nchan + f) * 4;
-                        const double2 b0 = bp[ej], b1 = bp[2 + ej];
-                        B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
-                    }
-                    C2 Gv = cmul(A0, B0);
-                    cmac(Gv, A1, B1);
-                    double *hs = H + r_sl * SRC_DOUBLES + 2 * ((r_ant & 3) * (NA / 4) + (r_ant >> 2)) + ei;
-                    double *gs = hs + G3_PLANES * CS;
-                    hs[ej * CS] = A.re; hs[(2 + ej) * CS] = A.im; hs[(4 + ej) * CS] = __dsub_rn(A.re, A.im);
-                    gs[ej * CS] = Gv.re; gs[(2 + ej) * CS] = Gv.im; gs[(4 + ej) * CS] = __dadd_rn(Gv.re, Gv.im);
-                };
-                using I0 = std::integral_constant<int, 0>;
-                using I1 = std::integral_constant<int, 1>;
-                using I2 = std::integral_constant<int, 2>;
-                using I3 = std::integral_constant<int, 3>;
-                Round R0, R1, R2, R3;
-                issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
-                // (EIGHT sampling waves, two per SIMD, beside four matrix waves on the four-product form -- the only split
-                // of 12 waves x 168 registers that has room for them -- sampled no faster: 68.6 ms alone against 68.7 with
-                // four waves, so a lone wave's dependent-issue latency is not what bounds the stage either; the matrix waves
-                // then hold 9 tiles x 16 accumulators and spill, 125 ms.  That experiment also showed the f64 MFMA's BLGP bit 0
-                // to negate the A operand, as the ISA says: -Gr needs no plane of its own.)
-                // (a lane sampling all four correlations of its own term -- no quads, a third fewer instructions -- was
-                // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
-                // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
-                // its instruction count: coherent gathers, --pa common, take 65 ms)
-                // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
-                // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
-                // stalls they fill)
-                finish(I0{}, R0); finish(I1{}, R1); finish(I2{}, R2); finish(I3{}, R3);
+                for (int c = 0; c < 4; ++c) xw[c] = bp[c];
             }
+            const int own_src = have ? T.src : 0;
+            const double2 lm2 = nxt.lm;
+            const double nn = nxt.n;
+            nxt = fetch(Tn);
+            FusedVoxels gx;
+            fused_voxels(grid, lm2.x, lm2.y, ldsA[0 * TPS + e_slot], ldsA[1 * TPS + e_slot], ldsA[2 * TPS + e_slot],
+                         ldsA[3 * TPS + e_slot], ldsA[4 * TPS + e_slot], ldsA[5 * TPS + e_slot], fscale, gx);
+            const C2 kph = table_phasor(ldsT, fma(nn, ldsU[2 * TPS + e_slot],
+                                                  fma(lm2.y, ldsU[1 * TPS + e_slot], __dmul_rn(lm2.x, ldsU[0 * TPS + e_slot]))));
+            // all four rounds' gathers first (the weights and the phasor are re-broadcast when a round is consumed:
+            // 33 registers per round in flight)
+            struct Round {
+                int info, slot, src;
+                double2 v[4];
+                double ab[4];
+            };
+            auto issue = [&](auto lane_c, Round &R) {
+                constexpr int QL = decltype(lane_c)::value;
+                R.info = quad_bcast<QL>(own_info);
+                if constexpr (FEED) R.slot = quad_bcast<QL>(e_slot);
+                if constexpr (TPS != 64) R.src = quad_bcast<QL>(own_src);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
+                    const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
+                    R.v[k] = *reinterpret_cast<const double2 *>(r);
+                    R.ab[k] = r[2];
+                }
+            };
+            auto finish = [&](auto lane_c, const Round &R) {
+                constexpr int QL = decltype(lane_c)::value;
+                const int info = R.info;
+                const bool r_have = info < 0;
+                double wt[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
+                C2 kk;
+                kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
+                double2 e2 = beam_reduce1(R.v, R.ab, wt);
+                if (!r_have) e2 = make_double2(0.0, 0.0);
+                C2 e;
+                e.re = e2.x; e.im = e2.y;
+                if constexpr (FEED) {
+                    C2 E0, E1;
+                    E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
+                    E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
+                    const double2 r0 = ldsR[4 * R.slot + ej], r1 = ldsR[4 * R.slot + 2 + ej];
+                    C2 R0, R1;
+                    R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
+                    e = cmul(E0, R0);
+                    cmac(e, E1, R1);
+                }
+                const C2 A = cmul(kk, e);
+                C2 A0, A1, B0, B1;
+                A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
+                A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
+                if constexpr (TPS == 64) {
+                    // the wave's source: its brightness matrix was loaded at the top of the super-round
+                    const double2 b0 = ej ? xw[1] : xw[0], b1 = ej ? xw[3] : xw[2];
+                    B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                } else {
+                    const double2 *bp = brightness + ((int64_t)R.src * nchan + f) * 4;
+                    const double2 b0 = bp[ej], b1 = bp[2 + ej];
+                    B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+                }
+                C2 Gv = cmul(A0, B0);
+                cmac(Gv, A1, B1);
+                if constexpr (!RECT) {
+                    // DIAG: NAR == NAC, the G planes of a slot lie G3_PLANES * CSH doubles behind its H planes
+                    double *hs = H + (info & 0x3fffffff) + ei;
+                    double *gs = hs + G3_PLANES * CSH;
+                    hs[ej * CSH] = A.re; hs[(2 + ej) * CSH] = A.im; hs[(4 + ej) * CSH] = __dsub_rn(A.re, A.im);
+                    gs[ej * CSG] = Gv.re; gs[(2 + ej) * CSG] = Gv.im; gs[(4 + ej) * CSG] = __dadd_rn(Gv.re, Gv.im);
+                } else {
+                    // RECT: a column antenna's term writes its H planes, a row antenna's its G planes: one address, one
+                    // plane stride and three values picked per lane, the stores themselves unconditional
+                    const bool r_col = (info >> 30) & 1;
+                    double *ws = H + (info & 0x3fffffff) + ei;
+                    const int cs = r_col ? CSH : CSG;
+                    const double v0 = r_col ? A.re : Gv.re, v1 = r_col ? A.im : Gv.im;
+                    const double v2 = r_col ? __dsub_rn(A.re, A.im) : __dadd_rn(Gv.re, Gv.im);
+                    ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1; ws[(4 + ej) * cs] = v2;
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            Round R0, R1, R2, R3;
+            issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
+            // (EIGHT sampling waves, two per SIMD, beside four matrix waves on the four-product form -- the only split
+            // of 12 waves x 168 registers that has room for them -- sampled no faster: 68.6 ms alone against 68.7 with
+            // four waves, so a lone wave's dependent-issue latency is not what bounds the stage either; the matrix waves
+            // then hold 9 tiles x 16 accumulators and spill, 125 ms.  That experiment also showed the f64 MFMA's BLGP bit 0
+            // to negate the A operand, as the ISA says: -Gr needs no plane of its own.)
+            // (a lane sampling all four correlations of its own term -- no quads, a third fewer instructions -- was
+            // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
+            // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
+            // its instruction count: coherent gathers, --pa common, take 65 ms)
+            // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
+            // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
+            // stalls they fill)
+            finish(I0{}, R0); finish(I1{}, R1); finish(I2{}, R2); finish(I3{}, R3);
+    };
+    if constexpr (!G::STRADDLE) {
+        for (int b = 0; b < nbatch; ++b) {
+            if (only_stage != 2) {
+                for (int task0 = 0; task0 < BT; task0 += G3_SAMPLERS)
+                    super_round(term_at(b, task0), task0 + G3_SAMPLERS < BT ? term_at(b, task0 + G3_SAMPLERS) : term_at(b + 1, 0));
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        int sr = 0;
+        for (int b = 0; b < nbatch; ++b) {
+            const int sr_end = ((b + 1) * BT + G3_SAMPLERS - 1) / G3_SAMPLERS;     // super-rounds that complete batch b
+            for (; sr < sr_end && only_stage != 2; ++sr) super_round(term_flat(sr), term_flat(sr + 1));
+            __syncthreads();
+        }
     }
 }
 
@@ -377,7 +514,7 @@ AF_EXPORT int af_fused_plan_antennas(const int64_t *time_index_host, const int32
     if (nrow == 0) { *decomposable = 1; return AF_OK; }
     AF_REQUIRE(time_index_host && antenna1_host && antenna2_host && uvw_host && ant_uvw_host && rowmap_host,
                "af_fused_plan_antennas: NULL array");
-    AF_REQUIRE(nant >= 1 && nant <= 64 && nrow < (1LL << 31) && nsteps >= 1, "af_fused_plan_antennas: bad extents");
+    AF_REQUIRE(nant >= 1 && nant <= 256 && nrow < (1LL << 31) && nsteps >= 1, "af_fused_plan_antennas: bad extents");
     int64_t tmin = time_index_host[0], tmax = tmin;
     for (int64_t r = 1; r < nrow; ++r) {
         tmin = time_index_host[r] < tmin ? time_index_host[r] : tmin;
@@ -546,6 +683,36 @@ AF_EXPORT int af_fused_plan_check(const void *time_index, const void *antenna1, 
     return AF_OK;
 }
 
+// How the 8-antenna blocks of M are cut into super-blocks (host): runs of 8 blocks, the last one shorter.
+struct GemmTiling {
+    int nsb;
+    int size[8], blk0[8];
+};
+constexpr int RECT_COLS = 4;      // column blocks of a RECT super-tile (rows: 8)
+static void gemm_tiling(int nb, GemmTiling &tl)
+{
+    tl.nsb = (nb + 7) / 8;
+    for (int i = 0; i < tl.nsb; ++i) {
+        tl.size[i] = nb - 8 * i < 8 ? nb - 8 * i : 8;
+        tl.blk0[i] = 8 * i;
+    }
+}
+
+// Baseline slots (8 x 8-antenna tiles x 64) the GEMM form evaluates per (timestep, channel) for `nant` antennas: what its
+// cost is proportional to (the caller's fill-factor rule divides the rows per step by it).  0 beyond 256 antennas.
+AF_EXPORT int64_t af_fused_gemm_slots(int64_t nant)
+{
+    if (nant < 1 || nant > 256) return 0;
+    GemmTiling tl;
+    gemm_tiling((int)((nant + 7) / 8), tl);
+    int64_t tiles = 0;
+    for (int i = 0; i < tl.nsb; ++i) {
+        tiles += tl.size[i] * (tl.size[i] + 1) / 2;
+        for (int j = i + 1; j < tl.nsb; ++j) tiles += tl.size[i] * tl.size[j];
+    }
+    return tiles * 64;
+}
+
 // The antenna-decomposed form of af_fused_predict_c128: same arguments, with the plan of af_fused_plan_antennas
 // (DEVICE copies: ant_uvw (nsteps, nant, 3), rowmap (nsteps, nap, nap)) in place of uvw, antenna1 / antenna2 and the
 // items; nsteps <= ntime; every row of `out` that the row map names is written, nothing else is touched.  Same workspace
@@ -564,7 +731,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
     AF_REQUIRE(nsteps >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_antennas_c128: negative extent");
-    AF_REQUIRE(nant <= 64, "af_fused_predict_antennas_c128: more than 64 antennas (use af_fused_predict_c128)");
+    AF_REQUIRE(nant <= 256, "af_fused_predict_antennas_c128: more than 256 antennas (use af_fused_predict_c128)");
     AF_REQUIRE(nsteps <= ntime, "af_fused_predict_antennas_c128: %lld steps but %lld timesteps of per-antenna terms",
                (long long)nsteps, (long long)ntime);
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nsteps < (1LL << 31), "af_fused_predict_antennas_c128: too large");
@@ -599,45 +766,76 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     static const int only_stage = AF_STAGE_ENV("AFHIP_FUSED_STAGE", 0);
     static const int sample_prio = AF_STAGE_ENV("AFHIP_GEMM_PRIO", 1);
     const bool feed = feed_rotation != nullptr;
-    const int nb = (int)((nant + 7) / 8);
-    auto launch = [&](auto kernel, int NBc, int STc, int planes, int threads) -> int {
-        const int na = NBc * 8, cs = na * 2 + COL_PAD;
-        const size_t lds_bytes = (size_t)2 * STc * planes * cs * sizeof(double) + (size_t)na * 6 * sizeof(double) +
-                                 (size_t)na * 4 * sizeof(double) + (size_t)na * 4 * sizeof(double2) + PH_TABLE * sizeof(double2);
-        AF_REQUIRE(lds_bytes <= 160 * 1024, "af_fused_predict_antennas_c128: %zu bytes of LDS needed", lds_bytes);
-        AF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-        for (int64_t f0 = 0; f0 < nchan; f0 += PLANE_GROUP) {
-            const int64_t nf = nchan - f0 < PLANE_GROUP ? nchan - f0 : PLANE_GROUP;
-            int64_t blocks = af_cdiv(ncell * 4, 256);
-            if (blocks > 1024) blocks = 1024;
-            hipLaunchKernelGGL(beam_plane_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, st_,
-                               reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes_buf);
-            AF_LAUNCH_CHECK();
-            if (f0 == 0) af_prof_begin(st_);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)nsteps, (unsigned)nf), dim3(threads), lds_bytes, st_, ant_uvw, rowmap,
-                               lmn, f4, reinterpret_cast<const double2 *>(brightness), planes_buf, beam_lw, beam_mh, beam_nud,
-                               beam_lm_extents, freq_data, parallactic_angles, point_errors, antenna_scaling,
-                               reinterpret_cast<const double2 *>(feed_rotation), (int)nsrc, nchan, ntime, (int)nant,
-                               reinterpret_cast<double2 *>(out), only_stage, f0, sample_prio);
-            if (f0 == 0) af_prof_end(st_);
-            AF_LAUNCH_CHECK();
-        }
-        return AF_OK;
+    const int nb = (int)((nant + 7) / 8), nap = 8 * nb;
+    // the super-tiles of M (see Geo): one DIAG for nant <= 64; beyond that super-blocks of 4 .. 6 blocks
+    GemmTiling tl;
+    gemm_tiling(nb, tl);
+    // one main-kernel launch per (channel group, super-tile shape)
+    struct Shape {
+        const void *kernel;
+        size_t lds;
+        SuperTileList list;
+        int count;
     };
-    // sources per batch: about one super-round of the 256 sampling lanes (ST x 8 NB terms), two buffers within ~110 KB
-#define AF_GEMM_PICK(NBC, STC)                                                                                          \
-    (feed ? launch(fused_gemm3_kernel<true, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS)                              \
-          : launch(fused_gemm3_kernel<false, NBC, STC>, NBC, STC, 2 * G3_PLANES, G3_THREADS))
-    switch (nb) {
-    case 1: return AF_GEMM_PICK(1, 16);
-    case 2: return AF_GEMM_PICK(2, 8);
-    case 3: return AF_GEMM_PICK(3, 8);
-    case 4: return AF_GEMM_PICK(4, 6);
-    case 5: return AF_GEMM_PICK(5, 4);
-    case 6: return AF_GEMM_PICK(6, 4);
-    case 7: return AF_GEMM_PICK(7, 4);
-    default: return AF_GEMM_PICK(8, 4);
+    std::vector<Shape> shapes;
+    auto add = [&](const void *kernel, size_t lds, const SuperTile &e) {
+        for (auto &s : shapes)
+            if (s.kernel == kernel && s.count < 16) { s.list.e[s.count++] = e; return; }
+        Shape s;
+        memset(&s, 0, sizeof(s));
+        s.kernel = kernel; s.lds = lds; s.list.e[0] = e; s.count = 1;
+        shapes.push_back(s);
+    };
+    // sources per batch: about one super-round of the 256 sampling lanes, the panel buffers within ~130 KB
+#define AF_GEMM_K(RECTC, NBRC, NBCC, STC)                                                                              \
+    (feed ? reinterpret_cast<const void *>(fused_gemm3_kernel<true, RECTC, NBRC, NBCC, STC>)                            \
+          : reinterpret_cast<const void *>(fused_gemm3_kernel<false, RECTC, NBRC, NBCC, STC>)),                         \
+        Geo<RECTC, NBRC, NBCC, STC>::lds_bytes()
+    for (int i = 0; i < tl.nsb; ++i) {
+        SuperTile e = {8 * tl.blk0[i], 8 * tl.blk0[i], tl.size[i], 0};
+        switch (tl.size[i]) {
+        case 1: add(AF_GEMM_K(false, 1, 1, 16), e); break;
+        case 2: add(AF_GEMM_K(false, 2, 2, 8), e); break;
+        case 3: add(AF_GEMM_K(false, 3, 3, 8), e); break;
+        case 4: add(AF_GEMM_K(false, 4, 4, 6), e); break;
+        case 5: add(AF_GEMM_K(false, 5, 5, 4), e); break;
+        case 6: add(AF_GEMM_K(false, 6, 6, 4), e); break;
+        case 7: add(AF_GEMM_K(false, 7, 7, 4), e); break;
+        default: add(AF_GEMM_K(false, 8, 8, 4), e); break;
+        }
+        // the pairs with the later super-blocks: rows = this (full, 8-block) super-block, columns = the later one in
+        // chunks of <= 4 blocks (8 x 4 tiles: 4 per matrix wave, wave w = block row w)
+        for (int j = i + 1; j < tl.nsb; ++j)
+            for (int c0 = 0; c0 < tl.size[j]; c0 += RECT_COLS) {
+                SuperTile r = {8 * tl.blk0[i], 8 * (tl.blk0[j] + c0), tl.size[j] - c0 < RECT_COLS ? tl.size[j] - c0 : RECT_COLS, 0};
+                add(AF_GEMM_K(true, 8, RECT_COLS, 4), r);
+            }
     }
-#undef AF_GEMM_PICK
+#undef AF_GEMM_K
+    for (auto &s : shapes) {
+        AF_REQUIRE(s.lds <= 160 * 1024, "af_fused_predict_antennas_c128: %zu bytes of LDS needed", s.lds);
+        AF_HIP(hipFuncSetAttribute(s.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds));
+    }
+    int nsrc_i = (int)nsrc, nant_i = (int)nant, nap_i = nap, stage_i = only_stage, prio_i = sample_prio;
+    const double2 *b2 = reinterpret_cast<const double2 *>(brightness), *fr2 = reinterpret_cast<const double2 *>(feed_rotation);
+    double2 *out2 = reinterpret_cast<double2 *>(out);
+    for (int64_t f0 = 0; f0 < nchan; f0 += PLANE_GROUP) {
+        const int64_t nf = nchan - f0 < PLANE_GROUP ? nchan - f0 : PLANE_GROUP;
+        int64_t blocks = af_cdiv(ncell * 4, 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(beam_plane_kernel, dim3((unsigned)blocks, (unsigned)nf), dim3(256), 0, st_,
+                           reinterpret_cast<const double2 *>(beam), ncell, beam_nud, freq_data, f0, planes_buf);
+        AF_LAUNCH_CHECK();
+        if (f0 == 0) af_prof_begin(st_);
+        for (auto &s : shapes) {
+            void *args[] = {&ant_uvw, &rowmap, &lmn, &f4, &b2, &planes_buf, &beam_lw, &beam_mh, &beam_nud, &beam_lm_extents,
+                            &freq_data, &parallactic_angles, &point_errors, &antenna_scaling, &fr2, &nsrc_i, &nchan, &ntime,
+                            &nant_i, &nap_i, &out2, &stage_i, &f0, &prio_i, &s.list};
+            AF_HIP(hipLaunchKernel(s.kernel, dim3((unsigned)nsteps, (unsigned)nf, (unsigned)s.count), dim3(G3_THREADS), args,
+                                   s.lds, st_));
+        }
+        if (f0 == 0) af_prof_end(st_);
+        AF_LAUNCH_CHECK();
+    }
+    return AF_OK;
 }

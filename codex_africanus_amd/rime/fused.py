@@ -65,6 +65,7 @@ class FusedPlan(object):
 
 
 DECOMPOSE_TOL = 1e-10      # metres: see fused_plan
+GEMM_MAX_ANTENNAS = 256    # af_fused_predict_antennas_c128: 32 blocks of 8 antennas in super-tiles of <= 40 tiles
 
 
 def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, decompose_tol=None):
@@ -80,7 +81,7 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
     by solving for per-antenna coordinates (``af_fused_plan_antennas``) and accepting them when
     ``max |uvw_p - uvw_q - uvw_pq| <= decompose_tol`` metres (default 1e-10: a phase error below
     ``2 pi nu / c |lmn| 1e-10`` = 2e-10 rad at 1.7 GHz, 0.05 rad off axis).  A decomposable plan (``plan.decomposable``;
-    at most 64 antennas, every (time, antenna1, antenna2) at most once) sends the call to the GEMM form of the predict,
+    at most 256 antennas, every (time, antenna1, antenna2) at most once) sends the call to the GEMM form of the predict,
     ``V(t, nu) = G H^H`` on the matrix cores (csrc/af_fused_gemm.hip: about half the arithmetic of the general kernel);
     such a plan is bound to these ``uvw``.  ``AFHIP_FUSED_GEMM=0`` switches the test off.
     """
@@ -115,7 +116,7 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
                   ctypes.byref(n_items))
     step = (ti - (ti.min() if nrow else 0)).astype(np.int32)
     plan = FusedPlan(nrow, nant, nsteps, items, groups, a1h, a2h, step)
-    if uvw is not None and nrow and nant <= 64 and os.environ.get("AFHIP_FUSED_GEMM", "1") != "0":
+    if uvw is not None and nrow and nant <= GEMM_MAX_ANTENNAS and os.environ.get("AFHIP_FUSED_GEMM", "1") != "0":
         uvw_h = np.ascontiguousarray(_host(uvw), dtype=np.float64)
         if uvw_h.shape != (nrow, 3):
             raise ValueError("uvw must have shape (row, 3)")
@@ -128,8 +129,7 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
                   uvw_h.ctypes.data_as(ctypes.c_void_p), nrow, nant, tol, nsteps, ant_uvw.ctypes.data_as(ctypes.c_void_p),
                   rowmap.ctypes.data_as(ctypes.c_void_p), ctypes.byref(resid), ctypes.byref(ok))
         plan.residual, plan.tol = resid.value, tol
-        nb = nap // 8
-        plan.fill = nrow / float(nsteps * (nb * (nb + 1) // 2) * 64)
+        plan.fill = nrow / float(nsteps * int(_lib.load().af_fused_gemm_slots(nant)))
         if ok.value:
             plan.ant_uvw, plan.rowmap = ant_uvw, rowmap
     return plan
@@ -137,7 +137,8 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
 
 # the GEMM form costs ~73 flop per baseline SLOT of the upper block triangle, the lane-per-row kernel ~126 per ROW
 # (csrc/af_fused_gemm.hip header): below this fill (sub-arrays, baseline selections, an antenna axis much larger than
-# the antennas present) the row kernel is the faster one.  A full 64-antenna step has fill 2016 / 2304 = 0.875.
+# the antennas present) the row kernel is the faster one.  A full 64-antenna step has fill 2016 / 2304 = 0.875; the
+# slots of an array come from af_fused_gemm_slots (the super-tiles the kernel runs: 136 tiles at 128 antennas).
 GEMM_MIN_FILL = 0.5
 
 

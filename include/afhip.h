@@ -325,13 +325,18 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
  *   *decomposable = 1 iff max_rows |x_p - x_q - uvw_pq|_inf <= tol [m] (reported in *max_residual) and no
  *   (step, antenna1, antenna2) occurs twice.  nsteps = max(time_index) - min(time_index) + 1;
  *   ant_uvw_host (nsteps, nant, 3) double; rowmap_host (nsteps, nap, nap) int32, nap = 8 ceil(nant / 8): the row of
- *   baseline (p, q) of the step or -1.  nant <= 64.
+ *   baseline (p, q) of the step or -1.  nant <= 256.
  * af_fused_predict_antennas_c128 (DEVICE pointers): ant_uvw / rowmap = device copies of the plan; the other arguments
  *   as af_fused_predict_c128 (same workspace size); writes out[row] for every row the map names.  No gauss_shape (it
- *   depends on the baseline: use af_fused_predict_c128). */
+ *   depends on the baseline: use af_fused_predict_c128).  nant <= 64: one workgroup per (timestep, channel) holds the
+ *   whole upper block triangle; 65 .. 256 antennas: the blocks of 8 antennas are cut into super-blocks of 8 blocks,
+ *   one workgroup per (timestep, channel, super-block or half of a pair of super-blocks).
+ * af_fused_gemm_slots(nant): baseline slots (8 x 8-antenna tiles x 64) the GEMM form evaluates per (timestep, channel),
+ *   what its cost is proportional to (rows per step / slots = the fill factor callers dispatch by); 0 beyond 256. */
 int af_fused_plan_antennas(const int64_t *time_index_host, const int32_t *antenna1_host, const int32_t *antenna2_host,
                            const double *uvw_host, int64_t nrow, int64_t nant, double tol, int64_t nsteps,
                            double *ant_uvw_host, int32_t *rowmap_host, double *max_residual, int *decomposable);
+int64_t af_fused_gemm_slots(int64_t nant);
 int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
                                    const double *lm, const double *frequency, const double *brightness, int64_t nsrc,
                                    int64_t nchan, const double *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,

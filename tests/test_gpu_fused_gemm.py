@@ -4,7 +4,7 @@ timestep -- every real Measurement Set) the chain phase_delay -> einsum -> beam_
 (africanus/rime/examples/predict.py:107-134,404-472,525) is V(t, nu) = G H^H, evaluated with fp64 MFMA.  Checked against
 the CPU oracle chain to 1e-9 of the per-visibility sum of |term| magnitudes (north star: 1e-8), against the general
 kernel on the same rows, and the dispatcher: rows that are not decomposable, repeated baselines, Gaussian shapes and
-more than 64 antennas stay on the general kernel.
+more than 256 antennas stay on the general kernel.
 """
 import numpy as np
 import pytest
@@ -61,7 +61,11 @@ def _call(d, **kw):
 
 
 @pytest.mark.parametrize("nant, nrow", [(5, 37), (7, 300), (8, 500), (12, 1000), (17, 1500), (24, 2000), (33, 2500),
-                                        (40, 1700), (47, 3000), (50, 3000), (57, 4000), (64, 4100)])
+                                        (40, 1700), (47, 3000), (50, 3000), (57, 4000), (64, 4100),
+                                        # beyond 64 antennas (round 5): super-tiles -- 65: 5 + 4 blocks; 80: 5 + 5; 96: 6 + 6;
+                                        # 100: 5 + 4 + 4; 128: 6 + 5 + 5; 197: 5 x 5; 256: 6 + 6 + 5 + 5 + 5 + 5
+                                        (65, 4300), (80, 3500), (96, 9300), (100, 5200), (128, 9000), (197, 20000),
+                                        (256, 33000)])
 def test_gemm_form_matches_the_reference_chain(nant, nrow):
     d = _decomposable(_problem(3, nrow, 6, 23, nant), nant)
     plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
@@ -146,7 +150,7 @@ def test_device_resident_call_and_time_offset():
 
 def test_dispatcher_falls_back():
     """what must NOT take the GEMM route: uvw drawn per row (BASELINE's recipe), uvw decomposable only to 1e-6 m, the same
-    baseline twice in a timestep, Gaussian shapes, more than 64 antennas -- all give the reference's answer"""
+    baseline twice in a timestep, Gaussian shapes, more than 256 antennas -- all give the reference's answer"""
     nant = 9
     base = _problem(12, 600, 4, 13, nant)
     plan = fused.fused_plan(base["time_index"], base["ant1"], base["ant2"], nant, uvw=base["uvw"])
@@ -176,8 +180,8 @@ def test_dispatcher_falls_back():
     ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, np.einsum("srf,sfij->srfij", phase, d["X"]), dde,
                              None, None, None)
     assert np.abs(out - ref).max() < 1e-9 * _scale(d)
-    big = _decomposable(_problem(13, 2500, 3, 5, 70), 70, seed=7)
-    plan = fused.fused_plan(big["time_index"], big["ant1"], big["ant2"], 70, uvw=big["uvw"])
+    big = _decomposable(_problem(13, 2500, 3, 5, 260), 260, seed=7)
+    plan = fused.fused_plan(big["time_index"], big["ant1"], big["ant2"], 260, uvw=big["uvw"])
     assert not plan.decomposable
     assert np.abs(_call(big) - _oracle_chain(big, True)).max() < 1e-9 * _scale(big)
 
@@ -321,3 +325,21 @@ def test_cached_plan_by_tensor_identity():
     p2 = fused.cached_plan(ti, a1, a2, nant, uvw=uvw)
     assert p2 is not p1 and p2.decomposable
     assert np.allclose(p2.ant_uvw, 2.0 * p1.ant_uvw)
+
+
+@pytest.mark.parametrize("nant", [72, 130])
+def test_large_arrays_row_layouts_feed_rotation_and_general_kernel(nant, monkeypatch):
+    """super-tiles with missing baselines, swapped antennas, shuffled rows and autocorrelations; feed rotation (the one
+    instantiation family that differs); GEMM form against the lane-per-row kernel on the same rows"""
+    d = _decomposable(_problem(31, 2 * nant * (nant - 1) // 2 + 100, 3, 9, nant), nant, seed=14, keep=0.85, swap=0.3,
+                      shuffle=True, autos=True)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable
+    out = _call(d, plan=plan)
+    ref = _oracle_chain(d, True)
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+    fr = oracle.feed_rotation(d["pa"], "linear")
+    out_fr = _call(d, feed_rotation=fr)
+    monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
+    assert np.abs(_call(d) - out).max() < 1e-10 * _scale(d)
+    assert np.abs(_call(d, feed_rotation=fr) - out_fr).max() < 1e-10 * _scale(d)
