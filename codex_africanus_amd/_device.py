@@ -187,6 +187,33 @@ class _DeferredStatus(object):
 _deferred = _DeferredStatus()
 
 
+class _CopyStreams(object):
+    """A second stream (downloads) and one event per (thread, device) for Call.result_rows, created on first use."""
+
+    def __init__(self):
+        import threading
+        self._tls = threading.local()
+
+    def get(self):
+        dev = _lib.get_device()
+        cache = getattr(self._tls, "cache", None)
+        if cache is None:
+            cache = self._tls.cache = {}
+        if dev not in cache:
+            st, ev = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.call("af_stream_create", ctypes.byref(st))
+            _lib.call("af_event_create", ctypes.byref(ev))
+            cache[dev] = (st, ev)
+        return cache[dev]
+
+
+_copy_streams = _CopyStreams()
+
+
+def _copy_stream():
+    return _copy_streams.get()
+
+
 def check_status(wait=True):
     """Raise ``ValueError`` if a device-mode call made so far met an out-of-range index (waits for those calls'
     streams when ``wait``)."""
@@ -321,6 +348,60 @@ class Call(object):
         buf = _OwnedBuffer(nbytes)
         self._owned.append(buf)
         return ctypes.c_void_p(buf.ptr), (buf, shape, dtype)
+
+    # ---- results produced and downloaded in row chunks ------------------------------------------------
+    def result_rows(self, handle, launch, cast=None):
+        """
+        The result of a call whose rows are independent, produced in ROW CHUNKS so that the download of chunk k (on the
+        thread's copy stream, behind an event) runs while chunk k + 1 is computed: ``launch(r0, r1, p_out)`` enqueues
+        the kernels of rows [r0, r1) on ``self.stream``, writing their rows at device pointer ``p_out``.  What the
+        reference gets from dask's thread pool -- one block's copy-out beside the next block's arithmetic
+        (africanus/dft/dask.py:37-51) -- for the plain numpy call: BASELINE configs[1] numpy in -> numpy out 95.5 -> 73.7
+        ms (copy alone 71.7, transform alone 20.7; tools/bench_d2h_overlap.py, profiles/r05_d2h_overlap_*).
+        ``cast`` complex64 / float32: converted ON THE DEVICE chunk by chunk, half the bytes cross PCIe.
+        Device mode, small results and AFHIP_D2H_PIPELINE=0: one launch over all rows, then ``result``.
+        """
+        if self.device_mode:
+            launch(0, int(handle.shape[0]), ctypes.c_void_p(handle.data_ptr()))
+            return self.result(handle, cast)
+        buf, shape, dtype = handle
+        nrow = int(shape[0])
+        row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * dtype.itemsize
+        out_dtype = dtype if cast is None else np.dtype(cast)
+        narrow = cast is not None and out_dtype.itemsize * 2 == dtype.itemsize and out_dtype.kind == dtype.kind
+        total = nrow * row_bytes
+        chunk_bytes = int(os.environ.get("AFHIP_D2H_CHUNK_MB", "256")) << 20       # read per call (tests use small chunks)
+        if (total < 2 * chunk_bytes or os.environ.get("AFHIP_D2H_PIPELINE", "1") == "0"
+                or not _USE_POOL or (cast is not None and not narrow)):
+            launch(0, nrow, ctypes.c_void_p(buf.ptr))
+            return self.result(handle, cast)
+        rows = max(256, (chunk_bytes // row_bytes) // 256 * 256)
+        arr = _pinned.array(shape, out_dtype)
+        if arr is None:
+            arr = np.empty(shape, dtype=out_dtype)
+        copy_stream, event = _copy_stream()
+        out_row_bytes = row_bytes // 2 if narrow else row_bytes
+        nbuf = None
+        if narrow:                       # the narrowed copy of the result (pool block, returned with the others)
+            nbuf = _OwnedBuffer(nrow * out_row_bytes)
+            self._owned.append(nbuf)
+        host = arr.ctypes.data
+        for r0 in range(0, nrow, rows):
+            r1 = min(nrow, r0 + rows)
+            launch(r0, r1, ctypes.c_void_p(buf.ptr + r0 * row_bytes))
+            src = buf.ptr + r0 * row_bytes
+            if narrow:
+                n = (r1 - r0) * row_bytes // 8       # doubles in, floats out (complex = pairs)
+                _lib.call("af_convert_f64_to_f32", ctypes.c_void_p(src), ctypes.c_void_p(nbuf.ptr + r0 * out_row_bytes), n,
+                          self.stream)
+                src = nbuf.ptr + r0 * out_row_bytes
+            _lib.call("af_event_record", event, self.stream)
+            _lib.call("af_stream_wait_event", copy_stream, event)
+            _lib.call("af_memcpy_d2h", ctypes.c_void_p(host + r0 * out_row_bytes), ctypes.c_void_p(src),
+                      (r1 - r0) * out_row_bytes, copy_stream)
+        _lib.call("af_stream_synchronize", copy_stream)
+        _lib.call("af_stream_synchronize", self.stream)
+        return arr
 
     def result(self, handle, cast=None):
         """Materialise the result: torch tensor (device mode) or numpy array (host mode)."""

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "af_event_create": (_int, [ctypes.POINTER(_vp)]),
     "af_event_destroy": (_int, [_vp]),
     "af_event_record": (_int, [_vp, _vp]),
+    "af_stream_wait_event": (_int, [_vp, _vp]),
     "af_event_synchronize": (_int, [_vp]),
     "af_event_elapsed_ms": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "af_profile_events": (_int, [_vp, _vp]),

@@ -495,6 +495,13 @@ AF_EXPORT int af_event_record(void *event, void *stream)
     return AF_OK;
 }
 
+AF_EXPORT int af_stream_wait_event(void *stream, void *event)
+{
+    AF_REQUIRE(event != nullptr, "af_stream_wait_event: event is NULL");
+    AF_HIP(hipStreamWaitEvent(af_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return AF_OK;
+}
+
 AF_EXPORT int af_event_synchronize(void *event)
 {
     AF_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));

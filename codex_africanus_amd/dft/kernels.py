@@ -105,9 +105,15 @@ def im_to_vis(image, uvw, lm, frequency, convention="fourier", dtype=None):
         p_out, h = c.out((nrow, nchan, ncorr), np.complex128)
         ws_bytes = _lib.load().af_im_to_vis_workspace_bytes(nsrc, nchan, ncorr, int(is_cplx))
         p_ws = c.scratch(ws_bytes)
-        _lib.call("af_im_to_vis_f64", p_img, int(is_cplx), p_uvw, p_lm, p_fr, nsrc, nrow, nchan, ncorr,
-                  _lib.CONVENTION[convention], _MODES[get_mode()], p_out, p_ws, max(int(ws_bytes), 256), c.stream)
-        return c.result(h, cast=None if out_dtype == np.complex128 else out_dtype)
+        conv, mode_, ws_n = _lib.CONVENTION[convention], _MODES[get_mode()], max(int(ws_bytes), 256)
+
+        def launch(r0, r1, p_rows):     # rows are independent: a row chunk is the same call on a slice of uvw
+            import ctypes
+            _lib.call("af_im_to_vis_f64", p_img, int(is_cplx), ctypes.c_void_p(p_uvw.value + r0 * 24), p_lm, p_fr, nsrc,
+                      r1 - r0, nchan, ncorr, conv, mode_, p_rows, p_ws, ws_n, c.stream)
+
+        # numpy callers: the result comes back in row chunks whose downloads overlap the next chunk's transform
+        return c.result_rows(h, launch, cast=None if out_dtype == np.complex128 else out_dtype)
 
 
 def im_to_vis_chi2(image, uvw, lm, frequency, data, weight=None, convention="fourier"):

@@ -104,6 +104,7 @@ int af_device_synchronize(void);
 int af_event_create(void **event);
 int af_event_destroy(void *event);
 int af_event_record(void *event, void *stream);
+int af_stream_wait_event(void *stream, void *event);   /* work enqueued on `stream` after this call waits for `event` */
 int af_event_synchronize(void *event);
 int af_event_elapsed_ms(void *start, void *stop, float *ms);
 /* Measurement hook (bench.py): while set (non-NULL) on the calling thread, entry

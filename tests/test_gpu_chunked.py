@@ -58,3 +58,24 @@ def test_chunked_vis_to_im():
                             chunks={"row": 77, "chan": 26})
     # same bound as the unchunked parity test: 1e-11 relative to sum_r |vis|
     assert np.abs(out - ref).max() <= 1e-11 * np.abs(g6["vis70"]).sum(axis=0).max()
+
+
+def test_numpy_result_downloaded_in_overlapped_row_chunks(monkeypatch):
+    """the numpy-in / numpy-out im_to_vis produces its result in row chunks whose downloads (copy
+    stream, behind an event) overlap the next chunk's transform.  Same bits as the one-piece call, ragged last chunk,
+    and dtype=complex64 converted on the device before the copy (= numpy's rounding of the complex128 result)."""
+    from codex_africanus_amd import dft
+    from codex_africanus_amd.testing import synthetic_inputs, real_image
+    d = synthetic_inputs(seed=12, nrow=70001, nchan=64, nsrc=30, nant=7)
+    image = real_image(d)
+    monkeypatch.setenv("AFHIP_D2H_PIPELINE", "0")
+    whole = dft.im_to_vis(image, d["uvw"], d["lm"], d["frequency"])
+    monkeypatch.delenv("AFHIP_D2H_PIPELINE")
+    monkeypatch.setenv("AFHIP_D2H_CHUNK_MB", "16")           # 70001 rows x 4 KB = 287 MB: 18 chunks of 4096 rows
+    piped = dft.im_to_vis(image, d["uvw"], d["lm"], d["frequency"])
+    assert piped.dtype == np.complex128 and np.array_equal(piped, whole)
+    c64 = dft.im_to_vis(image, d["uvw"], d["lm"], d["frequency"], dtype=np.complex64)
+    assert c64.dtype == np.complex64 and np.array_equal(c64, whole.astype(np.complex64))
+    cplx = dft.im_to_vis(image * (1 + 0.5j), d["uvw"], d["lm"], d["frequency"])
+    monkeypatch.setenv("AFHIP_D2H_PIPELINE", "0")
+    assert np.array_equal(cplx, dft.im_to_vis(image * (1 + 0.5j), d["uvw"], d["lm"], d["frequency"]))
