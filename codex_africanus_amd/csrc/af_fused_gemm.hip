@@ -468,6 +468,10 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
             // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
             // its instruction count: coherent gathers, --pa common, take 65 ms)
+            // (round 5: the super-round split at the batch barrier -- geometry and the four rounds' gathers BEFORE the barrier
+            // that starts the matrix waves' burst on the previous batch, the rounds' arithmetic after it (the samplers' side
+            // of the barrier then waits for LDS only, s_waitcnt lgkmcnt(0); s_barrier, so the gathers stay in flight across
+            // it) -- 109.1 ms against 97 for this order; the sampling stage alone 67.9 either way)
             // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
             // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
             // stalls they fill)

@@ -162,7 +162,11 @@ int af_im_to_vis_chi2_f64(const double *image, int image_is_complex, const doubl
  * close to the float64 transform of the same inputs as the reference's float32 loop.  ncorr in {1, 2, 4}
  * (AF_ENOTSUP otherwise: promote and call af_im_to_vis_f64).  Same zero-pixel / NaN-source semantics, same `mode`
  * values (AF_DFT_RECURRENCE additionally asserts that the float32 frequency axis is meant to be uniform: its
- * rounding is then not followed channel by channel). */
+ * rounding is then not followed channel by channel).
+ * The _f32 transforms are a CONVENIENCE for single-precision callers (the dtype contract, half the bytes), not a fast
+ * path: at BASELINE configs[1]'s counts af_im_to_vis_f32 runs 1.08 x the rate of af_im_to_vis_f64 (0.46 of the fp32
+ * vector peak: the 8-cycle v_mfma_f32_4x4x1 blocks leave no issue slots for the float32 phasor recurrence beside them,
+ * DESIGN.md 3.10); the fp64 entry is the one the roofline of this library is stated on. */
 size_t af_im_to_vis_f32_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t ncorr, int image_is_complex);
 int af_im_to_vis_f32(const float *image, int image_is_complex, const float *uvw, const float *lm,
                      const float *frequency, int64_t nsrc, int64_t nrow, int64_t nchan, int64_t ncorr,
@@ -392,7 +396,10 @@ int af_gauss_predict_chi2_c128(const double *lm, const double *uvw, const double
  * (weight NULL = 1).  model/data (nrow,nchan,ncorr) complex128, weight real float64,
  * chi2_per_chan (nchan) float64, zeroed by the call.  No reference counterpart (the
  * reference has no chi^2; africanus/calibration/utils/residual_vis.py:63 forms the
- * residual): this is the quantity the row-sharded multi-GPU predict all-reduces. */
+ * residual): this is the quantity the row-sharded multi-GPU predict all-reduces.
+ * ORDER DEPENDENCE: the per-channel sums are accumulated with floating-point atomic adds (here and in the _chi2
+ * epilogues of the transforms): two calls on the same inputs agree to the order of the adds, ~1e-13 relative -- a
+ * statistic, not a bit pattern.  Tests compare chi^2 with rtol 1e-12, visibilities bit for bit. */
 int af_chi2_c128(const double *model, const double *data, const double *weight, int64_t nrow,
                  int64_t nchan, int64_t ncorr, double *chi2_per_chan, void *stream);
 
