@@ -15,12 +15,13 @@ class FusedDde(object):
     brightness = flat-spectrum coherency matrices of the synthetic sky.  The reference chain it replaces:
     phase_delay -> einsum -> beam_cube_dde -> predict_vis (africanus/rime/examples/predict.py:404-525)."""
     NANT, LW, MH, NUD = 64, 257, 257, 33
+    FORCE_ANTENNAS = None
 
     def __init__(self, args, rank, dev, lib, _lib, t):
         import torch
         from codex_africanus_amd.testing import synthetic_inputs
         self.args, self._lib = args, _lib
-        self.NANT = int(getattr(args, "antennas", 64))          # instance attribute: 64 unless --antennas says otherwise
+        self.NANT = self.FORCE_ANTENNAS or int(getattr(args, "antennas", 64))     # 64 unless --antennas says otherwise
         nrow, nchan, nsrc, nant = args.rows, args.chans, args.sources, self.NANT
         d = synthetic_inputs(seed=args.seed, nrow=16, nchan=nchan, nsrc=nsrc, nant=64)
         rng = np.random.default_rng(1000 + args.seed + rank)
@@ -35,7 +36,7 @@ class FusedDde(object):
         ant1 = np.tile(a1, ntime)[:nrow].astype(np.int32)
         ant2 = np.tile(a2, ntime)[:nrow].astype(np.int32)
         time_index = np.repeat(np.arange(ntime, dtype=np.int64), nbl)[:nrow]
-        self.antennas = args.workload == "fused_dde_ant" or getattr(args, "uvw", "random") == "antennas"
+        self.antennas = args.workload.startswith("fused_dde_ant") or getattr(args, "uvw", "random") == "antennas"
         if self.antennas:
             # a Measurement Set's uvw: per-(time, antenna) coordinates, baselines are their differences (same extent as
             # the per-row recipe: |u|, |v| <= 4000 m, |w| <= 400 m)
@@ -234,3 +235,10 @@ class FusedDde(object):
             "probe_rows": n1, "sample_rows": n, "sample_seconds": dt,
         }
 
+
+
+class FusedDdeAnt128(FusedDde):
+    """The GEMM form on a 128-antenna array (8128 baselines per timestep, the same 1e6 x 64 x 1000 counts): M is cut into
+    super-tiles -- two 64-antenna diagonal super-blocks and two 8 x 4-block rectangles per (timestep, channel) (round 5;
+    the reference's sum has no antenna limit, africanus/rime/predict.py:199-212)."""
+    FORCE_ANTENNAS = 128

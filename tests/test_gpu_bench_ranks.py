@@ -107,7 +107,7 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
     assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
     w = r["workloads"]
-    assert set(w) == {"dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes"}
+    assert set(w) == {"dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "degrid", "wgrid", "wgrid_f32planes"}
     for name, e in w.items():
         assert "error" not in e, (name, e)
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
@@ -130,7 +130,7 @@ def test_the_driver_visible_keys_of_the_default_line():
     line = lines[0]
     r = json.loads(line)
     roof = r["roofline"]
-    names = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "degrid", "wgrid", "wgrid_f32planes")
+    names = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "degrid", "wgrid", "wgrid_f32planes")
     assert set(roof["others"]) == set(names)
     for n in names:
         ms, kernel_ms, frac, err_, value = roof["others"][n]

@@ -2,13 +2,13 @@
 # rocprofv3 evidence for one round: every bench.py workload (kernel-trace stats + PMC passes, each in its own run:
 # counters are never combined with other trace domains) and the auxiliary benches.  On the GPU box, from the repo root:
 #   gpurun --timeout 2400 -- 'bash tools/profile_round.sh'
-# then here: python tools/summarize_round.py r04
+# then here: python tools/summarize_round.py r05
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 gauss fused_dde fused_dde_ant degrid wgrid wgrid_f32planes}"
+WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 gauss fused_dde fused_dde_ant fused_dde_ant128 degrid wgrid wgrid_f32planes}"
 T="timeout 900"    # a profiler pass that hangs must not take the box with it
 # the line the driver gets: headline + every other single-GPU workload under "workloads"
 python3 bench.py > "$OUT/default_line.json" 2> "$OUT/default_stderr.log"
