@@ -109,6 +109,9 @@ def parse(argv=None):
                         "on a one-GPU box this loads librccl, builds a communicator and runs the collective on the device")
     p.add_argument("--launch-timeout", type=int, default=3600, help="self-launched ranks: seconds before they are killed")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-end-to-end", action="store_true",
+                   help="skip the numpy-in -> numpy-out measurement (profiling runs: its chunked calls launch the same "
+                        "kernels at other sizes and would mix into per-kernel averages)")
     p.add_argument("--cpu-seconds", type=float, default=2.0,
                    help="minimum wall time of the all-cores CPU baseline sample (the single-thread probe runs "
                         ">= a quarter of it)")

@@ -111,7 +111,7 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         res["per_rank"] = {"kernel_ms": [round(float(x), 4) for x in k_ms], "kernel_ms_min": float(k_ms.min()),
                            "kernel_ms_max": float(k_ms.max()), "ms_per_step": [round(float(x), 4) for x in e_ms],
                            "ms_per_step_min": float(e_ms.min()), "ms_per_step_max": float(e_ms.max())}
-    if hasattr(wl, "end_to_end") and world == 1:
+    if hasattr(wl, "end_to_end") and world == 1 and not getattr(args, "no_end_to_end", False):
         res["end_to_end"] = wl.end_to_end()
     if cpu_seconds > 0 and world == 1:
         res["cpu_baseline"] = wl.cpu_baseline(cpu_seconds)

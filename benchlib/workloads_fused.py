@@ -228,8 +228,8 @@ class FusedDde(object):
             "value": len(rows_t) * a.chans / t_step / 1e6, "unit": "Mvis/s", "cores": threads, "kind": "port",
             "sample": "oracle chain beam_cube_dde -> phase_delay -> einsum -> predict_vis (C restatements of "
                       "africanus/rime/fast_beam_cubes.py:57-240, phase.py:20-63, predict.py:193-252) for ONE "
-                      "timestep (%d rows x %d chan x %d src, 64 antennas): beam terms %.2f s on 1 thread + %d rows on "
-                      "%d threads in %.2f s scaled to the timestep's rows" % (len(rows_t), a.chans, a.sources,
+                      "timestep (%d rows x %d chan x %d src, %d antennas): beam terms %.2f s on 1 thread + %d rows on "
+                      "%d threads in %.2f s scaled to the timestep's rows" % (len(rows_t), a.chans, a.sources, self.NANT,
                                                                              t_beam, n, threads, dt),
             "single_thread_value": a.chans / (per_row + t_beam / len(rows_t)) / 1e6,
             "probe_rows": n1, "sample_rows": n, "sample_seconds": dt,

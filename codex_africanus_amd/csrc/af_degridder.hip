@@ -323,6 +323,12 @@ __global__ __launch_bounds__(256) void degrid_coop_kernel(const double *__restri
     }
 }
 
+// ======================================================================================================================
+// NOT ON THE SURVEY 8 HOT PATH from here to af_degridder_c128's host code: the Perley GRIDDER (visibilities -> grid:
+// grid_kernel, grid_wave7_kernel, grid_tile_*; entry af_gridder_c128), built in round 2 as the degridder's adjoint
+// cross-check (gridding/perleypolyhedron/gridder.py:12-117).  Not tuned since, not a roofline row; the degridder above
+// (BASELINE configs[4]) uses none of it.
+// ======================================================================================================================
 // ---- gridder (the adjoint): scatter with fp64 hardware atomics ------------------------------------------------
 // One lane per visibility (row, chan): Stokes value = sum_k factor[k] * vis[k] * phase, then W x W atomic adds of
 // weight * value into the band's grid; the visibility's weight sum over ALL taps (on or off the grid, as the

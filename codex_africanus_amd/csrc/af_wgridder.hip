@@ -1098,6 +1098,13 @@ __global__ void wg_finish(double2 *__restrict__ vis, const double *__restrict__ 
 // into the staging array, rows along v), multiplied by exp(-2 pi i w_k (n - 1)) and by the same taper A, and its real
 // part added to the image.
 
+// ======================================================================================================================
+// NOT ON THE SURVEY 8 HOT PATH from here to the host section: the ADJOINT side (visibilities -> image: wg_grid_planes,
+// wg_grid_tiles, wg_gather_rows, wg_add_plane; entry af_wgrid_vis2im_f64).  Built in round 2 beside the forward operator
+// because the reference's only pin for its wgridder wrappers is the pair's adjointness and DFT accuracy
+// (gridding/wgridder/tests/test_wgridder.py:116-); kept as the forward path's cross-check, not tuned since, not a
+// roofline row.  The forward path (BASELINE configs[4] as named) uses nothing below this line except the host dispatch.
+// ======================================================================================================================
 // (small calls) one lane per visibility, hardware fp64 atomics into the planes
 template <int W>
 __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__ uvw, const double *__restrict__ freq,

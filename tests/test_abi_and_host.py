@@ -201,3 +201,37 @@ def test_fused_group_plan_covers_every_row_once(nant, nrow):
     with pytest.raises(ValueError, match="antenna index out of range"):
         _lib.call("af_fused_plan_groups", P(ti), P(a1 + nant), P(a2), nrow, nant, None, 0, ctypes.byref(ni), None, 0,
                   ctypes.byref(ng))
+
+
+def test_gemm_plan_host_side_up_to_256_antennas():
+    """Round 5 (host side only, no GPU work): the antenna planner and the plan object for arrays beyond 64 antennas --
+    decomposable, residual, row map, the slots the GEMM form pays for (super-tiles: super-blocks of 8 blocks, DIAG + 8 x 4
+    RECT tiles) and the fill factor the dispatcher uses."""
+    from codex_africanus_amd import _lib
+    from codex_africanus_amd.rime import fused
+    lib = _lib.load()
+    tri = lambda n: n * (n + 1) // 2
+    # tiles: one DIAG for <= 8 blocks; beyond, DIAGs of the 8-block super-blocks plus every pair's rectangle
+    assert lib.af_fused_gemm_slots(64) == 36 * 64 and lib.af_fused_gemm_slots(5) == 64 and lib.af_fused_gemm_slots(0) == 0
+    assert lib.af_fused_gemm_slots(128) == (2 * tri(8) + 64) * 64
+    assert lib.af_fused_gemm_slots(197) == (3 * tri(8) + tri(1) + 3 * 64 + 3 * 8) * 64      # 25 blocks: 8 + 8 + 8 + 1
+    assert lib.af_fused_gemm_slots(256) == (4 * tri(8) + 6 * 64) * 64 and lib.af_fused_gemm_slots(257) == 0
+    rng = np.random.default_rng(5)
+    for nant in (70, 130, 256):
+        a1, a2 = np.triu_indices(nant, 1)
+        nbl, ntime = a1.shape[0], 2
+        ti = np.repeat(np.arange(ntime), nbl) + 3                      # an offset: the plan normalises it
+        a1, a2 = np.tile(a1, ntime).astype(np.int32), np.tile(a2, ntime).astype(np.int32)
+        x = rng.uniform(-1, 1, (ntime, nant, 3)) * [3000.0, 3000.0, 300.0]
+        uvw = x[ti - 3, a1] - x[ti - 3, a2]
+        plan = fused.fused_plan(ti, a1, a2, nant, uvw=uvw)
+        assert plan.decomposable and plan.residual <= 1e-10 and plan.nsteps == ntime
+        nap = 8 * ((nant + 7) // 8)
+        assert plan.rowmap.shape == (ntime, nap, nap) and (plan.rowmap >= 0).sum() == ti.shape[0]
+        assert np.array_equal(plan.rowmap[ti - 3, a1, a2], np.arange(ti.shape[0]))
+        assert np.abs(plan.ant_uvw[ti - 3, a1] - plan.ant_uvw[ti - 3, a2] - uvw).max() <= 1e-10
+        assert plan.fill == pytest.approx(nbl / lib.af_fused_gemm_slots(nant)) and 0.75 < plan.fill < 1.0
+        assert np.array_equal(plan.step, ti - 3) and plan.step.dtype == np.int32
+        # per-row uvw does not decompose: the plan says so and the caller stays on the lane-per-row kernel
+        assert not fused.fused_plan(ti, a1, a2, nant, uvw=rng.standard_normal(uvw.shape)).decomposable
+    assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 260, uvw=uvw[:10]).decomposable is False   # > 256 antennas

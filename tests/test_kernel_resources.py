@@ -111,7 +111,8 @@ def test_gemm_form_of_the_fused_predict_fits_three_waves_per_simd(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        m = re.search(r"fused_gemm3_kernelILb([01])ELi(\d+)ELi(\d+)E", name)
+        # template <bool FEED, bool RECT, int NBR, int NBC, int ST>
+        m = re.search(r"fused_gemm3_kernelILb([01])ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)E", name)
         if not m:
             continue
         seen += 1
@@ -120,6 +121,6 @@ def test_gemm_form_of_the_fused_predict_fits_three_waves_per_simd(tmp_path):
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
         assert vgprs + agprs <= 168 and scratch <= 32 and lds == 0, (name, scratch, vgprs, agprs, lds)   # LDS is dynamic
-        if m.group(2) == "8" and m.group(1) == "0":
-            assert scratch == 0, (name, scratch)          # BASELINE configs[2]'s instantiation
-    assert seen == 16, seen     # 8 antenna-block counts x FEED
+        if m.group(1) == "0" and (m.group(3) == "8"):
+            assert scratch == 0, (name, scratch)          # BASELINE configs[2]'s instantiation (DIAG<8>) and the RECT super-tile
+    assert seen == 18, seen     # (8 DIAG antenna-block counts + the 8 x 4 RECT super-tile of arrays beyond 64 antennas) x FEED
