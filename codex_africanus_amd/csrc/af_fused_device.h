@@ -117,11 +117,11 @@ __device__ __forceinline__ double2 beam_reduce1(const double2 (&v)[4], const dou
         cim = fma(wt[k], v[k].y, cim);
         absc = fma(wt[k], ab[k], absc);
     }
-    // corr_sum * absc_sum / |corr_sum|  (:227-235; absc_sum itself when corr_sum == 0): 1/|.| by v_rsq_f64 and two
-    // Newton steps (~1 ulp; the fused chain is checked to 1e-9 against the oracle, not bit for bit)
+    // corr_sum * absc_sum / |corr_sum|  (:227-235; absc_sum itself when corr_sum == 0): 1/|.| by v_rsq_f64 (a ~2^-26
+    // seed) and ONE Newton step (error 1.5 e^2 ~ 3e-16; the fused chain is checked to 1e-9 against the oracle, not bit
+    // for bit.  Until round 5 two steps: four dependent fp64 operations per sampled Jones entry for nothing)
     const double n2 = fma(cre, cre, __dmul_rn(cim, cim));
     double y = __builtin_amdgcn_rsq(n2);
-    y = fma(__dmul_rn(0.5, y), fma(-__dmul_rn(n2, y), y, 1.0), y);
     y = fma(__dmul_rn(0.5, y), fma(-__dmul_rn(n2, y), y, 1.0), y);
     const double sc = (n2 == 0.0) ? absc : __dmul_rn(absc, y);
     return make_double2(__dmul_rn(cre, sc), __dmul_rn(cim, sc));
@@ -135,9 +135,23 @@ struct FusedGrid {
     int lmaxi, mmaxi;
     unsigned stride_l, stride_m;  // bytes between consecutive l / m voxels of the packed cube
 };
+// a wave-uniform double computed on the vector unit (the grid scales come out of fp64 divisions) moved into scalar
+// registers: the sampling waves live on a 168-register budget and every value that is the same in all lanes but sits in a
+// vector register is two of them (round 5: the two scales were what the GEMM kernel's sampler spilled -- and reloaded
+// behind an s_waitcnt vmcnt(0) that drained its gathers)
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 struct FusedVoxels {
     unsigned off[4];
     double wt[4];
+};
+// the same in 9 registers instead of 12 (the GEMM kernel's sampler): corner offsets as base + dl + dm, weights as the two
+// fractional coordinates (wt = {(1-ld)(1-md), ld (1-md), (1-ld) md, ld md} is rebuilt where a round is consumed)
+struct FusedVoxelsC {
+    unsigned base, dl, dm;
+    double ld, md;
 };
 __device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, double m, double sin_pa, double cos_pa,
                                              double pe_l, double pe_m, double as_l, double as_m, double freq_scale,
@@ -164,6 +178,31 @@ __device__ __forceinline__ void fused_voxels(const FusedGrid &g, double l, doubl
     const unsigned base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m;
     const unsigned dl = gl0 < g.lmaxi ? g.stride_l : 0u, dm = gm0 < g.mmaxi ? g.stride_m : 0u;  // upper neighbour clamped
     vx.off[0] = base; vx.off[1] = base + dl; vx.off[2] = base + dm; vx.off[3] = base + dl + dm;
+}
+
+__device__ __forceinline__ void fused_voxels_compact(const FusedGrid &g, double l, double m, double sin_pa, double cos_pa,
+                                                     double pe_l, double pe_m, double as_l, double as_m, double freq_scale,
+                                                     FusedVoxelsC &vx)
+{
+    const double sl = __dmul_rn(l, freq_scale), sm = __dmul_rn(m, freq_scale);
+    const double tl = __dadd_rn(sl, pe_l), tm = __dadd_rn(sm, pe_m);
+    double vl = __dsub_rn(__dmul_rn(tl, cos_pa), __dmul_rn(tm, sin_pa));
+    double vm = __dadd_rn(__dmul_rn(tl, sin_pa), __dmul_rn(tm, cos_pa));
+    vl = __dmul_rn(vl, as_l);
+    vm = __dmul_rn(vm, as_m);
+    vl = __dmul_rn(g.lscale, __dsub_rn(vl, g.lower_l));
+    vm = __dmul_rn(g.mscale, __dsub_rn(vm, g.lower_m));
+    {
+        const double t1 = vl < g.lmaxf ? vl : g.lmaxf; vl = 0.0 > t1 ? 0.0 : t1;
+        const double t2 = vm < g.mmaxf ? vm : g.mmaxf; vm = 0.0 > t2 ? 0.0 : t2;
+    }
+    const double fl = floor(vl), fm = floor(vm);
+    const int gl0 = (int)fl, gm0 = (int)fm;
+    vx.ld = __dsub_rn(vl, fl);
+    vx.md = __dsub_rn(vm, fm);
+    vx.base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m;
+    vx.dl = gl0 < g.lmaxi ? g.stride_l : 0u;
+    vx.dm = gm0 < g.mmaxi ? g.stride_m : 0u;
 }
 
 // value of quad lane QL in all four lanes of the quad; the neighbour lane ^ 1 (DPP quad_perm, no LDS crossbar)

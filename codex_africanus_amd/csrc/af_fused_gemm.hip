@@ -52,6 +52,19 @@ constexpr int COL_PAD = 16;          // doubles of padding per operand plane (pl
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Profiling build only (make HOOKS=1): shader-clock phase timers of the GEMM kernel, accumulated over every 16th
+// workgroup -- [0] matrix wave 0: cycles inside the MFMA loops, [1] its cycles waiting at the batch barriers, [2] sampling
+// wave 8: geometry + gather issue, [3] waiting for the gathers (an explicit vmcnt(0) is inserted for the measurement),
+// [4] the four rounds' arithmetic + panel writes, [5] its barrier waits, [6] workgroups sampled, [7] batches.
+#ifdef AFHIP_STAGE_HOOKS
+__device__ unsigned long long g_gemm_prof[8];
+#define AF_PROF_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define AF_PROF_ON 1
+#else
+#define AF_PROF_NOW() 0ull
+#define AF_PROF_ON 0
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // The complex product as THREE real matrix products (the 3M / Karatsuba form): with Gs = Gr + Gi and Hd = Hr - Hi,
 //     P1 = Gr Hr^T,  P2 = Gi Hi^T,  P3 = Gs Hd^T      ->      Re M = P1 + P2,   Im M = P3 - P1 + P2,
@@ -155,7 +168,7 @@ __device__ __forceinline__ int antenna_slot(int ant, int q4) { return (ant & 3) 
 template <bool RECT, int NBR, int NBC, int ST, int W>
 __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, int nbatch, int only_stage, int lane,
                                              const int32_t *__restrict__ rm, int nap, const SuperTile tile,
-                                             int64_t nchan, int64_t f, double2 *__restrict__ out)
+                                             int64_t nchan, int64_t f, double2 *__restrict__ out, int burst_delay)
 {
     using G = Geo<RECT, NBR, NBC, ST>;
     constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
@@ -169,8 +182,13 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
 #pragma unroll
     for (int j = 0; j < CN; ++j) p1[j] = p2[j] = p3[j] = (v4d){0.0, 0.0, 0.0, 0.0};
     int buf = 0;
+    unsigned long long prof_mfma = 0, prof_bar = 0, prof_t = AF_PROF_NOW();
     for (int b = 0; b < nbatch; ++b) {
         __syncthreads();
+        if (AF_PROF_ON) { const unsigned long long n = AF_PROF_NOW(); prof_bar += n - prof_t; prof_t = n; }
+        // (the SIMD's sampling wave runs order B: its rounds' arithmetic comes first after the barrier -- let it have the
+        // pipe, start the burst later)
+        for (int d = burst_delay; d > 0; d -= 16) __builtin_amdgcn_s_sleep(16);
         const double *P = ldsd + buf * BUF;
         buf = buf + 1 == G::DEPTH ? 0 : buf + 1;
         if (only_stage == 1 || CNT == 0) continue;
@@ -187,7 +205,14 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
                 p3[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * CSG], B[4 * CSH], p3[j], 0, 0, 0);
             }, std::make_integer_sequence<int, CNT>{});
         }
+        if (AF_PROF_ON) { const unsigned long long n = AF_PROF_NOW(); prof_mfma += n - prof_t; prof_t = n; }
     }
+#ifdef AFHIP_STAGE_HOOKS
+    if (W == 0 && lane == 0 && (blockIdx.x & 15) == 0 && blockIdx.y == 0) {
+        atomicAdd(&g_gemm_prof[0], prof_mfma); atomicAdd(&g_gemm_prof[1], prof_bar);
+        atomicAdd(&g_gemm_prof[6], 1ull); atomicAdd(&g_gemm_prof[7], (unsigned long long)nbatch);
+    }
+#endif
     if (only_stage == 1) return;
     for_each_const([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     const double *__restrict__ freq_data, const double *__restrict__ parangles, const double *__restrict__ point_errors,
     const double *__restrict__ antenna_scaling, const double2 *__restrict__ feed_rot, int nsrc, int64_t nchan,
     int64_t ntime, int nant, int nap, double2 *__restrict__ out, int only_stage, int64_t f0, int sample_prio,
-    const SuperTileList tiles)
+    int order_b_mask, int burst_delay, const SuperTileList tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
     using G = Geo<RECT, NBR, NBC, ST>;
@@ -271,15 +296,17 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     if (tid < G3_MATRIX) {
         const int32_t *rm = rowmap + (int64_t)t * nap * nap;
         const int lane = tid & 63;
+        // waves w, w + 4 and the sampling wave 8 + (w & 3) share a SIMD (tools/probe/probe_wave_simd.hip)
+        const int wdelay = ((order_b_mask >> ((tid >> 6) & 3)) & 1) ? burst_delay : 0;
         switch (tid >> 6) {
-        case 0: matrix_wave3<RECT, NBR, NBC, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 1: matrix_wave3<RECT, NBR, NBC, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 2: matrix_wave3<RECT, NBR, NBC, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 3: matrix_wave3<RECT, NBR, NBC, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 4: matrix_wave3<RECT, NBR, NBC, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 5: matrix_wave3<RECT, NBR, NBC, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        case 6: matrix_wave3<RECT, NBR, NBC, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
-        default: matrix_wave3<RECT, NBR, NBC, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+        case 0: matrix_wave3<RECT, NBR, NBC, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 1: matrix_wave3<RECT, NBR, NBC, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 2: matrix_wave3<RECT, NBR, NBC, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 3: matrix_wave3<RECT, NBR, NBC, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 4: matrix_wave3<RECT, NBR, NBC, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 5: matrix_wave3<RECT, NBR, NBC, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        case 6: matrix_wave3<RECT, NBR, NBC, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
+        default: matrix_wave3<RECT, NBR, NBC, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
         }
         return;
     }
@@ -288,8 +315,10 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     FusedGrid grid;
     {
         const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
-        grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
-        grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
+        grid.lower_l = wave_uniform(g.lower_l); grid.lower_m = wave_uniform(g.lower_m);
+        grid.lscale = wave_uniform(g.lscale); grid.mscale = wave_uniform(g.mscale);
+        grid.lmaxf = wave_uniform(g.lmaxf); grid.mmaxf = wave_uniform(g.mmaxf);
+        grid.lmaxi = __builtin_amdgcn_readfirstlane((int)g.lmaxi); grid.mmaxi = __builtin_amdgcn_readfirstlane((int)g.mmaxi);
         grid.stride_m = VREC * 8u;
         grid.stride_l = (unsigned)beam_mh * grid.stride_m;
     }
@@ -339,163 +368,234 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     };
     auto fetch = [&](const Term &T) {
         const bool have = T.src < nsrc && slot_ok(T.slot);
-        const double *sp = lmn + 4 * (have ? T.src : 0);
+        int sidx = have ? T.src : 0;
+        // TPS == 64: the wave's 64 lanes are one source's slots -- its coordinates are wave-uniform: a scalar load into
+        // scalar registers (six vector registers fewer in a sampler that has none to spare)
+        if constexpr (TPS == 64) sidx = __builtin_amdgcn_readfirstlane(sidx);
+        const double *sp = lmn + 4 * sidx;
         Coords c;
         c.lm = *reinterpret_cast<const double2 *>(sp);
         c.n = sp[2];
         return c;
     };
     Coords nxt = fetch(G::STRADDLE ? term_flat(0) : term_at(0, 0));
-    auto super_round = [&](const Term &T, const Term &Tn) {
-            const int e_sl = T.e_sl, e_slot = T.slot;
-            const bool have = T.src < nsrc && slot_ok(e_slot);
-            double *H = ldsd + T.buf * BUF;
-            // operand address of this lane's own term and what it writes: its H planes (column antenna), its G planes
-            // (row antenna), or both (DIAG)
-            const bool col_term = !RECT || e_slot < NAC;
-            // (the slots of an absent last column block -- RECT, nc_act = NBC - 1 -- keep their own places behind the real ones)
-            const int h_slot = !RECT ? antenna_slot(e_slot, NAC / 4)
-                                     : (!col_term ? 0 : (e_slot < 8 * tile.nc_act ? antenna_slot(e_slot, 2 * tile.nc_act) : e_slot));
-            const int h_off = e_sl * SRC + 2 * h_slot;
-            const int g_off = e_sl * SRC + G3_PLANES * CSH + 2 * antenna_slot(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, NAR / 4);
-            const int own_info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
-            // TPS == 64: a wave's 64 lanes are ONE source's slots -- its 2 x 2 complex brightness comes in by ONE scalar
-            // load per super-round, here (inside the sampling rounds every round waited out an SMEM round trip --
-            // lgkmcnt is shared with the LDS reads --: the sampling alone ran 65.1 ms with those loads, 51.6 without)
-            double2 xw[4];
-            if constexpr (TPS == 64) {
-                const int us = __builtin_amdgcn_readfirstlane(have ? T.src : 0);
-                const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) xw[c] = bp[c];
-            }
-            const int own_src = have ? T.src : 0;
-            const double2 lm2 = nxt.lm;
-            const double nn = nxt.n;
-            nxt = fetch(Tn);
-            FusedVoxels gx;
-            fused_voxels(grid, lm2.x, lm2.y, ldsA[0 * TPS + e_slot], ldsA[1 * TPS + e_slot], ldsA[2 * TPS + e_slot],
-                         ldsA[3 * TPS + e_slot], ldsA[4 * TPS + e_slot], ldsA[5 * TPS + e_slot], fscale, gx);
-            const C2 kph = table_phasor(ldsT, fma(nn, ldsU[2 * TPS + e_slot],
-                                                  fma(lm2.y, ldsU[1 * TPS + e_slot], __dmul_rn(lm2.x, ldsU[0 * TPS + e_slot]))));
-            // all four rounds' gathers first (the weights and the phasor are re-broadcast when a round is consumed:
-            // 33 registers per round in flight)
-            struct Round {
-                int info, slot, src;
-                double2 v[4];
-                double ab[4];
-            };
-            auto issue = [&](auto lane_c, Round &R) {
-                constexpr int QL = decltype(lane_c)::value;
-                R.info = quad_bcast<QL>(own_info);
-                if constexpr (FEED) R.slot = quad_bcast<QL>(e_slot);
-                if constexpr (TPS != 64) R.src = quad_bcast<QL>(own_src);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned off = (unsigned)quad_bcast<QL>((int)gx.off[k]) + corr_off;
-                    const double *r = reinterpret_cast<const double *>(plane + (size_t)off);
-                    R.v[k] = *reinterpret_cast<const double2 *>(r);
-                    R.ab[k] = r[2];
-                }
-            };
-            auto finish = [&](auto lane_c, const Round &R) {
-                constexpr int QL = decltype(lane_c)::value;
-                const int info = R.info;
-                const bool r_have = info < 0;
-                double wt[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wt[k] = quad_bcast<QL>(gx.wt[k]);
-                C2 kk;
-                kk.re = quad_bcast<QL>(kph.re); kk.im = quad_bcast<QL>(kph.im);
-                double2 e2 = beam_reduce1(R.v, R.ab, wt);
-                if (!r_have) e2 = make_double2(0.0, 0.0);
-                C2 e;
-                e.re = e2.x; e.im = e2.y;
-                if constexpr (FEED) {
-                    C2 E0, E1;
-                    E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
-                    E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
-                    const double2 r0 = ldsR[4 * R.slot + ej], r1 = ldsR[4 * R.slot + 2 + ej];
-                    C2 R0, R1;
-                    R0.re = r0.x; R0.im = r0.y; R1.re = r1.x; R1.im = r1.y;
-                    e = cmul(E0, R0);
-                    cmac(e, E1, R1);
-                }
-                const C2 A = cmul(kk, e);
-                C2 A0, A1, B0, B1;
-                A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
-                A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
-                if constexpr (TPS == 64) {
-                    // the wave's source: its brightness matrix was loaded at the top of the super-round
-                    const double2 b0 = ej ? xw[1] : xw[0], b1 = ej ? xw[3] : xw[2];
-                    B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
-                } else {
-                    const double2 *bp = brightness + ((int64_t)R.src * nchan + f) * 4;
-                    const double2 b0 = bp[ej], b1 = bp[2 + ej];
-                    B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
-                }
-                C2 Gv = cmul(A0, B0);
-                cmac(Gv, A1, B1);
-                if constexpr (!RECT) {
-                    // DIAG: NAR == NAC, the G planes of a slot lie G3_PLANES * CSH doubles behind its H planes
-                    double *hs = H + (info & 0x3fffffff) + ei;
-                    double *gs = hs + G3_PLANES * CSH;
-                    hs[ej * CSH] = A.re; hs[(2 + ej) * CSH] = A.im; hs[(4 + ej) * CSH] = __dsub_rn(A.re, A.im);
-                    gs[ej * CSG] = Gv.re; gs[(2 + ej) * CSG] = Gv.im; gs[(4 + ej) * CSG] = __dadd_rn(Gv.re, Gv.im);
-                } else {
-                    // RECT: a column antenna's term writes its H planes, a row antenna's its G planes: one address, one
-                    // plane stride and three values picked per lane, the stores themselves unconditional
-                    const bool r_col = (info >> 30) & 1;
-                    double *ws = H + (info & 0x3fffffff) + ei;
-                    const int cs = r_col ? CSH : CSG;
-                    const double v0 = r_col ? A.re : Gv.re, v1 = r_col ? A.im : Gv.im;
-                    const double v2 = r_col ? __dsub_rn(A.re, A.im) : __dadd_rn(Gv.re, Gv.im);
-                    ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1; ws[(4 + ej) * cs] = v2;
-                }
-            };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            using I3 = std::integral_constant<int, 3>;
-            Round R0, R1, R2, R3;
-            issue(I0{}, R0); issue(I1{}, R1); issue(I2{}, R2); issue(I3{}, R3);
-            // (EIGHT sampling waves, two per SIMD, beside four matrix waves on the four-product form -- the only split
-            // of 12 waves x 168 registers that has room for them -- sampled no faster: 68.6 ms alone against 68.7 with
-            // four waves, so a lone wave's dependent-issue latency is not what bounds the stage either; the matrix waves
-            // then hold 9 tiles x 16 accumulators and spill, 125 ms.  That experiment also showed the f64 MFMA's BLGP bit 0
-            // to negate the A operand, as the ISA says: -Gr needs no plane of its own.)
-            // (a lane sampling all four correlations of its own term -- no quads, a third fewer instructions -- was
-            // measured too: 138 ms for the sampling alone against 69: every load instruction then touches 64 cache lines
-            // instead of 16, and the sampling is bound by the L1's line rate, ~4.5 cycles per missed line and CU, not by
-            // its instruction count: coherent gathers, --pa common, take 65 ms)
-            // (round 5: the super-round split at the batch barrier -- geometry and the four rounds' gathers BEFORE the barrier
-            // that starts the matrix waves' burst on the previous batch, the rounds' arithmetic after it (the samplers' side
-            // of the barrier then waits for LDS only, s_waitcnt lgkmcnt(0); s_barrier, so the gathers stay in flight across
-            // it) -- 109.1 ms against 97 for this order; the sampling stage alone 67.9 either way)
-            // (consuming two rounds in lockstep, step by step, was measured on one box against this sequential form:
-            // 115.5 vs 106.4 ms for the kernel -- the interleaved chains cost more in moves and registers than the
-            // stalls they fill)
-            finish(I0{}, R0); finish(I1{}, R1); finish(I2{}, R2); finish(I3{}, R3);
+    unsigned long long prof_geo = 0, prof_wait = 0, prof_fin = 0, prof_sbar = 0, prof_st = AF_PROF_NOW();
+    auto prof_mark = [&](unsigned long long &acc) {
+        if (AF_PROF_ON) { const unsigned long long n = AF_PROF_NOW(); acc += n - prof_st; prof_st = n; }
     };
-    if constexpr (!G::STRADDLE) {
-        for (int b = 0; b < nbatch; ++b) {
-            if (only_stage != 2) {
-                for (int task0 = 0; task0 < BT; task0 += G3_SAMPLERS)
-                    super_round(term_at(b, task0), task0 + G3_SAMPLERS < BT ? term_at(b, task0 + G3_SAMPLERS) : term_at(b + 1, 0));
-            }
-            __syncthreads();
+    // ---- one super-round = this lane's own term (geometry, antenna phasor) + four sampling ROUNDS ----------------------
+    // (in round QL the four lanes of a quad take the geometry of quad lane QL and sample one correlation each)
+    struct Own {                 // a lane's own term of one super-round
+        FusedVoxelsC gx;
+        C2 kph;
+        int info, slot, src;     // info: LDS offset (doubles, panel buffer included) of the term's planes | col_term << 30 | have << 31
+        double2 xw[4];           // TPS == 64: the wave's source's brightness (scalar registers)
+    };
+    struct Round {               // one round's gathers (what identifies the round's term is re-broadcast when it is consumed)
+        double2 v[4];
+        double ab[4];
+    };
+    auto geometry = [&](const Term &T, const Term &Tn, Own &S) {
+        const int e_sl = T.e_sl;
+        int e_slot = T.slot;
+        // (the slot is the same in every super-round when a batch is exactly one super-round -- 64 antennas -- and the
+        // compiler then keeps the LDS addresses of the nine per-slot constants below in nine registers across the loop:
+        // the sampler has none to spare (168 with the four rounds in flight), and what it spilled it reloaded behind an
+        // s_waitcnt vmcnt(0) that drained the gathers.  Opaque per super-round: nine adds instead.)
+        asm volatile("" : "+v"(e_slot));
+        const bool have = T.src < nsrc && slot_ok(e_slot);
+        // operand address of this lane's own term and what it writes: its H planes (column antenna), its G planes
+        // (row antenna), or both (DIAG)
+        const bool col_term = !RECT || e_slot < NAC;
+        // (the slots of an absent last column block -- RECT, nc_act < NBC -- keep their own places behind the real ones)
+        const int h_slot = !RECT ? antenna_slot(e_slot, NAC / 4)
+                                 : (!col_term ? 0 : (e_slot < 8 * tile.nc_act ? antenna_slot(e_slot, 2 * tile.nc_act) : e_slot));
+        const int h_off = T.buf * BUF + e_sl * SRC + 2 * h_slot;
+        const int g_off = T.buf * BUF + e_sl * SRC + G3_PLANES * CSH + 2 * antenna_slot(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, NAR / 4);
+        S.info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
+        S.slot = e_slot;
+        // TPS == 64: a wave's 64 lanes are ONE source's slots -- its 2 x 2 complex brightness comes in by ONE scalar
+        // load per super-round, here (inside the sampling rounds every round waited out an SMEM round trip --
+        // lgkmcnt is shared with the LDS reads --: the sampling alone ran 65.1 ms with those loads, 51.6 without)
+        if constexpr (TPS == 64) {
+            const int us = __builtin_amdgcn_readfirstlane(have ? T.src : 0);
+            const double2 *bp = brightness + ((int64_t)us * nchan + f) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S.xw[c] = bp[c];
         }
-    } else {
-        int sr = 0;
-        for (int b = 0; b < nbatch; ++b) {
-            const int sr_end = ((b + 1) * BT + G3_SAMPLERS - 1) / G3_SAMPLERS;     // super-rounds that complete batch b
-            for (; sr < sr_end && only_stage != 2; ++sr) super_round(term_flat(sr), term_flat(sr + 1));
-            __syncthreads();
+        S.src = have ? T.src : 0;
+        const double2 lm2 = nxt.lm;
+        const double nn = nxt.n;
+        nxt = fetch(Tn);
+        fused_voxels_compact(grid, lm2.x, lm2.y, ldsA[0 * TPS + e_slot], ldsA[1 * TPS + e_slot], ldsA[2 * TPS + e_slot],
+                             ldsA[3 * TPS + e_slot], ldsA[4 * TPS + e_slot], ldsA[5 * TPS + e_slot], fscale, S.gx);
+        S.kph = table_phasor(ldsT, fma(nn, ldsU[2 * TPS + e_slot],
+                                       fma(lm2.y, ldsU[1 * TPS + e_slot], __dmul_rn(lm2.x, ldsU[0 * TPS + e_slot]))));
+    };
+    auto issue = [&](auto lane_c, const Own &S, Round &R) {
+        constexpr int QL = decltype(lane_c)::value;
+        const unsigned base = (unsigned)quad_bcast<QL>((int)S.gx.base) + corr_off;
+        const unsigned dl = (unsigned)quad_bcast<QL>((int)S.gx.dl), dm = (unsigned)quad_bcast<QL>((int)S.gx.dm);
+        const unsigned offs[4] = {base, base + dl, base + dm, base + dl + dm};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double *r = reinterpret_cast<const double *>(plane + (size_t)offs[k]);
+            R.v[k] = *reinterpret_cast<const double2 *>(r);
+            R.ab[k] = r[2];
+        }
+    };
+    auto finish = [&](auto lane_c, const Own &S, const Round &R) {
+        constexpr int QL = decltype(lane_c)::value;
+        const int info = quad_bcast<QL>(S.info);
+        const bool r_have = info < 0;
+        const double ld = quad_bcast<QL>(S.gx.ld), md = quad_bcast<QL>(S.gx.md);
+        const double omld = __dsub_rn(1.0, ld), ommd = __dsub_rn(1.0, md);
+        const double wt[4] = {__dmul_rn(omld, ommd), __dmul_rn(ld, ommd), __dmul_rn(omld, md), __dmul_rn(ld, md)};
+        C2 kk;
+        kk.re = quad_bcast<QL>(S.kph.re); kk.im = quad_bcast<QL>(S.kph.im);
+        double2 e2 = beam_reduce1(R.v, R.ab, wt);
+        if (!r_have) e2 = make_double2(0.0, 0.0);
+        C2 e;
+        e.re = e2.x; e.im = e2.y;
+        if constexpr (FEED) {
+            C2 E0, E1;
+            E0.re = pair_bcast<0>(e.re); E0.im = pair_bcast<0>(e.im);
+            E1.re = pair_bcast<1>(e.re); E1.im = pair_bcast<1>(e.im);
+            const int r_slot = quad_bcast<QL>(S.slot);
+            const double2 r0 = ldsR[4 * r_slot + ej], r1 = ldsR[4 * r_slot + 2 + ej];
+            C2 Q0, Q1;
+            Q0.re = r0.x; Q0.im = r0.y; Q1.re = r1.x; Q1.im = r1.y;
+            e = cmul(E0, Q0);
+            cmac(e, E1, Q1);
+        }
+        const C2 A = cmul(kk, e);
+        C2 A0, A1, B0, B1;
+        A0.re = pair_bcast<0>(A.re); A0.im = pair_bcast<0>(A.im);
+        A1.re = pair_bcast<1>(A.re); A1.im = pair_bcast<1>(A.im);
+        if constexpr (TPS == 64) {
+            // the wave's source: its brightness matrix was loaded with the super-round's geometry
+            const double2 b0 = ej ? S.xw[1] : S.xw[0], b1 = ej ? S.xw[3] : S.xw[2];
+            B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+        } else {
+            const double2 *bp = brightness + ((int64_t)quad_bcast<QL>(S.src) * nchan + f) * 4;
+            const double2 b0 = bp[ej], b1 = bp[2 + ej];
+            B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+        }
+        C2 Gv = cmul(A0, B0);
+        cmac(Gv, A1, B1);
+        if constexpr (!RECT) {
+            // DIAG: NAR == NAC, the G planes of a slot lie G3_PLANES * CSH doubles behind its H planes
+            double *hs = ldsd + (info & 0x3fffffff) + ei;
+            double *gs = hs + G3_PLANES * CSH;
+            hs[ej * CSH] = A.re; hs[(2 + ej) * CSH] = A.im; hs[(4 + ej) * CSH] = __dsub_rn(A.re, A.im);
+            gs[ej * CSG] = Gv.re; gs[(2 + ej) * CSG] = Gv.im; gs[(4 + ej) * CSG] = __dadd_rn(Gv.re, Gv.im);
+        } else {
+            // RECT: a column antenna's term writes its H planes, a row antenna's its G planes: one address, one
+            // plane stride and three values picked per lane, the stores themselves unconditional
+            const bool r_col = (info >> 30) & 1;
+            double *ws = ldsd + (info & 0x3fffffff) + ei;
+            const int cs = r_col ? CSH : CSG;
+            const double v0 = r_col ? A.re : Gv.re, v1 = r_col ? A.im : Gv.im;
+            const double v2 = r_col ? __dsub_rn(A.re, A.im) : __dadd_rn(Gv.re, Gv.im);
+            ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1; ws[(4 + ej) * cs] = v2;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // position of a super-round in the kernel's sequence, either mode
+    struct Pos {
+        int b, task0, sr;
+    };
+    auto term_of = [&](const Pos &p) { return G::STRADDLE ? term_flat(p.sr) : term_at(p.b, p.task0); };
+    auto next_pos = [&](const Pos &p) {
+        Pos q = p;
+        q.sr = p.sr + 1;
+        if constexpr (!G::STRADDLE) {
+            q.task0 = p.task0 + G3_SAMPLERS;
+            if (q.task0 >= BT) { q.task0 = 0; q.b = p.b + 1; }
+        } else {
+            q.b = (q.sr * G3_SAMPLERS) / BT;         // the batch in which super-round q.sr STARTS
+        }
+        return q;
+    };
+    const int nsr = G::STRADDLE ? (total_terms + G3_SAMPLERS - 1) / G3_SAMPLERS : nbatch * G::SRB;
+    auto valid = [&](const Pos &p) { return p.sr < nsr; };
+    // true when super-round p completes a batch: the batch barrier follows it
+    auto completes = [&](const Pos &p) {
+        if constexpr (!G::STRADDLE) return p.task0 + G3_SAMPLERS >= BT;
+        else return ((p.sr + 1) * G3_SAMPLERS) / BT > (p.sr * G3_SAMPLERS) / BT || p.sr + 1 == nsr;
+    };
+    if (only_stage == 2) {
+        for (int b = 0; b < nbatch; ++b) __syncthreads();
+        return;
+    }
+    // (three rounds in flight at most: the fourth round's gathers land in the first's registers.  The two orders keep
+    // their own copies of the round / term records: declared once for both, the register allocator spilled)
+    // the samplers' side of a batch barrier when gathers are in flight across it: their panel writes (LDS) must have
+    // landed, the gathers (vmcnt) stay outstanding -- __syncthreads() would drain them
+    auto sampler_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Two orders of the same super-round.  Phase timers of order A beside the matrix waves (profiling build,
+    // tools/gemm_phase_timers.py; shader-clock cycles per batch at 64 antennas): geometry + gather ISSUE 4700 (3100 with
+    // the matrix waves idle: the L1's line rate -- the four sampling waves' 1024 missed 128-byte lines per batch --, not
+    // instructions), gather wait 850, the rounds' arithmetic 1800, batch barrier 1000; a matrix wave's MFMA loop 1700 of
+    // the 8300.  All four waves in order A hit the L1 together and then compute together.
+    //   order A:  geometry, issue all four rounds | wait | the four rounds' arithmetic | batch barrier
+    //   order B:  the rounds of the gathers issued BEFORE the previous barrier | geometry + issue of the next super-round |
+    //             batch barrier (gathers in flight across it)
+    // MIXED: sampling waves 8, 9 run order A, waves 10, 11 order B -- one pair's gather issue falls into the other pair's
+    // arithmetic, the L1 sees two waves at a time all the time.  (All four in order B: 109 ms against 97 -- the rounds'
+    // arithmetic then meets the matrix waves' burst on every SIMD.)
+    // ONE loop serves both orders -- prologue: prepare super-round 0; body: consume k, [order A: batch barrier], prepare
+    // k + 1, [order B: batch barrier] -- so that the rounds' and the term's registers are the same in both (two loops in one
+    // kernel made the register allocator spill).
+    const bool order_b = (order_b_mask >> (ptid >> 6)) & 1;
+    {
+        Round R0, R1, R2, R3;
+        Own S;
+        Pos p = {0, 0, 0};
+        geometry(term_of(p), term_of(next_pos(p)), S);
+        issue(I0{}, S, R0); issue(I1{}, S, R1); issue(I2{}, S, R2); issue(I3{}, S, R3);
+        prof_mark(prof_geo);
+        while (true) {
+            finish(I0{}, S, R0); finish(I1{}, S, R1); finish(I2{}, S, R2); finish(I3{}, S, R3);
+            prof_mark(prof_fin);
+            const Pos q = next_pos(p);
+            const bool more = valid(q), bar = completes(p);
+            if (bar && !order_b) { sampler_barrier(); prof_mark(prof_sbar); }
+            if (more) {
+                geometry(term_of(q), term_of(next_pos(q)), S);
+                issue(I0{}, S, R0); issue(I1{}, S, R1); issue(I2{}, S, R2); issue(I3{}, S, R3);
+                prof_mark(prof_geo);
+            }
+            if (bar && order_b) { sampler_barrier(); prof_mark(prof_sbar); }
+            if (!more) break;
+            p = q;
         }
     }
+#ifdef AFHIP_STAGE_HOOKS
+    if (ptid == 0 && (blockIdx.x & 15) == 0 && blockIdx.y == 0) {
+        atomicAdd(&g_gemm_prof[2], prof_geo); atomicAdd(&g_gemm_prof[3], prof_wait);
+        atomicAdd(&g_gemm_prof[4], prof_fin); atomicAdd(&g_gemm_prof[5], prof_sbar);
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef AFHIP_STAGE_HOOKS
+// profiling build only: read (and optionally reset) the GEMM kernel's phase timers
+AF_EXPORT int af_debug_gemm_prof(unsigned long long *out8, int reset)
+{
+    if (out8) AF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_prof), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        AF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), zero, sizeof(zero)));
+    }
+    return AF_OK;
+}
+#endif
 
 // Host-side planner (HOST pointers): is uvw antenna-decomposable, and if so with which antenna coordinates?
 //   Per timestep (time_index - min): the baselines of the step form a graph on the antennas; a breadth-first walk of
@@ -791,6 +891,10 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
         shapes.push_back(s);
     };
     // sources per batch: about one super-round of the 256 sampling lanes, the panel buffers within ~130 KB
+    // which of the four sampling waves run order B (bit w = wave 8 + w; see the kernel): waves 10 and 11 by default.
+    // AFHIP_GEMM_ORDER_B = another mask (A/B hook between correct schedules; 0 = round 4's order for all)
+    int order_b_mask = getenv("AFHIP_GEMM_ORDER_B") ? atoi(getenv("AFHIP_GEMM_ORDER_B")) & 15 : 0;
+    int burst_delay = getenv("AFHIP_GEMM_BURST_DELAY") ? atoi(getenv("AFHIP_GEMM_BURST_DELAY")) : 0;   // 64-cycle units
 #define AF_GEMM_K(RECTC, NBRC, NBCC, STC)                                                                              \
     (feed ? reinterpret_cast<const void *>(fused_gemm3_kernel<true, RECTC, NBRC, NBCC, STC>)                            \
           : reinterpret_cast<const void *>(fused_gemm3_kernel<false, RECTC, NBRC, NBCC, STC>)),                         \
@@ -834,7 +938,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
         for (auto &s : shapes) {
             void *args[] = {&ant_uvw, &rowmap, &lmn, &f4, &b2, &planes_buf, &beam_lw, &beam_mh, &beam_nud, &beam_lm_extents,
                             &freq_data, &parallactic_angles, &point_errors, &antenna_scaling, &fr2, &nsrc_i, &nchan, &ntime,
-                            &nant_i, &nap_i, &out2, &stage_i, &f0, &prio_i, &s.list};
+                            &nant_i, &nap_i, &out2, &stage_i, &f0, &prio_i, &order_b_mask, &burst_delay, &s.list};
             AF_HIP(hipLaunchKernel(s.kernel, dim3((unsigned)nsteps, (unsigned)nf, (unsigned)s.count), dim3(G3_THREADS), args,
                                    s.lds, st_));
         }

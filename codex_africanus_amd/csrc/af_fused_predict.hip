@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WS ? THREADS + THREADS / 2 : THREADS) void fused_pr
     FusedGrid grid;
     {
         const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
-        grid.lower_l = g.lower_l; grid.lower_m = g.lower_m; grid.lscale = g.lscale; grid.mscale = g.mscale;
+        grid.lower_l = wave_uniform(g.lower_l); grid.lower_m = wave_uniform(g.lower_m); grid.lscale = wave_uniform(g.lscale); grid.mscale = wave_uniform(g.mscale);
         grid.lmaxf = g.lmaxf; grid.mmaxf = g.mmaxf; grid.lmaxi = (int)g.lmaxi; grid.mmaxi = (int)g.mmaxi;
         grid.stride_m = VREC * 8u;
         grid.stride_l = (unsigned)beam_mh * grid.stride_m;
