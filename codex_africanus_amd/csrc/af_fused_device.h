@@ -205,6 +205,30 @@ __device__ __forceinline__ void fused_voxels_compact(const FusedGrid &g, double 
     vx.dm = gm0 < g.mmaxi ? g.stride_m : 0u;
 }
 
+// The same with the per-antenna part of the coordinate map folded into six coefficients per slot (the GEMM kernel's set-up
+// computes them once per (timestep, channel, antenna)):
+//     vl = (((l fs + pe_l) cos - (m fs + pe_m) sin) as_l - lower_l) lscale = l c1l + m c2l + c0l     (vm likewise)
+// -- four FMAs where the reference-ordered form above spends sixteen operations per sampled term; the coordinates differ
+// from it by ~1e-16 of the cube's extent (a voxel boundary crossed that late moves a weight of ~1e-14: the bilinear
+// sample is continuous), far inside the 1e-9 the fused chain is checked to.
+__device__ __forceinline__ void fused_voxels_folded(const FusedGrid &g, double l, double m, double c1l, double c2l, double c0l,
+                                                    double c1m, double c2m, double c0m, FusedVoxelsC &vx)
+{
+    double vl = fma(l, c1l, fma(m, c2l, c0l));
+    double vm = fma(l, c1m, fma(m, c2m, c0m));
+    {
+        const double t1 = vl < g.lmaxf ? vl : g.lmaxf; vl = 0.0 > t1 ? 0.0 : t1;
+        const double t2 = vm < g.mmaxf ? vm : g.mmaxf; vm = 0.0 > t2 ? 0.0 : t2;
+    }
+    const double fl = floor(vl), fm = floor(vm);
+    const int gl0 = (int)fl, gm0 = (int)fm;
+    vx.ld = __dsub_rn(vl, fl);
+    vx.md = __dsub_rn(vm, fm);
+    vx.base = (unsigned)gl0 * g.stride_l + (unsigned)gm0 * g.stride_m;
+    vx.dl = gl0 < g.lmaxi ? g.stride_l : 0u;
+    vx.dm = gm0 < g.mmaxi ? g.stride_m : 0u;
+}
+
 // value of quad lane QL in all four lanes of the quad; the neighbour lane ^ 1 (DPP quad_perm, no LDS crossbar)
 template <int QL> __device__ __forceinline__ int quad_bcast(int x)
 {

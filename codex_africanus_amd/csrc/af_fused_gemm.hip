@@ -225,8 +225,8 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int p = tile.row_ant0 + slot_antenna(pb * 8 + ((kq + 4 * reg) >> 1), G::NAR / 4);
-            r1[reg] = rm[(int64_t)p * nap + q];
-            r2[reg] = (RECT || pb != qb) ? rm[(int64_t)q * nap + p] : -1;   // the same antennas the other way round: V_qp = V_pq^H
+            r1[reg] = rm[p * nap + q];          // (< 2^16: 32-bit index arithmetic)
+            r2[reg] = (RECT || pb != qb) ? rm[q * nap + p] : -1;   // the same antennas the other way round: V_qp = V_pq^H
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -271,6 +271,8 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
 
     fine_table_init(ldsT, tid, G3_THREADS);
     const double FT = f4[f] * (PH_TABLE / 4.0);
+    const BeamGrid<double> bg = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
+    const double fscale = freq_data[3 * f + 0];
     for (int a = tid; a < TPS; a += G3_THREADS) {
         double sp = 0.0, cp = 1.0, pl = 0.0, pm = 0.0, sl_ = 1.0, sm_ = 1.0, u = 0.0, v = 0.0, w = 0.0;
         if (slot_ok(a)) {
@@ -282,9 +284,15 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             const double *x = ant_uvw + ((int64_t)t * nant + ant) * 3;
             u = __dmul_rn(x[0], FT); v = __dmul_rn(x[1], FT); w = __dmul_rn(x[2], FT);
         }
-        // one plane per constant (consecutive lanes = consecutive slots read consecutive doubles: no bank conflicts)
-        ldsA[0 * TPS + a] = sp; ldsA[1 * TPS + a] = cp; ldsA[2 * TPS + a] = pl; ldsA[3 * TPS + a] = pm;
-        ldsA[4 * TPS + a] = sl_; ldsA[5 * TPS + a] = sm_;
+        // the slot's coordinate map, folded (fused_voxels_folded): one plane per coefficient (consecutive lanes =
+        // consecutive slots read consecutive doubles: no bank conflicts)
+        const double kl = sl_ * bg.lscale, km = sm_ * bg.mscale;
+        ldsA[0 * TPS + a] = fscale * cp * kl;                               // c1l
+        ldsA[1 * TPS + a] = -fscale * sp * kl;                              // c2l
+        ldsA[2 * TPS + a] = (pl * cp - pm * sp) * kl - bg.lower_l * bg.lscale;   // c0l
+        ldsA[3 * TPS + a] = fscale * sp * km;                               // c1m
+        ldsA[4 * TPS + a] = fscale * cp * km;                               // c2m
+        ldsA[5 * TPS + a] = (pl * sp + pm * cp) * km - bg.lower_m * bg.mscale;   // c0m
         ldsU[0 * TPS + a] = u; ldsU[1 * TPS + a] = v; ldsU[2 * TPS + a] = w;
     }
     if constexpr (FEED)
@@ -314,15 +322,12 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     // =================================== sampling waves (8-11) ======================================
     FusedGrid grid;
     {
-        const BeamGrid<double> g = beam_grid<double>(lm_ext, beam_lw, beam_mh, beam_nud);
-        grid.lower_l = wave_uniform(g.lower_l); grid.lower_m = wave_uniform(g.lower_m);
-        grid.lscale = wave_uniform(g.lscale); grid.mscale = wave_uniform(g.mscale);
-        grid.lmaxf = wave_uniform(g.lmaxf); grid.mmaxf = wave_uniform(g.mmaxf);
-        grid.lmaxi = __builtin_amdgcn_readfirstlane((int)g.lmaxi); grid.mmaxi = __builtin_amdgcn_readfirstlane((int)g.mmaxi);
+        grid.lower_l = grid.lower_m = grid.lscale = grid.mscale = 0.0;      // folded into the slots' coefficients
+        grid.lmaxf = wave_uniform(bg.lmaxf); grid.mmaxf = wave_uniform(bg.mmaxf);
+        grid.lmaxi = __builtin_amdgcn_readfirstlane((int)bg.lmaxi); grid.mmaxi = __builtin_amdgcn_readfirstlane((int)bg.mmaxi);
         grid.stride_m = VREC * 8u;
         grid.stride_l = (unsigned)beam_mh * grid.stride_m;
     }
-    const double fscale = freq_data[3 * f + 0];
     const int e_corr = ptid & 3;
     const int ei = e_corr >> 1, ej = e_corr & 1;
     const char *plane = reinterpret_cast<const char *>(vrec + (int64_t)blockIdx.y * beam_lw * beam_mh * VREC);
@@ -427,8 +432,8 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         const double2 lm2 = nxt.lm;
         const double nn = nxt.n;
         nxt = fetch(Tn);
-        fused_voxels_compact(grid, lm2.x, lm2.y, ldsA[0 * TPS + e_slot], ldsA[1 * TPS + e_slot], ldsA[2 * TPS + e_slot],
-                             ldsA[3 * TPS + e_slot], ldsA[4 * TPS + e_slot], ldsA[5 * TPS + e_slot], fscale, S.gx);
+        fused_voxels_folded(grid, lm2.x, lm2.y, ldsA[0 * TPS + e_slot], ldsA[1 * TPS + e_slot], ldsA[2 * TPS + e_slot],
+                            ldsA[3 * TPS + e_slot], ldsA[4 * TPS + e_slot], ldsA[5 * TPS + e_slot], S.gx);
         S.kph = table_phasor(ldsT, fma(nn, ldsU[2 * TPS + e_slot],
                                        fma(lm2.y, ldsU[1 * TPS + e_slot], __dmul_rn(lm2.x, ldsU[0 * TPS + e_slot]))));
     };
