@@ -566,6 +566,10 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         while (true) {
             finish(I0{}, S, R0); finish(I1{}, S, R1); finish(I2{}, S, R2); finish(I3{}, S, R3);
             prof_mark(prof_fin);
+            // (the two conditional barrier sites below are also what keeps the consume / barrier / geometry phases in
+            // separate scheduling regions: with ONE unconditional barrier here -- order A hard-wired -- hipcc merges the
+            // phases into one block and the same kernel takes 107.5 ms instead of 87.7, same box; with the matrix waves'
+            // burst-delay loop removed 89.0.  Measured with tools/ab_libs.sh on three builds; do not "simplify".)
             const Pos q = next_pos(p);
             const bool more = valid(q), bar = completes(p);
             if (bar && !order_b) { sampler_barrier(); prof_mark(prof_sbar); }
