@@ -350,7 +350,7 @@ class Call(object):
         return ctypes.c_void_p(buf.ptr), (buf, shape, dtype)
 
     # ---- results produced and downloaded in row chunks ------------------------------------------------
-    def result_rows(self, handle, launch, cast=None):
+    def result_rows(self, handle, launch, cast=None, edges=None):
         """
         The result of a call whose rows are independent, produced in ROW CHUNKS so that the download of chunk k (on the
         thread's copy stream, behind an event) runs while chunk k + 1 is computed: ``launch(r0, r1, p_out)`` enqueues
@@ -359,6 +359,8 @@ class Call(object):
         (africanus/dft/dask.py:37-51) -- for the plain numpy call: BASELINE configs[1] numpy in -> numpy out 95.5 -> 73.7
         ms (copy alone 71.7, transform alone 20.7; tools/bench_d2h_overlap.py, profiles/r05_d2h_overlap_*).
         ``cast`` complex64 / float32: converted ON THE DEVICE chunk by chunk, half the bytes cross PCIe.
+        ``edges``: row numbers at which the result may be cut (ascending, from 0 to nrow; e.g. timestep boundaries of
+        the fused predict, whose kernels work on whole timesteps) -- chunks then end on the edge nearest to every 256 MB.
         Device mode, small results and AFHIP_D2H_PIPELINE=0: one launch over all rows, then ``result``.
         """
         if self.device_mode:
@@ -370,12 +372,21 @@ class Call(object):
         out_dtype = dtype if cast is None else np.dtype(cast)
         narrow = cast is not None and out_dtype.itemsize * 2 == dtype.itemsize and out_dtype.kind == dtype.kind
         total = nrow * row_bytes
-        chunk_bytes = int(os.environ.get("AFHIP_D2H_CHUNK_MB", "256")) << 20       # read per call (tests use small chunks)
+        chunk_bytes = int(float(os.environ.get("AFHIP_D2H_CHUNK_MB", "256")) * (1 << 20))    # read per call (tests use small chunks)
         if (total < 2 * chunk_bytes or os.environ.get("AFHIP_D2H_PIPELINE", "1") == "0"
                 or not _USE_POOL or (cast is not None and not narrow)):
             launch(0, nrow, ctypes.c_void_p(buf.ptr))
             return self.result(handle, cast)
         rows = max(256, (chunk_bytes // row_bytes) // 256 * 256)
+        if edges is None:
+            cuts = list(range(0, nrow, rows)) + [nrow]
+        else:
+            edges = np.asarray(edges, dtype=np.int64)
+            cuts = [0]
+            while cuts[-1] < nrow:
+                k = int(np.searchsorted(edges, cuts[-1] + rows, side="right")) - 1      # last edge within the chunk size
+                nxt = int(edges[k]) if k >= 0 and edges[k] > cuts[-1] else int(edges[np.searchsorted(edges, cuts[-1], side="right")])
+                cuts.append(min(nxt, nrow))
         arr = _pinned.array(shape, out_dtype)
         if arr is None:
             arr = np.empty(shape, dtype=out_dtype)
@@ -386,8 +397,7 @@ class Call(object):
             nbuf = _OwnedBuffer(nrow * out_row_bytes)
             self._owned.append(nbuf)
         host = arr.ctypes.data
-        for r0 in range(0, nrow, rows):
-            r1 = min(nrow, r0 + rows)
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
             launch(r0, r1, ctypes.c_void_p(buf.ptr + r0 * row_bytes))
             src = buf.ptr + r0 * row_bytes
             if narrow:

@@ -37,6 +37,9 @@ class FusedPlan(object):
         self.items, self.groups = items, groups
         self.antenna1, self.antenna2 = antenna1, antenna2
         self.step = step            # (row,) int32: time_index - min(time_index) -- what af_fused_plan_check compares
+        # rows in time order?  then step_first[t] = first row of step t (and nrow at the end): where a result may be cut
+        self.time_sorted = bool(nrow) and bool(np.all(np.diff(step) >= 0))
+        self.step_first = np.searchsorted(step, np.arange(nsteps + 1)) if self.time_sorted else None
         self.n_items = int(items.shape[0]) if nrow else 0
         # antenna decomposition of uvw (fused_plan(..., uvw=...)): per-antenna coordinates (nsteps, nant, 3), the row of
         # every (step, antenna1, antenna2) (nsteps, nap, nap) and the largest |x_p - x_q - uvw_pq| [m]; None = the rows
@@ -397,6 +400,19 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             elif gemm:
                 ws_bytes = int(_lib.load().af_fused_predict_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
                 p_ws = c.scratch(ws_bytes)
+                nap = int(plan.rowmap.shape[1])
+                if not c.device_mode and plan.time_sorted and not explicit_plan and die1_jones is None and base_vis is None:
+                    # numpy caller, rows in time order: the result comes back in timestep-aligned row chunks whose
+                    # downloads overlap the next chunk's kernels (Call.result_rows).  A chunk = the steps [t0, t1): the
+                    # same entry on slices of the per-step arrays; the row map holds absolute rows, `out` stays the base
+                    def launch(r0, r1, p_rows):
+                        t0, t1 = int(plan.step[r0]), int(plan.step[r1 - 1]) + 1
+                        off = lambda ptr, nbytes: None if ptr is None else ctypes.c_void_p(ptr.value + nbytes)
+                        _lib.call("af_fused_predict_antennas_c128", off(p_au, t0 * nant * 24), off(p_rm, t0 * nap * nap * 4),
+                                  t1 - t0, nrow, p_lm, p_fr, p_b, nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map,
+                                  off(p_pa, t0 * nant * 8), ntime - t0, nant, off(p_pe, t0 * nant * nchan * 16), p_as,
+                                  off(p_fr_rot, t0 * nant * 64), conv, p_out, p_ws, max(ws_bytes, 256), c.stream)
+                    return c.result_rows(h, launch, edges=plan.step_first)
                 _lib.call("af_fused_predict_antennas_c128", p_au, p_rm, plan.nsteps, nrow, p_lm, p_fr, p_b, nsrc, nchan,
                           p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_fr_rot, conv,
                           p_out, p_ws, max(ws_bytes, 256), c.stream)

@@ -343,3 +343,23 @@ def test_large_arrays_row_layouts_feed_rotation_and_general_kernel(nant, monkeyp
     monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
     assert np.abs(_call(d) - out).max() < 1e-10 * _scale(d)
     assert np.abs(_call(d, feed_rotation=fr) - out_fr).max() < 1e-10 * _scale(d)
+
+
+def test_numpy_call_downloads_in_timestep_aligned_chunks(monkeypatch):
+    """the numpy-in / numpy-out GEMM route produces its result in timestep-aligned row chunks whose downloads overlap the
+    next chunk's kernels (Call.result_rows with the plan's step boundaries as cut points): same bits as the one-piece call,
+    also with steps that have no rows and a time offset"""
+    nant = 24
+    d = _decomposable(_problem(41, 6 * 276 + 100, 5, 13, nant), nant, seed=15)
+    keep = (d["time_index"] != 2)                       # a step without rows in the middle
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        d[k] = d[k][keep]
+    d["time_index"] = d["time_index"] + 4               # the per-time arrays are indexed from min(time_index), as in predict_vis
+    monkeypatch.setenv("AFHIP_D2H_PIPELINE", "0")
+    whole = _call(d)
+    monkeypatch.delenv("AFHIP_D2H_PIPELINE")
+    monkeypatch.setenv("AFHIP_D2H_CHUNK_MB", "0.1")      # 320 B per row: ~330 rows per chunk, cut at step boundaries (276 rows)
+    piped = _call(d)
+    assert np.array_equal(piped, whole)
+    ref_d = dict(d, time_index=d["time_index"] - 4)
+    assert np.abs(whole - _oracle_chain(ref_d, True)).max() < 1e-9 * _scale(d)
