@@ -363,3 +363,18 @@ def test_numpy_call_downloads_in_timestep_aligned_chunks(monkeypatch):
     assert np.array_equal(piped, whole)
     ref_d = dict(d, time_index=d["time_index"] - 4)
     assert np.abs(whole - _oracle_chain(ref_d, True)).max() < 1e-9 * _scale(d)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3020))
+def test_gemm_form_random_arrays_and_layouts(seed):
+    """seeded sweep over array sizes 2 .. 256 antennas (every DIAG size, RECT super-tiles with 1 .. 4 column blocks), source
+    counts that leave partial batches, missing / swapped / shuffled / autocorrelation rows (tools/stress_random.py runs the
+    same sweep on any number of further seeds)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("stress_random_fg", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "stress_random.py"))
+    src = open(spec.origin).read().split("first = int(sys.argv[1])")[0]       # the sweep functions, not the driver loop
+    ns = {"__file__": spec.origin, "__name__": "stress_random_fg"}
+    exec(compile(src, spec.origin, "exec"), ns)
+    ns["fused_gemm_sweep"](seed)

@@ -59,6 +59,27 @@ def fused_sweep(seed):
     assert np.abs(out - ref).max() < 1e-9 * FU._scale(d), (nant, nrow, nchan, nsrc)
 
 
+def fused_gemm_sweep(seed):
+    """the GEMM form (Measurement-Set uvw) at random array sizes 2 .. 256 antennas -- every DIAG size, the RECT super-tiles
+    with 1 .. 4 column blocks, the flat term stream's tail -- and random row layouts, against the oracle chain"""
+    os.environ["AFHIP_GEMM_MIN_FILL"] = "0"
+    try:
+        import test_gpu_fused_gemm as FG
+        rng = np.random.default_rng(seed)
+        nant = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 31, 33, 48, 57, 64, 65, 66, 72, 73, 80, 95, 96, 97, 104, 127, 128, 129, 160,
+                               192, 197, 200, 224, 255, 256]))
+        nbl = nant * (nant - 1) // 2
+        nrow = int(rng.integers(1, min(2 * nbl, nbl + 3000) + 2))
+        nchan, nsrc = int(rng.integers(1, 5)), int(rng.integers(1, 30))
+        d = FG._decomposable(FU._problem(seed, nrow, nchan, nsrc, nant), nant, seed=seed, keep=float(rng.choice([1.0, 0.8])),
+                             swap=float(rng.choice([0.0, 0.3])), shuffle=bool(rng.integers(0, 2)), autos=bool(rng.integers(0, 2)))
+        out = FG._call(d)
+        ref = FU._oracle_chain(d, True)
+        assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-9 * FU._scale(d), (nant, nrow, nchan, nsrc)
+    finally:
+        os.environ.pop("AFHIP_GEMM_MIN_FILL", None)
+
+
 def beam_and_phase_sweep(seed):
     """beam_cube_dde (arbitrary correlation dims, out-of-band channels, off-cube sources) and phase_delay"""
     rng = np.random.default_rng(seed)
@@ -113,7 +134,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 sweeps = [F.test_im_to_vis_random_shapes, F.test_vis_to_im_random_shapes, F.test_wsclean_predict_random_shapes,
           F.test_predict_vis_random_shapes_bit_exact, F.test_degridder_gridder_random_shapes, calibration_sweep,
-          fused_sweep, beam_and_phase_sweep, convert_and_chi2_sweep]
+          fused_sweep, fused_gemm_sweep, beam_and_phase_sweep, convert_and_chi2_sweep]
 t0 = time.time()
 for seed in range(first, first + count):
     for fn in sweeps:
