@@ -566,6 +566,11 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         while (true) {
             finish(I0{}, S, R0); finish(I1{}, S, R1); finish(I2{}, S, R2); finish(I3{}, S, R3);
             prof_mark(prof_fin);
+            // (round 5, measured and removed: an 8-wave kernel -- FOUR matrix waves, one per SIMD with nine tiles each, + the four
+            // sampling waves on a 256-register budget, the sampler software-pipelined over half super-rounds (two rounds'
+            // gathers always in flight while the other two are consumed) -- 99.6 ms against 87.7, same box; phase timers: its
+            // sampling stage ALONE 5150 cycles per batch against ~5300: the stage is bound by the L1's miss rate, ~5 cycles per
+            // 128-byte line and CU = 66 ms for the kernel's 1.04 TB of records, pipelined or not)
             // (the two conditional barrier sites below are also what keeps the consume / barrier / geometry phases in
             // separate scheduling regions: with ONE unconditional barrier here -- order A hard-wired -- hipcc merges the
             // phases into one block and the same kernel takes 107.5 ms instead of 87.7, same box; with the matrix waves'
