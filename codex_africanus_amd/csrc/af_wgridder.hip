@@ -69,6 +69,54 @@ std::mutex g_plan_mu;
 std::map<PlanKey, PlanEntry> g_plans;
 uint64_t g_plan_tick = 0;
 
+// A side stream per caller stream (image -> vis): the visibility sort and the zero fill of the output band need nothing
+// from the plane transforms, are bound by atomics' latency where those are bound by HBM, and run beside them: the side
+// stream starts behind everything the caller's stream holds at the call (`fork`), the tile pass waits for it (`join`).
+// Keyed and released like the FFT plans (af_wgrid_drop_stream, af_wgrid_shutdown); bounded: an entry whose caller
+// stream is gone is only ever one stream and two events.
+struct WgSide { hipStream_t stream; hipEvent_t fork, join; };
+std::map<std::pair<int, hipStream_t>, WgSide> g_side;
+constexpr size_t WG_MAX_SIDE = 64;
+int wg_side_stream(hipStream_t st, WgSide &out)
+{
+    int dev = 0;
+    AF_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    auto it = g_side.find({dev, st});
+    if (it == g_side.end()) {
+        if (g_side.size() >= WG_MAX_SIDE) {           // caller streams come and go (torch streams): start over
+            for (auto &kv : g_side) {
+                (void)hipStreamSynchronize(kv.second.stream);
+                (void)hipEventDestroy(kv.second.fork);
+                (void)hipEventDestroy(kv.second.join);
+                (void)hipStreamDestroy(kv.second.stream);
+            }
+            g_side.clear();
+        }
+        WgSide e{};
+        AF_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+        AF_HIP(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming));
+        AF_HIP(hipEventCreateWithFlags(&e.join, hipEventDisableTiming));
+        it = g_side.emplace(std::make_pair(dev, st), e).first;
+    }
+    out = it->second;
+    return AF_OK;
+}
+void wg_side_release(bool all, hipStream_t st)
+{
+    for (auto it = g_side.begin(); it != g_side.end();) {
+        if (all || it->first.second == st) {
+            (void)hipStreamSynchronize(it->second.stream);
+            (void)hipEventDestroy(it->second.fork);
+            (void)hipEventDestroy(it->second.join);
+            (void)hipStreamDestroy(it->second.stream);
+            it = g_side.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 __device__ __forceinline__ double es_kernel(double t, double inv_half_w, double beta)
 {
     const double x = t * inv_half_w;           // [-1, 1] inside the support
@@ -491,11 +539,11 @@ __device__ __forceinline__ unsigned wg_morton6(unsigned x, unsigned y)
     return k;
 }
 __global__ void wg_bin_rows(const double *__restrict__ uvw, int64_t nrow, const double *__restrict__ freq, int64_t nchan_b,
-                            double su, double sv, unsigned short *__restrict__ key, int *__restrict__ hist)
+                            double su, double sv, int do_w, unsigned short *__restrict__ key, int *__restrict__ hist)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrow) return;
-    const double fl = freq[nchan_b / 2] / AF_LIGHTSPEED;
+    const double fl = freq[nchan_b / 2] / AF_LIGHTSPEED * (do_w && uvw[3 * r + 2] < 0.0 ? -1.0 : 1.0);
     // fraction of the padded grid, origin in the middle, wrapped
     double x = uvw[3 * r] * fl * su + 0.5, y = uvw[3 * r + 1] * fl * sv + 0.5;
     x = (x - floor(x)) * 64.0; y = (y - floor(y)) * 64.0;
@@ -555,6 +603,15 @@ struct WgSort {
 // (in everything below "u" is the SLOW axis of the stored planes and "v" the fast one: the planes are v-major, so the
 // host hands uvw's v as this code's u -- component 1 -- and u as its v)
 constexpr int WG_CU = 1, WG_CV = 0;
+// The w fold.  The image is real, so V(-u, -v, -w) = conj V(u, v, w): with w-stacking every visibility with w < 0 is
+// evaluated (or, in the adjoint, gridded) at the mirrored point and conjugated.  The planes then cover [min |w|, max |w|]
+// instead of [min w, max w] -- about half as many for an array whose baselines point either way (ducc0's wgridder
+// treats w < 0 the same way).  Every kernel takes a row's sign from here, so they agree on it to the last bit; the
+// products with +-1.0 are exact.
+__device__ __forceinline__ double wg_fold_sign(const double *__restrict__ uvw_row, int do_w)
+{
+    return do_w && uvw_row[2] < 0.0 ? -1.0 : 1.0;
+}
 // first cell of a visibility's support along one axis, wrapped onto the grid: the sort key and the tile kernel must
 // agree on it to the last bit, so both call this
 __device__ __forceinline__ int wg_first_cell(double g, int W, int n)
@@ -569,8 +626,8 @@ __device__ __forceinline__ int wg_vis_key(const WgSort &q, int64_t i)
 {
     const unsigned r = (unsigned)i / (unsigned)q.nchan_b, c = (unsigned)i - r * (unsigned)q.nchan_b;   // nvis < 2^31
     if (q.mask && !q.mask[(int64_t)r * q.nchan_total + q.chan0 + c]) return -1;
-    const double fl = q.freq[c] / AF_LIGHTSPEED;
     const double *__restrict__ p = q.uvw + 3 * (int64_t)r;
+    const double fl = wg_fold_sign(p, q.do_w) * (q.freq[c] / AF_LIGHTSPEED);
     const double gu = p[WG_CU] * fl * q.cellx * (double)q.nu, gv = p[WG_CV] * fl * q.celly * (double)q.nv;
     if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return -1;
     int kb = 0;
@@ -874,7 +931,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     if (tid < n) {
         const unsigned i = idx[ch.y + tid];
         const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
-        const double fl = freq[c] / AF_LIGHTSPEED;
+        const double fl = wg_fold_sign(uvw + 3 * (int64_t)r, do_w) * (freq[c] / AF_LIGHTSPEED);
         const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
         const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
         const int first = (wg_first_cell(gu, W, (int)nu) - tu * WG_TILE) * R + wg_first_cell(gv, W, (int)nv) - tv * WG_TILE;
@@ -899,6 +956,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     double ku[W], kv[W], kwv[W], gw = 0.0;
     int k0 = 0x7fffffff, k1 = -0x7fffffff, k0u = 0, lofs = 0;
     int64_t o = 0;
+    bool conj_out = false;                                  // w < 0: the mirrored point's value, conjugated (wg_fold_sign)
 #pragma unroll
     for (int t = 0; t < W; ++t) kwv[t] = t == 0 ? 1.0 : 0.0;       // without w-stacking: the one plane, weight 1
     const unsigned mine = place[tid];
@@ -906,7 +964,9 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         const unsigned i = mine;
         const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
         o = (int64_t)r * nchan_total + chan0 + c;
-        const double fl = freq[c] / AF_LIGHTSPEED;
+        const double sg = wg_fold_sign(uvw + 3 * (int64_t)r, do_w);
+        conj_out = sg < 0.0;
+        const double fl = sg * (freq[c] / AF_LIGHTSPEED);
         k0 = 0; k1 = 1;
         if (do_w) {
             gw = (uvw[3 * (int64_t)r + 2] * fl - w0) / dw;
@@ -1001,7 +1061,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         // the first plane batch adds to the zeros the call has just written: no need to read them back (scattered 16-byte reads)
         double2 acc = pk0 == 0 ? make_double2(0.0, 0.0) : vis[o];
         acc.x += are;
-        acc.y += aim;
+        acc.y += conj_out ? -aim : aim;
         vis[o] = acc;
     }
 }
@@ -1023,7 +1083,8 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
     const int64_t r = perm ? perm[p] : p;                   // rows in uv-tile order
     const int64_t o = r * nchan_total + chan0 + c;
     if (mask && !mask[o]) return;
-    const double fl = freq[c] / AF_LIGHTSPEED;
+    const double sg = wg_fold_sign(uvw + 3 * r, do_w);
+    const double fl = sg * (freq[c] / AF_LIGHTSPEED);
     double gw = 0.0;
     int k0 = 0, k1 = 1, k0u = 0;                        // this visibility's planes [k0, k1), clipped to the batch
     if (do_w) {
@@ -1075,7 +1136,7 @@ __global__ __launch_bounds__(256) void wg_degrid_planes(const double *__restrict
     }
     double2 acc = vis[o];
     acc.x += are;
-    acc.y += aim;
+    acc.y += sg < 0.0 ? -aim : aim;
     vis[o] = acc;
 }
 
@@ -1122,7 +1183,9 @@ __global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__
     if (mask && !mask[o]) return;
     double2 val = vis[o];
     if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
-    const double fl = freq[c] / AF_LIGHTSPEED;
+    const double sg = wg_fold_sign(uvw + 3 * r, do_w);
+    val.y *= sg;                                            // w < 0: conj(vis) at the mirrored point
+    const double fl = sg * (freq[c] / AF_LIGHTSPEED);
     double gw = 0.0;
     int k0 = 0, k1 = 1, k0u = 0;
     if (do_w) {
@@ -1262,13 +1325,15 @@ __global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ 
             const unsigned i = idx[ch.y + base + lane];
             const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
             const int64_t o = (int64_t)r * nchan_total + chan0 + c;
-            in.fl = freq[c] / AF_LIGHTSPEED;
+            const double sg = wg_fold_sign(uvw + 3 * (int64_t)r, do_w);
+            in.fl = sg * (freq[c] / AF_LIGHTSPEED);
             in.u = uvw[3 * (int64_t)r + WG_CU];
             in.v = uvw[3 * (int64_t)r + WG_CV];
             in.w = uvw[3 * (int64_t)r + 2];
             if (wave == 0) {
                 in.val = vis[o];
                 if (wgt) { const double g = wgt[o]; in.val.x *= g; in.val.y *= g; }
+                in.val.y *= sg;                             // w < 0: conj(vis) at the mirrored point
             }
         }
         return in;
@@ -1568,15 +1633,37 @@ AF_EXPORT size_t af_wgrid_workspace_bytes(int64_t nx, int64_t ny, int64_t planes
                  kernel_width).total;
 }
 
-// number of w-planes a call will work through: the wrapper sizes its workspace with it
+namespace {
+// [min, max] of w nu / c over the visibilities -> [min, max] of |w nu / c|: the range the planes cover (wg_fold_sign)
+inline void wg_fold_range(double &lo, double &hi)
+{
+    if (lo >= 0.0) return;
+    const double a = -lo, b = hi;
+    if (hi <= 0.0) { lo = -b; hi = a; }
+    else { lo = 0.0; hi = a > b ? a : b; }
+}
+// Planes of a (folded) range of `span` plane spacings.  A visibility at plane coordinate gw takes the W planes
+// ceil(gw - W / 2) .. + W - 1 (the kernel is zero at distance W / 2 exactly).  Plane 0 sits W / 2 - 1 + eta spacings
+// below the smallest w (wg_plane_origin): that visibility's first plane is ceil(-1 + eta) = 0, the largest w has
+// gw = span + W / 2 - 1 + eta and first plane ceil(span - 1 + eta).  eta absorbs the rounding of gw at either end (a
+// visibility an ulp outside loses a tap at the edge of the support, where the kernel is ~ 1e-7 of its peak and falling
+// to zero).  One plane fewer than an origin W / 2 below the smallest w needs -- that plane would receive nothing.
+constexpr double WG_PLANE_ETA = 1e-6;
+inline double wg_plane_origin(double wl_min, double dw, int kernel_width) { return wl_min - (0.5 * kernel_width - 1.0 + WG_PLANE_ETA) * dw; }
+inline int64_t wg_plane_count(double span, int kernel_width) { return (int64_t)ceil(span - 1.0 + 2.0 * WG_PLANE_ETA) + kernel_width; }
+}  // namespace
+
+// number of w-planes a call will work through: the wrapper sizes its workspace with it.  [wl_min, wl_max]: the range of
+// w nu / c over the visibilities, signs as they are in uvw
 AF_EXPORT int64_t af_wgrid_planes(double wl_min, double wl_max, double max_abs_nm1, int kernel_width, int do_wstacking)
 {
     if (!do_wstacking) return 1;
     if (!(std::isfinite(wl_min) && std::isfinite(wl_max) && wl_max >= wl_min && max_abs_nm1 >= 0.0)) return -1;
+    wg_fold_range(wl_min, wl_max);
     const double dw = 1.0 / (2.0 * 2.0 * (max_abs_nm1 > 1e-12 ? max_abs_nm1 : 1e-12));
     const double span = (wl_max - wl_min) / (dw > 1e12 ? 1e12 : dw);
     if (!(span < 1e6)) return -1;
-    return (int64_t)ceil(span) + kernel_width + 1;
+    return wg_plane_count(span, kernel_width);
 }
 
 namespace {
@@ -1614,12 +1701,13 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (do_wstacking) {
         AF_REQUIRE(std::isfinite(wl_min) && std::isfinite(wl_max) && wl_max >= wl_min && max_abs_nm1 >= 0.0,
                    "af_wgrid_im2vis_f64: bad w range");
+        wg_fold_range(wl_min, wl_max);
         dw = 1.0 / (2.0 * 2.0 * (max_abs_nm1 > 1e-12 ? max_abs_nm1 : 1e-12));
         if (dw > 1e12) dw = 1e12;
-        w0 = wl_min - 0.5 * kernel_width * dw;
+        w0 = wg_plane_origin(wl_min, dw, kernel_width);
         const double span = (wl_max - wl_min) / dw;
         AF_REQUIRE(span < 1e6, "af_wgrid_im2vis_f64: %g w-planes", span);
-        nplanes = (int)ceil(span) + kernel_width + 1;
+        nplanes = (int)wg_plane_count(span, kernel_width);
     }
     // as many resident planes as the workspace holds
     const int64_t nvis = nrow * nchan_band;
@@ -1634,23 +1722,34 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     double *A = reinterpret_cast<double *>(ws + L.A), *nm1 = reinterpret_cast<double *>(ws + L.nm1);
 
     const unsigned nb_img = (unsigned)af_cdiv(nx * ny, 256), nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
+    // large image -> vis calls: the sort and the zero fill on the side stream (wg_side_stream), beside the transforms
+    static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
+    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
+    const bool beside = !adjoint && tiled && AF_STAGE_ENV("AFHIP_WGRID_SIDE", 1) != 0;
+    WgSide side{};
+    hipStream_t sst = st;           // the stream of the sort
+    if (beside) {
+        const int rc = wg_side_stream(st, side);
+        if (rc != AF_OK) return rc;
+        AF_HIP(hipEventRecord(side.fork, st));
+        AF_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        sst = side.stream;
+    }
     hipLaunchKernelGGL(wg_geometry, dim3((unsigned)af_cdiv((nx / 2 + 1) * (ny / 2 + 1), 256)), dim3(256), 0, st, nx, ny, cellx, celly, corr_u, corr_v, quad_t, quad_w,
                        kernel_width, beta, dw, do_wstacking, A, nm1, adjoint ? nullptr : image);
     AF_LAUNCH_CHECK();
     // the band's columns start from zero
     if (!adjoint)
-        hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, st, reinterpret_cast<double2 *>(vis), nrow, nchan_total,
+        hipLaunchKernelGGL((wg_zero_band<double2>), dim3(4096), dim3(256), 0, sst, reinterpret_cast<double2 *>(vis), nrow, nchan_total,
                            chan0, chan0 + nchan_band);
     const int *perm = nullptr;
     // large calls: visibilities in (tile, w-plane) order, tiles through LDS (AFHIP_WGRID_SORT=0: the gather kernel)
-    static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
-    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
     if (!adjoint && !tiled && nrow >= 4096 && nrow < (1LL << 31)) {
         int *hist = reinterpret_cast<int *>(ws + L.hist), *pm = reinterpret_cast<int *>(ws + L.perm);
         unsigned short *key = reinterpret_cast<unsigned short *>(ws + L.key);
         AF_HIP(hipMemsetAsync(hist, 0, WG_NBIN * sizeof(int), st));
         hipLaunchKernelGGL(wg_bin_rows, dim3((unsigned)af_cdiv(nrow, 256)), dim3(256), 0, st, uvw, nrow, freq, nchan_band,
-                           cellx, celly, key, hist);
+                           cellx, celly, do_wstacking, key, hist);
         AF_LAUNCH_CHECK();
         hipLaunchKernelGGL(wg_scan_bins, dim3(1), dim3(1024), 0, st, hist);
         AF_LAUNCH_CHECK();
@@ -1673,7 +1772,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         int *vcursor = reinterpret_cast<int *>(ws + L.vcursor);
         WgSort q{uvw, freq, mask, nvis, nchan_band, chan0, nchan_total, nv, nu, celly, cellx, w0, dw,
                  kernel_width, do_wstacking, nplanes, kb, (int)((nu + tile - 1) / tile), tile, exact, kfirst};
-        AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), st));
+        AF_HIP(hipMemsetAsync(vcount, 0, (size_t)(nbins + 2) * sizeof(int), sst));
         int64_t blocks = af_cdiv(nvis, 256);
         if (blocks > 16384) blocks = 16384;
         const int sort_env = getenv("AFHIP_WGRID_SORT1") ? atoi(getenv("AFHIP_WGRID_SORT1")) : 2;     // read per call (A/B, tests)
@@ -1687,45 +1786,45 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             int *keys = reinterpret_cast<int *>(ws + L.vidx);          // the keys live where the final indices go
             int *hist = reinterpret_cast<int *>(ws + L.shist), *offs = reinterpret_cast<int *>(ws + L.soffs);
             const int hn = C * NB, hblk = (int)af_cdiv(hn, 1024);
-            hipLaunchKernelGGL(wg_sort_hist, dim3((unsigned)NB), dim3(256), (size_t)C * sizeof(int), st, q, S, C, NB, keys, hist);
+            hipLaunchKernelGGL(wg_sort_hist, dim3((unsigned)NB), dim3(256), (size_t)C * sizeof(int), sst, q, S, C, NB, keys, hist);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_scan_sums, dim3((unsigned)hblk), dim3(256), 0, st, hist, hn, sums);
+            hipLaunchKernelGGL(wg_scan_sums, dim3((unsigned)hblk), dim3(256), 0, sst, hist, hn, sums);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_scan_top, dim3(1), dim3(1024), 0, st, sums, hblk, offs + hn);
+            hipLaunchKernelGGL(wg_scan_top, dim3(1), dim3(1024), 0, sst, sums, hblk, offs + hn);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)hblk), dim3(256), 0, st, hist, hn, sums, offs, hist);
+            hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)hblk), dim3(256), 0, sst, hist, hn, sums, offs, hist);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_sort_spread, dim3((unsigned)NB), dim3(256), (size_t)C * sizeof(int), st, nvis, S, C, NB, keys,
+            hipLaunchKernelGGL(wg_sort_spread, dim3((unsigned)NB), dim3(256), (size_t)C * sizeof(int), sst, nvis, S, C, NB, keys,
                                offs, keyrank);
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_sort_fine, dim3((unsigned)C), dim3(WG_FINE_T), (size_t)(1 << S) * sizeof(int), st, keyrank, offs, S, C,
+            hipLaunchKernelGGL(wg_sort_fine, dim3((unsigned)C), dim3(WG_FINE_T), (size_t)(1 << S) * sizeof(int), sst, keyrank, offs, S, C,
                                NB, nbins, offs + hn, vstart, reinterpret_cast<unsigned *>(ws + L.vidx));
             AF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
+            hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
                                reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
             AF_LAUNCH_CHECK();
             nchunks = vcount + nbins + 1;
             return AF_OK;
         }
         const int onepass = sort_env != 0;
-        if (onepass) hipLaunchKernelGGL(wg_vis_rank, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount, keyrank);
-        else hipLaunchKernelGGL(wg_vis_count, dim3((unsigned)blocks), dim3(256), 0, st, q, vcount);
+        if (onepass) hipLaunchKernelGGL(wg_vis_rank, dim3((unsigned)blocks), dim3(256), 0, sst, q, vcount, keyrank);
+        else hipLaunchKernelGGL(wg_vis_count, dim3((unsigned)blocks), dim3(256), 0, sst, q, vcount);
         AF_LAUNCH_CHECK();
         const int nblk = (int)af_cdiv(nbins, 1024);
-        hipLaunchKernelGGL(wg_scan_sums, dim3((unsigned)nblk), dim3(256), 0, st, vcount, nbins, sums);
+        hipLaunchKernelGGL(wg_scan_sums, dim3((unsigned)nblk), dim3(256), 0, sst, vcount, nbins, sums);
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wg_scan_top, dim3(1), dim3(1024), 0, st, sums, nblk, vstart + nbins);
+        hipLaunchKernelGGL(wg_scan_top, dim3(1), dim3(1024), 0, sst, sums, nblk, vstart + nbins);
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)nblk), dim3(256), 0, st, vcount, nbins, sums, vstart, vcursor);
+        hipLaunchKernelGGL(wg_scan_bins_from, dim3((unsigned)nblk), dim3(256), 0, sst, vcount, nbins, sums, vstart, vcursor);
         AF_LAUNCH_CHECK();
         if (onepass)
-            hipLaunchKernelGGL(wg_vis_place, dim3((unsigned)af_cdiv(nvis, 256)), dim3(256), 0, st, nvis, keyrank, vstart,
+            hipLaunchKernelGGL(wg_vis_place, dim3((unsigned)af_cdiv(nvis, 256)), dim3(256), 0, sst, nvis, keyrank, vstart,
                                reinterpret_cast<unsigned *>(ws + L.vidx));
         else
-            hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, st, q, vcursor,
+            hipLaunchKernelGGL(wg_vis_scatter, dim3((unsigned)blocks), dim3(256), 0, sst, q, vcursor,
                                reinterpret_cast<unsigned *>(ws + L.vidx));
         AF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, st, vstart, ntiles, kb, chunk,
+        hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
                            reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
         AF_LAUNCH_CHECK();
         nchunks = vcount + nbins + 1;
@@ -1734,6 +1833,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (tiled && !adjoint) {
         const int rc = sort_visibilities(0, 0);
         if (rc != AF_OK) return rc;
+        if (beside) AF_HIP(hipEventRecord(side.join, side.stream));
     }
     // planes per pass of the gridding direction: what is resident, and what one exact sort covers
     const int gbatch = (int)resident < WG_GKB - kernel_width + 1 ? (int)resident : WG_GKB - kernel_width + 1;
@@ -1910,6 +2010,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     do {                                                                                                               \
         if (single) { AF_WG_LAUNCH_P(WC, float2); } else { AF_WG_LAUNCH_P(WC, double2); }                              \
     } while (0)
+        if (beside && pk0 == 0) AF_HIP(hipStreamWaitEvent(st, side.join, 0));     // the sorted list, the zeroed band
         af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
@@ -1978,6 +2079,7 @@ AF_EXPORT int af_wgrid_vis2im_f64(const double *uvw, const double *freq, int64_t
 void af_wgrid_drop_stream(hipStream_t st)
 {
     std::lock_guard<std::mutex> g(g_plan_mu);
+    wg_side_release(false, st);
     for (auto it = g_plans.begin(); it != g_plans.end();) {
         if (it->first.stream == st) {
             (void)hipfftDestroy(it->second.plan);
@@ -1992,6 +2094,7 @@ void af_wgrid_drop_stream(hipStream_t st)
 void af_wgrid_shutdown()
 {
     std::lock_guard<std::mutex> g(g_plan_mu);
+    wg_side_release(true, nullptr);
     for (auto &kv : g_plans) (void)hipfftDestroy(kv.second.plan);
     g_plans.clear();
 }

@@ -341,7 +341,7 @@ def test_hundreds_of_w_planes_are_sorted_per_batch():
     from codex_africanus_amd.gridding.wgridder import dirty
     nx, ny, nrow, nchan = 32, 32, 6000, 12
     cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 50.0, nrow, nchan, 1, seed=8)
-    uvw[:, 2] *= 10.0
+    uvw[:, 2] *= 20.0          # (the planes cover |w| only: the w fold)
     eps = 1e-6
     emax = 2 * (nx / 2 * cell) ** 2
     wl = np.abs(uvw[:, 2]).max() * freq.max() / LIGHTSPEED
@@ -452,3 +452,28 @@ def test_own_row_transforms_with_float32_planes(monkeypatch):
     src = np.broadcast_to((image[0][nz] / n)[:, None, None], (x.size, nchan, 1)).copy()
     direct = oracle.im_to_vis(src, uvw * np.array([1.0, 1.0, -1.0]), np.stack([x, y], 1), freq, omp=True)[:, :, 0]
     assert _l2error(own, direct) <= 1e-5 and _l2error(lib, direct) <= 1e-5
+
+
+@pytest.mark.parametrize("nrow", (900, 40000))          # the gather kernel / the tile kernel (>= 65536 visibilities)
+def test_w_fold_one_sign_both_signs_and_the_mirror_property(nrow):
+    """Visibilities with w < 0 are evaluated at the mirrored point and conjugated (real image: V(-u,-v,-w) = conj V),
+    so the planes cover the range of |w| only.  All-negative, all-positive and mixed w meet the accuracy contract; the
+    mirrored call returns the conjugate BIT FOR BIT (same planes, same taps); the plane count of a symmetric range is
+    that of its positive half."""
+    from codex_africanus_amd import _lib
+    nx, ny, nchan = 24, 20, 3
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 20.0, nrow, nchan, 1, seed=31)
+    sample = np.random.default_rng(5).choice(nrow, 600, replace=False)
+    for sign in (-1.0, 1.0, 0.0):
+        u = uvw.copy()
+        if sign:
+            u[:, 2] = sign * (np.abs(u[:, 2]) + 0.1 * np.abs(u[:, 2]).max())       # one sign, away from zero
+        vis = model(u, freq, image, fbi, fbc, cell, epsilon=1e-6)
+        ref = _explicit_degridder(u[sample], freq, image[0], cell, cell)
+        assert _l2error(vis[sample], ref) <= 1e-6, sign
+        mirrored = model(-u, freq, image, fbi, fbc, cell, epsilon=1e-6)
+        assert np.array_equal(mirrored, np.conj(vis)), sign
+    lib = _lib.load()
+    assert lib.af_wgrid_planes(-5e3, 5e3, 1e-3, 7, 1) == lib.af_wgrid_planes(0.0, 5e3, 1e-3, 7, 1)
+    assert lib.af_wgrid_planes(-5e3, -2e3, 1e-3, 7, 1) == lib.af_wgrid_planes(2e3, 5e3, 1e-3, 7, 1)
+    assert lib.af_wgrid_planes(-5e3, 5e3, 1e-3, 7, 1) < lib.af_wgrid_planes(0.0, 1e4, 1e-3, 7, 1)
