@@ -126,7 +126,16 @@ class FusedDde(object):
             v["pa"], v["pe"], v["asc"], bounds=(rank * a.rows, (rank + 1) * a.rows))
         same = bool(torch.equal(vis.reshape(d_vis.shape), d_vis))
         if not same:
-            raise SystemExit("rank %d: sharding.fused_predict_shard differs from the C-ABI call" % rank)
+            a_, b_ = torch.view_as_real(vis.reshape(d_vis.shape)), torch.view_as_real(d_vis)
+            bad = ((a_ != b_) | torch.isnan(a_) | torch.isnan(b_)).any(-1)
+            idx = bad.nonzero()
+            rows = idx[:, 0].unique()
+            raise SystemExit("rank %d: sharding.fused_predict_shard differs from the C-ABI call in %d cells: rows %d..%d (%d rows; "
+                             "timesteps %s), channels %s, correlations %s, NaNs %d / %d, largest difference %.3e" % (
+                                 rank, idx.shape[0], int(rows.min()), int(rows.max()), rows.numel(),
+                                 sorted(set((rows // self.nbl).tolist()))[:12], sorted(set(idx[:, 1].tolist()))[:12],
+                                 sorted(set(idx[:, 2].tolist())), int(torch.isnan(a_).sum()), int(torch.isnan(b_).sum()),
+                                 float(torch.nan_to_num(a_ - b_).abs().max())))
         return "sharding.fused_predict_shard(rank %d of %d, rows %s) == the direct C-ABI call (%s): bit-equal" % (
             rank, world, bounds, "af_fused_predict_antennas_c128" if self.antennas else "af_fused_predict_c128")
 

@@ -54,6 +54,13 @@ def np_dtype_of(x):
     return np.asarray(x).dtype if not hasattr(x, "dtype") else np.dtype(x.dtype)
 
 
+# Debugging aid (AFHIP_POISON=1, or set by a test): every scratch block and every result buffer of a call starts as 0xFF
+# bytes (NaN in every floating-point format) instead of whatever the allocator hands out -- a kernel that reads a cell
+# before writing it, or leaves a result cell unwritten, then shows in the result instead of depending on what ran before
+# (tests/test_gpu_uninitialised.py requires bit-identical results with and without it).
+POISON = os.environ.get("AFHIP_POISON", "0") not in ("", "0")
+
+
 class _OwnedBuffer(object):
     """Device memory of one host-mode call, drawn from libafhip's per-device scratch pool (af_pool_malloc): in
     steady state no hipMalloc / hipFree happens on this path.  Returned to the pool only after the call's stream
@@ -318,12 +325,16 @@ class Call(object):
         if self.device_mode:
             import torch
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.torch_device)
+            if POISON:
+                t.fill_(0xFF)
             self._keep.append(t)
             self._last_scratch = t
             return ctypes.c_void_p(t.data_ptr())
         buf = _OwnedBuffer(nbytes)
         self._owned.append(buf)
         self._last_scratch = buf
+        if POISON:
+            _lib.call("af_memset", buf.ptr, 0xFF, nbytes, self.stream)
         return ctypes.c_void_p(buf.ptr)
 
     def watch_status(self, offset_bytes, message):
@@ -343,10 +354,14 @@ class Call(object):
         if self.device_mode:
             import torch
             t = torch.empty(shape, dtype=_torch_dtype(dtype), device=self.torch_device)
+            if POISON:
+                t.view(torch.uint8).fill_(0xFF)
             return ctypes.c_void_p(t.data_ptr()), t
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         buf = _OwnedBuffer(nbytes)
         self._owned.append(buf)
+        if POISON and nbytes:
+            _lib.call("af_memset", buf.ptr, 0xFF, nbytes, self.stream)
         return ctypes.c_void_p(buf.ptr), (buf, shape, dtype)
 
     # ---- results produced and downloaded in row chunks ------------------------------------------------

@@ -551,8 +551,12 @@ int af_fused_predict_antennas_model_c128(const double *stokes, const double *spi
  * image (nx, ny) float64; corr_u (nx) / corr_v (ny): 1 / Fourier transform of the kernel along the padded axes
  * (af_wgrid_padded: the smallest even 2-3-5-7-smooth size >= 2 n); quad_t / quad_w (48): Gauss-Legendre nodes / weights on (0, 1); kernel_width W and beta: the
  * exponential-of-semicircle kernel exp(beta (sqrt(1 - (2t/W)^2) - 1)); [wl_min, wl_max]: range of w nu / c over the
- * band (HOST scalars, they size the w-plane loop); max_abs_nm1: largest |n - 1| of the image.  All device work is
- * enqueued on `stream`; the plane transforms of image rows / columns of 512, 1024, 2048 or 4096 cells are own kernels
+ * band, signs as they are in uvw (HOST scalars, they size the w-plane loop; any superset of the true range is valid);
+ * max_abs_nm1: largest |n - 1| of the image.  The image is real, so V(-u,-v,-w) = conj V(u,v,w): visibilities with w < 0
+ * are evaluated at the mirrored point and conjugated (the adjoint grids their conjugates there), and the planes cover
+ * [min |w nu/c|, max |w nu/c|] only -- af_wgrid_planes() counts them.  All device work is
+ * enqueued on `stream` (the visibility sort of large image -> vis calls on a library-owned side stream that starts
+ * behind `stream`'s work at the call and is joined before the visibilities are written); the plane transforms of image rows / columns of 512, 1024, 2048 or 4096 cells are own kernels
  * (csrc/af_wgridder.hip, wg_fill_fft_rows), every other size uses hipFFT (plans cached per device and size, released by
  * af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);

@@ -1,0 +1,89 @@
+"""
+No result may depend on what the allocator hands out.  Every call draws its scratch and result buffers from a pool (host
+mode) or torch's caching allocator (device mode): memory that holds whatever ran before, including other processes' data.
+With ``_device.POISON`` every such block starts as 0xFF bytes (NaN): a kernel that reads a cell before writing it, or
+leaves a result cell unwritten, changes the result.  Each entry point below must return the same bits with and without
+it, in both modes (numpy in -> numpy out, tensors in -> tensor out).
+"""
+import numpy as np
+import pytest
+
+from codex_africanus_amd import _device, dft, rime
+from codex_africanus_amd.gridding.wgridder import model
+from codex_africanus_amd.rime import fused
+from test_gpu_fused import _problem
+from test_gpu_fused_gemm import _call, _decomposable
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(monkeypatch, f):
+    monkeypatch.setattr(_device, "POISON", False)
+    clean = f()
+    monkeypatch.setattr(_device, "POISON", True)
+    dirty = f()
+    return clean, dirty
+
+
+def _same(a, b):
+    a, b = (x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x) for x in (a, b))
+    assert not np.isnan(a.view(np.float64) if a.dtype.kind == "c" else a).any()
+    assert np.array_equal(a, b)
+
+
+def _tensors(d, keys):
+    import torch
+    d = dict(d)
+    for k in keys:
+        d[k] = torch.from_numpy(np.ascontiguousarray(d[k])).cuda()
+    return d
+
+
+KEYS = ("time_index", "ant1", "ant2", "lm", "uvw", "frequency", "X", "beam", "extents", "beam_freq_map", "pa", "pe", "as")
+
+
+@pytest.mark.parametrize("nant, nrow", [(7, 300), (64, 4100), (100, 5200)])
+@pytest.mark.parametrize("device", (False, True))
+def test_fused_predict_gemm_form(monkeypatch, nant, nrow, device):
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+    d = _decomposable(_problem(3, nrow, 6, 23, nant), nant, keep=0.9)
+    plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
+    assert plan.decomposable
+    if device:
+        d = _tensors(d, KEYS)
+    _same(*_both(monkeypatch, lambda: _call(d, plan=plan)))
+    _same(*_both(monkeypatch, lambda: _call(d)))
+
+
+@pytest.mark.parametrize("device", (False, True))
+def test_fused_predict_lane_per_row(monkeypatch, device):
+    d = _problem(3, 1500, 6, 23, 17)
+    if device:
+        d = _tensors(d, KEYS)
+    _same(*_both(monkeypatch, lambda: _call(d)))
+
+
+@pytest.mark.parametrize("device", (False, True))
+def test_direct_transforms_and_the_chain(monkeypatch, device):
+    rng = np.random.default_rng(3)
+    nrow, nchan, nsrc = 3000, 5, 37
+    uvw = rng.standard_normal((nrow, 3)) * 100
+    lm = rng.standard_normal((nsrc, 2)) * 0.01
+    freq = np.linspace(1e9, 2e9, nchan)
+    image = rng.standard_normal((nsrc, nchan, 4))
+    vis = rng.standard_normal((nrow, nchan, 4)) + 1j * rng.standard_normal((nrow, nchan, 4))
+    arrs = dict(uvw=uvw, lm=lm, freq=freq, image=image, vis=vis)
+    if device:
+        arrs = _tensors(arrs, arrs.keys())
+    _same(*_both(monkeypatch, lambda: dft.im_to_vis(arrs["image"], arrs["uvw"], arrs["lm"], arrs["freq"])))
+    _same(*_both(monkeypatch, lambda: dft.vis_to_im(arrs["vis"], arrs["uvw"], arrs["lm"], arrs["freq"],
+                                                    np.zeros((nrow, nchan, 4), bool) if not device else
+                                                    __import__("torch").zeros((nrow, nchan, 4), dtype=__import__("torch").bool, device="cuda"))))
+    _same(*_both(monkeypatch, lambda: rime.phase_delay(arrs["lm"], arrs["uvw"], arrs["freq"])))
+
+
+@pytest.mark.parametrize("nrow", (900, 40000))
+def test_wgridder_model(monkeypatch, nrow):
+    from test_gpu_wgridder import _case
+    cell, freq, uvw, fbi, fbc, image = _case(24, 20, 20.0, nrow, 3, 1, seed=31)
+    _same(*_both(monkeypatch, lambda: model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-6)))
