@@ -571,6 +571,19 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             // gathers always in flight while the other two are consumed) -- 99.6 ms against 87.7, same box; phase timers: its
             // sampling stage ALONE 5150 cycles per batch against ~5300: the stage is bound by the L1's miss rate, ~5 cycles per
             // 128-byte line and CU = 66 ms for the kernel's 1.04 TB of records, pipelined or not)
+            // (round 5, measured and removed, same box, same bits, 87.7 ms as it stands:
+            //  * a ROLLING order -- round q of super-round k + 1 issued right after round q of k is consumed, k + 1's three
+            //    address words computed beforehand and the rest of its term parked in LDS: 164 registers, no spill,
+            //    vmcnt(24) waits, 24-32 gathers in flight all the time -- 93.2 ms.  The rounds' arithmetic then runs beside
+            //    the matrix waves' burst: a sampling wave issues in order, and every fp64 operation of its dependent chains
+            //    that becomes ready while a 64-cycle MFMA holds the SIMD's pipe waits that MFMA out, priority or not.
+            //  * order C -- the next term's geometry BEFORE the batch barrier (pipe free), only the gathers' issue after
+            //    it -- 94.6 ms: the gathers then land ~1200 cycles earlier and the rounds' arithmetic starts inside the
+            //    matrix waves' burst instead of behind it.  Order A's geometry is the delay that keeps the two apart.
+            //  * s_nop gaps of 8 or 16 cycles behind every MFMA of the matrix waves (windows for the sampling wave's
+            //    operations): 108 ms in order A, 93.6 in order C.
+            //  The batch is the SUM of the burst (3460 pipe cycles per SIMD) and the sampling wave's own chains (~3100
+            //  elapsed at half the pipe's rate), with the gathers' latency hidden under the burst: 6700 cycles = 87.5 ms.)
             // (the two conditional barrier sites below are also what keeps the consume / barrier / geometry phases in
             // separate scheduling regions: with ONE unconditional barrier here -- order A hard-wired -- hipcc merges the
             // phases into one block and the same kernel takes 107.5 ms instead of 87.7, same box; with the matrix waves'
