@@ -53,6 +53,9 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
     # (AFHIP_FUSED_STAGE runs one stage of the fused kernels for profiling: their output is meaningless)
     staged = os.environ.get("AFHIP_FUSED_STAGE", "0") != "0"
     front_end = wl.front_end_check(d_vis, rank, world, dev) if hasattr(wl, "front_end_check") and not staged else None
+    for _ in range(int(os.environ.get("AFHIP_BENCH_FRONT_END_REPEATS", "1")) - 1):      # stress runs (tools/): the same check again
+        if front_end is not None:
+            wl.front_end_check(d_vis, rank, world, dev)
     for _ in range(warmup):
         step()
     ev = Events(_lib, steps)

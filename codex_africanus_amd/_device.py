@@ -59,6 +59,7 @@ def np_dtype_of(x):
 # before writing it, or leaves a result cell unwritten, then shows in the result instead of depending on what ran before
 # (tests/test_gpu_uninitialised.py requires bit-identical results with and without it).
 POISON = os.environ.get("AFHIP_POISON", "0") not in ("", "0")
+POISON_BYTE = int(os.environ.get("AFHIP_POISON_BYTE", "255"))   # other patterns: 1 (small integers, denormal doubles), 64 (doubles ~ 32)
 
 
 class _OwnedBuffer(object):
@@ -326,7 +327,7 @@ class Call(object):
             import torch
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.torch_device)
             if POISON:
-                t.fill_(0xFF)
+                t.fill_(POISON_BYTE)
             self._keep.append(t)
             self._last_scratch = t
             return ctypes.c_void_p(t.data_ptr())
@@ -334,7 +335,7 @@ class Call(object):
         self._owned.append(buf)
         self._last_scratch = buf
         if POISON:
-            _lib.call("af_memset", buf.ptr, 0xFF, nbytes, self.stream)
+            _lib.call("af_memset", buf.ptr, POISON_BYTE, nbytes, self.stream)
         return ctypes.c_void_p(buf.ptr)
 
     def watch_status(self, offset_bytes, message):
@@ -355,13 +356,13 @@ class Call(object):
             import torch
             t = torch.empty(shape, dtype=_torch_dtype(dtype), device=self.torch_device)
             if POISON:
-                t.view(torch.uint8).fill_(0xFF)
+                t.view(torch.uint8).fill_(POISON_BYTE)
             return ctypes.c_void_p(t.data_ptr()), t
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         buf = _OwnedBuffer(nbytes)
         self._owned.append(buf)
         if POISON and nbytes:
-            _lib.call("af_memset", buf.ptr, 0xFF, nbytes, self.stream)
+            _lib.call("af_memset", buf.ptr, POISON_BYTE, nbytes, self.stream)
         return ctypes.c_void_p(buf.ptr), (buf, shape, dtype)
 
     # ---- results produced and downloaded in row chunks ------------------------------------------------

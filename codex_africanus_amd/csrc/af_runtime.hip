@@ -545,3 +545,25 @@ AF_EXPORT int af_convert_f64_to_f32(const double *src, float *dst, int64_t n, vo
 {
     return convert(src, dst, n, stream);
 }
+
+#ifdef AFHIP_STAGE_HOOKS
+// profiling build only (tools/check_lds_independence.py): every CU's LDS <- `pattern` bytes, so that a kernel which reads
+// LDS it has not written -- whatever the workgroup before it left there, usually one of its own -- shows in its result
+__global__ __launch_bounds__(1024) void debug_fill_lds_kernel(unsigned pattern, unsigned *sink)
+{
+    extern __shared__ unsigned lds_all[];
+    const int n = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds_all[i] = pattern;
+    __syncthreads();
+    if (sink && lds_all[(threadIdx.x * 977) % n] != pattern) *sink = 1;     // keeps the stores
+}
+AF_EXPORT int af_debug_fill_lds(unsigned pattern, void *stream)
+{
+    const void *k = reinterpret_cast<const void *>(debug_fill_lds_kernel);
+    AF_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // one workgroup owns a whole CU's LDS: several rounds over the chip so that every CU is certainly visited
+    hipLaunchKernelGGL(debug_fill_lds_kernel, dim3(256 * 16), dim3(1024), 160 * 1024, af_stream(stream), pattern, (unsigned *)nullptr);
+    AF_LAUNCH_CHECK();
+    return AF_OK;
+}
+#endif

@@ -18,17 +18,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(monkeypatch, f):
+    """f() without poison, and with every block starting as 0xFF bytes (NaN / -1), 0x01 bytes (small positive integers,
+    denormal doubles) and 0x40 bytes (doubles ~ 32, floats ~ 3): what reads as "no entry" in one pattern is data in another"""
     monkeypatch.setattr(_device, "POISON", False)
     clean = f()
-    monkeypatch.setattr(_device, "POISON", True)
-    dirty = f()
+    dirty = []
+    for byte in (0xFF, 0x01, 0x40):
+        monkeypatch.setattr(_device, "POISON", True)
+        monkeypatch.setattr(_device, "POISON_BYTE", byte)
+        dirty.append(f())
     return clean, dirty
 
 
-def _same(a, b):
-    a, b = (x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x) for x in (a, b))
+def _same(a, bs):
+    a = a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
     assert not np.isnan(a.view(np.float64) if a.dtype.kind == "c" else a).any()
-    assert np.array_equal(a, b)
+    for b in bs:
+        b = b.cpu().numpy() if hasattr(b, "cpu") else np.asarray(b)
+        assert np.array_equal(a, b)
 
 
 def _tensors(d, keys):

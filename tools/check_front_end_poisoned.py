@@ -35,8 +35,9 @@ stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 w.predict(d_vis, stream, P)
 torch.cuda.synchronize()
 print("direct call: NaNs", int(torch.isnan(torch.view_as_real(d_vis)).sum()))
-for poison in [False, True] * a.reps:
-    _device.POISON = poison
-    junk = torch.empty(int(6e9), dtype=torch.uint8, device=dev).fill_(0x7F if poison else 0xFF)   # what the allocator will hand out next
+for byte in [None, 0xFF, 0x01, 0x40, 0x7F] * a.reps:
+    _device.POISON = byte is not None
+    _device.POISON_BYTE = byte or 0
+    junk = torch.empty(int(6e9), dtype=torch.uint8, device=dev).fill_(0x3C if byte is None else byte)   # what the allocator will hand out next
     del junk
-    print("poison", poison, w.front_end_check(d_vis, 0, 1, dev))
+    print("poison", byte, w.front_end_check(d_vis, 0, 1, dev))
