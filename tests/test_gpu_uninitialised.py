@@ -94,3 +94,35 @@ def test_wgridder_model(monkeypatch, nrow):
     from test_gpu_wgridder import _case
     cell, freq, uvw, fbi, fbc, image = _case(24, 20, 20.0, nrow, 3, 1, seed=31)
     _same(*_both(monkeypatch, lambda: model(uvw, freq, image, fbi, fbc, cell, epsilon=1e-6)))
+
+
+@pytest.mark.parametrize("corrs", [(2, 2), (1,)])
+@pytest.mark.parametrize("device", (False, True))
+def test_predict_vis_apply_gains_and_beam_cube(monkeypatch, corrs, device):
+    from test_gpu_predict_tile import _case as tile_case
+    rng = np.random.default_rng(11)
+    d = tile_case(rng, 2500, 37, 4, 7, 21, corrs)
+    if device:
+        d = _tensors(d, d.keys())
+    _same(*_both(monkeypatch, lambda: rime.predict_vis(d["ti"], d["a1"], d["a2"], d["dde"], d["coh"], d["dde"], d["die"], d["bvis"], d["die"])))
+    _same(*_both(monkeypatch, lambda: rime.predict_vis(d["ti"], d["a1"], d["a2"], None, d["coh"], None, None, None, None)))
+    _same(*_both(monkeypatch, lambda: rime.apply_gains(d["ti"], d["a1"], d["a2"], d["die"], d["bvis"], d["die"])))
+    if corrs == (2, 2):
+        p = _problem(3, 300, 6, 23, 7)
+        if device:
+            p = _tensors(p, ("beam", "extents", "beam_freq_map", "lm", "pa", "pe", "as", "frequency"))
+        _same(*_both(monkeypatch, lambda: rime.beam_cube_dde(p["beam"], p["extents"], p["beam_freq_map"], p["lm"], p["pa"], p["pe"],
+                                                             p["as"], p["frequency"])))
+
+
+@pytest.mark.parametrize("nrow", (900, 40000))
+def test_wgridder_dirty(monkeypatch, nrow):
+    """(gridding with atomics: the sums' order varies from run to run, so to rounding, not bit for bit)"""
+    from codex_africanus_amd.gridding.wgridder import dirty
+    from test_gpu_wgridder import _case
+    cell, freq, uvw, fbi, fbc, _ = _case(24, 20, 20.0, nrow, 3, 1, seed=31)
+    rng = np.random.default_rng(5)
+    vis = rng.standard_normal((nrow, 3)) + 1j * rng.standard_normal((nrow, 3))
+    clean, dirties = _both(monkeypatch, lambda: dirty(uvw, freq, vis, fbi, fbc, 24, 20, cell, epsilon=1e-6))
+    for d in dirties:
+        assert np.abs(d - clean).max() <= 1e-11 * np.abs(clean).max()
