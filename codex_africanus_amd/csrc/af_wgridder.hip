@@ -1728,12 +1728,28 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     const bool beside = !adjoint && tiled && AF_STAGE_ENV("AFHIP_WGRID_SIDE", 1) != 0;
     WgSide side{};
     hipStream_t sst = st;           // the stream of the sort
+    // (an error return between the fork and the tile pass still joins the side stream: the caller's stream never runs ahead
+    // of work this call has put beside it)
+    struct SideJoin {
+        const WgSide *s = nullptr;
+        hipStream_t main = nullptr;
+        bool joined = false;
+        void join()
+        {
+            if (!s || joined) return;
+            joined = true;
+            if (hipEventRecord(s->join, s->stream) == hipSuccess) (void)hipStreamWaitEvent(main, s->join, 0);
+        }
+        ~SideJoin() { join(); }
+    } side_join;
     if (beside) {
         const int rc = wg_side_stream(st, side);
         if (rc != AF_OK) return rc;
         AF_HIP(hipEventRecord(side.fork, st));
         AF_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
         sst = side.stream;
+        side_join.s = &side;
+        side_join.main = st;
     }
     hipLaunchKernelGGL(wg_geometry, dim3((unsigned)af_cdiv((nx / 2 + 1) * (ny / 2 + 1), 256)), dim3(256), 0, st, nx, ny, cellx, celly, corr_u, corr_v, quad_t, quad_w,
                        kernel_width, beta, dw, do_wstacking, A, nm1, adjoint ? nullptr : image);
@@ -1833,7 +1849,6 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (tiled && !adjoint) {
         const int rc = sort_visibilities(0, 0);
         if (rc != AF_OK) return rc;
-        if (beside) AF_HIP(hipEventRecord(side.join, side.stream));
     }
     // planes per pass of the gridding direction: what is resident, and what one exact sort covers
     const int gbatch = (int)resident < WG_GKB - kernel_width + 1 ? (int)resident : WG_GKB - kernel_width + 1;
@@ -2010,7 +2025,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     do {                                                                                                               \
         if (single) { AF_WG_LAUNCH_P(WC, float2); } else { AF_WG_LAUNCH_P(WC, double2); }                              \
     } while (0)
-        if (beside && pk0 == 0) AF_HIP(hipStreamWaitEvent(st, side.join, 0));     // the sorted list, the zeroed band
+        if (beside && pk0 == 0) side_join.join();                                  // the sorted list, the zeroed band
         af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
         switch (kernel_width) {
         case 4: AF_WG_LAUNCH(4); break;
