@@ -582,6 +582,10 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             //    matrix waves' burst instead of behind it.  Order A's geometry is the delay that keeps the two apart.
             //  * s_nop gaps of 8 or 16 cycles behind every MFMA of the matrix waves (windows for the sampling wave's
             //    operations): 108 ms in order A, 93.6 in order C.
+            //  * a SECOND barrier per batch behind the matrix waves' burst (the rounds' arithmetic held back until the pipe
+            //    is free), gathers issued before the first barrier: 128.7 ms; after it: 103.0 (the gather issue beside the
+            //    burst: 4300 cycles instead of 3100); the sixteen gather addresses computed before the batch barrier and only
+            //    the 32 loads behind it: 93.2, with the second barrier 102.4.  The gather issue wants the CU to itself.
             //  The batch is the SUM of the burst (3460 pipe cycles per SIMD) and the sampling wave's own chains (~3100
             //  elapsed at half the pipe's rate), with the gathers' latency hidden under the burst: 6700 cycles = 87.5 ms.)
             // (the two conditional barrier sites below are also what keeps the consume / barrier / geometry phases in

@@ -4,7 +4,7 @@ here).  Shader-clock cycles per batch, averaged over every 16th workgroup of cha
 matrix wave 0 (MFMA loop, barrier wait) and sampling wave 8 (geometry + issue, gather wait, rounds, barrier wait)."""
 import ctypes, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["AFHIP_LIB"] = os.path.join(ROOT, "codex_africanus_amd", "lib", "prof", "libafhip.so")
+os.environ.setdefault("AFHIP_LIB", os.path.join(ROOT, "codex_africanus_amd", "lib", "prof", "libafhip.so"))
 sys.path.insert(0, ROOT)
 import argparse
 import numpy as np
