@@ -73,7 +73,8 @@ uint64_t g_plan_tick = 0;
 // from the plane transforms, are bound by atomics' latency where those are bound by HBM, and run beside them: the side
 // stream starts behind everything the caller's stream holds at the call (`fork`), the tile pass waits for it (`join`).
 // Keyed and released like the FFT plans (af_wgrid_drop_stream, af_wgrid_shutdown); bounded: an entry whose caller
-// stream is gone is only ever one stream and two events.
+// stream is gone is only ever one stream and two events, and past WG_MAX_SIDE caller streams a call simply runs its sort on
+// the caller's stream.
 struct WgSide { hipStream_t stream; hipEvent_t fork, join; };
 std::map<std::pair<int, hipStream_t>, WgSide> g_side;
 constexpr size_t WG_MAX_SIDE = 64;
@@ -84,14 +85,9 @@ int wg_side_stream(hipStream_t st, WgSide &out)
     std::lock_guard<std::mutex> g(g_plan_mu);
     auto it = g_side.find({dev, st});
     if (it == g_side.end()) {
-        if (g_side.size() >= WG_MAX_SIDE) {           // caller streams come and go (torch streams): start over
-            for (auto &kv : g_side) {
-                (void)hipStreamSynchronize(kv.second.stream);
-                (void)hipEventDestroy(kv.second.fork);
-                (void)hipEventDestroy(kv.second.join);
-                (void)hipStreamDestroy(kv.second.stream);
-            }
-            g_side.clear();
+        if (g_side.size() >= WG_MAX_SIDE) {           // more caller streams than anyone should have: this one goes without
+            out = WgSide{};                           // (another thread may be using any of the existing ones: none is destroyed here)
+            return AF_OK;
         }
         WgSide e{};
         AF_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
@@ -1725,7 +1721,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // large image -> vis calls: the sort and the zero fill on the side stream (wg_side_stream), beside the transforms
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
     const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
-    const bool beside = !adjoint && tiled && AF_STAGE_ENV("AFHIP_WGRID_SIDE", 1) != 0;
+    bool beside = !adjoint && tiled && AF_STAGE_ENV("AFHIP_WGRID_SIDE", 1) != 0;
     WgSide side{};
     hipStream_t sst = st;           // the stream of the sort
     // (an error return between the fork and the tile pass still joins the side stream: the caller's stream never runs ahead
@@ -1745,6 +1741,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     if (beside) {
         const int rc = wg_side_stream(st, side);
         if (rc != AF_OK) return rc;
+        beside = side.stream != nullptr;
+    }
+    if (beside) {
         AF_HIP(hipEventRecord(side.fork, st));
         AF_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
         sst = side.stream;

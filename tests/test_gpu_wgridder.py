@@ -477,3 +477,24 @@ def test_w_fold_one_sign_both_signs_and_the_mirror_property(nrow):
     assert lib.af_wgrid_planes(-5e3, 5e3, 1e-3, 7, 1) == lib.af_wgrid_planes(0.0, 5e3, 1e-3, 7, 1)
     assert lib.af_wgrid_planes(-5e3, -2e3, 1e-3, 7, 1) == lib.af_wgrid_planes(2e3, 5e3, 1e-3, 7, 1)
     assert lib.af_wgrid_planes(-5e3, 5e3, 1e-3, 7, 1) < lib.af_wgrid_planes(0.0, 1e4, 1e-3, 7, 1)
+
+
+def test_many_caller_streams_share_nothing_and_overflow_gracefully():
+    """The sort of a large image -> vis call runs on a library-owned side stream per caller stream; past 64 caller streams a
+    call sorts on the caller's stream instead (no entry another thread might be using is ever destroyed).  70 torch streams,
+    the same bits from each."""
+    import torch
+    nx, ny, nrow, nchan = 24, 20, 30000, 3            # 90000 visibilities: the tile kernel, hence the sorted path
+    cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 20.0, nrow, nchan, 1, seed=77)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d = [t(uvw), t(freq), t(image)]
+    ref = model(*d, fbi, fbc, cell, epsilon=1e-6).cpu().numpy()
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    outs = []
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            outs.append(model(*d, fbi, fbc, cell, epsilon=1e-6))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), ref)
