@@ -235,3 +235,21 @@ def test_gemm_plan_host_side_up_to_256_antennas():
         # per-row uvw does not decompose: the plan says so and the caller stays on the lane-per-row kernel
         assert not fused.fused_plan(ti, a1, a2, nant, uvw=rng.standard_normal(uvw.shape)).decomposable
     assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 260, uvw=uvw[:10]).decomposable is False   # > 256 antennas
+
+
+def test_wgridder_plane_count_folds_the_w_range():
+    """af_wgrid_planes (host arithmetic only): the planes cover [min |w|, max |w|] -- visibilities with w < 0 are evaluated
+    at their mirror points (real image) -- with plane 0 W/2 - 1 spacings below the smallest |w| and no spare plane behind
+    the largest: ceil(span - 1) + W planes of spacing 1 / (4 max|n - 1|)."""
+    from codex_africanus_amd import _lib
+    lib = _lib.load()
+    nm1, W = 1e-3, 7
+    dw = 1.0 / (4.0 * nm1)
+    planes = lambda lo, hi: int(lib.af_wgrid_planes(float(lo), float(hi), nm1, W, 1))
+    assert planes(0.0, 0.0) == W and planes(5.0, 5.0) == W and planes(-3.0, 3.0) == W      # one w (or a range below one spacing)
+    assert planes(0.0, 3.6 * dw) == 3 + W and planes(0.0, 4.0 * dw) == 4 + W                # ceil(span - 1 + eta) + W
+    assert planes(-3.6 * dw, 3.6 * dw) == planes(0.0, 3.6 * dw)                              # symmetric range: its positive half
+    assert planes(-9.3 * dw, -2.0 * dw) == planes(2.0 * dw, 9.3 * dw) == 7 + W               # all-negative: mirrored (span 7.3)
+    assert planes(-2.0 * dw, 9.3 * dw) == planes(0.0, 9.3 * dw) == 9 + W                     # mixed: [0, max |w|]
+    assert int(lib.af_wgrid_planes(-1e9, 1e9, nm1, W, 0)) == 1                               # no w-stacking: one plane
+    assert planes(1.0, -1.0) == -1 and int(lib.af_wgrid_planes(0.0, float("nan"), nm1, W, 1)) == -1
