@@ -55,7 +55,7 @@ def _run(args, env):
 
 
 def _run_keeping_a_first_failure(args, env, tag):
-    """Ranks aliased onto one device, the GEMM form: seen about once in forty runs on some boxes of the pool, only inside
+    """Ranks aliased onto one device, the GEMM form: seen twice in about a hundred runs of this file, on two boxes of the pool, only inside
     pytest sessions, never reproduced outside (576 repeats of the same check, tools/stress_gemm_determinism.py: all
     bit-identical; results proven independent of allocator and LDS contents) -- one rank's front-end result differing from
     its direct call.  The full text of a failure is kept (pytest cuts it) and the job is run ONCE more: a second failure
