@@ -124,20 +124,89 @@ class FusedDde(object):
         vis, _, bounds = sharding.fused_predict_shard(
             rank, world, ti, v["a1"], v["a2"], v["lm"], v["uvw"], v["freq"], v["X"], v["beam"], v["ext"], v["fmap"],
             v["pa"], v["pe"], v["asc"], bounds=(rank * a.rows, (rank + 1) * a.rows))
+        if os.environ.get("AFHIP_BENCH_FORCE_MISMATCH"):       # exercises the forensics below (tests): one value off by one ulp
+            vis = vis.clone()
+            torch.view_as_real(vis).reshape(-1).view(torch.int64)[12345] += 1
         same = bool(torch.equal(vis.reshape(d_vis.shape), d_vis))
         if not same:
-            a_, b_ = torch.view_as_real(vis.reshape(d_vis.shape)), torch.view_as_real(d_vis)
-            bad = ((a_ != b_) | torch.isnan(a_) | torch.isnan(b_)).any(-1)
-            idx = bad.nonzero()
-            rows = idx[:, 0].unique()
-            raise SystemExit("rank %d: sharding.fused_predict_shard differs from the C-ABI call in %d cells: rows %d..%d (%d rows; "
-                             "timesteps %s), channels %s, correlations %s, NaNs %d / %d, largest difference %.3e" % (
-                                 rank, idx.shape[0], int(rows.min()), int(rows.max()), rows.numel(),
-                                 sorted(set((rows // self.nbl).tolist()))[:12], sorted(set(idx[:, 1].tolist()))[:12],
-                                 sorted(set(idx[:, 2].tolist())), int(torch.isnan(a_).sum()), int(torch.isnan(b_).sum()),
-                                 float(torch.nan_to_num(a_ - b_).abs().max())))
+            raise SystemExit(self._front_end_forensics(vis.reshape(d_vis.shape), d_vis, ti, rank, world, dev))
         return "sharding.fused_predict_shard(rank %d of %d, rows %s) == the direct C-ABI call (%s): bit-equal" % (
             rank, world, bounds, "af_fused_predict_antennas_c128" if self.antennas else "af_fused_predict_c128")
+
+    def _front_end_forensics(self, vis, d_vis, ti, rank, world, dev):
+        """A front-end result that differs from the direct call's: everything needed to tell host planner from scratch
+        aliasing from kernel -- digests of both calls' plan arrays, a THIRD and FOURTH opinion (the
+        direct call and the front-end once more, each into a fresh buffer), where the bits differ ((timestep, channel)
+        workgroups, 8 x 8-antenna tiles, correlations), NaN or value.  Written to gpurun_out/front_end_mismatch_*.json
+        (+ .npz with the differing cells) and returned as the failure text."""
+        import ctypes
+        import hashlib
+        import json
+        import torch
+        from codex_africanus_amd import sharding
+        from codex_africanus_amd.rime import fused
+        v, a = self.dv, self.args
+        torch.cuda.synchronize(dev)
+        dig = lambda x: hashlib.blake2b(np.ascontiguousarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x)
+                                        .view(np.uint8).reshape(-1), digest_size=8).hexdigest()
+        rep = {"rank": rank, "world": world, "pid": os.getpid(), "time": time.time()}
+        A_, B_ = torch.view_as_real(vis), torch.view_as_real(d_vis)
+        bad = ((A_ != B_) | torch.isnan(A_) | torch.isnan(B_)).any(-1)
+        idx = bad.nonzero()
+        rows = idx[:, 0]
+        rep["cells"] = int(idx.shape[0])
+        rep["nan_front_end"], rep["nan_direct"] = int(torch.isnan(A_).sum()), int(torch.isnan(B_).sum())
+        rep["largest_difference"] = float(torch.nan_to_num(A_ - B_).abs().max())
+        steps = (rows // self.nbl)
+        rep["timesteps"] = sorted(set(steps.tolist()))[:64]
+        rep["channels"] = sorted(set(idx[:, 1].tolist()))
+        rep["correlations"] = sorted(set(idx[:, 2].tolist()))
+        wg = torch.stack([steps, idx[:, 1]], 1).unique(dim=0, return_counts=True)
+        rep["workgroups_t_chan_cells"] = [[int(x[0]), int(x[1]), int(c)] for x, c in zip(wg[0][:64], wg[1][:64])]
+        a1 = torch.from_numpy(self.h["ant1"]).to(dev)[rows].long()
+        a2 = torch.from_numpy(self.h["ant2"]).to(dev)[rows].long()
+        tl = torch.stack([a1 // 8, a2 // 8], 1).unique(dim=0, return_counts=True)
+        rep["tiles_p8_q8_cells"] = [[int(x[0]), int(x[1]), int(c)] for x, c in zip(tl[0][:64], tl[1][:64])]
+        rep["antennas_p"] = sorted(set(a1.tolist()))[:64]
+        rep["antennas_q"] = sorted(set(a2.tolist()))[:64]
+        # the two calls' plan arrays: the bench's own (made on the host at start-up) against the front-end's cached plan
+        plan = fused.cached_plan(ti, v["a1"], v["a2"], self.NANT, uvw=v["uvw"])
+        rep["plan"] = {"decomposable": bool(plan.decomposable), "fill": plan.fill, "residual": plan.residual}
+        if plan.decomposable and self.antennas:
+            rep["plan"].update(
+                ant_uvw_front_end=dig(plan.ant_uvw), ant_uvw_direct=dig(self.d_au), rowmap_front_end=dig(plan.rowmap),
+                rowmap_direct=dig(self.d_rm),
+                ant_uvw_device_copy=[dig(t_) for k_, t_ in plan._dev.items() if k_[0] == id(plan.ant_uvw)],
+                rowmap_device_copy=[dig(t_) for k_, t_ in plan._dev.items() if k_[0] == id(plan.rowmap)])
+        rep["inputs"] = {k_: dig(v[k_]) for k_ in ("lm", "uvw", "freq", "X", "pa", "pe", "asc", "beam", "ext", "fmap")}
+        rep["inputs_host"] = {k_: dig(self.h[k2]) for k_, k2 in (("lm", "lm"), ("uvw", "uvw"), ("freq", "freq"), ("X", "X"), ("pa", "pa"),
+                                                                ("pe", "pe"), ("asc", "asc"), ("beam", "beam"))}
+        # third and fourth opinions
+        P = lambda x: ctypes.c_void_p(x.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        C = torch.full_like(d_vis, complex(float("nan"), 0.0))
+        self.predict(C, stream, P)
+        D, _, _ = sharding.fused_predict_shard(rank, world, ti, v["a1"], v["a2"], v["lm"], v["uvw"], v["freq"], v["X"], v["beam"], v["ext"],
+                                               v["fmap"], v["pa"], v["pe"], v["asc"], bounds=(rank * a.rows, (rank + 1) * a.rows))
+        D = D.reshape(d_vis.shape)
+        torch.cuda.synchronize(dev)
+        eq = lambda x, y: bool(torch.equal(x, y))
+        rep["agreement"] = {"front_end==direct": eq(vis, d_vis), "direct==direct_again": eq(d_vis, C), "front_end==front_end_again": eq(vis, D),
+                            "direct_again==front_end_again": eq(C, D), "front_end==direct_again": eq(vis, C),
+                            "direct==front_end_again": eq(d_vis, D)}
+        rep["digests"] = {"front_end": dig(vis), "direct": dig(d_vis), "direct_again": dig(C), "front_end_again": dig(D)}
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        tag = "%d_%d_%d" % (int(rep["time"]), os.getpid(), rank)
+        n = min(int(idx.shape[0]), 200000)
+        np.savez_compressed(os.path.join(out_dir, "front_end_mismatch_%s.npz" % tag), idx=idx[:n].cpu().numpy(),
+                            front_end=vis[bad][:n].cpu().numpy(), direct=d_vis[bad][:n].cpu().numpy(),
+                            direct_again=C[bad][:n].cpu().numpy())
+        with open(os.path.join(out_dir, "front_end_mismatch_%s.json" % tag), "w") as f:
+            json.dump(rep, f, indent=1)
+        return ("rank %d: sharding.fused_predict_shard differs from the C-ABI call in %d cells (NaNs %d / %d, largest difference "
+                "%.3e); forensics: %s" % (rank, rep["cells"], rep["nan_front_end"], rep["nan_direct"], rep["largest_difference"],
+                                          json.dumps(rep)))
 
     def _chain(self, rows, dde=None, tinv=None):
         """The reference chain on `rows` (only their timesteps' Jones terms are built)."""

@@ -413,20 +413,32 @@ class Call(object):
             nbuf = _OwnedBuffer(nrow * out_row_bytes)
             self._owned.append(nbuf)
         host = arr.ctypes.data
-        for r0, r1 in zip(cuts[:-1], cuts[1:]):
-            launch(r0, r1, ctypes.c_void_p(buf.ptr + r0 * row_bytes))
-            src = buf.ptr + r0 * row_bytes
-            if narrow:
-                n = (r1 - r0) * row_bytes // 8       # doubles in, floats out (complex = pairs)
-                _lib.call("af_convert_f64_to_f32", ctypes.c_void_p(src), ctypes.c_void_p(nbuf.ptr + r0 * out_row_bytes), n,
-                          self.stream)
-                src = nbuf.ptr + r0 * out_row_bytes
-            _lib.call("af_event_record", event, self.stream)
-            _lib.call("af_stream_wait_event", copy_stream, event)
-            _lib.call("af_memcpy_d2h", ctypes.c_void_p(host + r0 * out_row_bytes), ctypes.c_void_p(src),
-                      (r1 - r0) * out_row_bytes, copy_stream)
-        _lib.call("af_stream_synchronize", copy_stream)
-        _lib.call("af_stream_synchronize", self.stream)
+        flags = ctypes.c_int32(0)
+        try:
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                launch(r0, r1, ctypes.c_void_p(buf.ptr + r0 * row_bytes))
+                src = buf.ptr + r0 * row_bytes
+                if narrow:
+                    n = (r1 - r0) * row_bytes // 8       # doubles in, floats out (complex = pairs)
+                    _lib.call("af_convert_f64_to_f32", ctypes.c_void_p(src), ctypes.c_void_p(nbuf.ptr + r0 * out_row_bytes), n,
+                              self.stream)
+                    src = nbuf.ptr + r0 * out_row_bytes
+                _lib.call("af_event_record", event, self.stream)
+                _lib.call("af_stream_wait_event", copy_stream, event)
+                _lib.call("af_memcpy_d2h", ctypes.c_void_p(host + r0 * out_row_bytes), ctypes.c_void_p(src),
+                          (r1 - r0) * out_row_bytes, copy_stream)
+            if self._status is not None:
+                _lib.call("af_memcpy_d2h", ctypes.byref(flags), self._status[0], 4, self.stream)
+        finally:
+            # also on an error inside the loop: downloads already queued write into `arr` and read `buf` / `nbuf`, which go
+            # back to their pools when this call ends -- nothing may still be in flight then
+            for st in (copy_stream, self.stream):
+                try:
+                    _lib.call("af_stream_synchronize", st)
+                except Exception:
+                    pass
+        if self._status is not None and flags.value:
+            raise ValueError(self._status[1](flags.value))
         return arr
 
     def result(self, handle, cast=None):

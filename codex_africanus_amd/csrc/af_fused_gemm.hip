@@ -60,9 +60,28 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_gemm_prof[8];
 #define AF_PROF_NOW() ((unsigned long long)__builtin_readcyclecounter())
 #define AF_PROF_ON 1
+// Timing perturbation (profiling build only): with a non-zero seed (af_debug_gemm_jitter) every wave
+// sleeps a pseudo-random 0 .. ~8000 cycles -- up to a whole batch -- at about one in three of the sites around the batch
+// barriers (matrix waves: behind the barrier and behind their burst; sampling waves: before / behind the barrier and
+// between the rounds' arithmetic and the next geometry).  The panel-buffer protocol must not care: results are required
+// bit-equal to the unperturbed kernel's in DIAG, RECT and STRADDLE instantiations (tools/stress_gemm_jitter.py).
+__device__ unsigned g_gemm_jitter;
+__device__ __forceinline__ void af_jitter(unsigned salt)
+{
+    const unsigned seed = g_gemm_jitter;
+    if (seed == 0) return;
+    unsigned h = seed ^ (blockIdx.x * 0x9E3779B1u) ^ (blockIdx.y * 0x85EBCA77u) ^ (blockIdx.z * 0xC2B2AE3Du) ^
+                 ((salt + 64u * (threadIdx.x >> 6)) * 0x27D4EB2Fu);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+    if (h % 3u != 0) return;
+    const int n = (h >> 8) & 127;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
 #else
 #define AF_PROF_NOW() 0ull
 #define AF_PROF_ON 0
+__device__ __forceinline__ void af_jitter(unsigned) {}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -182,9 +201,11 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
 #pragma unroll
     for (int j = 0; j < CN; ++j) p1[j] = p2[j] = p3[j] = (v4d){0.0, 0.0, 0.0, 0.0};
     int buf = 0;
-    unsigned long long prof_mfma = 0, prof_bar = 0, prof_t = AF_PROF_NOW();
+    [[maybe_unused]] unsigned long long prof_mfma = 0, prof_bar = 0, prof_t = AF_PROF_NOW();
     for (int b = 0; b < nbatch; ++b) {
+        af_jitter(4u * b + 1u);
         __syncthreads();
+        af_jitter(4u * b + 2u);
         if (AF_PROF_ON) { const unsigned long long n = AF_PROF_NOW(); prof_bar += n - prof_t; prof_t = n; }
         // (the SIMD's sampling wave runs order B: its rounds' arithmetic comes first after the barrier -- let it have the
         // pipe, start the burst later)
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         return c;
     };
     Coords nxt = fetch(G::STRADDLE ? term_flat(0) : term_at(0, 0));
-    unsigned long long prof_geo = 0, prof_wait = 0, prof_fin = 0, prof_sbar = 0, prof_st = AF_PROF_NOW();
+    [[maybe_unused]] unsigned long long prof_geo = 0, prof_wait = 0, prof_fin = 0, prof_sbar = 0, prof_st = AF_PROF_NOW();
     auto prof_mark = [&](unsigned long long &acc) {
         if (AF_PROF_ON) { const unsigned long long n = AF_PROF_NOW(); acc += n - prof_st; prof_st = n; }
     };
@@ -395,6 +416,7 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         C2 kph;
         int info, slot, src;     // info: LDS offset (doubles, panel buffer included) of the term's planes | col_term << 30 | have << 31
         double2 xw[4];           // TPS == 64: the wave's source's brightness (scalar registers)
+        double2 xb0, xb1;        // otherwise: column ej of the QUAD's source's brightness (see geometry)
     };
     struct Round {               // one round's gathers (what identifies the round's term is re-broadcast when it is consumed)
         double2 v[4];
@@ -429,6 +451,16 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             for (int c = 0; c < 4; ++c) S.xw[c] = bp[c];
         }
         S.src = have ? T.src : 0;
+        if constexpr (TPS != 64) {
+            // The four terms of a quad are four consecutive slots of ONE source (TPS and the super-round's first term
+            // are multiples of 4), so the brightness column this lane multiplies with in each of the four rounds is the
+            // same two values: loaded HERE, once per super-round and ahead of the gathers.  (Until round 6 every round
+            // loaded them again inside its arithmetic -- behind the gathers in the vector-memory queue, i.e. four more
+            // dependent memory round trips per super-round: the RECT super-tile's batch took 13 100 cycles where a DIAG
+            // batch of 36 tiles takes 6 700.)  A padded slot (have == false) still belongs to a real source.
+            const double2 *bp = brightness + ((int64_t)(T.src < nsrc ? T.src : 0) * nchan + f) * 4;
+            S.xb0 = bp[ej]; S.xb1 = bp[2 + ej];
+        }
         const double2 lm2 = nxt.lm;
         const double nn = nxt.n;
         nxt = fetch(Tn);
@@ -482,9 +514,7 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             const double2 b0 = ej ? S.xw[1] : S.xw[0], b1 = ej ? S.xw[3] : S.xw[2];
             B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
         } else {
-            const double2 *bp = brightness + ((int64_t)quad_bcast<QL>(S.src) * nchan + f) * 4;
-            const double2 b0 = bp[ej], b1 = bp[2 + ej];
-            B0.re = b0.x; B0.im = b0.y; B1.re = b1.x; B1.im = b1.y;
+            B0.re = S.xb0.x; B0.im = S.xb0.y; B1.re = S.xb1.x; B1.im = S.xb1.y;
         }
         C2 Gv = cmul(A0, B0);
         cmac(Gv, A1, B1);
@@ -594,13 +624,16 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             // burst-delay loop removed 89.0.  Measured with tools/ab_libs.sh on three builds; do not "simplify".)
             const Pos q = next_pos(p);
             const bool more = valid(q), bar = completes(p);
+            af_jitter(4u * p.sr + 1u);
             if (bar && !order_b) { sampler_barrier(); prof_mark(prof_sbar); }
+            af_jitter(4u * p.sr + 2u);
             if (more) {
                 geometry(term_of(q), term_of(next_pos(q)), S);
                 issue(I0{}, S, R0); issue(I1{}, S, R1); issue(I2{}, S, R2); issue(I3{}, S, R3);
                 prof_mark(prof_geo);
             }
             if (bar && order_b) { sampler_barrier(); prof_mark(prof_sbar); }
+            af_jitter(4u * p.sr + 3u);
             if (!more) break;
             p = q;
         }
@@ -616,6 +649,13 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
 }  // namespace
 
 #ifdef AFHIP_STAGE_HOOKS
+// profiling build only: seed of the timing perturbation (0 = off)
+AF_EXPORT int af_debug_gemm_jitter(unsigned seed)
+{
+    AF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_jitter), &seed, sizeof(seed)));
+    return AF_OK;
+}
+
 // profiling build only: read (and optionally reset) the GEMM kernel's phase timers
 AF_EXPORT int af_debug_gemm_prof(unsigned long long *out8, int reset)
 {
@@ -851,7 +891,7 @@ AF_EXPORT int64_t af_fused_gemm_slots(int64_t nant)
 // The antenna-decomposed form of af_fused_predict_c128: same arguments, with the plan of af_fused_plan_antennas
 // (DEVICE copies: ant_uvw (nsteps, nant, 3), rowmap (nsteps, nap, nap)) in place of uvw, antenna1 / antenna2 and the
 // items; nsteps <= ntime; every row of `out` that the row map names is written, nothing else is touched.  Same workspace
-// as af_fused_predict_c128 (af_fused_predict_workspace_bytes).  nant <= 64; no gauss_shape.
+// as af_fused_predict_c128 (af_fused_predict_workspace_bytes).  nant <= 256; no gauss_shape.
 AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
                                              const double *lm, const double *frequency, const double *brightness,
                                              int64_t nsrc, int64_t nchan, const double *beam, int64_t beam_lw,
@@ -924,8 +964,12 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     // sources per batch: about one super-round of the 256 sampling lanes, the panel buffers within ~130 KB
     // which of the four sampling waves run order B (bit w = wave 8 + w; see the kernel): waves 10 and 11 by default.
     // AFHIP_GEMM_ORDER_B = another mask (A/B hook between correct schedules; 0 = round 4's order for all)
-    int order_b_mask = getenv("AFHIP_GEMM_ORDER_B") ? atoi(getenv("AFHIP_GEMM_ORDER_B")) & 15 : 0;
-    int burst_delay = getenv("AFHIP_GEMM_BURST_DELAY") ? atoi(getenv("AFHIP_GEMM_BURST_DELAY")) : 0;   // 64-cycle units
+    // (profiling build only, like the other stage hooks: the shipped library does not read the environment; the delay is
+    // clamped -- every matrix wave sleeps it on every batch)
+    static const int order_b_env = AF_STAGE_ENV("AFHIP_GEMM_ORDER_B", 0) & 15;
+    static const int burst_delay_env = AF_STAGE_ENV("AFHIP_GEMM_BURST_DELAY", 0);   // 64-cycle units
+    int order_b_mask = order_b_env;
+    int burst_delay = burst_delay_env < 0 ? 0 : (burst_delay_env > 4096 ? 4096 : burst_delay_env);
 #define AF_GEMM_K(RECTC, NBRC, NBCC, STC)                                                                              \
     (feed ? reinterpret_cast<const void *>(fused_gemm3_kernel<true, RECTC, NBRC, NBCC, STC>)                            \
           : reinterpret_cast<const void *>(fused_gemm3_kernel<false, RECTC, NBRC, NBCC, STC>)),                         \

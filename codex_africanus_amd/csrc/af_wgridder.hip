@@ -72,40 +72,68 @@ uint64_t g_plan_tick = 0;
 // A side stream per caller stream (image -> vis): the visibility sort and the zero fill of the output band need nothing
 // from the plane transforms, are bound by atomics' latency where those are bound by HBM, and run beside them: the side
 // stream starts behind everything the caller's stream holds at the call (`fork`), the tile pass waits for it (`join`).
-// Keyed and released like the FFT plans (af_wgrid_drop_stream, af_wgrid_shutdown); bounded: an entry whose caller
-// stream is gone is only ever one stream and two events, and past WG_MAX_SIDE caller streams a call simply runs its sort on
-// the caller's stream.
-struct WgSide { hipStream_t stream; hipEvent_t fork, join; };
-std::map<std::pair<int, hipStream_t>, WgSide> g_side;
+// Keyed and released like the FFT plans (af_wgrid_drop_stream, af_wgrid_shutdown); bounded by WG_MAX_SIDE entries with
+// least-recently-used eviction (wg_side_stream).
+struct WgSide { hipStream_t stream; hipEvent_t fork, join; int dev; };
+struct WgSideEntry { WgSide s; uint64_t tick; int users; };
+std::map<std::pair<int, hipStream_t>, WgSideEntry> g_side;
 constexpr size_t WG_MAX_SIDE = 64;
+static void wg_side_destroy(WgSide &s)
+{
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.fork) (void)hipEventDestroy(s.fork);
+    if (s.join) (void)hipEventDestroy(s.join);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = WgSide{};
+}
+// Takes a USE of the caller stream's side stream (wg_side_done gives it back when the call has enqueued its last
+// operation on it).  Caller streams the library never sees destroyed (torch streams in device mode) leave entries
+// behind: past WG_MAX_SIDE the least recently used entry that no call is using is synchronised and destroyed (under the
+// lock), so a long-lived process with many short-lived streams keeps the overlap; only when every entry is in
+// use does a call go without (out.stream == nullptr: its sort runs on the caller's stream).
 int wg_side_stream(hipStream_t st, WgSide &out)
 {
     int dev = 0;
+    out = WgSide{};
     AF_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(g_plan_mu);
     auto it = g_side.find({dev, st});
     if (it == g_side.end()) {
-        if (g_side.size() >= WG_MAX_SIDE) {           // more caller streams than anyone should have: this one goes without
-            out = WgSide{};                           // (another thread may be using any of the existing ones: none is destroyed here)
-            return AF_OK;
+        if (g_side.size() >= WG_MAX_SIDE) {
+            auto lru = g_side.end();
+            for (auto j = g_side.begin(); j != g_side.end(); ++j)
+                if (j->second.users == 0 && j->first.first == dev && (lru == g_side.end() || j->second.tick < lru->second.tick)) lru = j;
+            if (lru == g_side.end()) return AF_OK;
+            wg_side_destroy(lru->second.s);
+            g_side.erase(lru);
         }
-        WgSide e{};
-        AF_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
-        AF_HIP(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming));
-        AF_HIP(hipEventCreateWithFlags(&e.join, hipEventDisableTiming));
+        WgSideEntry e{};
+        e.s.dev = dev;
+        hipError_t err = hipStreamCreateWithFlags(&e.s.stream, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e.s.fork, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e.s.join, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            wg_side_destroy(e.s);                     // nothing half-made stays behind
+            AF_HIP(err);
+        }
         it = g_side.emplace(std::make_pair(dev, st), e).first;
     }
-    out = it->second;
+    it->second.tick = ++g_plan_tick;
+    ++it->second.users;
+    out = it->second.s;
     return AF_OK;
+}
+void wg_side_done(int dev, hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    auto it = g_side.find({dev, st});
+    if (it != g_side.end() && it->second.users > 0) --it->second.users;
 }
 void wg_side_release(bool all, hipStream_t st)
 {
     for (auto it = g_side.begin(); it != g_side.end();) {
         if (all || it->first.second == st) {
-            (void)hipStreamSynchronize(it->second.stream);
-            (void)hipEventDestroy(it->second.fork);
-            (void)hipEventDestroy(it->second.join);
-            (void)hipStreamDestroy(it->second.stream);
+            wg_side_destroy(it->second.s);
             it = g_side.erase(it);
         } else {
             ++it;
@@ -862,17 +890,46 @@ __global__ __launch_bounds__(WG_FINE_T) void wg_sort_fine(const int2 *__restrict
     }
 }
 
-// chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them
+// chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them.
+// close_at > 0 (image -> vis; round 6): a tile's list is sorted by w bucket (= first plane while there are no more planes
+// than buckets), and a chunk that runs across a bucket boundary makes its workgroup stage one more plane per boundary
+// with only part of its lanes at work in the first and last of them.  A chunk is therefore CLOSED at the first bucket
+// boundary at which it holds >= close_at visibilities; a shorter piece runs on into the next bucket (a chunk costs its
+// planes whatever its fill).  The chunk's length then no longer follows from the table: packed into the record,
+// x = tile | (n - 1) << WG_CHUNK_TILE_BITS.  At most ntiles + nvis / close_at + 1 chunks.
+constexpr int WG_CHUNK_TILE_BITS = 23;
+constexpr int WG_CHUNK_CLOSE = 160;
 __global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int chunk, int2 *__restrict__ chunks,
-                              int *__restrict__ nchunks)
+                              int *__restrict__ nchunks, int close_at)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const int lo = start[t * kb], hi = start[(t + 1) * kb];
-    const int n = (hi - lo + chunk - 1) / chunk;
-    if (n == 0) return;
-    const int base = atomicAdd(nchunks, n);
-    for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
+    if (hi <= lo) return;
+    if (close_at <= 0) {
+        const int n = (hi - lo + chunk - 1) / chunk;
+        const int base = atomicAdd(nchunks, n);
+        for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
+        return;
+    }
+    // two passes over the same cuts: count, then write behind one atomic
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int pos = lo, n = 0, b = 1;                          // b: the next bucket boundary start[t * kb + b] to look at
+        while (pos < hi) {
+            int end = pos + chunk < hi ? pos + chunk : hi;
+            while (b < kb && start[t * kb + b] <= pos) ++b;
+            for (int c = b; c < kb; ++c) {
+                const int at = start[t * kb + c];
+                if (at >= end) break;
+                if (at - pos >= close_at) { end = at; break; }
+            }
+            if (pass) chunks[base + n] = make_int2(t | ((end - pos - 1) << WG_CHUNK_TILE_BITS), pos);
+            ++n;
+            pos = end;
+        }
+        if (!pass) base = atomicAdd(nchunks, n);
+    }
 }
 
 // one workgroup per chunk: vis[...] += sum over the resident planes [pk0, pk1) the chunk's visibilities touch
@@ -884,7 +941,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
                                                        int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
                                                        const int *__restrict__ nchunks, double2 *__restrict__ vis,
-                                                       const WgPoly poly, int xcd_order)
+                                                       const WgPoly poly, int xcd_order, int packed_chunks, int concentrate)
 {
     constexpr int R = WG_TILE + W - 1;
     constexpr int NL = (R * R + 255) / 256;
@@ -902,12 +959,18 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         if (((int)blockIdx.x >> 3) >= per) return;
     }
     if (cidx >= total) return;
-    const int2 ch = chunks[cidx];
+    int2 ch = chunks[cidx];
     const int tid = threadIdx.x;
     const int nty = (int)((nv + WG_TILE - 1) / WG_TILE);
+    int n;
+    if (packed_chunks) {                                    // chunks closed at bucket boundaries carry their length
+        n = ((unsigned)ch.x >> WG_CHUNK_TILE_BITS) + 1;
+        ch.x &= (1 << WG_CHUNK_TILE_BITS) - 1;
+    } else {
+        n = start[(ch.x + 1) * kb] - ch.y;
+        n = n > WG_CHUNK ? WG_CHUNK : n;
+    }
     const int tu = ch.x / nty, tv = ch.x - tu * nty;
-    int n = start[(ch.x + 1) * kb] - ch.y;
-    n = n > WG_CHUNK ? WG_CHUNK : n;
 
     // Which lane takes which visibility.  Every lane reads its own W x W cells with ds_read_b128, which the LDS serves
     // in four fixed groups of 16 lanes, one cycle per group when the 16 lanes hit 16 different 16-byte slots of the
@@ -917,11 +980,19 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     // the s-th lane of a group, 16 groups = 16 places per slot value -- and the ~10 % that do not fit (random cells
     // do not fill 16 x 16 evenly) take the places left over.  Measured before: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
     // = 0.59 with the LDS 85 % busy.
-    __shared__ unsigned place[WG_CHUNK], spill[WG_CHUNK];
-    __shared__ int per_slot[16], nspill, nfree;
+    // The visibilities beyond 16 of a slot value cannot be placed without a conflict (16 groups, one place per slot value
+    // each), but what they cost depends on WHERE they go: a group's read takes as many cycles as its busiest bank has
+    // distinct addresses, so sixteen surplus lanes of sixteen DIFFERENT slot values in one group cost that group one extra
+    // cycle, while the same sixteen spread over sixteen groups cost sixteen.  Round 6: the (16 + m)-th visibility of a slot
+    // value goes to group 15 - m -- at most one surplus lane per slot value and group, into the places that group has
+    // free (it holds the 16 - m-th of each slot value: about half of them exist) -- and only what finds no place there
+    // takes any place left over.  (Until round 6 every surplus lane took the next free place anywhere:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 with the LDS 80 % busy.)
+    __shared__ unsigned place[WG_CHUNK], spill[WG_CHUNK], gspill[16][16];
+    __shared__ int per_slot[16], gcount[16], gtaken[16], nspill, nfree;
     constexpr unsigned NOBODY = 0xffffffffu;
     place[tid] = NOBODY;
-    if (tid < 16) per_slot[tid] = 0;
+    if (tid < 16) { per_slot[tid] = 0; gcount[tid] = 0; gtaken[tid] = 0; }
     if (tid == 0) { nspill = 0; nfree = 0; }
     __syncthreads();
     if (tid < n) {
@@ -937,9 +1008,27 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
             // the s-th lane of ds_read_b128's lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and + 32)
             const int even = s < 4 ? s : (s < 8 ? s + 8 : s + 12), odd = s < 8 ? s + 4 : (s < 12 ? s + 8 : s + 16);
             place[(rank >> 2) * 64 + (rank & 2) * 16 + ((rank & 1) ? odd : even)] = i;
+        } else if (rank < 2 * (WG_CHUNK / 16) && concentrate) {
+            const int g = 31 - rank;                         // group 15 - (rank - 16): at most one entry per slot value
+            gspill[g][atomicAdd(&gcount[g], 1)] = i;
         } else {
             spill[atomicAdd(&nspill, 1)] = i;
         }
+    }
+    __syncthreads();
+    if (concentrate) {
+        // this lane's group (the inverse of the placement above)
+        const int l32 = tid & 31;
+        const int odd_group = (l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28;
+        const int grp = (tid >> 6) * 4 + ((tid >> 5) & 1) * 2 + odd_group;
+        if (place[tid] == NOBODY && gcount[grp] > 0) {
+            const int e = atomicAdd(&gtaken[grp], 1);
+            if (e < gcount[grp]) place[tid] = gspill[grp][e];
+        }
+        __syncthreads();
+        // what found no place in its group goes to the common list
+        const int g = tid >> 4, e = tid & 15;
+        if (e >= gtaken[g] && e < gcount[g]) spill[atomicAdd(&nspill, 1)] = gspill[g][e];
     }
     __syncthreads();
     if (place[tid] == NOBODY) {
@@ -1499,7 +1588,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.vcursor = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vidx = take((size_t)nvis_max * sizeof(unsigned));
     w.vkr = take((size_t)nvis_max * sizeof(int2));              // (key, rank within the bin) of the one-pass sort
-    w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / WG_CHUNK + 1) * sizeof(int2));
+    w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / 64 + 1) * sizeof(int2));   // (chunks closed at >= 64: wg_vis_chunks)
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.stage_in = take((size_t)(nx * nv) * 2 * sizeof(double));   // image -> vis: the first transform's input (zero band kept)
     w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
@@ -1736,7 +1825,11 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             joined = true;
             if (hipEventRecord(s->join, s->stream) == hipSuccess) (void)hipStreamWaitEvent(main, s->join, 0);
         }
-        ~SideJoin() { join(); }
+        ~SideJoin()
+        {
+            join();
+            if (s && s->stream) wg_side_done(s->dev, main);
+        }
     } side_join;
     if (beside) {
         const int rc = wg_side_stream(st, side);
@@ -1744,11 +1837,13 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         beside = side.stream != nullptr;
     }
     if (beside) {
+        side_join.s = &side;          // (from here on the use is given back, error return or not)
+        side_join.main = st;
+        side_join.joined = true;      // nothing to join until the fork below has succeeded
         AF_HIP(hipEventRecord(side.fork, st));
         AF_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        side_join.joined = false;
         sst = side.stream;
-        side_join.s = &side;
-        side_join.main = st;
     }
     hipLaunchKernelGGL(wg_geometry, dim3((unsigned)af_cdiv((nx / 2 + 1) * (ny / 2 + 1), 256)), dim3(256), 0, st, nx, ny, cellx, celly, corr_u, corr_v, quad_t, quad_w,
                        kernel_width, beta, dw, do_wstacking, A, nm1, adjoint ? nullptr : image);
@@ -1779,8 +1874,12 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     int *vcount = reinterpret_cast<int *>(ws + L.vcount), *vstart = reinterpret_cast<int *>(ws + L.vstart);
     const unsigned *vidx = reinterpret_cast<unsigned *>(ws + L.vidx);
     const int2 *chunks = reinterpret_cast<int2 *>(ws + L.chunks);
-    const unsigned max_chunks = (unsigned)(ntiles + nvis / chunk + 1);
     int kb = wg_kb(nplanes);
+    // image -> vis: chunks closed at w-bucket boundaries (wg_vis_chunks; AFHIP_WGRID_CLOSE=0: plain cuts of 256, for A/B runs)
+    static const int conc_env = getenv("AFHIP_WGRID_CONCENTRATE") ? atoi(getenv("AFHIP_WGRID_CONCENTRATE")) : 1;     // A/B: 0 = round 5's dealing
+    static const int close_env = getenv("AFHIP_WGRID_CLOSE") ? atoi(getenv("AFHIP_WGRID_CLOSE")) : 0;   // A/B: default off until measured
+    const int close_at = (!adjoint && kb > 1 && ntiles < (1 << WG_CHUNK_TILE_BITS) && close_env > 0) ? (close_env > WG_CHUNK ? WG_CHUNK : (close_env < 64 ? 64 : close_env)) : 0;
+    const unsigned max_chunks = (unsigned)(ntiles + nvis / (close_at > 0 ? close_at : chunk) + 1);
     const int *nchunks = nullptr;
     auto sort_visibilities = [&](int exact, int kfirst) -> int {
         const int nbins = ntiles * kb;
@@ -1816,7 +1915,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                                NB, nbins, offs + hn, vstart, reinterpret_cast<unsigned *>(ws + L.vidx));
             AF_LAUNCH_CHECK();
             hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
-                               reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
+                               reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1, exact ? 0 : close_at);
             AF_LAUNCH_CHECK();
             nchunks = vcount + nbins + 1;
             return AF_OK;
@@ -1840,7 +1939,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                                reinterpret_cast<unsigned *>(ws + L.vidx));
         AF_LAUNCH_CHECK();
         hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
-                           reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
+                           reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1, exact ? 0 : close_at);
         AF_LAUNCH_CHECK();
         nchunks = vcount + nbins + 1;
         return AF_OK;
@@ -2015,7 +2114,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL((wg_degrid_tiles<WC, P>), dim3(max_chunks + 8), dim3(256), 0, st, uvw, freq, nchan_band,      \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
                            pk0, pk1, do_wstacking, vidx, vstart, kb, chunks, nchunks, reinterpret_cast<double2 *>(vis),  \
-                           poly, xcd_env);                                                                               \
+                           poly, xcd_env, close_at > 0, conc_env);                                                                         \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_degrid_planes<WC, P>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band,       \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \

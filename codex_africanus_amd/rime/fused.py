@@ -188,8 +188,13 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
             hit = _plan_ident.get(ikey)
             if hit is not None and all((r is None and a is None) or (r is not None and r() is a)
                                        for r, a in zip(hit[0], arrays)):
-                _plan_ident.move_to_end(ikey)
-                return hit[1]
+                plan = hit[1]()
+                if plan is not None:                 # (None: evicted from _plan_cache since -- digest and rebuild)
+                    _plan_ident.move_to_end(ikey)
+                    if hit[2] in _plan_cache:
+                        _plan_cache.move_to_end(hit[2])      # an identity hit is a use of the plan
+                    return plan
+                del _plan_ident[ikey]
     h = hashlib.blake2b(digest_size=16)
     n = 0
     for a in arrays:
@@ -214,7 +219,12 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
         import weakref
         refs = tuple(None if a is None else weakref.ref(a) for a in arrays)
         with _plan_lock:
-            _plan_ident[ikey] = (refs, plan)
+            # entries whose tensors are gone can never hit again and would keep their plan (host arrays + device copies)
+            # alive past its eviction from _plan_cache: dropped here.  The entry holds the plan WEAKLY --
+            # _plan_cache alone decides how many plans live.
+            for k in [k for k, (rs, _, _) in _plan_ident.items() if any(r is not None and r() is None for r in rs)]:
+                del _plan_ident[k]
+            _plan_ident[ikey] = (refs, weakref.ref(plan), key)
             while len(_plan_ident) > 4 * limit:
                 _plan_ident.popitem(last=False)
     return plan

@@ -237,6 +237,56 @@ def test_gemm_plan_host_side_up_to_256_antennas():
     assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 260, uvw=uvw[:10]).decomposable is False   # > 256 antennas
 
 
+def test_plan_cache_by_identity_does_not_outlive_the_plan_cache(monkeypatch):
+    """the identity index of cached_plan (tensor objects -> plan) held strong references to plans keyed by
+    tensors that no longer exist -- the row-chunk front-ends pass fresh slices every call -- so plans (host arrays + device
+    copies) outlived their eviction from the plan cache.  Host side only: CPU tensors take the same code path."""
+    import gc
+    import weakref
+    import torch
+    from codex_africanus_amd.rime import fused
+    monkeypatch.setenv("AFHIP_PLAN_CACHE", "2")
+    fused._plan_cache.clear()
+    fused._plan_ident.clear()
+    nant = 5
+    a1n, a2n = np.triu_indices(nant, 1)
+    nbl = a1n.shape[0]
+
+    def arrays(ntime):
+        ti = torch.from_numpy(np.repeat(np.arange(ntime), nbl))
+        return ti, torch.from_numpy(np.tile(a1n, ntime).astype(np.int32)), torch.from_numpy(np.tile(a2n, ntime).astype(np.int32))
+
+    ti, a1, a2 = arrays(3)
+    p = fused.cached_plan(ti, a1, a2, nant)
+    assert fused.cached_plan(ti, a1, a2, nant) is p                     # same objects, same version: identity hit
+    assert fused.cached_plan(ti[:], a1[:], a2[:], nant) is p            # fresh views (same address: same key): digest hit
+    assert len(fused._plan_ident) == 1
+    gc.collect()
+    assert fused.cached_plan(ti, a1, a2, nant) is p                     # the views are gone: their entry cannot hit, digest
+    ti.add_(0)                                                          # in-place write: the version counter moves on
+    assert fused.cached_plan(ti, a1, a2, nant) is p                     # digest hit again (same contents)
+    # the views of the call above died with it: their entry is purged at the next insert
+    assert all(all(r is None or r() is not None for r in refs) for refs, _, _ in fused._plan_ident.values())
+    # 20 other layouts through a cache of 2: the first plan is evicted and must be FREED, identity entries or not
+    ref = weakref.ref(p)
+    del p
+    keep = []
+    for k in range(20):
+        t3 = arrays(4 + k)
+        keep.append(t3)                                                 # the tensors stay alive: only the cache limit frees plans
+        fused.cached_plan(*t3, nant)
+    gc.collect()
+    assert ref() is None
+    assert len(fused._plan_cache) == 2 and len(fused._plan_ident) <= 8
+    live = [e[1]() for e in fused._plan_ident.values()]
+    assert sum(x is not None for x in live) <= 2
+    # an identity entry whose plan was evicted falls through to the digest and rebuilds
+    q = fused.cached_plan(ti, a1, a2, nant)
+    assert q.nrow == 3 * nbl and fused.cached_plan(ti, a1, a2, nant) is q
+    fused._plan_cache.clear()
+    fused._plan_ident.clear()
+
+
 def test_wgridder_plane_count_folds_the_w_range():
     """af_wgrid_planes (host arithmetic only): the planes cover [min |w|, max |w|] -- visibilities with w < 0 are evaluated
     at their mirror points (real image) -- with plane 0 W/2 - 1 spacings below the smallest |w| and no spare plane behind

@@ -480,9 +480,10 @@ def test_w_fold_one_sign_both_signs_and_the_mirror_property(nrow):
 
 
 def test_many_caller_streams_share_nothing_and_overflow_gracefully():
-    """The sort of a large image -> vis call runs on a library-owned side stream per caller stream; past 64 caller streams a
-    call sorts on the caller's stream instead (no entry another thread might be using is ever destroyed).  70 torch streams,
-    the same bits from each."""
+    """The sort of a large image -> vis call runs on a library-owned side stream per caller stream; past 64 caller streams
+    the least recently used entry that no call is using is synchronised and destroyed (round 6; until then such a call lost
+    the overlap for good), and only when every entry is in use does a call sort on the caller's stream.  70 torch streams,
+    the same bits from each -- twice, so that evicted entries come back."""
     import torch
     nx, ny, nrow, nchan = 24, 20, 30000, 3            # 90000 visibilities: the tile kernel, hence the sorted path
     cell, freq, uvw, fbi, fbc, image = _case(nx, ny, 20.0, nrow, nchan, 1, seed=77)
@@ -493,6 +494,9 @@ def test_many_caller_streams_share_nothing_and_overflow_gracefully():
     outs = []
     for s in streams:
         s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            outs.append(model(*d, fbi, fbc, cell, epsilon=1e-6))
+    for s in streams[:10] + streams[60:]:                 # entries evicted above are made again, others evicted in turn
         with torch.cuda.stream(s):
             outs.append(model(*d, fbi, fbc, cell, epsilon=1e-6))
     torch.cuda.synchronize()
