@@ -320,3 +320,89 @@ class FusedDdeAnt128(FusedDde):
     super-tiles -- two 64-antenna diagonal super-blocks and two 8 x 4-block rectangles per (timestep, channel) (round 5;
     the reference's sum has no antenna limit, africanus/rime/predict.py:199-212)."""
     FORCE_ANTENNAS = 128
+
+
+class FusedDdeAntC64(FusedDde):
+    """BASELINE configs[2]'s counts on a Measurement Set's uvw in SINGLE PRECISION: every input float32 / complex64,
+    complex64 out (af_fused_predict_antennas_c64: v_mfma_f32_16x16x4_f32 on float operand panels, float32 beam planes,
+    the antenna phasors in double) -- the precision in which the reference runs this chain for such callers
+    (africanus/util/type_inference.py:24-26).  No chi^2 in its step (the chi^2 entry is complex128).  Errors are against
+    the float64 chain on the same float32 values."""
+    vis_dtype, chi2 = "complex64", False
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        FusedDde.__init__(self, args, rank, dev, lib, _lib, t)
+        h = self.h
+        f, c = np.float32, np.complex64
+        # a Measurement Set written in single precision: float32 differences of the antenna coordinates
+        ti, a1, a2 = h["time_index"], h["ant1"], h["ant2"]
+        xyz = (np.random.default_rng(3000 + args.seed + rank).uniform(-1, 1, (self.ntime, self.NANT, 3)) *
+               np.array([2000.0, 2000.0, 200.0])).astype(f)
+        uvw = xyz[ti, a1] - xyz[ti, a2]
+        for k, dt in (("lm", f), ("freq", f), ("extents", f), ("beam_freq_map", f), ("pa", f), ("pe", f), ("asc", f), ("X", c), ("beam", c)):
+            h[k] = h[k].astype(dt)
+        h["uvw"] = uvw
+        nap = 8 * ((self.NANT + 7) // 8)
+        au, rm = np.zeros((self.ntime, self.NANT, 3)), np.zeros((self.ntime, nap, nap), np.int32)
+        res, ok = ctypes.c_double(), ctypes.c_int()
+        HP = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        uvw64 = uvw.astype(np.float64)
+        tol = float(np.abs(uvw64).max()) * 2.0 ** -22
+        _lib.call("af_fused_plan_antennas", HP(np.ascontiguousarray(ti, np.int64)), HP(a1), HP(a2), HP(uvw64), args.rows, self.NANT, tol,
+                  self.ntime, HP(au), HP(rm), ctypes.byref(res), ctypes.byref(ok))
+        if not ok.value:
+            raise SystemExit("fused_dde_ant_c64: the float32 uvw did not decompose (residual %g m, tolerance %g)" % (res.value, tol))
+        self.plan_residual = res.value
+        self.d_au, self.d_rm = t(au), t(rm)
+        self.dv = dict(X=t(h["X"]), beam=t(h["beam"]), ext=t(h["extents"]), fmap=t(h["beam_freq_map"]), pa=t(h["pa"]), pe=t(h["pe"]),
+                       asc=t(h["asc"]), lm=t(h["lm"]), uvw=t(uvw), freq=t(h["freq"]), a1=t(a1), a2=t(a2))
+        self.ws_bytes = int(lib.af_fused_predict_c64_workspace_bytes(args.sources, args.chans, self.LW, self.MH, self.NUD))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.label = ("fused predict with per-antenna beam-cube DDEs, %d antennas, Measurement-Set uvw, SINGLE precision "
+                      "(float32 / complex64 in, complex64 out): GEMM form on the fp32 matrix cores" % self.NANT)
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_fused_predict_antennas_c64", P(self.d_au), P(self.d_rm), self.ntime, a.rows, P(v["lm"]), P(v["freq"]),
+                       P(v["X"]), a.sources, a.chans, P(v["beam"]), self.LW, self.MH, self.NUD, P(v["ext"]), P(v["fmap"]), P(v["pa"]),
+                       self.ntime, self.NANT, P(v["pe"]), P(v["asc"]), None, self._lib.CONVENTION["fourier"], P(d_vis), P(self.d_ws),
+                       self.ws_bytes, stream)
+
+    def front_end_check(self, d_vis, rank, world, dev):
+        """rime.fused_predict_vis on the same single-precision tensors must take the same route: same bits"""
+        import torch
+        from codex_africanus_amd import rime
+        v = self.dv
+        ti = torch.from_numpy(self.h["time_index"]).to(dev)
+        vis = rime.fused_predict_vis(ti, v["a1"], v["a2"], v["lm"], v["uvw"], v["freq"], v["X"], v["beam"], v["ext"], v["fmap"], v["pa"],
+                                     v["pe"], v["asc"])
+        if vis.dtype != torch.complex64 or not bool(torch.equal(vis.reshape(d_vis.shape), d_vis)):
+            raise SystemExit("rank %d: rime.fused_predict_vis on single-precision tensors differs from af_fused_predict_antennas_c64" % rank)
+        return "rime.fused_predict_vis(float32 / complex64 tensors) == af_fused_predict_antennas_c64: bit-equal, complex64"
+
+    def _chain(self, rows, dde=None, tinv=None):
+        """The reference chain in float64 on the promoted single-precision values."""
+        import oracle
+        h = self.h
+        p = lambda a: a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+        if dde is None:
+            tsel, tinv = np.unique(h["time_index"][rows], return_inverse=True)
+            dde = oracle.beam_cube_dde(p(h["beam"]), p(h["extents"]), p(h["beam_freq_map"]), p(h["lm"]), p(h["pa"][tsel]),
+                                       p(h["pe"][tsel]), p(h["asc"]), p(h["freq"]))
+        phase = oracle.phase_delay(p(h["lm"]), p(h["uvw"][rows]), p(h["freq"]))
+        coh = np.einsum("srf,sfij->srfij", phase, p(h["X"]))
+        return oracle.predict_vis(tinv, h["ant1"][rows], h["ant2"][rows], dde, coh, dde, None, None, None)
+
+    def roofline(self, kernel_s):
+        r = FusedDde.roofline(self, kernel_s)
+        a = self.args
+        units = float(a.rows) * a.chans * a.sources
+        tiles = self._lib.load().af_fused_gemm_slots(self.NANT) / 64.0
+        # four-product form: 4 v_mfma_f32_16x16x4_f32 (2048 flop each) per tile and source PAIR
+        self.mfma_per_launch = tiles * 2.0 * a.sources * self.ntime * a.chans
+        r.update(kernel="fused_gemm_c64_kernel", peak_tflops=FP32_PEAK_TFLOPS,
+                 executed={"mfma_instructions": self.mfma_per_launch, "mfma_tflops": self.mfma_per_launch * 2048 / kernel_s / 1e12},
+                 note="single precision: 64 flop per (row, chan, src) (8 complex MACs) against the fp32 matrix peak (157.3 TFLOP/s); "
+                      "four-product form on v_mfma_f32_16x16x4_f32")
+        return r

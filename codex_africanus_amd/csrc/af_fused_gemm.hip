@@ -97,7 +97,7 @@ __device__ __forceinline__ void af_jitter(unsigned) {}
 // immediate offset.
 constexpr int G3_THREADS = 768, G3_MATRIX = 512, G3_SAMPLERS = 256, G3_PLANES = 6;
 
-// ---- super-tiles (round 5: 65 .. 256 antennas) ---------------------------------------------------------------------
+// ---- super-tiles (round 5: 65 .. 256 antennas; round 6: .. 512) ---------------------------------------------------------------------
 // A workgroup owns one (timestep, channel, SUPER-TILE of M): its eight matrix waves hold at most 5 tiles each (12
 // accumulator doubles per tile and lane: 168 registers at three waves per SIMD), i.e. <= 40 tiles of 8 x 8 antennas.
 //   DIAG<nb>   block rows = block columns = nb consecutive 8-antenna blocks: the upper block triangle, nb (nb + 1) / 2
@@ -112,11 +112,18 @@ constexpr int G3_THREADS = 768, G3_MATRIX = 512, G3_SAMPLERS = 256, G3_PLANES = 
 // per baseline costs 1.24 x what it does at 64 antennas, and far less than the lane-per-row kernel's arithmetic.
 // (Round 5's first tiling -- super-blocks of 4 .. 6 blocks, square RECTs of a x a tiles -- sampled 400 terms at 128
 // antennas: 160.6 ms for 1e6 rows x 64 channels x 1000 sources against 206.3 for the lane-per-row kernel.)
-template <bool RECT, int NBR, int NBC, int ST>
+//   FOURM      (round 6) the complex product in its direct four-product form on TWO accumulators per tile (8 doubles instead of
+//              the 3M form's 12): Re += Gr Hr + Gi Hi, Im += Gi Hr + Gr (-Hi), with H planes re, im, -im and G planes re, im.
+//              A matrix wave then holds EIGHT tiles in the registers that hold five in the 3M form, so a RECT super-tile can
+//              be 8 x 8 blocks: 128 sampled terms per source for 64 tiles (2.0 per tile; RECT 8 x 4: 96 for 32 = 3.0).  A
+//              third more matrix instructions per tile -- affordable exactly where it is used: a batch lasts as long as its
+//              sampling waves' serial chains (6700 cycles per 256 terms), the matrix waves' burst hides inside it.
+template <bool RECT, int NBR, int NBC, int ST, bool FOURM = false>
 struct Geo {
     static constexpr int NAR = 8 * NBR, NAC = 8 * NBC;                      // antennas of the G (row) / H (column) panels
     static constexpr int CSG = 2 * NAR + COL_PAD, CSH = 2 * NAC + COL_PAD;  // doubles per operand plane
-    static constexpr int SRC = G3_PLANES * (CSH + CSG);                     // one source: H planes, then G planes
+    static constexpr int HP = G3_PLANES, GP = FOURM ? 4 : G3_PLANES;        // planes of a source's H / G panels
+    static constexpr int SRC = HP * CSH + GP * CSG;                         // one source: H planes, then G planes
     static constexpr int BUF = ST * SRC;                                    // one batch
     static constexpr int TPS = RECT ? NAR + NAC : NAR;                      // sampled terms (antenna slots) per source
     static constexpr int BT = ST * TPS;                                     // terms per batch
@@ -259,8 +266,70 @@ __device__ __forceinline__ void matrix_wave3(const double *__restrict__ ldsd, in
     }, std::make_integer_sequence<int, CNT>{});
 }
 
+// The four-product form's matrix wave (FOURM, RECT only: wave W = block row W, NBC tiles): two accumulators per tile.
+template <int NBR, int NBC, int ST, int W>
+__device__ __forceinline__ void matrix_wave4(const double *__restrict__ ldsd, int nbatch, int only_stage, int lane,
+                                             const int32_t *__restrict__ rm, int nap, const SuperTile tile,
+                                             int64_t nchan, int64_t f, double2 *__restrict__ out)
+{
+    using G = Geo<true, NBR, NBC, ST, true>;
+    constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
+    static_assert(NBR == 8, "one block row per matrix wave");
+    const int kq = lane >> 4, c16 = lane & 15;
+    const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
+    const int offA = (kq >> 1) * SRC + G::HP * CSH + (kq & 1) * CSG + c16 + W * 16;
+    v4d cr[NBC], ci[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) cr[j] = ci[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int buf = 0;
+    for (int b = 0; b < nbatch; ++b) {
+        af_jitter(4u * b + 1u);
+        __syncthreads();
+        af_jitter(4u * b + 2u);
+        const double *P = ldsd + buf * BUF;
+        buf = buf + 1 == G::DEPTH ? 0 : buf + 1;
+        if (only_stage == 1) continue;
+#pragma unroll
+        for (int s2 = 0; s2 < ST / 2; ++s2) {
+            const double *A = P + 2 * s2 * SRC + offA, *Bp = P + 2 * s2 * SRC + offB;
+            const double gr = A[0], gi = A[2 * CSG];
+            for_each_const([&](auto jc) {
+                constexpr int qb = decltype(jc)::value;
+                if (qb >= tile.nc_act) return;                   // block-uniform: the column super-block is short
+                const double *B = Bp + qb * 16;
+                const double hr = B[0], hi = B[2 * CSH], nhi = B[4 * CSH];
+                cr[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gr, hr, cr[qb], 0, 0, 0);
+                ci[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gi, hr, ci[qb], 0, 0, 0);
+                cr[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gi, hi, cr[qb], 0, 0, 0);
+                ci[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(gr, nhi, ci[qb], 0, 0, 0);
+            }, std::make_integer_sequence<int, NBC>{});
+        }
+    }
+    if (only_stage == 1) return;
+    for_each_const([&](auto jc) {
+        constexpr int qb = decltype(jc)::value;
+        if (qb >= tile.nc_act) return;
+        const int jj = c16 & 1;
+        const int q = tile.col_ant0 + slot_antenna(qb * 8 + (c16 >> 1), 2 * tile.nc_act);
+        int r1[4], r2[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int p = tile.row_ant0 + slot_antenna(W * 8 + ((kq + 4 * reg) >> 1), G::NAR / 4);
+            r1[reg] = rm[p * nap + q];
+            r2[reg] = rm[q * nap + p];          // the same antennas the other way round: V_qp = V_pq^H
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ii = (kq + 4 * reg) & 1;
+            const double re = cr[qb][reg], im = ci[qb][reg];
+            if (r1[reg] >= 0) out[((int64_t)r1[reg] * nchan + f) * 4 + ii * 2 + jj] = make_double2(re, im);
+            if (r2[reg] >= 0) out[((int64_t)r2[reg] * nchan + f) * 4 + jj * 2 + ii] = make_double2(re, -im);
+        }
+    }, std::make_integer_sequence<int, NBC>{});
+}
+
 // grid: (nsteps, channels of the plane group, super-tiles of this shape); block 768.
-template <bool FEED, bool RECT, int NBR, int NBC, int ST>
+template <bool FEED, bool RECT, int NBR, int NBC, int ST, bool FOURM = false>
 __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
     const double *__restrict__ f4, const double2 *__restrict__ brightness, const double *__restrict__ vrec,
@@ -271,7 +340,8 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
     int order_b_mask, int burst_delay, const SuperTileList tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
-    using G = Geo<RECT, NBR, NBC, ST>;
+    static_assert(!FOURM || RECT, "the four-product form serves RECT super-tiles");
+    using G = Geo<RECT, NBR, NBC, ST, FOURM>;
     constexpr int NAR = G::NAR, NAC = G::NAC, CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF, TPS = G::TPS, BT = G::BT;
     extern __shared__ double ldsd[];
     double *ldsA = ldsd + G::DEPTH * BUF;                      // six planes of per-slot constants
@@ -327,6 +397,19 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         const int lane = tid & 63;
         // waves w, w + 4 and the sampling wave 8 + (w & 3) share a SIMD (tools/probe/probe_wave_simd.hip)
         const int wdelay = ((order_b_mask >> ((tid >> 6) & 3)) & 1) ? burst_delay : 0;
+        if constexpr (FOURM) {
+            switch (tid >> 6) {
+            case 0: matrix_wave4<NBR, NBC, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 1: matrix_wave4<NBR, NBC, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 2: matrix_wave4<NBR, NBC, ST, 2>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 3: matrix_wave4<NBR, NBC, ST, 3>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 4: matrix_wave4<NBR, NBC, ST, 4>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 5: matrix_wave4<NBR, NBC, ST, 5>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            case 6: matrix_wave4<NBR, NBC, ST, 6>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            default: matrix_wave4<NBR, NBC, ST, 7>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out); break;
+            }
+            return;
+        }
         switch (tid >> 6) {
         case 0: matrix_wave3<RECT, NBR, NBC, ST, 0>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
         case 1: matrix_wave3<RECT, NBR, NBC, ST, 1>(ldsd, nbatch, only_stage, lane, rm, nap, tile, nchan, f, out, wdelay); break;
@@ -438,7 +521,7 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
         const int h_slot = !RECT ? antenna_slot(e_slot, NAC / 4)
                                  : (!col_term ? 0 : (e_slot < 8 * tile.nc_act ? antenna_slot(e_slot, 2 * tile.nc_act) : e_slot));
         const int h_off = T.buf * BUF + e_sl * SRC + 2 * h_slot;
-        const int g_off = T.buf * BUF + e_sl * SRC + G3_PLANES * CSH + 2 * antenna_slot(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, NAR / 4);
+        const int g_off = T.buf * BUF + e_sl * SRC + G::HP * CSH + 2 * antenna_slot(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, NAR / 4);
         S.info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
         S.slot = e_slot;
         // TPS == 64: a wave's 64 lanes are ONE source's slots -- its 2 x 2 complex brightness comes in by ONE scalar
@@ -531,8 +614,14 @@ __global__ __launch_bounds__(G3_THREADS) void fused_gemm3_kernel(
             double *ws = ldsd + (info & 0x3fffffff) + ei;
             const int cs = r_col ? CSH : CSG;
             const double v0 = r_col ? A.re : Gv.re, v1 = r_col ? A.im : Gv.im;
-            const double v2 = r_col ? __dsub_rn(A.re, A.im) : __dadd_rn(Gv.re, Gv.im);
-            ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1; ws[(4 + ej) * cs] = v2;
+            if constexpr (!FOURM) {
+                const double v2 = r_col ? __dsub_rn(A.re, A.im) : __dadd_rn(Gv.re, Gv.im);
+                ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1; ws[(4 + ej) * cs] = v2;
+            } else {
+                // four-product form: H planes re, im, -im; G planes re, im (a row antenna's term has no third plane)
+                ws[ej * cs] = v0; ws[(2 + ej) * cs] = v1;
+                if (r_col) ws[(4 + ej) * CSH] = -A.im;
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -689,7 +778,7 @@ AF_EXPORT int af_fused_plan_antennas(const int64_t *time_index_host, const int32
     if (nrow == 0) { *decomposable = 1; return AF_OK; }
     AF_REQUIRE(time_index_host && antenna1_host && antenna2_host && uvw_host && ant_uvw_host && rowmap_host,
                "af_fused_plan_antennas: NULL array");
-    AF_REQUIRE(nant >= 1 && nant <= 256 && nrow < (1LL << 31) && nsteps >= 1, "af_fused_plan_antennas: bad extents");
+    AF_REQUIRE(nant >= 1 && nant <= 512 && nrow < (1LL << 31) && nsteps >= 1, "af_fused_plan_antennas: bad extents");
     int64_t tmin = time_index_host[0], tmax = tmin;
     for (int64_t r = 1; r < nrow; ++r) {
         tmin = time_index_host[r] < tmin ? time_index_host[r] : tmin;
@@ -874,10 +963,10 @@ static void gemm_tiling(int nb, GemmTiling &tl)
 }
 
 // Baseline slots (8 x 8-antenna tiles x 64) the GEMM form evaluates per (timestep, channel) for `nant` antennas: what its
-// cost is proportional to (the caller's fill-factor rule divides the rows per step by it).  0 beyond 256 antennas.
+// cost is proportional to (the caller's fill-factor rule divides the rows per step by it).  0 beyond 512 antennas.
 AF_EXPORT int64_t af_fused_gemm_slots(int64_t nant)
 {
-    if (nant < 1 || nant > 256) return 0;
+    if (nant < 1 || nant > 512) return 0;
     GemmTiling tl;
     gemm_tiling((int)((nant + 7) / 8), tl);
     int64_t tiles = 0;
@@ -891,7 +980,8 @@ AF_EXPORT int64_t af_fused_gemm_slots(int64_t nant)
 // The antenna-decomposed form of af_fused_predict_c128: same arguments, with the plan of af_fused_plan_antennas
 // (DEVICE copies: ant_uvw (nsteps, nant, 3), rowmap (nsteps, nap, nap)) in place of uvw, antenna1 / antenna2 and the
 // items; nsteps <= ntime; every row of `out` that the row map names is written, nothing else is touched.  Same workspace
-// as af_fused_predict_c128 (af_fused_predict_workspace_bytes).  nant <= 256; no gauss_shape.
+// as af_fused_predict_c128 (af_fused_predict_workspace_bytes).  nant <= 512 (64 blocks of 8 antennas in <= 8 super-blocks);
+// no gauss_shape.
 AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
                                              const double *lm, const double *frequency, const double *brightness,
                                              int64_t nsrc, int64_t nchan, const double *beam, int64_t beam_lw,
@@ -906,7 +996,7 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     AF_REQUIRE(beam_lw >= 2 && beam_mh >= 2 && beam_nud >= 2, "beam_lw, beam_mh and beam_nud must be >= 2");
     AF_REQUIRE(nsteps >= 0 && nrow >= 0 && nsrc >= 0 && nchan >= 0 && ntime >= 0 && nant >= 0,
                "af_fused_predict_antennas_c128: negative extent");
-    AF_REQUIRE(nant <= 256, "af_fused_predict_antennas_c128: more than 256 antennas (use af_fused_predict_c128)");
+    AF_REQUIRE(nant <= 512, "af_fused_predict_antennas_c128: more than 512 antennas (use af_fused_predict_c128)");
     AF_REQUIRE(nsteps <= ntime, "af_fused_predict_antennas_c128: %lld steps but %lld timesteps of per-antenna terms",
                (long long)nsteps, (long long)ntime);
     AF_REQUIRE(nsrc < (1LL << 31) && nchan <= 65535 && nsteps < (1LL << 31), "af_fused_predict_antennas_c128: too large");
@@ -974,6 +1064,13 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
     (feed ? reinterpret_cast<const void *>(fused_gemm3_kernel<true, RECTC, NBRC, NBCC, STC>)                            \
           : reinterpret_cast<const void *>(fused_gemm3_kernel<false, RECTC, NBRC, NBCC, STC>)),                         \
         Geo<RECTC, NBRC, NBCC, STC>::lds_bytes()
+#define AF_GEMM_K4(NBRC, NBCC, STC)                                                                                    \
+    (feed ? reinterpret_cast<const void *>(fused_gemm3_kernel<true, true, NBRC, NBCC, STC, true>)                       \
+          : reinterpret_cast<const void *>(fused_gemm3_kernel<false, true, NBRC, NBCC, STC, true>)),                    \
+        Geo<true, NBRC, NBCC, STC, true>::lds_bytes()
+    // pairs of super-blocks: a column super-block of more than 4 blocks takes ONE 8 x 8 super-tile in the four-product form
+    // (AFHIP_GEMM_RECT8=0 in the profiling build: round 5's two 8 x 4 super-tiles, for A/B runs)
+    static const int rect8 = AF_STAGE_ENV("AFHIP_GEMM_RECT8", 1);
     for (int i = 0; i < tl.nsb; ++i) {
         SuperTile e = {8 * tl.blk0[i], 8 * tl.blk0[i], tl.size[i], 0};
         switch (tl.size[i]) {
@@ -988,13 +1085,20 @@ AF_EXPORT int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_
         }
         // the pairs with the later super-blocks: rows = this (full, 8-block) super-block, columns = the later one in
         // chunks of <= 4 blocks (8 x 4 tiles: 4 per matrix wave, wave w = block row w)
-        for (int j = i + 1; j < tl.nsb; ++j)
+        for (int j = i + 1; j < tl.nsb; ++j) {
+            if (rect8 && tl.size[j] > RECT_COLS) {
+                SuperTile r = {8 * tl.blk0[i], 8 * tl.blk0[j], tl.size[j], 0};
+                add(AF_GEMM_K4(8, 8, 4), r);
+                continue;
+            }
             for (int c0 = 0; c0 < tl.size[j]; c0 += RECT_COLS) {
                 SuperTile r = {8 * tl.blk0[i], 8 * (tl.blk0[j] + c0), tl.size[j] - c0 < RECT_COLS ? tl.size[j] - c0 : RECT_COLS, 0};
                 add(AF_GEMM_K(true, 8, RECT_COLS, 4), r);
             }
+        }
     }
 #undef AF_GEMM_K
+#undef AF_GEMM_K4
     for (auto &s : shapes) {
         AF_REQUIRE(s.lds <= 160 * 1024, "af_fused_predict_antennas_c128: %zu bytes of LDS needed", s.lds);
         AF_HIP(hipFuncSetAttribute(s.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds));

@@ -890,46 +890,20 @@ __global__ __launch_bounds__(WG_FINE_T) void wg_sort_fine(const int2 *__restrict
     }
 }
 
-// chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them.
-// close_at > 0 (image -> vis; round 6): a tile's list is sorted by w bucket (= first plane while there are no more planes
-// than buckets), and a chunk that runs across a bucket boundary makes its workgroup stage one more plane per boundary
-// with only part of its lanes at work in the first and last of them.  A chunk is therefore CLOSED at the first bucket
-// boundary at which it holds >= close_at visibilities; a shorter piece runs on into the next bucket (a chunk costs its
-// planes whatever its fill).  The chunk's length then no longer follows from the table: packed into the record,
-// x = tile | (n - 1) << WG_CHUNK_TILE_BITS.  At most ntiles + nvis / close_at + 1 chunks.
-constexpr int WG_CHUNK_TILE_BITS = 23;
-constexpr int WG_CHUNK_CLOSE = 160;
+// chunk table: (tile, first sorted index) of every <= `chunk` visibilities of one tile; *nchunks counts them
+// (round 6, measured and removed: chunks CLOSED at the first w-bucket boundary behind 160 / 192 / 224 visibilities, so that a
+// chunk's lanes share their first plane -- 7.31 -> 7.43-7.57 ms: with bins of 30 .. 900 visibilities the number of
+// (chunk, plane) passes does not go down, the chunks get emptier)
 __global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb, int chunk, int2 *__restrict__ chunks,
-                              int *__restrict__ nchunks, int close_at)
+                              int *__restrict__ nchunks)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const int lo = start[t * kb], hi = start[(t + 1) * kb];
-    if (hi <= lo) return;
-    if (close_at <= 0) {
-        const int n = (hi - lo + chunk - 1) / chunk;
-        const int base = atomicAdd(nchunks, n);
-        for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
-        return;
-    }
-    // two passes over the same cuts: count, then write behind one atomic
-    int base = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        int pos = lo, n = 0, b = 1;                          // b: the next bucket boundary start[t * kb + b] to look at
-        while (pos < hi) {
-            int end = pos + chunk < hi ? pos + chunk : hi;
-            while (b < kb && start[t * kb + b] <= pos) ++b;
-            for (int c = b; c < kb; ++c) {
-                const int at = start[t * kb + c];
-                if (at >= end) break;
-                if (at - pos >= close_at) { end = at; break; }
-            }
-            if (pass) chunks[base + n] = make_int2(t | ((end - pos - 1) << WG_CHUNK_TILE_BITS), pos);
-            ++n;
-            pos = end;
-        }
-        if (!pass) base = atomicAdd(nchunks, n);
-    }
+    const int n = (hi - lo + chunk - 1) / chunk;
+    if (n == 0) return;
+    const int base = atomicAdd(nchunks, n);
+    for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
 }
 
 // one workgroup per chunk: vis[...] += sum over the resident planes [pk0, pk1) the chunk's visibilities touch
@@ -941,7 +915,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
                                                        int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
                                                        const int *__restrict__ nchunks, double2 *__restrict__ vis,
-                                                       const WgPoly poly, int xcd_order, int packed_chunks, int concentrate)
+                                                       const WgPoly poly, int xcd_order, int concentrate)
 {
     constexpr int R = WG_TILE + W - 1;
     constexpr int NL = (R * R + 255) / 256;
@@ -959,18 +933,12 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         if (((int)blockIdx.x >> 3) >= per) return;
     }
     if (cidx >= total) return;
-    int2 ch = chunks[cidx];
+    const int2 ch = chunks[cidx];
     const int tid = threadIdx.x;
     const int nty = (int)((nv + WG_TILE - 1) / WG_TILE);
-    int n;
-    if (packed_chunks) {                                    // chunks closed at bucket boundaries carry their length
-        n = ((unsigned)ch.x >> WG_CHUNK_TILE_BITS) + 1;
-        ch.x &= (1 << WG_CHUNK_TILE_BITS) - 1;
-    } else {
-        n = start[(ch.x + 1) * kb] - ch.y;
-        n = n > WG_CHUNK ? WG_CHUNK : n;
-    }
     const int tu = ch.x / nty, tv = ch.x - tu * nty;
+    int n = start[(ch.x + 1) * kb] - ch.y;
+    n = n > WG_CHUNK ? WG_CHUNK : n;
 
     // Which lane takes which visibility.  Every lane reads its own W x W cells with ds_read_b128, which the LDS serves
     // in four fixed groups of 16 lanes, one cycle per group when the 16 lanes hit 16 different 16-byte slots of the
@@ -1091,8 +1059,11 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     }
     if (kmin >= kmax) return;
 
-    // this lane's cells of the tile region: element e = tid + 256 q -> (row e / R, column e % R), wrapped on the grid
-    int64_t gofs[NL];
+    // this lane's cells of the tile region: element e = tid + 256 q -> (row e / R, column e % R), wrapped on the grid.
+    // 32-bit cell offsets into the plane (nu nv < 2^31 wherever this kernel runs: 16 bytes a cell) on top of a uniform
+    // plane pointer: the loads take an SGPR base and a VGPR offset, no 64-bit vector arithmetic per plane; lanes beyond the
+    // region (e >= R R) read cell 0 and never store what they read (round 6: the select per load and plane went as well).
+    unsigned gofs[NL];
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
         const int e = tid + 256 * q, a = e / R, b = e - a * R;
@@ -1101,7 +1072,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         int gu_ = tu * WG_TILE + a, gv_ = tv * WG_TILE + b;
         while (gu_ >= (int)nu) gu_ -= (int)nu;
         while (gv_ >= (int)nv) gv_ -= (int)nv;
-        gofs[q] = e < R * R ? (int64_t)gu_ * nv + gv_ : -1;
+        gofs[q] = e < R * R ? (unsigned)gu_ * (unsigned)nv + (unsigned)gv_ : 0u;
     }
     const int64_t plane = nu * nv;
     // (float32 planes are widened on their way into LDS: half the bytes from memory, the same 16-byte slots and the same
@@ -1109,7 +1080,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
     P pre[NL];
     const P *__restrict__ g = grids + (int64_t)(kmin - pk0) * plane;
 #pragma unroll
-    for (int q = 0; q < NL; ++q) pre[q] = gofs[q] >= 0 ? g[gofs[q]] : wg_cell<P>(0.0, 0.0);
+    for (int q = 0; q < NL; ++q) pre[q] = g[gofs[q]];
     double are = 0.0, aim = 0.0;
     for (int k = kmin; k < kmax; ++k) {
 #pragma unroll
@@ -1119,7 +1090,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         if (k + 1 < kmax) {                                  // next plane's cells travel while this one is summed
             g += plane;
 #pragma unroll
-            for (int q = 0; q < NL; ++q) pre[q] = gofs[q] >= 0 ? g[gofs[q]] : wg_cell<P>(0.0, 0.0);
+            for (int q = 0; q < NL; ++q) pre[q] = g[gofs[q]];
         }
         if (k >= k0 && k < k1) {
             const double kw = wg_pick<W>(kwv, k - k0u);
@@ -1588,7 +1559,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.vcursor = take((size_t)(w.nbins + 1) * sizeof(int));
     w.vidx = take((size_t)nvis_max * sizeof(unsigned));
     w.vkr = take((size_t)nvis_max * sizeof(int2));              // (key, rank within the bin) of the one-pass sort
-    w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / 64 + 1) * sizeof(int2));   // (chunks closed at >= 64: wg_vis_chunks)
+    w.chunks = take((size_t)((w.gtiles > w.ntiles ? w.gtiles : w.ntiles) + nvis_max / WG_CHUNK + 1) * sizeof(int2));
     w.stage = take((size_t)(nx * nv) * 2 * sizeof(double));
     w.stage_in = take((size_t)(nx * nv) * 2 * sizeof(double));   // image -> vis: the first transform's input (zero band kept)
     w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
@@ -1809,7 +1780,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     const unsigned nb_img = (unsigned)af_cdiv(nx * ny, 256), nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
     // large image -> vis calls: the sort and the zero fill on the side stream (wg_side_stream), beside the transforms
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
-    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31);
+    const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31) && nu * nv < (1LL << 32);   // (32-bit cell offsets in the tile kernels)
     bool beside = !adjoint && tiled && AF_STAGE_ENV("AFHIP_WGRID_SIDE", 1) != 0;
     WgSide side{};
     hipStream_t sst = st;           // the stream of the sort
@@ -1875,11 +1846,8 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     const unsigned *vidx = reinterpret_cast<unsigned *>(ws + L.vidx);
     const int2 *chunks = reinterpret_cast<int2 *>(ws + L.chunks);
     int kb = wg_kb(nplanes);
-    // image -> vis: chunks closed at w-bucket boundaries (wg_vis_chunks; AFHIP_WGRID_CLOSE=0: plain cuts of 256, for A/B runs)
+    const unsigned max_chunks = (unsigned)(ntiles + nvis / chunk + 1);
     static const int conc_env = getenv("AFHIP_WGRID_CONCENTRATE") ? atoi(getenv("AFHIP_WGRID_CONCENTRATE")) : 1;     // A/B: 0 = round 5's dealing
-    static const int close_env = getenv("AFHIP_WGRID_CLOSE") ? atoi(getenv("AFHIP_WGRID_CLOSE")) : 0;   // A/B: default off until measured
-    const int close_at = (!adjoint && kb > 1 && ntiles < (1 << WG_CHUNK_TILE_BITS) && close_env > 0) ? (close_env > WG_CHUNK ? WG_CHUNK : (close_env < 64 ? 64 : close_env)) : 0;
-    const unsigned max_chunks = (unsigned)(ntiles + nvis / (close_at > 0 ? close_at : chunk) + 1);
     const int *nchunks = nullptr;
     auto sort_visibilities = [&](int exact, int kfirst) -> int {
         const int nbins = ntiles * kb;
@@ -1915,7 +1883,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                                NB, nbins, offs + hn, vstart, reinterpret_cast<unsigned *>(ws + L.vidx));
             AF_LAUNCH_CHECK();
             hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
-                               reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1, exact ? 0 : close_at);
+                               reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
             AF_LAUNCH_CHECK();
             nchunks = vcount + nbins + 1;
             return AF_OK;
@@ -1939,7 +1907,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
                                reinterpret_cast<unsigned *>(ws + L.vidx));
         AF_LAUNCH_CHECK();
         hipLaunchKernelGGL(wg_vis_chunks, dim3((unsigned)af_cdiv(ntiles, 256)), dim3(256), 0, sst, vstart, ntiles, kb, chunk,
-                           reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1, exact ? 0 : close_at);
+                           reinterpret_cast<int2 *>(ws + L.chunks), vcount + nbins + 1);
         AF_LAUNCH_CHECK();
         nchunks = vcount + nbins + 1;
         return AF_OK;
@@ -2114,7 +2082,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL((wg_degrid_tiles<WC, P>), dim3(max_chunks + 8), dim3(256), 0, st, uvw, freq, nchan_band,      \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
                            pk0, pk1, do_wstacking, vidx, vstart, kb, chunks, nchunks, reinterpret_cast<double2 *>(vis),  \
-                           poly, xcd_env, close_at > 0, conc_env);                                                                         \
+                           poly, xcd_env, conc_env);                                                                     \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_degrid_planes<WC, P>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band,       \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \

@@ -68,10 +68,10 @@ class FusedPlan(object):
 
 
 DECOMPOSE_TOL = 1e-10      # metres: see fused_plan
-GEMM_MAX_ANTENNAS = 256    # af_fused_predict_antennas_c128: 32 blocks of 8 antennas in super-tiles of <= 40 tiles
+GEMM_MAX_ANTENNAS = 512    # af_fused_predict_antennas_c128: 64 blocks of 8 antennas in <= 8 super-blocks (SKA-low: 512 stations)
 
 
-def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, decompose_tol=None):
+def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, decompose_tol=None, single=False):
     """
     Plan of a row layout for :func:`fused_predict_vis` with DDEs (host side, O(row)): runs of consecutive rows with
     equal ``time_index`` become workgroup items.  ``grouped`` (default): rows are dealt in 2 x 2 blocks of baselines that
@@ -84,9 +84,14 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
     by solving for per-antenna coordinates (``af_fused_plan_antennas``) and accepting them when
     ``max |uvw_p - uvw_q - uvw_pq| <= decompose_tol`` metres (default 1e-10: a phase error below
     ``2 pi nu / c |lmn| 1e-10`` = 2e-10 rad at 1.7 GHz, 0.05 rad off axis).  A decomposable plan (``plan.decomposable``;
-    at most 256 antennas, every (time, antenna1, antenna2) at most once) sends the call to the GEMM form of the predict,
+    at most 512 antennas, every (time, antenna1, antenna2) at most once) sends the call to the GEMM form of the predict,
     ``V(t, nu) = G H^H`` on the matrix cores (csrc/af_fused_gemm.hip: about half the arithmetic of the general kernel);
     such a plan is bound to these ``uvw``.  ``AFHIP_FUSED_GEMM=0`` switches the test off.
+
+    ``single`` (with float32 ``uvw``; :func:`fused_predict_vis` sets it when EVERY input of the call is single precision):
+    the test is made at the rows' own precision, ``decompose_tol = 2^-22 max |uvw|`` -- float32 differences of antenna
+    coordinates carry 2^-24 of rounding each, which no antenna coordinates reproduce -- and such a plan serves the
+    single-precision GEMM form (``af_fused_predict_antennas_c64``).
     """
     ti = np.ascontiguousarray(_host(time_index), dtype=np.int64)
     a1h = np.ascontiguousarray(_host(antenna1), dtype=np.int32)
@@ -127,7 +132,12 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
         ant_uvw = np.zeros((nsteps, nant, 3), dtype=np.float64)
         rowmap = np.zeros((nsteps, nap, nap), dtype=np.int32)
         resid, ok = ctypes.c_double(0.0), ctypes.c_int(0)
-        tol = DECOMPOSE_TOL if decompose_tol is None else float(decompose_tol)
+        if decompose_tol is not None:
+            tol = float(decompose_tol)
+        elif single and np_dtype_of(uvw) == np.float32 and nrow:
+            tol = float(np.abs(uvw_h).max()) * 2.0 ** -22
+        else:
+            tol = DECOMPOSE_TOL
         _lib.call("af_fused_plan_antennas", tip, a1h.ctypes.data_as(ctypes.c_void_p), a2h.ctypes.data_as(ctypes.c_void_p),
                   uvw_h.ctypes.data_as(ctypes.c_void_p), nrow, nant, tol, nsteps, ant_uvw.ctypes.data_as(ctypes.c_void_p),
                   rowmap.ctypes.data_as(ctypes.c_void_p), ctypes.byref(resid), ctypes.byref(ok))
@@ -165,7 +175,7 @@ def _tensor_ident(arrays):
     return tuple(key)
 
 
-def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
+def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, single=False):
     """:func:`fused_plan` memoised on the CONTENTS of the three index arrays (a 16-byte digest: ~1 ms per 1e6 rows):
     what the row-chunk front-ends call (``rime.dask.fused_predict_vis``, ``chunked.fused_predict_vis``,
     ``sharding.fused_predict_shard``), where the same row chunk comes back for every channel block, every source chunk
@@ -179,11 +189,11 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
     against the call's arrays on the device, so a wrong hit cannot produce a wrong result."""
     limit = int(os.environ.get("AFHIP_PLAN_CACHE", "16"))
     if limit <= 0:
-        return fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
+        return fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw, single=single)
     arrays = (time_index, antenna1, antenna2, uvw)
     ident = _tensor_ident(arrays)
     if ident is not None:
-        ikey = (int(nant), bool(grouped), ident)
+        ikey = (int(nant), bool(grouped), bool(single), ident)
         with _plan_lock:
             hit = _plan_ident.get(ikey)
             if hit is not None and all((r is None and a is None) or (r is not None and r() is a)
@@ -204,13 +214,13 @@ def cached_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None):
         n = int(a.shape[0])
         h.update(a.dtype.str.encode())
         h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")
-    key = (n, int(nant), bool(grouped), uvw is not None, h.digest())
+    key = (n, int(nant), bool(grouped), uvw is not None, bool(single), h.digest())
     with _plan_lock:
         plan = _plan_cache.get(key)
         if plan is not None:
             _plan_cache.move_to_end(key)
     if plan is None:
-        plan = fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw)
+        plan = fused_plan(time_index, antenna1, antenna2, nant, grouped, uvw, single=single)
         with _plan_lock:
             _plan_cache[key] = plan
             while len(_plan_cache) > limit:
@@ -347,6 +357,42 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
             else:
                 brightness = np.broadcast_to(np.asarray(brightness)[:, None], (nsrc, nchan, 2, 2))
+        explicit_plan = plan is not None
+        gemm = single_route = False
+        if have_beam:
+            if len(beam.shape) != 5 or tuple(beam.shape[3:]) != (2, 2):
+                raise ValueError("beam must have shape (beam_lw, beam_mh, beam_nud, 2, 2)")
+            beam_lw, beam_mh, beam_nud = (int(s) for s in beam.shape[:3])
+            if beam_lw < 2 or beam_mh < 2 or beam_nud < 2:
+                raise ValueError("beam_lw, beam_mh and beam_nud must be >= 2")
+            ntime, nant = (int(s) for s in parallactic_angles.shape)
+            if tuple(point_errors.shape) != (ntime, nant, nchan, 2):
+                raise ValueError("point_errors must have shape (time, ant, chan, 2)")
+            if tuple(antenna_scaling.shape) != (nant, nchan, 2):
+                raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
+            if feed_rotation is not None and tuple(feed_rotation.shape) != (ntime, nant, 2, 2):
+                raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
+            all_single = not model and _all_single(lm, uvw, frequency, brightness, feed_rotation, *beam_args)
+            if plan is None:
+                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True,
+                                  uvw=None if gauss_shape is not None else uvw, single=all_single)
+            if plan.nrow != nrow or plan.nant != nant or plan.nsteps > ntime:
+                raise ValueError("plan was made for %d rows, %d antennas, %d timesteps; the call has %d, %d, %d"
+                                 % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
+            # antenna-decomposable rows: the GEMM form (Gaussian shapes depend on the baseline: general kernel)
+            gemm = plan.decomposable and gauss_shape is None and nrow > 0 and \
+                plan.fill >= float(os.environ.get("AFHIP_GEMM_MIN_FILL", GEMM_MIN_FILL)) and \
+                os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
+            # every input single precision: the reference computes this chain in float32 / complex64
+            # (africanus/util/type_inference.py:24-26); the GEMM form has a single-precision kernel of its own
+            single_route = gemm and all_single and os.environ.get("AFHIP_FUSED_C64", "1") != "0"
+        if single_route:
+            vis = _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
+                            beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,
+                            convention, nsrc, nrow, nchan)
+            if die1_jones is None and base_vis is None:
+                return vis
+            return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
         p_lm, p_uvw, p_fr = c.inp(lm, np.float64), c.inp(uvw, np.float64), c.inp(frequency, np.float64)
         p_b = c.inp(brightness, np.complex128)
         if model:
@@ -361,27 +407,6 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
             _lib.call("af_im_to_vis_f64", p_b, 1, p_uvw, p_lm, p_fr, nsrc, nrow, nchan, 4, conv,
                       _lib.AF_DFT_AUTO | _lib.AF_DFT_CLAMP_N, p_out, p_ws, max(ws_bytes, 256), c.stream)
         else:
-            if len(beam.shape) != 5 or tuple(beam.shape[3:]) != (2, 2):
-                raise ValueError("beam must have shape (beam_lw, beam_mh, beam_nud, 2, 2)")
-            beam_lw, beam_mh, beam_nud = (int(s) for s in beam.shape[:3])
-            if beam_lw < 2 or beam_mh < 2 or beam_nud < 2:
-                raise ValueError("beam_lw, beam_mh and beam_nud must be >= 2")
-            ntime, nant = (int(s) for s in parallactic_angles.shape)
-            if tuple(point_errors.shape) != (ntime, nant, nchan, 2):
-                raise ValueError("point_errors must have shape (time, ant, chan, 2)")
-            if tuple(antenna_scaling.shape) != (nant, nchan, 2):
-                raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
-            explicit_plan = plan is not None
-            if plan is None:
-                plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True,
-                                  uvw=None if gauss_shape is not None else uvw)
-            if plan.nrow != nrow or plan.nant != nant or plan.nsteps > ntime:
-                raise ValueError("plan was made for %d rows, %d antennas, %d timesteps; the call has %d, %d, %d"
-                                 % (plan.nrow, plan.nant, plan.nsteps, nrow, nant, ntime))
-            # antenna-decomposable rows: the GEMM form (Gaussian shapes depend on the baseline: general kernel)
-            gemm = plan.decomposable and gauss_shape is None and nrow > 0 and \
-                plan.fill >= float(os.environ.get("AFHIP_GEMM_MIN_FILL", GEMM_MIN_FILL)) and \
-                os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
             if gemm:
                 p_au = c.inp(plan.device(plan.ant_uvw, c), np.float64)
                 p_rm = c.inp(plan.device(plan.rowmap, c), np.int32)
@@ -395,8 +420,6 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                 c.inp(beam_freq_map, np.float64)
             p_pa, p_pe, p_as = c.inp(parallactic_angles, np.float64), c.inp(point_errors, np.float64), \
                 c.inp(antenna_scaling, np.float64)
-            if feed_rotation is not None and tuple(feed_rotation.shape) != (ntime, nant, 2, 2):
-                raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
             p_fr_rot = c.inp(feed_rotation, np.complex128)
             p_gs = c.inp(gauss_shape, np.float64)
             if model and gemm:
@@ -447,6 +470,44 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         return vis
     # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
     return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+
+
+def _all_single(*arrays):
+    """every array present is float32 / complex64"""
+    single = (np.dtype(np.float32), np.dtype(np.complex64))
+    return all(a is None or np_dtype_of(a) in single for a in arrays)
+
+
+def _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents,
+              beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation, convention, nsrc, nrow, nchan):
+    """The single-precision GEMM form (af_fused_predict_antennas_c64) inside an open Call: complex64 result."""
+    bshape = tuple(int(s) for s in brightness.shape)
+    if bshape == (nsrc, 2, 2):
+        if _is_torch(brightness):
+            brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
+        else:
+            brightness = np.broadcast_to(np.asarray(brightness)[:, None], (nsrc, nchan, 2, 2))
+    elif bshape != (nsrc, nchan, 2, 2):
+        raise ValueError("brightness must have shape (source, chan, 2, 2) or (source, 2, 2)")
+    beam_lw, beam_mh, beam_nud = (int(s) for s in beam.shape[:3])
+    ntime, nant = (int(s) for s in parallactic_angles.shape)
+    f32, c64 = np.float32, np.complex64
+    p_au = c.inp(plan.device(plan.ant_uvw, c), np.float64)
+    p_rm = c.inp(plan.device(plan.rowmap, c), np.int32)
+    p_lm, p_fr, p_b = c.inp(lm, f32), c.inp(frequency, f32), c.inp(brightness, c64)
+    p_beam, p_ext, p_map = c.inp(beam, c64), c.inp(beam_lm_extents, f32), c.inp(beam_freq_map, f32)
+    p_pa, p_pe, p_as = c.inp(parallactic_angles, f32), c.inp(point_errors, f32), c.inp(antenna_scaling, f32)
+    p_rot = c.inp(feed_rotation, c64)
+    p_out, h = c.out((nrow, nchan, 2, 2), c64)
+    ws_bytes = int(_lib.load().af_fused_predict_c64_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
+    p_ws = c.scratch(ws_bytes)
+    _lib.call("af_fused_predict_antennas_c64", p_au, p_rm, plan.nsteps, nrow, p_lm, p_fr, p_b, nsrc, nchan, p_beam, beam_lw,
+              beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_rot, _lib.CONVENTION[convention], p_out, p_ws,
+              max(ws_bytes, 256), c.stream)
+    if explicit_plan and nrow:
+        # (the guard fills float64 words with NaN: a complex64 result is nrow * nchan * 4 of them)
+        _check_plan(c, plan, True, time_index, antenna1, antenna2, c.inp(uvw, np.float64), nrow, p_out, nrow * nchan * 4)
+    return c.result(h)
 
 
 def _plan_status_message(flags):

@@ -168,8 +168,11 @@ def fused_predict_shard(rank, world_size, time_index, antenna1, antenna2, lm, uv
     ti, a1, a2 = time_index[rows], antenna1[rows], antenna2[rows]
     plan = None
     if beam is not None and stop > start:
+        from .rime.fused import _all_single
+        single = kwargs.get("stokes") is None and _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents,
+                                                              beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
         plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]),
-                           uvw=None if kwargs.get("gauss_shape") is not None else uvw[rows])
+                           uvw=None if kwargs.get("gauss_shape") is not None else uvw[rows], single=single)
     vis = fused_predict_vis(ti, a1, a2, lm, uvw[rows], frequency, brightness, beam, beam_lm_extents, beam_freq_map,
                             cut(parallactic_angles, times), cut(point_errors, times), antenna_scaling,
                             cut(die1_jones, times), cut(base_vis, rows), cut(die2_jones, times),

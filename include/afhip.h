@@ -330,14 +330,14 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
  *   *decomposable = 1 iff max_rows |x_p - x_q - uvw_pq|_inf <= tol [m] (reported in *max_residual) and no
  *   (step, antenna1, antenna2) occurs twice.  nsteps = max(time_index) - min(time_index) + 1;
  *   ant_uvw_host (nsteps, nant, 3) double; rowmap_host (nsteps, nap, nap) int32, nap = 8 ceil(nant / 8): the row of
- *   baseline (p, q) of the step or -1.  nant <= 256.
+ *   baseline (p, q) of the step or -1.  nant <= 512.
  * af_fused_predict_antennas_c128 (DEVICE pointers): ant_uvw / rowmap = device copies of the plan; the other arguments
  *   as af_fused_predict_c128 (same workspace size); writes out[row] for every row the map names.  No gauss_shape (it
  *   depends on the baseline: use af_fused_predict_c128).  nant <= 64: one workgroup per (timestep, channel) holds the
- *   whole upper block triangle; 65 .. 256 antennas: the blocks of 8 antennas are cut into super-blocks of 8 blocks,
+ *   whole upper block triangle; 65 .. 512 antennas: the blocks of 8 antennas are cut into super-blocks of 8 blocks,
  *   one workgroup per (timestep, channel, super-block or half of a pair of super-blocks).
  * af_fused_gemm_slots(nant): baseline slots (8 x 8-antenna tiles x 64) the GEMM form evaluates per (timestep, channel),
- *   what its cost is proportional to (rows per step / slots = the fill factor callers dispatch by); 0 beyond 256. */
+ *   what its cost is proportional to (rows per step / slots = the fill factor callers dispatch by); 0 beyond 512. */
 int af_fused_plan_antennas(const int64_t *time_index_host, const int32_t *antenna1_host, const int32_t *antenna2_host,
                            const double *uvw_host, int64_t nrow, int64_t nant, double tol, int64_t nsteps,
                            double *ant_uvw_host, int32_t *rowmap_host, double *max_residual, int *decomposable);
@@ -350,6 +350,22 @@ int af_fused_predict_antennas_c128(const double *ant_uvw, const int32_t *rowmap,
                                    const double *point_errors, const double *antenna_scaling,
                                    const double *feed_rotation, int convention, double *out, void *workspace,
                                    size_t workspace_bytes, void *stream);
+
+/* The SINGLE-PRECISION form of af_fused_predict_antennas_c128 (round 6): every array float32 / complex64 (pairs of
+ * floats) except the plan's (ant_uvw stays double: the planner solves in double), complex64 out -- the precision in which
+ * the reference runs this chain when every input is single precision (africanus/util/type_inference.py:24-26: the promoted
+ * input type; africanus/rime/predict.py:542-544, phase.py:28-61 and fast_beam_cubes.py:57-240 with float32 arguments).
+ * v_mfma_f32_16x16x4_f32 on float operand panels, float32 beam planes and sampler arithmetic; the antenna phasor and the
+ * voxel coordinates in double (csrc/af_fused_gemm_c64.hip): CLOSER to the float64 chain on the same float32 inputs than
+ * the reference's own float32 chain (golden G17).  Workspace: af_fused_predict_c64_workspace_bytes.  nant <= 512. */
+size_t af_fused_predict_c64_workspace_bytes(int64_t nsrc, int64_t nchan, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud);
+int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t *rowmap, int64_t nsteps, int64_t nrow,
+                                  const float *lm, const float *frequency, const float *brightness, int64_t nsrc,
+                                  int64_t nchan, const float *beam, int64_t beam_lw, int64_t beam_mh, int64_t beam_nud,
+                                  const float *beam_lm_extents, const float *beam_freq_map,
+                                  const float *parallactic_angles, int64_t ntime, int64_t nant,
+                                  const float *point_errors, const float *antenna_scaling, const float *feed_rotation,
+                                  int convention, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Plan guard (DEVICE pointers except none; O(row) on the device, no host round trip).  The predict entries above read
  * the PLAN's arrays (items / groups / antenna1 / antenna2, ant_uvw / rowmap), not the call's own index arrays and uvw: a

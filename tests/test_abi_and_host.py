@@ -203,7 +203,7 @@ def test_fused_group_plan_covers_every_row_once(nant, nrow):
                   ctypes.byref(ng))
 
 
-def test_gemm_plan_host_side_up_to_256_antennas():
+def test_gemm_plan_host_side_up_to_512_antennas():
     """Round 5 (host side only, no GPU work): the antenna planner and the plan object for arrays beyond 64 antennas --
     decomposable, residual, row map, the slots the GEMM form pays for (super-tiles: super-blocks of 8 blocks, DIAG + 8 x 4
     RECT tiles) and the fill factor the dispatcher uses."""
@@ -215,9 +215,10 @@ def test_gemm_plan_host_side_up_to_256_antennas():
     assert lib.af_fused_gemm_slots(64) == 36 * 64 and lib.af_fused_gemm_slots(5) == 64 and lib.af_fused_gemm_slots(0) == 0
     assert lib.af_fused_gemm_slots(128) == (2 * tri(8) + 64) * 64
     assert lib.af_fused_gemm_slots(197) == (3 * tri(8) + tri(1) + 3 * 64 + 3 * 8) * 64      # 25 blocks: 8 + 8 + 8 + 1
-    assert lib.af_fused_gemm_slots(256) == (4 * tri(8) + 6 * 64) * 64 and lib.af_fused_gemm_slots(257) == 0
+    assert lib.af_fused_gemm_slots(256) == (4 * tri(8) + 6 * 64) * 64
+    assert lib.af_fused_gemm_slots(512) == (8 * tri(8) + 28 * 64) * 64 and lib.af_fused_gemm_slots(513) == 0       # round 6: 512 stations
     rng = np.random.default_rng(5)
-    for nant in (70, 130, 256):
+    for nant in (70, 130, 256, 300):
         a1, a2 = np.triu_indices(nant, 1)
         nbl, ntime = a1.shape[0], 2
         ti = np.repeat(np.arange(ntime), nbl) + 3                      # an offset: the plan normalises it
@@ -234,7 +235,7 @@ def test_gemm_plan_host_side_up_to_256_antennas():
         assert np.array_equal(plan.step, ti - 3) and plan.step.dtype == np.int32
         # per-row uvw does not decompose: the plan says so and the caller stays on the lane-per-row kernel
         assert not fused.fused_plan(ti, a1, a2, nant, uvw=rng.standard_normal(uvw.shape)).decomposable
-    assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 260, uvw=uvw[:10]).decomposable is False   # > 256 antennas
+    assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 520, uvw=uvw[:10]).decomposable is False   # > 512 antennas
 
 
 def test_plan_cache_by_identity_does_not_outlive_the_plan_cache(monkeypatch):

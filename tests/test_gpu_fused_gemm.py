@@ -4,7 +4,7 @@ timestep -- every real Measurement Set) the chain phase_delay -> einsum -> beam_
 (africanus/rime/examples/predict.py:107-134,404-472,525) is V(t, nu) = G H^H, evaluated with fp64 MFMA.  Checked against
 the CPU oracle chain to 1e-9 of the per-visibility sum of |term| magnitudes (north star: 1e-8), against the general
 kernel on the same rows, and the dispatcher: rows that are not decomposable, repeated baselines, Gaussian shapes and
-more than 256 antennas stay on the general kernel.
+more than 512 antennas stay on the general kernel.
 """
 import numpy as np
 import pytest
@@ -65,7 +65,11 @@ def _call(d, **kw):
                                         # beyond 64 antennas (round 5): super-tiles -- 65: 5 + 4 blocks; 80: 5 + 5; 96: 6 + 6;
                                         # 100: 5 + 4 + 4; 128: 6 + 5 + 5; 197: 5 x 5; 256: 6 + 6 + 5 + 5 + 5 + 5
                                         (65, 4300), (80, 3500), (96, 9300), (100, 5200), (128, 9000), (197, 20000),
-                                        (256, 33000)])
+                                        (256, 33000),
+                                        # round 6: 8 x 8 RECT super-tiles (four-product form) wherever a column super-block has
+                                        # more than 4 blocks (96: 8 + 4 stays 8 x 4; 104: 8 + 5; 128; 197; 256), and arrays up
+                                        # to 512 antennas -- 300: 8 + 8 + 8 + 8 + 6 blocks; 512: eight full super-blocks
+                                        (104, 5400), (300, 45000), (512, 131000)])
 def test_gemm_form_matches_the_reference_chain(nant, nrow):
     d = _decomposable(_problem(3, nrow, 6, 23, nant), nant)
     plan = fused.fused_plan(d["time_index"], d["ant1"], d["ant2"], nant, uvw=d["uvw"])
@@ -150,7 +154,7 @@ def test_device_resident_call_and_time_offset():
 
 def test_dispatcher_falls_back():
     """what must NOT take the GEMM route: uvw drawn per row (BASELINE's recipe), uvw decomposable only to 1e-6 m, the same
-    baseline twice in a timestep, Gaussian shapes, more than 256 antennas -- all give the reference's answer"""
+    baseline twice in a timestep, Gaussian shapes, more than 512 antennas -- all give the reference's answer"""
     nant = 9
     base = _problem(12, 600, 4, 13, nant)
     plan = fused.fused_plan(base["time_index"], base["ant1"], base["ant2"], nant, uvw=base["uvw"])
@@ -180,8 +184,8 @@ def test_dispatcher_falls_back():
     ref = oracle.predict_vis(d["time_index"], d["ant1"], d["ant2"], dde, np.einsum("srf,sfij->srfij", phase, d["X"]), dde,
                              None, None, None)
     assert np.abs(out - ref).max() < 1e-9 * _scale(d)
-    big = _decomposable(_problem(13, 2500, 3, 5, 260), 260, seed=7)
-    plan = fused.fused_plan(big["time_index"], big["ant1"], big["ant2"], 260, uvw=big["uvw"])
+    big = _decomposable(_problem(13, 2500, 3, 5, 520), 520, seed=7)
+    plan = fused.fused_plan(big["time_index"], big["ant1"], big["ant2"], 520, uvw=big["uvw"])
     assert not plan.decomposable
     assert np.abs(_call(big) - _oracle_chain(big, True)).max() < 1e-9 * _scale(big)
 

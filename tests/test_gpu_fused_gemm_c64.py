@@ -1,0 +1,159 @@
+"""
+The single-precision GEMM form of the fused predict (csrc/af_fused_gemm_c64.hip, af_fused_predict_antennas_c64): every
+input float32 / complex64 -> complex64, the precision in which the reference runs the chain for such callers
+(africanus/util/type_inference.py:24-26).  Contract (as af_im_to_vis_f32's, G13): CLOSER to the float64 chain on the same
+float32 inputs than the reference's own float32 chain is.  Golden G17 (tests/golden/make_golden_gemm_f32.py) holds both
+of the REFERENCE's results -- float32 chain and float64 chain of the promoted values -- for two cases; larger arrays (every
+super-tile kind) are checked against the oracle's float64 chain with the error the reference's float32 arithmetic shows on
+G17 as the yardstick.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from codex_africanus_amd import rime
+from codex_africanus_amd.rime import fused
+from test_gpu_fused import _problem, _scale
+from test_gpu_fused_gemm import _decomposable
+
+pytestmark = pytest.mark.gpu
+G17 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g17_fused_gemm_f32.npz"))
+NAMES = ("lm", "uvw", "frequency", "brightness", "beam", "beam_lm_extents", "beam_freq_map", "parallactic_angles", "point_errors",
+         "antenna_scaling")
+
+
+@pytest.fixture(autouse=True)
+def _gemm_at_any_fill(monkeypatch):
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+
+
+def _case(name):
+    d = {k: G17["%s_%s" % (name, k)] for k in NAMES + ("time_index", "antenna1", "antenna2", "ant_xyz")}
+    for k in NAMES:
+        assert d[k].dtype in (np.float32, np.complex64), k
+    return d
+
+
+def _call(d, **kw):
+    return rime.fused_predict_vis(d["time_index"], d["antenna1"], d["antenna2"], d["lm"], d["uvw"], d["frequency"], d["brightness"],
+                                  d["beam"], d["beam_lm_extents"], d["beam_freq_map"], d["parallactic_angles"], d["point_errors"],
+                                  d["antenna_scaling"], **kw)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("feed", [False, True])
+def test_closer_to_the_float64_chain_than_the_reference_float32_chain(name, feed):
+    d = _case(name)
+    nant = d["parallactic_angles"].shape[1]
+    plan = fused.fused_plan(d["time_index"], d["antenna1"], d["antenna2"], nant, uvw=d["uvw"], single=True)
+    # float32 rows decompose at their own precision: the residual is a few float32 roundings of a 6 km difference
+    assert plan.decomposable and plan.residual <= plan.tol and plan.tol < 2e-3
+    kw = {}
+    if feed:
+        kw["feed_rotation"] = rime.feed_rotation(d["parallactic_angles"], "linear")
+        assert kw["feed_rotation"].dtype == np.complex64
+    got = _call(d, plan=plan, **kw)
+    tag = "_feed" if feed else ""
+    ref32, truth = G17["%s_vis32%s" % (name, tag)], G17["%s_vis64%s" % (name, tag)]
+    assert got.dtype == np.complex64 and got.shape == ref32.shape
+    peak = np.abs(truth).max()
+    e_ours, e_ref = np.abs(got - truth).max() / peak, np.abs(ref32 - truth).max() / peak
+    assert e_ours < 0.5 * e_ref, (e_ours, e_ref)
+    assert e_ours < 1e-4, e_ours
+    # without an explicit plan: the call plans for itself and takes the same route
+    assert np.array_equal(_call(d, **kw), got)
+
+
+def _single(d):
+    """A test_gpu_fused problem in single precision: float32 antenna coordinates, rows = their float32 differences."""
+    s = dict(d)
+    f, c = np.float32, np.complex64
+    xyz = d["ant_xyz"].astype(f)
+    s["uvw"] = xyz[d["time_index"], d["ant1"]] - xyz[d["time_index"], d["ant2"]]
+    for k in ("lm", "frequency", "extents", "beam_freq_map", "pa", "pe", "as"):
+        s[k] = d[k].astype(f)
+    s["X"], s["beam"] = d["X"].astype(c), d["beam"].astype(c)
+    return s
+
+
+def _chain64(s, rows=None):
+    """the oracle's float64 chain on the promoted single-precision values"""
+    r = slice(None) if rows is None else rows
+    p = lambda a: a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+    dde = oracle.beam_cube_dde(p(s["beam"]), p(s["extents"]), p(s["beam_freq_map"]), p(s["lm"]), p(s["pa"]), p(s["pe"]), p(s["as"]),
+                               p(s["frequency"]))
+    phase = oracle.phase_delay(p(s["lm"]), p(s["uvw"])[r], p(s["frequency"]))
+    coh = np.einsum("srf,sfij->srfij", phase, p(s["X"]))
+    return oracle.predict_vis(s["time_index"][r], s["ant1"][r], s["ant2"][r], dde, coh, dde, None, None, None)
+
+
+def _call_s(s, **kw):
+    return rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], s["lm"], s["uvw"], s["frequency"], s["X"], s["beam"],
+                                  s["extents"], s["beam_freq_map"], s["pa"], s["pe"], s["as"], **kw)
+
+
+# every instantiation kind: DIAG of 1 .. 8 blocks (padded super-rounds below 8), RECT 8 x 4 with a full and a short column
+# super-block (100: 5 blocks = 4 + 1; 128: 8 = 4 + 4; 197: three super-blocks)
+@pytest.mark.parametrize("nant, nrow", [(5, 37), (12, 600), (17, 1500), (24, 2000), (33, 2500), (40, 1700), (47, 3000), (57, 4000),
+                                        (64, 4100), (65, 4300), (100, 5200), (128, 9000), (197, 20000)])
+def test_against_the_float64_chain_at_every_super_tile_kind(nant, nrow):
+    d = _decomposable(_problem(3, nrow, 6, 23, nant), nant)
+    s = _single(d)
+    got = _call_s(s)
+    assert got.dtype == np.complex64
+    truth = _chain64(s)
+    # G17: the reference's own float32 chain is off by 2-3e-4 of the peak at these baselines (float32 phases of ~5000 rad).
+    # What bounds this entry is the rows themselves: float32 differences of antenna coordinates carry 2^-25 of 6 km =
+    # 1e-4 m of rounding that no antenna coordinates reproduce -- 1e-4 rad of phase per term, a few 1e-5 of the sum.
+    assert np.abs(got - truth).max() < 1e-4 * _scale(d), np.abs(got - truth).max() / _scale(d)
+
+
+def test_row_layouts_dies_and_the_plan_guard():
+    nant = 19
+    d = _decomposable(_problem(5, 1500, 4, 17, nant), nant, seed=2, keep=0.8, swap=0.3, shuffle=True, autos=True)
+    s = _single(d)
+    got = _call_s(s)
+    truth = _chain64(s)
+    assert np.abs(got - truth).max() < 1e-4 * _scale(d)
+    # DIEs and base visibilities on top: predict_vis's complex64 kernel
+    rng = np.random.default_rng(5)
+    shp = (d["ntime"], nant, 4, 2, 2)
+    die = (1.0 + 0.1 * rng.standard_normal(shp) + 0.1j * rng.standard_normal(shp)).astype(np.complex64)
+    bvis = (0.1 * (rng.standard_normal(got.shape) + 1j * rng.standard_normal(got.shape))).astype(np.complex64)
+    full = _call_s(s, die1_jones=die, base_vis=bvis, die2_jones=die)
+    assert full.dtype == np.complex64
+    ref = oracle.predict_vis(s["time_index"], s["ant1"], s["ant2"], None, got[None], None, die, bvis, die)
+    assert np.array_equal(full, ref)
+    # a plan of other rows is refused: NaN result and ValueError (af_fused_plan_check on the complex64 result)
+    plan = fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"], single=True)
+    other = dict(s)
+    other["uvw"] = (s["uvw"] * np.float32(1.01)).astype(np.float32)
+    with pytest.raises(ValueError, match="stale plan"):
+        _call_s(other, plan=plan)
+
+
+def test_mixed_precision_inputs_take_the_float64_route():
+    """one float64 array among the inputs: the promoted type is double (africanus/util/type_inference.py:24-26), and the
+    float32 rows -- decomposable only at their own precision -- are then NOT handed to the GEMM form: the double result
+    follows the rows exactly (lane-per-row kernel), checked against the float64 chain to 1e-9"""
+    nant = 12
+    d = _decomposable(_problem(7, 600, 4, 9, nant), nant)
+    s = _single(d)
+    s["lm"] = s["lm"].astype(np.float64)
+    out = _call_s(s)
+    assert out.dtype == np.complex128
+    assert not fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"]).decomposable
+    assert np.abs(out - _chain64(s)).max() < 1e-9 * _scale(d)
+
+
+def test_device_resident_tensors():
+    import torch
+    nant = 24
+    s = _single(_decomposable(_problem(9, 2000, 5, 15, nant), nant))
+    host = _call_s(s)
+    t = {k: (torch.from_numpy(np.ascontiguousarray(v)).cuda() if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+    dev = _call_s(t)
+    assert dev.dtype == torch.complex64 and dev.is_cuda
+    assert np.array_equal(dev.cpu().numpy(), host)

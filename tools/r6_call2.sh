@@ -37,3 +37,7 @@ for c in (0,1):
                 acc[r['Counter_Name']]+=float(r['Counter_Value']); n[r['Counter_Name']]+=1
         print('CONCENTRATE',c,{k:round(v/max(n[k],1)) for k,v in acc.items()})
 PY
+# E. f32 MFMA probe (layout, rate, overlap with VALU of another wave)
+./tools/probe/probe_mfma_f32_16x16x4 > gpurun_out/r6/probe_mfma_f32.log 2>&1; cat gpurun_out/r6/probe_mfma_f32.log
+# F. the bench-ranks test file (forensics test included)
+timeout 900 python -m pytest tests/test_gpu_bench_ranks.py -x -q > gpurun_out/r6/tests_ranks.log 2>&1; echo "ranks tests rc $?"; tail -3 gpurun_out/r6/tests_ranks.log
