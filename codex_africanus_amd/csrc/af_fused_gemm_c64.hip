@@ -26,7 +26,7 @@
 // super-round of 512 terms as in af_fused_predict.hip): a batch lasts as long as a sampling wave's serial chain (coordinates
 // -> gathers -> arithmetic -> panel stores), and single precision leaves the registers for twice the fp64 kernel's four
 // (first version, 12 waves: 68.9 ms for 1e6 rows x 64 channels x 1000 sources against the fp64 kernel's 87.4).
-// Super-tiles (DIAG / RECT 8 x 4) and the row map as in af_fused_gemm.hip.
+// Super-tiles (DIAG / RECT 8 x 4 / RECT 8 x 8 in the NEG form) and the row map as in af_fused_gemm.hip.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,11 +48,15 @@ constexpr int VREC32 = 16;          // floats per cell record: 4 correlations x 
 // matrix wave's lanes 0-15 / 16-31 read with one ds_read_b32 then sit on disjoint halves of the 32 banks
 constexpr int plane_stride(int nant) { return 2 * nant + ((2 * nant) % 32 == 0 ? 16 : 32); }
 
-template <bool RECT, int NBR, int NBC, int ST>
+// NEG (RECT 8 x 8, as the fp64 kernel's FOURM): a third pair of H planes holds -im, so that Im accumulates in ONE register set
+// (Im += Gi Hr + Gr (-Hi)) and a matrix wave holds eight tiles (its block row) in 64 accumulator registers: one super-tile per
+// pair of super-blocks, 128 sampled terms for 64 tiles instead of two 8 x 4 super-tiles' 192.
+template <bool RECT, int NBR, int NBC, int ST, bool NEG = false>
 struct GeoS {
     static constexpr int NAR = 8 * NBR, NAC = 8 * NBC;
     static constexpr int CSG = plane_stride(NAR), CSH = plane_stride(NAC);     // floats per operand plane
-    static constexpr int SRC = S_PLANES * (CSH + CSG);                         // one source: H planes, then G planes
+    static constexpr int HP = NEG ? 6 : S_PLANES;                              // H planes of a source
+    static constexpr int SRC = HP * CSH + S_PLANES * CSG;                      // one source: H planes, then G planes
     static constexpr int BUF = ST * SRC;                                       // one batch
     static constexpr int TPS = RECT ? NAR + NAC : NAR;                         // sampled terms (antenna slots) per source
     static constexpr int BT = ST * TPS;                                        // terms per batch
@@ -207,7 +211,7 @@ __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int
     const int kq = lane >> 4, c16 = lane & 15;
     // K index kq = 2 (source of the pair) + (column of the Jones row): this lane's element of every operand plane
     const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
-    const int offA = (kq >> 1) * SRC + S_PLANES * CSH + (kq & 1) * CSG + c16;
+    const int offA = (kq >> 1) * SRC + G::HP * CSH + (kq & 1) * CSG + c16;
     v4f cr[CN], ci1[CN], ci2[CN];
 #pragma unroll
     for (int j = 0; j < CN; ++j) cr[j] = ci1[j] = ci2[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
@@ -217,6 +221,9 @@ __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int
         const float *P = lds + buf * BUF;
         buf ^= 1;
         if (CNT == 0) continue;
+#ifdef AF_C64_STAGE_SAMPLE        // (diagnostic build: the sampling waves alone; the output is meaningless)
+        continue;
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < ST / 2; ++s2) {
             const float *S = P + 2 * s2 * SRC;
@@ -257,8 +264,67 @@ __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int
     }, std::make_integer_sequence<int, CNT>{});
 }
 
+// NEG form (RECT 8 x NBC): wave W = block row W, two accumulators per tile
+template <int NBC, int ST, int W>
+__device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, int nbatch, int lane, const int32_t *__restrict__ rm,
+                                                int nap, const SuperTileS tile, int64_t nchan, int64_t f, float2 *__restrict__ out)
+{
+    using G = GeoS<true, 8, NBC, ST, true>;
+    constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
+    const int kq = lane >> 4, c16 = lane & 15;
+    const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
+    const int offA = (kq >> 1) * SRC + G::HP * CSH + (kq & 1) * CSG + c16 + W * 16;
+    v4f cr[NBC], ci[NBC];
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) cr[j] = ci[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    int buf = 0;
+    for (int b = 0; b < nbatch; ++b) {
+        __syncthreads();
+        const float *P = lds + buf * BUF;
+        buf ^= 1;
+#ifdef AF_C64_STAGE_SAMPLE
+        continue;
+#endif
+#pragma unroll
+        for (int s2 = 0; s2 < ST / 2; ++s2) {
+            const float *A = P + 2 * s2 * SRC + offA, *Bp = P + 2 * s2 * SRC + offB;
+            const float gr = A[0], gi = A[2 * CSG];
+            for_each_const_s([&](auto jc) {
+                constexpr int qb = decltype(jc)::value;
+                if (qb >= tile.nc_act) return;                   // block-uniform: the column super-block is short
+                const float *B = Bp + qb * 16;
+                const float hr = B[0], hi = B[2 * CSH], nhi = B[4 * CSH];
+                cr[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hr, cr[qb], 0, 0, 0);
+                ci[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hr, ci[qb], 0, 0, 0);
+                cr[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hi, cr[qb], 0, 0, 0);
+                ci[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, nhi, ci[qb], 0, 0, 0);
+            }, std::make_integer_sequence<int, NBC>{});
+        }
+    }
+    for_each_const_s([&](auto jc) {
+        constexpr int qb = decltype(jc)::value;
+        if (qb >= tile.nc_act) return;
+        const int jj = c16 & 1;
+        const int q = tile.col_ant0 + qb * 8 + (c16 >> 1);
+        int r1[4], r2[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int p = tile.row_ant0 + W * 8 + ((4 * kq + reg) >> 1);
+            r1[reg] = rm[p * nap + q];
+            r2[reg] = rm[q * nap + p];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ii = (4 * kq + reg) & 1;
+            const float re = cr[qb][reg], im = ci[qb][reg];
+            if (r1[reg] >= 0) out[((int64_t)r1[reg] * nchan + f) * 4 + ii * 2 + jj] = make_float2(re, im);
+            if (r2[reg] >= 0) out[((int64_t)r2[reg] * nchan + f) * 4 + jj * 2 + ii] = make_float2(re, -im);
+        }
+    }, std::make_integer_sequence<int, NBC>{});
+}
+
 // grid: (nsteps, channels of the plane group, super-tiles of this shape); block 1024.
-template <bool FEED, bool RECT, int NBR, int NBC, int ST>
+template <bool FEED, bool RECT, int NBR, int NBC, int ST, bool NEG = false>
 __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
     const double *__restrict__ f4, const float2 *__restrict__ brightness, const float *__restrict__ vrec, int64_t beam_lw,
@@ -268,7 +334,8 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     int64_t f0, const SuperTileListS tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
-    using G = GeoS<RECT, NBR, NBC, ST>;
+    static_assert(!NEG || (RECT && NBR == 8), "the NEG form serves RECT super-tiles of eight block rows");
+    using G = GeoS<RECT, NBR, NBC, ST, NEG>;
     constexpr int NAC = G::NAC, CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF, TPS = G::TPS, BT = G::BT;
     extern __shared__ double lds_raw[];
     // doubles first (alignment): per-slot constants, then the phasor table, then the float panels
@@ -323,6 +390,19 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     if (tid < S_MATRIX) {
         const int32_t *rm = rowmap + (int64_t)t * nap * nap;
         const int lane = tid & 63;
+        if constexpr (NEG) {
+            switch (tid >> 6) {
+            case 0: matrix_wave_neg<NBC, ST, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 1: matrix_wave_neg<NBC, ST, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 2: matrix_wave_neg<NBC, ST, 2>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 3: matrix_wave_neg<NBC, ST, 3>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 4: matrix_wave_neg<NBC, ST, 4>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 5: matrix_wave_neg<NBC, ST, 5>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 6: matrix_wave_neg<NBC, ST, 6>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            default: matrix_wave_neg<NBC, ST, 7>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            }
+            return;
+        }
         switch (tid >> 6) {
         case 0: matrix_wave_s<RECT, NBR, NBC, ST, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
         case 1: matrix_wave_s<RECT, NBR, NBC, ST, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
@@ -401,7 +481,7 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
         // operand rows / columns are the antennas in their own order (element 2 antenna + Jones row): eight consecutive
         // terms' stores cover 16 consecutive banks per Jones column, the other column 16 banks further (plane_stride)
         const int h_off = T.buf * BUF + e_sl * SRC + 2 * (col_term ? e_slot : 0);
-        const int g_off = T.buf * BUF + e_sl * SRC + S_PLANES * CSH + 2 * (RECT ? (col_term ? 0 : e_slot - NAC) : e_slot);
+        const int g_off = T.buf * BUF + e_sl * SRC + G::HP * CSH + 2 * (RECT ? (col_term ? 0 : e_slot - NAC) : e_slot);
         S.info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
         S.slot = e_slot;
         const int bsrc = T.src < nsrc ? T.src : 0;
@@ -472,7 +552,7 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
         cmacf(Gv, A1, B1);
         if constexpr (!RECT) {
             float *hs = ldsp + (info & 0x3fffffff) + ei;
-            float *gs = hs + S_PLANES * CSH;
+            float *gs = hs + G::HP * CSH;
             hs[ej * CSH] = A.re; hs[(2 + ej) * CSH] = A.im;
             gs[ej * CSG] = Gv.re; gs[(2 + ej) * CSG] = Gv.im;
         } else {
@@ -482,6 +562,8 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
             const int cs = r_col ? CSH : CSG;
             ws[ej * cs] = r_col ? A.re : Gv.re;
             ws[(2 + ej) * cs] = r_col ? A.im : Gv.im;
+            if constexpr (NEG)
+                if (r_col) ws[(4 + ej) * CSH] = -A.im;
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -491,6 +573,10 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     // the samplers' side of a batch barrier: their panel writes (LDS) must have landed; the coordinate prefetch (vmcnt)
     // stays outstanding
     auto sampler_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#ifdef AF_C64_STAGE_MATRIX            // (diagnostic build: the matrix waves alone on whatever the LDS holds)
+    for (int bb = 0; bb < nbatch; ++bb) sampler_barrier();
+    return;
+#endif
     {
         Round R0, R1, R2, R3;
         Own S;
@@ -507,6 +593,12 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
             finish(I0{}, S, R0); finish(I1{}, S, R1); finish(I2{}, S, R2); finish(I3{}, S, R3);
             next_of(b, task0, b1, t1);
             const bool bar = b1 != b, more = b1 < nbatch;
+            // (measured and removed, same box, 54.5 ms as it stands: the next super-round's gathers issued BEFORE the batch
+            //  barrier and in flight across it 58.4; 16-byte gathers incl. the record's padding word 54.5; without the
+            //  sampling waves' raised priority 62.2.  Diagnostic builds -DAF_C64_STAGE_SAMPLE / _MATRIX: the sampling waves
+            //  alone 35.8 ms, the matrix waves' 72 000 instructions per workgroup 29.8 ms at one per 32 cycles and SIMD: the
+            //  two overlap to 54.5 of their sum of 65.6 -- float32 VALU beside a stream of f32 MFMAs on the same SIMD runs at
+            //  ~0.4 of its rate, tools/probe/probe_mfma_f32_16x16x4.hip)
             if (bar) sampler_barrier();
             if (!more) break;
             next_of(b1, t1, b2, t2);
@@ -632,6 +724,10 @@ AF_EXPORT int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t
     (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, RECTC, NBRC, NBCC, STC>)                         \
           : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, RECTC, NBRC, NBCC, STC>)),                      \
         GeoS<RECTC, NBRC, NBCC, STC>::lds_bytes()
+#define AF_GEMMS_KN(NBCC, STC)                                                                                         \
+    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, true, 8, NBCC, STC, true>)                       \
+          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, true, 8, NBCC, STC, true>)),                    \
+        GeoS<true, 8, NBCC, STC, true>::lds_bytes()
     for (int i = 0; i < tl.nsb; ++i) {
         SuperTileS e = {8 * tl.blk0[i], 8 * tl.blk0[i], tl.size[i], 0};
         switch (tl.size[i]) {
@@ -645,13 +741,20 @@ AF_EXPORT int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t
         case 7: add(AF_GEMMS_K(false, 7, 7, 8), e); break;
         default: add(AF_GEMMS_K(false, 8, 8, 8), e); break;
         }
-        for (int j = i + 1; j < tl.nsb; ++j)
+        for (int j = i + 1; j < tl.nsb; ++j) {
+            if (tl.size[j] > RECT_COLS_S) {        // one 8 x 8 super-tile (NEG form) per pair of super-blocks
+                SuperTileS r = {8 * tl.blk0[i], 8 * tl.blk0[j], tl.size[j], 0};
+                add(AF_GEMMS_KN(8, 8), r);
+                continue;
+            }
             for (int c0 = 0; c0 < tl.size[j]; c0 += RECT_COLS_S) {
                 SuperTileS r = {8 * tl.blk0[i], 8 * (tl.blk0[j] + c0), tl.size[j] - c0 < RECT_COLS_S ? tl.size[j] - c0 : RECT_COLS_S, 0};
                 add(AF_GEMMS_K(true, 8, RECT_COLS_S, 16), r);
             }
+        }
     }
 #undef AF_GEMMS_K
+#undef AF_GEMMS_KN
     for (auto &s : shapes) {
         AF_REQUIRE(s.lds <= 160 * 1024, "af_fused_predict_antennas_c64: %zu bytes of LDS needed", s.lds);
         AF_HIP(hipFuncSetAttribute(s.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds));

@@ -175,6 +175,36 @@ __device__ __forceinline__ void wg_taps(const WgPoly &P, double f, double beta, 
         for (int a = 0; a < W; ++a) out[a] = es_kernel(f + (double)a, inv_half_w, beta);
     }
 }
+// The three axes' taps of one visibility in ONE walk over the coefficients (same Horner steps per polynomial as wg_taps:
+// the same bits).  The coefficients are kernel arguments -- W (W + 3) doubles in scalar registers, 140 registers at W = 7,
+// more than a wave has: three separate walks made the compiler keep them all and park them in vector-register lanes
+// (v_writelane / v_readlane: ~400 instructions per chunk of the tile kernel); walked once, each is loaded, used three times
+// and forgotten.
+template <int W>
+__device__ __forceinline__ void wg_taps3(const WgPoly &P, double fu, double fv, double fw, double beta, double (&ku)[W],
+                                         double (&kv)[W], double (&kw)[W])
+{
+    if constexpr (W <= WG_POLYW) {
+        const double uu = 2.0 * (fu + 0.5 * (double)W) - 1.0, uv = 2.0 * (fv + 0.5 * (double)W) - 1.0,
+                     uw = 2.0 * (fw + 0.5 * (double)W) - 1.0;
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+            double au = P.c[a][W + 2], av = au, aw = au;
+#pragma unroll
+            for (int d = W + 1; d >= 0; --d) {
+                const double c = P.c[a][d];
+                au = fma(au, uu, c);
+                av = fma(av, uv, c);
+                aw = fma(aw, uw, c);
+            }
+            ku[a] = au; kv[a] = av; kw[a] = aw;
+        }
+    } else {
+        wg_taps<W>(P, fu, beta, ku);
+        wg_taps<W>(P, fv, beta, kv);
+        wg_taps<W>(P, fw, beta, kw);
+    }
+}
 // the weight of plane k0 + a, a = k - k0 in 0 .. W - 1 (lane-dependent): a chain of selects, no indexed registers
 template <int W>
 __device__ __forceinline__ double wg_pick(const double (&kw)[W], int a)
@@ -906,6 +936,14 @@ __global__ void wg_vis_chunks(const int *__restrict__ start, int ntiles, int kb,
     for (int j = 0; j < n; ++j) chunks[base + j] = make_int2(t, lo + j * chunk);
 }
 
+__global__ void wg_store_poly(const WgPoly poly, WgPoly *__restrict__ dst)
+{
+    const int n = (int)(sizeof(WgPoly) / sizeof(double));
+    const double *src = &poly.c[0][0];
+    double *d = &dst->c[0][0];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+}
+
 // one workgroup per chunk: vis[...] += sum over the resident planes [pk0, pk1) the chunk's visibilities touch
 template <int W, typename P>
 __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
@@ -915,7 +953,7 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
                                                        int pk0, int pk1, int do_w, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ start, int kb, const int2 *__restrict__ chunks,
                                                        const int *__restrict__ nchunks, double2 *__restrict__ vis,
-                                                       const WgPoly poly, int xcd_order, int concentrate)
+                                                       const WgPoly *__restrict__ poly_dev, int xcd_order, int concentrate)
 {
     constexpr int R = WG_TILE + W - 1;
     constexpr int NL = (R * R + 255) / 256;
@@ -1032,12 +1070,24 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
         const double gu = uvw[3 * (int64_t)r + WG_CU] * fl * cellx * (double)nu;
         const double gv = uvw[3 * (int64_t)r + WG_CV] * fl * celly * (double)nv;
         const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;   // first tap's offset
-        wg_taps<W>(poly, fu, beta, ku);
-        wg_taps<W>(poly, fv, beta, kv);
-        if (do_w) wg_taps<W>(poly, (double)k0u - gw, beta, kwv);
+        // (the polynomials are read from memory HERE, by scalar loads next to their use: as a by-value kernel argument the
+        // 140 scalar registers they fill were loaded at the kernel's entry and kept across the dealing above in vector-
+        // register lanes -- ~280 v_readlane / v_writelane per chunk)
+        const WgPoly &poly = *poly_dev;
+        if (do_w) {
+            wg_taps3<W>(poly, fu, fv, (double)k0u - gw, beta, ku, kv, kwv);
+        } else {
+            wg_taps<W>(poly, fu, beta, ku);
+            wg_taps<W>(poly, fv, beta, kv);
+        }
         const int lu = wg_first_cell(gu, W, (int)nu) - tu * WG_TILE, lv = wg_first_cell(gv, W, (int)nv) - tv * WG_TILE;
         lofs = lu * R + lv;
         if (k0 >= k1) { k0 = 0x7fffffff; k1 = -0x7fffffff; }
+        // (a plane batch that starts inside the lane's range: the weights of the planes before it are not used)
+        for (int sh = k0u; sh < k0 && sh < k0u + W; ++sh) {
+#pragma unroll
+            for (int t = 0; t + 1 < W; ++t) kwv[t] = kwv[t + 1];
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < W; ++t) { ku[t] = 0.0; kv[t] = 0.0; }
@@ -1093,7 +1143,11 @@ __global__ __launch_bounds__(256) void wg_degrid_tiles(const double *__restrict_
             for (int q = 0; q < NL; ++q) pre[q] = g[gofs[q]];
         }
         if (k >= k0 && k < k1) {
-            const double kw = wg_pick<W>(kwv, k - k0u);
+            // this plane's weight: the lane's weights are a shift register that moves one place per plane the lane takes
+            // part in (W - 1 register moves; until round 6 a chain of 2 W selects + W compares on k - k0u)
+            const double kw = kwv[0];
+#pragma unroll
+            for (int t = 0; t + 1 < W; ++t) kwv[t] = kwv[t + 1];
             const double2 *__restrict__ cell = reg + lofs;
             double pre_ = 0.0, pim_ = 0.0;
 #pragma unroll
@@ -1531,7 +1585,7 @@ __global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ 
     image[i] = first ? v : image[i] + v;
 }
 
-struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, tw2, grid, A, nm1, total; int nbins, ntiles, gtiles; };
+struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, tw2, poly, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
 int64_t wg_ntiles(int64_t nu, int64_t nv, int tile) { return ((nu + tile - 1) / tile) * ((nv + tile - 1) / tile); }
 // nplanes_total, W: the largest number of w-planes and the kernel width of the calls the workspace serves (they size
@@ -1565,6 +1619,7 @@ WgWs wg_ws(int64_t nx, int64_t ny, int64_t nu, int64_t nv, int64_t planes, int64
     w.col_in = take((size_t)(nu * nv) * 2 * sizeof(double));     // ... and the second transform's (zero band kept)
     w.tw = take((size_t)nv * 2 * sizeof(double));                // W_nv^k of the fused fill + first transform
     w.tw2 = take((size_t)nu * 2 * sizeof(double));               // W_nu^k of the fused second transform
+    w.poly = take(sizeof(WgPoly));                               // the tap polynomials where the tile kernel reads them (wg_store_poly)
     w.grid = take((size_t)(planes > 0 ? planes : 1) * (size_t)(nu * nv) * 2 * sizeof(double));
     w.A = take((size_t)(nx * ny) * sizeof(double));
     w.nm1 = take((size_t)(nx * ny) * sizeof(double));
@@ -1776,6 +1831,11 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     char *ws = static_cast<char *>(workspace);
     double2 *grid = reinterpret_cast<double2 *>(ws + L.grid), *S = reinterpret_cast<double2 *>(ws + L.stage);
     double *A = reinterpret_cast<double *>(ws + L.A), *nm1 = reinterpret_cast<double *>(ws + L.nm1);
+    WgPoly *poly_dev = reinterpret_cast<WgPoly *>(ws + L.poly);
+    if (!adjoint) {
+        hipLaunchKernelGGL(wg_store_poly, dim3(1), dim3(256), 0, st, poly, poly_dev);
+        AF_LAUNCH_CHECK();
+    }
 
     const unsigned nb_img = (unsigned)af_cdiv(nx * ny, 256), nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
     // large image -> vis calls: the sort and the zero fill on the side stream (wg_side_stream), beside the transforms
@@ -2082,7 +2142,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         hipLaunchKernelGGL((wg_degrid_tiles<WC, P>), dim3(max_chunks + 8), dim3(256), 0, st, uvw, freq, nchan_band,      \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
                            pk0, pk1, do_wstacking, vidx, vstart, kb, chunks, nchunks, reinterpret_cast<double2 *>(vis),  \
-                           poly, xcd_env, conc_env);                                                                     \
+                           poly_dev, xcd_env, conc_env);                                                                     \
     else                                                                                                               \
         hipLaunchKernelGGL((wg_degrid_planes<WC, P>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band,       \
                            chan0, nchan_total, reinterpret_cast<const P *>(grid), nv, nu, celly, cellx, beta, w0, dw,    \
