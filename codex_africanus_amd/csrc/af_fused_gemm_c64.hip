@@ -48,15 +48,23 @@ constexpr int VREC32 = 16;          // floats per cell record: 4 correlations x 
 // matrix wave's lanes 0-15 / 16-31 read with one ds_read_b32 then sit on disjoint halves of the 32 banks
 constexpr int plane_stride(int nant) { return 2 * nant + ((2 * nant) % 32 == 0 ? 16 : 32); }
 
-// NEG (RECT 8 x 8, as the fp64 kernel's FOURM): a third pair of H planes holds -im, so that Im accumulates in ONE register set
-// (Im += Gi Hr + Gr (-Hi)) and a matrix wave holds eight tiles (its block row) in 64 accumulator registers: one super-tile per
-// pair of super-blocks, 128 sampled terms for 64 tiles instead of two 8 x 4 super-tiles' 192.
-template <bool RECT, int NBR, int NBC, int ST, bool NEG = false>
+// Three forms of the complex product, chosen per super-tile shape:
+//   FORM_4P  (RECT 8 x 4) four products on three accumulators, Im = sum Gi Hr - sum Gr Hi in the epilogue; planes re, im.
+//   FORM_3M  (DIAG)       P1 = Gr Hr, P2 = Gi Hi, P3 = (Gr + Gi)(Hr - Hi): three matrix instructions per tile and source pair
+//                         for two more planes per term (re -+ im) -- 54.6 -> 47.2 ms at 64 antennas, where the matrix
+//                         instructions are half of what a SIMD issues; a RECT 8 x 4 batch of whole super-rounds would not fit
+//                         the LDS with six + six planes.
+//   FORM_NEG (RECT 8 x 8, as the fp64 kernel's FOURM) a third pair of H planes holds -im, so that Im accumulates in ONE
+//                         register set (Im += Gi Hr + Gr (-Hi)) and a matrix wave holds eight tiles (its block row) in 64
+//                         accumulator registers: one super-tile per pair of super-blocks, 128 sampled terms for 64 tiles
+//                         instead of two 8 x 4 super-tiles' 192.
+constexpr int FORM_4P = 0, FORM_3M = 1, FORM_NEG = 2;
+template <bool RECT, int NBR, int NBC, int ST, int FORM = FORM_4P>
 struct GeoS {
     static constexpr int NAR = 8 * NBR, NAC = 8 * NBC;
     static constexpr int CSG = plane_stride(NAR), CSH = plane_stride(NAC);     // floats per operand plane
-    static constexpr int HP = NEG ? 6 : S_PLANES;                              // H planes of a source
-    static constexpr int SRC = HP * CSH + S_PLANES * CSG;                      // one source: H planes, then G planes
+    static constexpr int HP = FORM == FORM_4P ? S_PLANES : 6, GPL = FORM == FORM_3M ? 6 : S_PLANES;   // H / G planes of a source
+    static constexpr int SRC = HP * CSH + GPL * CSG;                           // one source: H planes, then G planes
     static constexpr int BUF = ST * SRC;                                       // one batch
     static constexpr int TPS = RECT ? NAR + NAC : NAR;                         // sampled terms (antenna slots) per source
     static constexpr int BT = ST * TPS;                                        // terms per batch
@@ -114,6 +122,28 @@ template <int ODD> __device__ __forceinline__ float pair_bcastf(float x)
 struct C2f {
     float re, im;
 };
+typedef float v2f __attribute__((ext_vector_type(2)));
+#if 1
+// complex arithmetic on (re, im) pairs: v_pk_mul_f32 / v_pk_fma_f32, two float32 operations per instruction (54.6 -> 53.5 ms)
+__device__ __forceinline__ C2f cmulf(C2f a, C2f b)
+{
+    const v2f bb = {b.re, b.im}, bs = {-b.im, b.re};
+    const v2f ar = {a.re, a.re}, ai = {a.im, a.im};
+    const v2f z = __builtin_elementwise_fma(ar, bb, ai * bs);
+    C2f r;
+    r.re = z.x; r.im = z.y;
+    return r;
+}
+__device__ __forceinline__ void cmacf(C2f &acc, C2f a, C2f b)
+{
+    const v2f bb = {b.re, b.im}, bs = {-b.im, b.re};
+    const v2f ar = {a.re, a.re}, ai = {a.im, a.im};
+    v2f z = {acc.re, acc.im};
+    z = __builtin_elementwise_fma(ar, bb, z);
+    z = __builtin_elementwise_fma(ai, bs, z);
+    acc.re = z.x; acc.im = z.y;
+}
+#else
 __device__ __forceinline__ C2f cmulf(C2f a, C2f b)
 {
     C2f z;
@@ -128,6 +158,7 @@ __device__ __forceinline__ void cmacf(C2f &acc, C2f a, C2f b)
     acc.im = fmaf(a.re, b.im, acc.im);
     acc.im = fmaf(a.im, b.re, acc.im);
 }
+#endif
 struct alignas(4) F3 {
     float x, y, z;
 };
@@ -182,12 +213,23 @@ __global__ void beam_plane_kernel_f32(const float2 *__restrict__ beam, int64_t n
 __device__ __forceinline__ C2f beam_reduce1f(const F3 (&v)[4], const float (&wt)[4])
 {
     float cre = 0.0f, cim = 0.0f, absc = 0.0f;
+#if 1
+    v2f c2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const v2f w2 = {wt[k], wt[k]}, x2 = {v[k].x, v[k].y};
+        c2 = __builtin_elementwise_fma(w2, x2, c2);
+        absc = fmaf(wt[k], v[k].z, absc);
+    }
+    cre = c2.x; cim = c2.y;
+#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cre = fmaf(wt[k], v[k].x, cre);
         cim = fmaf(wt[k], v[k].y, cim);
         absc = fmaf(wt[k], v[k].z, absc);
     }
+#endif
     const float n2 = fmaf(cre, cre, __fmul_rn(cim, cim));
     const float sc = (n2 == 0.0f) ? absc : __fmul_rn(absc, __builtin_amdgcn_rsqf(n2));
     C2f r;
@@ -199,12 +241,12 @@ __device__ __forceinline__ C2f beam_reduce1f(const F3 (&v)[4], const float (&wt)
 // ---- matrix waves ------------------------------------------------------------------------------------------------------
 // D_LAYOUT_STD: accumulator register r of lane l holds D[4 (l >> 4) + r][l & 15] (v_mfma_f32_16x16x4_f32;
 // tools/probe/probe_mfma_f32_16x16x4.hip prints it).
-template <bool RECT, int NBR, int NBC, int ST, int W>
+template <bool RECT, int NBR, int NBC, int ST, int FORM, int W>
 __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int nbatch, int lane,
                                               const int32_t *__restrict__ rm, int nap, const SuperTileS tile, int64_t nchan,
                                               int64_t f, float2 *__restrict__ out)
 {
-    using G = GeoS<RECT, NBR, NBC, ST>;
+    using G = GeoS<RECT, NBR, NBC, ST, FORM>;
     constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
     constexpr int T0 = chunk_lo_s(G::NTILE, W), CNT = chunk_lo_s(G::NTILE, W + 1) - T0;
     constexpr int CN = CNT > 0 ? CNT : 1;
@@ -232,11 +274,17 @@ __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int
                 constexpr int pb = tile_row_s<RECT, NBR, NBC>(T0 + j), qb = tile_col_s<RECT, NBR, NBC>(T0 + j);
                 if (RECT && qb >= tile.nc_act) return;           // block-uniform: the column super-block is short
                 const float *A = S + offA + pb * 16, *B = S + offB + qb * 16;
-                const float gr = A[0], gi = A[2 * CSG], hr = B[0], hi = B[2 * CSH];
-                cr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hr, cr[j], 0, 0, 0);
-                ci1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hr, ci1[j], 0, 0, 0);
-                ci2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hi, ci2[j], 0, 0, 0);
-                cr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hi, cr[j], 0, 0, 0);
+if constexpr (FORM == FORM_3M) {
+                    cr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0], B[0], cr[j], 0, 0, 0);                       // P1 = Gr Hr
+                    ci1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2 * CSG], B[2 * CSH], ci1[j], 0, 0, 0);         // P2 = Gi Hi
+                    ci2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * CSG], B[4 * CSH], ci2[j], 0, 0, 0);         // P3 = (Gr + Gi)(Hr - Hi)
+                } else {
+                    const float gr = A[0], gi = A[2 * CSG], hr = B[0], hi = B[2 * CSH];
+                    cr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hr, cr[j], 0, 0, 0);
+                    ci1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hr, ci1[j], 0, 0, 0);
+                    ci2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hi, ci2[j], 0, 0, 0);
+                    cr[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hi, cr[j], 0, 0, 0);
+                }
             }, std::make_integer_sequence<int, CNT>{});
         }
     }
@@ -257,7 +305,8 @@ __device__ __forceinline__ void matrix_wave_s(const float *__restrict__ lds, int
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int ii = (4 * kq + reg) & 1;
-            const float re = cr[j][reg], im = ci1[j][reg] - ci2[j][reg];
+const float re = FORM == FORM_3M ? cr[j][reg] + ci1[j][reg] : cr[j][reg];
+            const float im = FORM == FORM_3M ? (ci2[j][reg] - cr[j][reg]) + ci1[j][reg] : ci1[j][reg] - ci2[j][reg];
             if (r1[reg] >= 0) out[((int64_t)r1[reg] * nchan + f) * 4 + ii * 2 + jj] = make_float2(re, im);
             if (r2[reg] >= 0) out[((int64_t)r2[reg] * nchan + f) * 4 + jj * 2 + ii] = make_float2(re, -im);
         }
@@ -269,7 +318,7 @@ template <int NBC, int ST, int W>
 __device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, int nbatch, int lane, const int32_t *__restrict__ rm,
                                                 int nap, const SuperTileS tile, int64_t nchan, int64_t f, float2 *__restrict__ out)
 {
-    using G = GeoS<true, 8, NBC, ST, true>;
+    using G = GeoS<true, 8, NBC, ST, FORM_NEG>;
     constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
     const int kq = lane >> 4, c16 = lane & 15;
     const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
@@ -324,7 +373,7 @@ __device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, i
 }
 
 // grid: (nsteps, channels of the plane group, super-tiles of this shape); block 1024.
-template <bool FEED, bool RECT, int NBR, int NBC, int ST, bool NEG = false>
+template <bool FEED, bool RECT, int NBR, int NBC, int ST, int FORM>
 __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     const double *__restrict__ ant_uvw, const int32_t *__restrict__ rowmap, const double *__restrict__ lmn,
     const double *__restrict__ f4, const float2 *__restrict__ brightness, const float *__restrict__ vrec, int64_t beam_lw,
@@ -334,8 +383,9 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     int64_t f0, const SuperTileListS tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
+    constexpr bool NEG = FORM == FORM_NEG;
     static_assert(!NEG || (RECT && NBR == 8), "the NEG form serves RECT super-tiles of eight block rows");
-    using G = GeoS<RECT, NBR, NBC, ST, NEG>;
+    using G = GeoS<RECT, NBR, NBC, ST, FORM>;
     constexpr int NAC = G::NAC, CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF, TPS = G::TPS, BT = G::BT;
     extern __shared__ double lds_raw[];
     // doubles first (alignment): per-slot constants, then the phasor table, then the float panels
@@ -404,14 +454,14 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
             return;
         }
         switch (tid >> 6) {
-        case 0: matrix_wave_s<RECT, NBR, NBC, ST, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 1: matrix_wave_s<RECT, NBR, NBC, ST, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 2: matrix_wave_s<RECT, NBR, NBC, ST, 2>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 3: matrix_wave_s<RECT, NBR, NBC, ST, 3>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 4: matrix_wave_s<RECT, NBR, NBC, ST, 4>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 5: matrix_wave_s<RECT, NBR, NBC, ST, 5>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        case 6: matrix_wave_s<RECT, NBR, NBC, ST, 6>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-        default: matrix_wave_s<RECT, NBR, NBC, ST, 7>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 0: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 1: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 2: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 2>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 3: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 3>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 4: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 4>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 5: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 5>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        case 6: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 6>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+        default: matrix_wave_s<RECT, NBR, NBC, ST, FORM, 7>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
         }
         return;
     }
@@ -555,6 +605,9 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
             float *gs = hs + G::HP * CSH;
             hs[ej * CSH] = A.re; hs[(2 + ej) * CSH] = A.im;
             gs[ej * CSG] = Gv.re; gs[(2 + ej) * CSG] = Gv.im;
+if constexpr (FORM == FORM_3M) {
+                hs[(4 + ej) * CSH] = __fsub_rn(A.re, A.im); gs[(4 + ej) * CSG] = __fadd_rn(Gv.re, Gv.im);
+            }
         } else {
             // a column antenna's term writes its H planes, a row antenna's its G planes
             const bool r_col = (info >> 30) & 1;
@@ -562,8 +615,11 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
             const int cs = r_col ? CSH : CSG;
             ws[ej * cs] = r_col ? A.re : Gv.re;
             ws[(2 + ej) * cs] = r_col ? A.im : Gv.im;
-            if constexpr (NEG)
+            if constexpr (NEG) {
                 if (r_col) ws[(4 + ej) * CSH] = -A.im;
+            } else if constexpr (FORM == FORM_3M) {
+                ws[(4 + ej) * cs] = r_col ? __fsub_rn(A.re, A.im) : __fadd_rn(Gv.re, Gv.im);
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -721,20 +777,20 @@ AF_EXPORT int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t
         shapes.push_back(s);
     };
 #define AF_GEMMS_K(RECTC, NBRC, NBCC, STC)                                                                             \
-    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, RECTC, NBRC, NBCC, STC>)                         \
-          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, RECTC, NBRC, NBCC, STC>)),                      \
-        GeoS<RECTC, NBRC, NBCC, STC>::lds_bytes()
+    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, RECTC, NBRC, NBCC, STC, RECTC ? FORM_4P : FORM_3M>)  \
+          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, RECTC, NBRC, NBCC, STC, RECTC ? FORM_4P : FORM_3M>)), \
+        GeoS<RECTC, NBRC, NBCC, STC, RECTC ? FORM_4P : FORM_3M>::lds_bytes()
 #define AF_GEMMS_KN(NBCC, STC)                                                                                         \
-    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, true, 8, NBCC, STC, true>)                       \
-          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, true, 8, NBCC, STC, true>)),                    \
-        GeoS<true, 8, NBCC, STC, true>::lds_bytes()
+    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, true, 8, NBCC, STC, FORM_NEG>)                   \
+          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, true, 8, NBCC, STC, FORM_NEG>)),                \
+        GeoS<true, 8, NBCC, STC, FORM_NEG>::lds_bytes()
     for (int i = 0; i < tl.nsb; ++i) {
         SuperTileS e = {8 * tl.blk0[i], 8 * tl.blk0[i], tl.size[i], 0};
         switch (tl.size[i]) {
-        // sources per batch: one super-round of the 512 sampling lanes where the panels fit (two buffers within ~100 KB)
-        case 1: add(AF_GEMMS_K(false, 1, 1, 32), e); break;
-        case 2: add(AF_GEMMS_K(false, 2, 2, 32), e); break;
-        case 3: add(AF_GEMMS_K(false, 3, 3, 20), e); break;
+        // sources per batch: one super-round of the 512 sampling lanes where two buffers of six + six planes fit the LDS
+        case 1: add(AF_GEMMS_K(false, 1, 1, 16), e); break;
+        case 2: add(AF_GEMMS_K(false, 2, 2, 24), e); break;
+        case 3: add(AF_GEMMS_K(false, 3, 3, 16), e); break;
         case 4: add(AF_GEMMS_K(false, 4, 4, 16), e); break;
         case 5: add(AF_GEMMS_K(false, 5, 5, 12), e); break;
         case 6: add(AF_GEMMS_K(false, 6, 6, 10), e); break;

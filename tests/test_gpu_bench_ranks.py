@@ -155,7 +155,8 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert w["dft_complex"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde"]["fp64_max_abs_err"] < 1e-8
     assert w["fused_dde_ant"]["fp64_max_abs_err"] < 1e-8 and w["fused_dde_ant"]["roofline"]["kernel"] == "fused_gemm3_kernel"
     assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
-    assert w["fused_dde_ant_c64"]["fp64_max_abs_err"] < 1e-3 and w["fused_dde_ant_c64"]["roofline"]["kernel"] == "fused_gemm_c64_kernel"
+    # (single precision rows: float32 differences of antenna coordinates carry ~1e-4 m of rounding = 1e-4 rad per term)
+    assert w["fused_dde_ant_c64"]["fp64_max_abs_err"] < 1e-2 and w["fused_dde_ant_c64"]["roofline"]["kernel"] == "fused_gemm_c64_kernel"
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
     assert w["gauss"]["fp64_max_abs_err"] < 1e-8 and w["gauss"]["roofline"]["kernel"].startswith("dft_mfma_kernel")
 
