@@ -111,8 +111,8 @@ def test_gemm_form_of_the_fused_predict_fits_three_waves_per_simd(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        # template <bool FEED, bool RECT, int NBR, int NBC, int ST>
-        m = re.search(r"fused_gemm3_kernelILb([01])ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        # template <bool FEED, bool RECT, int NBR, int NBC, int ST, bool FOURM>
+        m = re.search(r"fused_gemm3_kernelILb([01])ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
         if not m:
             continue
         seen += 1
@@ -123,4 +123,29 @@ def test_gemm_form_of_the_fused_predict_fits_three_waves_per_simd(tmp_path):
         assert vgprs + agprs <= 168 and scratch <= 32 and lds == 0, (name, scratch, vgprs, agprs, lds)   # LDS is dynamic
         if m.group(1) == "0" and (m.group(3) == "8"):
             assert scratch == 0, (name, scratch)          # BASELINE configs[2]'s instantiation (DIAG<8>) and the RECT super-tile
-    assert seen == 18, seen     # (8 DIAG antenna-block counts + the 8 x 4 RECT super-tile of arrays beyond 64 antennas) x FEED
+    # (8 DIAG antenna-block counts + the 8 x 4 RECT super-tile + the 8 x 8 RECT super-tile in the four-product form) x FEED
+    assert seen == 20, seen
+
+
+def test_single_precision_gemm_form_fits_four_waves_per_simd(tmp_path):
+    """The 16-wave single-precision GEMM-form kernel (8 matrix + 8 sampling waves, csrc/af_fused_gemm_c64.hip) lives on 128
+    registers with nothing in scratch: DIAG of 1 .. 8 blocks (3M form), RECT 8 x 4 (four products), RECT 8 x 8 (NEG form),
+    each with and without feed rotation."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+           "--cuda-device-only", "-c", os.path.join(CSRC, "af_fused_gemm_c64.hip"), "-o", str(tmp_path / "k.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    text = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "fused_gemm_c64_kernel" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        assert scratch == 0 and vgprs + agprs <= 128, (name, scratch, vgprs, agprs)
+    assert seen == 20, seen
