@@ -26,7 +26,7 @@
 // super-round of 512 terms as in af_fused_predict.hip): a batch lasts as long as a sampling wave's serial chain (coordinates
 // -> gathers -> arithmetic -> panel stores), and single precision leaves the registers for twice the fp64 kernel's four
 // (first version, 12 waves: 68.9 ms for 1e6 rows x 64 channels x 1000 sources against the fp64 kernel's 87.4).
-// Super-tiles (DIAG / RECT 8 x 4 / RECT 8 x 8 in the NEG form) and the row map as in af_fused_gemm.hip.
+// Super-tiles (DIAG / RECT 8 x 4 / RECT 8 x 8) and the row map as in af_fused_gemm.hip.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -54,16 +54,16 @@ constexpr int plane_stride(int nant) { return 2 * nant + ((2 * nant) % 32 == 0 ?
 //                         for two more planes per term (re -+ im) -- 54.6 -> 47.2 ms at 64 antennas, where the matrix
 //                         instructions are half of what a SIMD issues; a RECT 8 x 4 batch of whole super-rounds would not fit
 //                         the LDS with six + six planes.
-//   FORM_NEG (RECT 8 x 8, as the fp64 kernel's FOURM) a third pair of H planes holds -im, so that Im accumulates in ONE
-//                         register set (Im += Gi Hr + Gr (-Hi)) and a matrix wave holds eight tiles (its block row) in 64
-//                         accumulator registers: one super-tile per pair of super-blocks, 128 sampled terms for 64 tiles
-//                         instead of two 8 x 4 super-tiles' 192.
-constexpr int FORM_4P = 0, FORM_3M = 1, FORM_NEG = 2;
+//   FORM_ROW (RECT 8 x 8) the 3M form with matrix wave W = block row W: eight tiles x three accumulators are 96 float
+//                         registers (the fp64 kernel needs its two-accumulator FOURM form for this shape; here the 3M form
+//                         fits: 116 registers in all) -- one super-tile per pair of super-blocks, 128 sampled terms for 64
+//                         tiles instead of two 8 x 4 super-tiles' 192.
+constexpr int FORM_4P = 0, FORM_3M = 1, FORM_ROW = 2;
 template <bool RECT, int NBR, int NBC, int ST, int FORM = FORM_4P>
 struct GeoS {
     static constexpr int NAR = 8 * NBR, NAC = 8 * NBC;
     static constexpr int CSG = plane_stride(NAR), CSH = plane_stride(NAC);     // floats per operand plane
-    static constexpr int HP = FORM == FORM_4P ? S_PLANES : 6, GPL = FORM == FORM_3M ? 6 : S_PLANES;   // H / G planes of a source
+    static constexpr int HP = FORM == FORM_4P ? S_PLANES : 6, GPL = HP;               // H / G planes of a source
     static constexpr int SRC = HP * CSH + GPL * CSG;                           // one source: H planes, then G planes
     static constexpr int BUF = ST * SRC;                                       // one batch
     static constexpr int TPS = RECT ? NAR + NAC : NAR;                         // sampled terms (antenna slots) per source
@@ -313,19 +313,19 @@ const float re = FORM == FORM_3M ? cr[j][reg] + ci1[j][reg] : cr[j][reg];
     }, std::make_integer_sequence<int, CNT>{});
 }
 
-// NEG form (RECT 8 x NBC): wave W = block row W, two accumulators per tile
+// ROW form (RECT 8 x NBC): wave W = block row W, 3M on three accumulators per tile
 template <int NBC, int ST, int W>
-__device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, int nbatch, int lane, const int32_t *__restrict__ rm,
+__device__ __forceinline__ void matrix_wave_row(const float *__restrict__ lds, int nbatch, int lane, const int32_t *__restrict__ rm,
                                                 int nap, const SuperTileS tile, int64_t nchan, int64_t f, float2 *__restrict__ out)
 {
-    using G = GeoS<true, 8, NBC, ST, FORM_NEG>;
+    using G = GeoS<true, 8, NBC, ST, FORM_ROW>;
     constexpr int CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF;
     const int kq = lane >> 4, c16 = lane & 15;
     const int offB = (kq >> 1) * SRC + (kq & 1) * CSH + c16;
     const int offA = (kq >> 1) * SRC + G::HP * CSH + (kq & 1) * CSG + c16 + W * 16;
-    v4f cr[NBC], ci[NBC];
+    v4f p1[NBC], p2[NBC], p3[NBC];                       // 3M: P1 = Gr Hr, P2 = Gi Hi, P3 = (Gr + Gi)(Hr - Hi)
 #pragma unroll
-    for (int j = 0; j < NBC; ++j) cr[j] = ci[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < NBC; ++j) p1[j] = p2[j] = p3[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     int buf = 0;
     for (int b = 0; b < nbatch; ++b) {
         __syncthreads();
@@ -337,16 +337,14 @@ __device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, i
 #pragma unroll
         for (int s2 = 0; s2 < ST / 2; ++s2) {
             const float *A = P + 2 * s2 * SRC + offA, *Bp = P + 2 * s2 * SRC + offB;
-            const float gr = A[0], gi = A[2 * CSG];
+            const float gr = A[0], gi = A[2 * CSG], gs = A[4 * CSG];      // the block row's operands: once per source pair
             for_each_const_s([&](auto jc) {
                 constexpr int qb = decltype(jc)::value;
                 if (qb >= tile.nc_act) return;                   // block-uniform: the column super-block is short
                 const float *B = Bp + qb * 16;
-                const float hr = B[0], hi = B[2 * CSH], nhi = B[4 * CSH];
-                cr[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, hr, cr[qb], 0, 0, 0);
-                ci[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hr, ci[qb], 0, 0, 0);
-                cr[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, hi, cr[qb], 0, 0, 0);
-                ci[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, nhi, ci[qb], 0, 0, 0);
+                p1[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr, B[0], p1[qb], 0, 0, 0);
+                p2[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gi, B[2 * CSH], p2[qb], 0, 0, 0);
+                p3[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gs, B[4 * CSH], p3[qb], 0, 0, 0);
             }, std::make_integer_sequence<int, NBC>{});
         }
     }
@@ -365,7 +363,7 @@ __device__ __forceinline__ void matrix_wave_neg(const float *__restrict__ lds, i
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int ii = (4 * kq + reg) & 1;
-            const float re = cr[qb][reg], im = ci[qb][reg];
+            const float re = p1[qb][reg] + p2[qb][reg], im = (p3[qb][reg] - p1[qb][reg]) + p2[qb][reg];
             if (r1[reg] >= 0) out[((int64_t)r1[reg] * nchan + f) * 4 + ii * 2 + jj] = make_float2(re, im);
             if (r2[reg] >= 0) out[((int64_t)r2[reg] * nchan + f) * 4 + jj * 2 + ii] = make_float2(re, -im);
         }
@@ -383,8 +381,8 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
     int64_t f0, const SuperTileListS tiles)
 {
     static_assert(ST % 2 == 0, "sources are consumed in pairs");
-    constexpr bool NEG = FORM == FORM_NEG;
-    static_assert(!NEG || (RECT && NBR == 8), "the NEG form serves RECT super-tiles of eight block rows");
+    constexpr bool NEG = FORM == FORM_ROW;
+    static_assert(!NEG || (RECT && NBR == 8), "the ROW form serves RECT super-tiles of eight block rows");
     using G = GeoS<RECT, NBR, NBC, ST, FORM>;
     constexpr int NAC = G::NAC, CSG = G::CSG, CSH = G::CSH, SRC = G::SRC, BUF = G::BUF, TPS = G::TPS, BT = G::BT;
     extern __shared__ double lds_raw[];
@@ -442,14 +440,14 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
         const int lane = tid & 63;
         if constexpr (NEG) {
             switch (tid >> 6) {
-            case 0: matrix_wave_neg<NBC, ST, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 1: matrix_wave_neg<NBC, ST, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 2: matrix_wave_neg<NBC, ST, 2>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 3: matrix_wave_neg<NBC, ST, 3>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 4: matrix_wave_neg<NBC, ST, 4>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 5: matrix_wave_neg<NBC, ST, 5>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            case 6: matrix_wave_neg<NBC, ST, 6>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
-            default: matrix_wave_neg<NBC, ST, 7>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 0: matrix_wave_row<NBC, ST, 0>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 1: matrix_wave_row<NBC, ST, 1>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 2: matrix_wave_row<NBC, ST, 2>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 3: matrix_wave_row<NBC, ST, 3>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 4: matrix_wave_row<NBC, ST, 4>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 5: matrix_wave_row<NBC, ST, 5>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            case 6: matrix_wave_row<NBC, ST, 6>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
+            default: matrix_wave_row<NBC, ST, 7>(ldsp, nbatch, lane, rm, nap, tile, nchan, f, out); break;
             }
             return;
         }
@@ -615,9 +613,7 @@ if constexpr (FORM == FORM_3M) {
             const int cs = r_col ? CSH : CSG;
             ws[ej * cs] = r_col ? A.re : Gv.re;
             ws[(2 + ej) * cs] = r_col ? A.im : Gv.im;
-            if constexpr (NEG) {
-                if (r_col) ws[(4 + ej) * CSH] = -A.im;
-            } else if constexpr (FORM == FORM_3M) {
+            if constexpr (FORM != FORM_4P) {
                 ws[(4 + ej) * cs] = r_col ? __fsub_rn(A.re, A.im) : __fadd_rn(Gv.re, Gv.im);
             }
         }
@@ -781,9 +777,9 @@ AF_EXPORT int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t
           : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, RECTC, NBRC, NBCC, STC, RECTC ? FORM_4P : FORM_3M>)), \
         GeoS<RECTC, NBRC, NBCC, STC, RECTC ? FORM_4P : FORM_3M>::lds_bytes()
 #define AF_GEMMS_KN(NBCC, STC)                                                                                         \
-    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, true, 8, NBCC, STC, FORM_NEG>)                   \
-          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, true, 8, NBCC, STC, FORM_NEG>)),                \
-        GeoS<true, 8, NBCC, STC, FORM_NEG>::lds_bytes()
+    (feed ? reinterpret_cast<const void *>(fused_gemm_c64_kernel<true, true, 8, NBCC, STC, FORM_ROW>)                   \
+          : reinterpret_cast<const void *>(fused_gemm_c64_kernel<false, true, 8, NBCC, STC, FORM_ROW>)),                \
+        GeoS<true, 8, NBCC, STC, FORM_ROW>::lds_bytes()
     for (int i = 0; i < tl.nsb; ++i) {
         SuperTileS e = {8 * tl.blk0[i], 8 * tl.blk0[i], tl.size[i], 0};
         switch (tl.size[i]) {
@@ -798,7 +794,7 @@ AF_EXPORT int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t
         default: add(AF_GEMMS_K(false, 8, 8, 8), e); break;
         }
         for (int j = i + 1; j < tl.nsb; ++j) {
-            if (tl.size[j] > RECT_COLS_S) {        // one 8 x 8 super-tile (NEG form) per pair of super-blocks
+            if (tl.size[j] > RECT_COLS_S) {        // one 8 x 8 super-tile (ROW form) per pair of super-blocks
                 SuperTileS r = {8 * tl.blk0[i], 8 * tl.blk0[j], tl.size[j], 0};
                 add(AF_GEMMS_KN(8, 8), r);
                 continue;

@@ -291,7 +291,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     block_ids = _row_block_ids(len(row_chunks))
     b_ix = ("src", "corr-1", "corr-2") if flat else ("src", "chan", "corr-1", "corr-2")
     new_axes = {"corr-1": 2, "corr-2": 2} if brightness is None else None
-    dtype = np.complex128
+    # the promoted type of the floating-point inputs (rime.fused_predict_vis's rule, africanus/util/type_inference.py:24-26)
+    dtype = np.result_type(np.complex64, *[a.dtype for a in (lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
+                                                             parallactic_angles, point_errors, antenna_scaling, feed_rotation,
+                                                             gauss_shape, stokes, spi, ref_freq) if a is not None])
 
     def blocks(src_sel, running):
         sel = lambda a: None if a is None else a.blocks[src_sel]

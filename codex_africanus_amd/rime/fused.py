@@ -246,6 +246,30 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                       die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
                       feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
                       corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, plan=None):
+    """See :func:`_fused_predict_vis` (below) for the arguments.  Result type: the reference's rule for the chain this
+    call replaces -- the promoted type of the inputs (africanus/util/type_inference.py:24-26): complex64 when EVERY
+    floating-point input is single precision, complex128 otherwise.  Single-precision calls on antenna-decomposable rows
+    with a beam are COMPUTED in single precision (``af_fused_predict_antennas_c64``); every other route computes in double and
+    rounds once at the end (closer to the float64 chain than the reference's float32 arithmetic)."""
+    vis = _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
+                             parallactic_angles, point_errors, antenna_scaling, die1_jones, base_vis, die2_jones, convention,
+                             feed_rotation, gauss_shape, stokes, spi, ref_freq, corr_schema, spectral_base, plan)
+    if np_dtype_of(vis) == np.complex128 and _all_single(lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
+                                                         parallactic_angles, point_errors, antenna_scaling, die1_jones, base_vis,
+                                                         die2_jones, feed_rotation, gauss_shape, stokes, spi, ref_freq):
+        if _is_torch(vis):
+            import torch
+            return vis.to(torch.complex64)
+        return vis.astype(np.complex64)
+    return vis
+
+
+def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness=None,
+                       beam=None, beam_lm_extents=None, beam_freq_map=None, parallactic_angles=None,
+                       point_errors=None, antenna_scaling=None,
+                       die1_jones=None, base_vis=None, die2_jones=None, convention="fourier",
+                       feed_rotation=None, gauss_shape=None, stokes=None, spi=None, ref_freq=None,
+                       corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, plan=None):
     """
     ``V_pq = G_p ( B_pq + sum_s E_ps (K_pqs X_s) E_qs^H ) G_q^H`` from source-level inputs.
 
@@ -268,9 +292,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     index arrays and O(row) host work.  A plan made with ``uvw=`` is bound to those ``uvw`` as well.  A plan passed in is
     VERIFIED against this call's ``time_index`` / ``antenna1`` / ``antenna2`` / ``uvw`` on the device
     (``af_fused_plan_check``, O(row), no host round trip): on a mismatch the result is NaN and ``ValueError`` is raised
-    -- at once for numpy arguments, at the next call / ``check_status()`` for device tensors.  Returns (row, chan, 2, 2) complex128.  With a beam, rows should be grouped by
+    -- at once for numpy arguments, at the next call / ``check_status()`` for device tensors.  Returns (row, chan, 2, 2) complex
+    (the type rule is :func:`fused_predict_vis`'s).  With a beam, rows should be grouped by
     ``time_index`` (Measurement-Set order): every run of equal ``time_index`` shares its
-    per-antenna Jones terms on the device.  float64 / complex128 only.
+    per-antenna Jones terms on the device.
     """
     if convention not in _lib.CONVENTION:
         raise ValueError("convention not in ('fourier', 'casa')")

@@ -94,10 +94,10 @@ def _call_s(s, **kw):
                                   s["extents"], s["beam_freq_map"], s["pa"], s["pe"], s["as"], **kw)
 
 
-# every instantiation kind: DIAG of 1 .. 8 blocks (padded super-rounds below 8), RECT 8 x 4 with a full and a short column
-# super-block (100: 5 blocks = 4 + 1; 128: 8 = 4 + 4; 197: three super-blocks)
+# every instantiation kind: DIAG of 1 .. 8 blocks (padded super-rounds below 8), RECT 8 x 4 (65, 100: a column super-block of
+# <= 4 blocks), RECT 8 x 8 with a short (104: 5 blocks) and full column super-block (128, 197, 300)
 @pytest.mark.parametrize("nant, nrow", [(5, 37), (12, 600), (17, 1500), (24, 2000), (33, 2500), (40, 1700), (47, 3000), (57, 4000),
-                                        (64, 4100), (65, 4300), (100, 5200), (128, 9000), (197, 20000)])
+                                        (64, 4100), (65, 4300), (100, 5200), (104, 5400), (128, 9000), (197, 20000), (300, 45000)])
 def test_against_the_float64_chain_at_every_super_tile_kind(nant, nrow):
     d = _decomposable(_problem(3, nrow, 6, 23, nant), nant)
     s = _single(d)
@@ -146,6 +146,23 @@ def test_mixed_precision_inputs_take_the_float64_route():
     assert out.dtype == np.complex128
     assert not fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"]).decomposable
     assert np.abs(out - _chain64(s)).max() < 1e-9 * _scale(d)
+
+
+def test_single_precision_rows_that_do_not_decompose_are_computed_in_double_and_rounded_once():
+    """uvw drawn per row (BASELINE's recipe) in float32: no antenna coordinates reproduce them, the lane-per-row kernel runs
+    in double on the promoted values and the result is rounded to the type the reference's rule gives such a call --
+    complex64 (africanus/util/type_inference.py:24-26) -- with half an ulp of float32 of error"""
+    nant = 12
+    d = _problem(7, 600, 4, 9, nant)
+    s = _single(dict(d, ant_xyz=np.zeros((d["ntime"], nant, 3))))
+    s["uvw"] = d["uvw"].astype(np.float32)
+    out = _call_s(s)
+    assert out.dtype == np.complex64
+    truth = _chain64(s)
+    assert np.abs(out - truth).max() <= 6.1e-8 * np.abs(truth).max() + 1e-9 * _scale(d)
+    # no beam: the direct transform route, same rule
+    nobeam = rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], s["lm"], s["uvw"], s["frequency"], s["X"])
+    assert nobeam.dtype == np.complex64
 
 
 def test_device_resident_tensors():
