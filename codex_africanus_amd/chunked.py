@@ -218,7 +218,10 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     are never chunked.  Source chunks are summed (serial chain when ``streams=True``); ``base_vis`` and the DIEs are
     applied to that sum.  The row layout's plan is made once per row chunk and re-used for its source and channel blocks.
     """
-    from .rime.fused import fused_predict_vis as _fused, cached_plan
+    from .rime.fused import fused_predict_vis as _fused, cached_plan, _all_single
+    # every input single precision: plans of float32 rows decompose at their own precision (the single-precision GEMM form)
+    single = stokes is None and _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents, beam_freq_map,
+                                            parallactic_angles, point_errors, antenna_scaling)
     chunks = chunks or {}
     if (die1_jones is None) != (die2_jones is None):
         raise ValueError("Both die1_jones and die2_jones must be present or absent")
@@ -247,7 +250,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
         ti, a1, a2, uv = time_index[r0:r1], antenna1[r0:r1], antenna2[r0:r1], uvw[r0:r1]
         plan = None
         if beam is not None:
-            plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]), uvw=None if gauss_shape is not None else uv)
+            plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]), uvw=None if gauss_shape is not None else uv,
+                               single=single)
         chan_blocks = []
         for (c0, c1) in _bounds(chan_chunks):
             acc = None

@@ -20,7 +20,7 @@
 // takes every visibility through its own planes.  All work is enqueued on the caller's stream.
 // Layout of the work (4096^2 image, 1e6 x 64 visibilities, W = 7, 16 planes: image -> vis 22.8 ms in round 4 (43 ms in
 // round 2), the transpose 62 ms; profiles/r04_wgrid_*):
-//   * planes, image -> vis: pruned 2-D transform, v-major.  Rows of 512 / 1024 / 2048 / 4096 image cells: the own row
+//   * planes, image -> vis: pruned 2-D transform, v-major.  Rows of 512 / 1024 / 2048 / 4096 / 8192 image cells: the own row
 //     transform (wg_fill_fft_rows: a padded row = two half-length Stockham transforms of its non-zero cells; the fill pass
 //     is the first transform's input stage) -> wg_transpose_compact -> the same kernel.  Other sizes: wg_fill_rows ->
 //     hipFFT rows -> wg_transpose_rows -> hipFFT rows, out of place from buffers whose zero bands are written once per call;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void wg_fill_rows(const double *__restrict__ i
     }
     S[ix * nv + pv] = out;
 }
-// ---- fill + row transform in one kernel (image -> vis; rows of 512, 1024, 2048 or 4096 image cells, padded to twice that) ----
+// ---- fill + row transform in one kernel (image -> vis; rows of 512 ... 8192 image cells, padded to twice that) ----
 // Row ix of the padded plane holds the image row's ny cells at pv = (iy - ny/2) mod nv and zeros elsewhere.  With
 // M = ny, N = 2 M and s[j] = the cell of iy = j:
 //     X[k] = sum_j s[j] W_N^((j - M/2) k) = (-i)^(-k) ... = i^k Spad[k],   W_N = exp(-2 pi i / N),
@@ -391,7 +391,7 @@ __host__ __device__ constexpr int wg_pad(int a) { return a + (a >> 3); }     // 
 // 74 KB for M = 4096, TWO workgroups per CU (with both halves side by side, 148 KB and one workgroup per CU, the kernel
 // only matched hipFFT on the second transform).
 // P: the planes' element (double2, or float2: fp64 arithmetic, results rounded once on their way out).
-// M = 2^LOGM = R0 8^L (512, 1024, 2048, 4096): when R0 = 2 or 4 the first pass is a twiddle-free radix-R0 pass over the
+// M = 2^LOGM = R0 8^L (512, 1024, 2048, 4096, 8192): when R0 = 2 or 4 the first pass is a twiddle-free radix-R0 pass over the
 // same eight register values (butterflies tt + m Q, m < 8 / R0), the radix-8 passes follow with Ns = R0, 8 R0, ...
 template <int LOGM, bool FROM_CELLS = false, typename P = double2>
 __global__ __launch_bounds__(1 << (LOGM - 3), 4) void wg_fill_fft_rows(const double *__restrict__ A, const double *__restrict__ nm1,
@@ -514,11 +514,12 @@ int wg_row_fft_launch(int logm, int64_t rows, const double *A, const double *nm1
     case 9: return wg_row_fft_launch1<9, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
     case 10: return wg_row_fft_launch1<10, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
     case 11: return wg_row_fft_launch1<11, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
-    default: return wg_row_fft_launch1<12, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    case 12: return wg_row_fft_launch1<12, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);
+    default: return wg_row_fft_launch1<13, FROM_CELLS, P>(rows, A, nm1, ny, wk, tw, out, src, st);   // 1024 lanes, 144 KB of LDS
     }
 }
-// log2(n) when n is 512, 1024, 2048 or 4096 (the sizes the own row transform serves), else 0
-inline int wg_row_fft_logm(int64_t n) { return n == 512 ? 9 : n == 1024 ? 10 : n == 2048 ? 11 : n == 4096 ? 12 : 0; }
+// log2(n) when n is 512 ... 8192 (the sizes the own row transform serves; 8192: round 6), else 0
+inline int wg_row_fft_logm(int64_t n) { return n == 512 ? 9 : n == 1024 ? 10 : n == 2048 ? 11 : n == 4096 ? 12 : n == 8192 ? 13 : 0; }
 
 // cells [lo, hi) of every one of `rows` rows of `width` cells <- 0 (hipMemset2DAsync does this at 0.8 TB/s)
 template <typename P>
@@ -2043,7 +2044,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
     // image -> vis: the first transform's input lives in its own buffer and the transform runs out of place, so the zero
     // band of the padded rows (half of every row) is written once per call, not once per plane (wg_fill_rows)
     double2 *S_in = reinterpret_cast<double2 *>(ws + L.stage_in), *T_in = reinterpret_cast<double2 *>(ws + L.col_in);
-    // rows of 512, 1024, 2048 or 4096 image cells: fill and first transform in ONE kernel (wg_fill_fft_rows;
+    // rows of 512 ... 8192 image cells: fill and first transform in ONE kernel (wg_fill_fft_rows;
     // AFHIP_WGRID_FFT1=0: wg_fill_rows + hipFFT as for every other size) ...
     int fused_first = 0;
     const double2 *twid = reinterpret_cast<const double2 *>(ws + L.tw);

@@ -201,13 +201,15 @@ def _fused_block(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
     """One (source chunk, row chunk, chan chunk) block: every contracted axis (lm / uvw components, antennas, the
     beam cube's axes) arrives as nested one-element lists; ``running`` is the previous link of a ``streams=True``
     chain (its length-1 source axis still on)."""
-    from .fused import fused_predict_vis as _np_fused, cached_plan
+    from .fused import fused_predict_vis as _np_fused, cached_plan, _all_single
     u = lambda x: None if x is None else _first(x)
     pa_ = u(pa)
     with placement.block(block_id):
         uvw_ = u(uvw)
+        single = stokes is None and _all_single(u(lm), uvw_, frequency, u(brightness), u(feed_rot), u(beam), u(extents), u(freq_map),
+                                                pa_, u(pe), u(ascale))
         plan = None if beam is None else cached_plan(time_index, antenna1, antenna2, pa_.shape[1],
-                                                      uvw=None if gauss_shape is not None else uvw_)
+                                                      uvw=None if gauss_shape is not None else uvw_, single=single)
         vis = _np_fused(time_index, antenna1, antenna2, u(lm), uvw_, frequency, u(brightness), u(beam), u(extents),
                         u(freq_map), pa_, u(pe), u(ascale), None, None, None, convention, u(feed_rot), u(gauss_shape),
                         u(stokes), u(spi), u(ref_freq), corr_schema, spectral_base, plan)

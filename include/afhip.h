@@ -572,7 +572,7 @@ int af_fused_predict_antennas_model_c128(const double *stokes, const double *spi
  * are evaluated at the mirrored point and conjugated (the adjoint grids their conjugates there), and the planes cover
  * [min |w nu/c|, max |w nu/c|] only -- af_wgrid_planes() counts them.  All device work is
  * enqueued on `stream` (the visibility sort of large image -> vis calls on a library-owned side stream that starts
- * behind `stream`'s work at the call and is joined before the visibilities are written); the plane transforms of image rows / columns of 512, 1024, 2048 or 4096 cells are own kernels
+ * behind `stream`'s work at the call and is joined before the visibilities are written); the plane transforms of image rows / columns of 512, 1024, 2048, 4096 or 8192 cells are own kernels
  * (csrc/af_wgridder.hip, wg_fill_fft_rows), every other size uses hipFFT (plans cached per device and size, released by
  * af_shutdown). */
 int64_t af_wgrid_padded(int64_t n);

@@ -174,3 +174,56 @@ def test_device_resident_tensors():
     dev = _call_s(t)
     assert dev.dtype == torch.complex64 and dev.is_cuda
     assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def test_the_entry_through_the_c_abi():
+    """af_fused_predict_antennas_c64 called directly (device pointers, explicit workspace): the same bits as the front-end,
+    its status codes and messages, the empty cases"""
+    import ctypes
+    import torch
+    from codex_africanus_amd import _lib
+    lib = _lib.load()
+    nant = 12
+    d = _decomposable(_problem(7, 600, 4, 9, nant), nant)
+    s = _single(d)
+    want = _call_s(s)
+    plan = fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"], single=True)
+    assert plan.decomposable
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    v = {k: t(s[k]) for k in ("lm", "frequency", "X", "beam", "extents", "beam_freq_map", "pa", "pe", "as")}
+    au, rm = t(plan.ant_uvw), t(plan.rowmap)
+    nsrc, nchan, nrow = 9, 4, 600
+    lw, mh, nud = s["beam"].shape[:3]
+    ntime = s["pa"].shape[0]
+    ws_bytes = int(lib.af_fused_predict_c64_workspace_bytes(nsrc, nchan, lw, mh, nud))
+    assert ws_bytes > 0 and lib.af_fused_predict_c64_workspace_bytes(-1, nchan, lw, mh, nud) == 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.full((nrow, nchan, 2, 2), complex(float("nan"), 0.0), dtype=torch.complex64, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def args(**kw):
+        return [P(au), P(rm), plan.nsteps, nrow, kw.get("lm", P(v["lm"])), P(v["frequency"]), P(v["X"]), kw.get("nsrc", nsrc), nchan,
+                P(v["beam"]), kw.get("lw", lw), mh, nud, P(v["extents"]), P(v["beam_freq_map"]), P(v["pa"]), kw.get("ntime", ntime),
+                kw.get("nant", nant), P(v["pe"]), P(v["as"]), None, kw.get("conv", _lib.CONVENTION["fourier"]), P(out),
+                kw.get("ws", P(ws)), kw.get("wsb", ws_bytes), stream]
+
+    assert lib.af_fused_predict_antennas_c64(*args()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert lib.af_fused_predict_antennas_c64(*args(conv=0)) == 1 and b"convention not in ('fourier', 'casa')" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(wsb=64)) == 1 and b"workspace too small" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(ws=ctypes.c_void_p(ws.data_ptr() + 8))) == 1 and b"aligned" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(lm=None)) == 1 and b"NULL" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(nant=513)) == 1 and b"512 antennas" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(ntime=plan.nsteps - 1)) == 1 and b"timesteps" in lib.af_last_error()
+    assert lib.af_fused_predict_antennas_c64(*args(lw=1)) == 1 and b"must be >= 2" in lib.af_last_error()
+    # no sources: zeros; a good call after failures still works
+    out.fill_(complex(float("nan"), 0.0))
+    assert lib.af_fused_predict_antennas_c64(*args(nsrc=0)) == 0
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
+    assert lib.af_fused_predict_antennas_c64(*args()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)

@@ -406,9 +406,9 @@ def test_model_with_caller_supplied_w_bounds_and_epsilon_floor():
 
 
 @pytest.mark.parametrize("nx, ny", [(16, 512), (64, 512), (512, 512), (512, 20), (16, 1024), (2048, 16), (16, 2048),
-                                    (1024, 2048)])
+                                    (1024, 2048), (16, 8192), (8192, 16)])
 def test_fused_fill_and_first_transform_equals_the_hipfft_route(nx, ny, monkeypatch):
-    """rows of 512, 1024, 2048 (and 4096: tests/test_gpu_full_size.py) image cells -- radix 8 throughout, or a radix-2 / radix-4
+    """rows of 512, 1024, 2048, 8192 (and 4096: tests/test_gpu_full_size.py) image cells -- radix 8 throughout, or a radix-2 / radix-4
     first pass: the fill pass and the transform along v in
     one kernel (wg_fill_fft_rows: two half-length Stockham transforms of the row, no zero ever stored).  Same visibilities
     as wg_fill_rows + hipFFT to rounding, and the accuracy contract against the direct transform on a sparse image."""

@@ -67,7 +67,7 @@ def fused_gemm_sweep(seed):
         import test_gpu_fused_gemm as FG
         rng = np.random.default_rng(seed)
         nant = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 31, 33, 48, 57, 64, 65, 66, 72, 73, 80, 95, 96, 97, 104, 127, 128, 129, 160,
-                               192, 197, 200, 224, 255, 256]))
+                               192, 197, 200, 224, 255, 256, 257, 300, 384]))
         nbl = nant * (nant - 1) // 2
         nrow = int(rng.integers(1, min(2 * nbl, nbl + 3000) + 2))
         nchan, nsrc = int(rng.integers(1, 5)), int(rng.integers(1, 30))
@@ -76,6 +76,29 @@ def fused_gemm_sweep(seed):
         out = FG._call(d)
         ref = FU._oracle_chain(d, True)
         assert out.shape == ref.shape and (out.size == 0 or np.abs(out - ref).max() < 1e-9 * FU._scale(d)), (nant, nrow, nchan, nsrc)
+    finally:
+        os.environ.pop("AFHIP_GEMM_MIN_FILL", None)
+
+
+def fused_gemm_c64_sweep(seed):
+    """the single-precision GEMM form (round 6) at random array sizes -- DIAG (3M), RECT 8 x 4 (four products), RECT 8 x 8 (3M on
+    block rows) -- and random row layouts, against the oracle's float64 chain on the promoted values"""
+    os.environ["AFHIP_GEMM_MIN_FILL"] = "0"
+    try:
+        import test_gpu_fused_gemm as FG
+        import test_gpu_fused_gemm_c64 as FC
+        rng = np.random.default_rng(seed)
+        nant = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 24, 31, 33, 40, 48, 57, 64, 65, 66, 72, 80, 96, 97, 104, 127, 128, 129, 160, 197, 256]))
+        nbl = nant * (nant - 1) // 2
+        nrow = int(rng.integers(1, min(2 * nbl, nbl + 3000) + 2))
+        nchan, nsrc = int(rng.integers(1, 5)), int(rng.integers(1, 30))
+        d = FG._decomposable(FU._problem(seed, nrow, nchan, nsrc, nant), nant, seed=seed, keep=float(rng.choice([1.0, 0.8])),
+                             swap=float(rng.choice([0.0, 0.3])), shuffle=bool(rng.integers(0, 2)), autos=bool(rng.integers(0, 2)))
+        s = FC._single(d)
+        out = FC._call_s(s)
+        assert out.dtype == np.complex64, out.dtype
+        ref = FC._chain64(s)
+        assert out.shape == ref.shape and (out.size == 0 or np.abs(out - ref).max() < 1e-4 * FU._scale(d)), (nant, nrow, nchan, nsrc)
     finally:
         os.environ.pop("AFHIP_GEMM_MIN_FILL", None)
 
@@ -154,9 +177,12 @@ def wgridder_sweep(seed):
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+only = os.environ.get("AFHIP_STRESS_ONLY")          # e.g. "fused_gemm_sweep,fused_gemm_c64_sweep": only the sweeps named
 sweeps = [F.test_im_to_vis_random_shapes, F.test_vis_to_im_random_shapes, F.test_wsclean_predict_random_shapes,
           F.test_predict_vis_random_shapes_bit_exact, F.test_degridder_gridder_random_shapes, calibration_sweep,
-          fused_sweep, fused_gemm_sweep, beam_and_phase_sweep, convert_and_chi2_sweep, wgridder_sweep]
+          fused_sweep, fused_gemm_sweep, fused_gemm_c64_sweep, beam_and_phase_sweep, convert_and_chi2_sweep, wgridder_sweep]
+if only:
+    sweeps = [fn for fn in sweeps if fn.__name__ in only.split(",")]
 t0 = time.time()
 for seed in range(first, first + count):
     for fn in sweeps:
