@@ -89,6 +89,22 @@ def _chain64(s, rows=None):
     return oracle.predict_vis(s["time_index"][r], s["ant1"][r], s["ant2"][r], dde, coh, dde, None, None, None)
 
 
+def _tol(s, d):
+    """What the single-precision GEMM form can differ from the float64 chain by, relative to _scale(d) = sum_s |X_s|: float32
+    rows are not EXACTLY differences of antenna coordinates (each was rounded when it was made), so the form's baseline
+    x_p - x_q differs from the row's uvw by the plan's residual (<= 2^-24 of 6 km = 3.6e-4 m): a phase of
+    2 pi nu / c (|l| + |m| + |n|) residual per term, the same sign for neighbouring sources -- plus float32 arithmetic (a few
+    1e-6 of the sum).  For scale: the reference's own float32 chain computes l u + m v + n w (hundreds of metres) in float32,
+    ~1e-4 m of rounding at best."""
+    nant = s["pa"].shape[1]
+    plan = fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"], single=True)
+    assert plan.decomposable and plan.residual <= plan.tol
+    lm = s["lm"].astype(np.float64)
+    n = np.sqrt(1.0 - (lm ** 2).sum(1)) - 1.0
+    reach = float((np.abs(lm).sum(1) + np.abs(n)).max())
+    return 2.0 * np.pi * float(s["frequency"].max()) / 299792458.0 * reach * plan.residual + 2e-5
+
+
 def _call_s(s, **kw):
     return rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], s["lm"], s["uvw"], s["frequency"], s["X"], s["beam"],
                                   s["extents"], s["beam_freq_map"], s["pa"], s["pe"], s["as"], **kw)
@@ -105,9 +121,18 @@ def test_against_the_float64_chain_at_every_super_tile_kind(nant, nrow):
     assert got.dtype == np.complex64
     truth = _chain64(s)
     # G17: the reference's own float32 chain is off by 2-3e-4 of the peak at these baselines (float32 phases of ~5000 rad).
-    # What bounds this entry is the rows themselves: float32 differences of antenna coordinates carry 2^-25 of 6 km =
-    # 1e-4 m of rounding that no antenna coordinates reproduce -- 1e-4 rad of phase per term, a few 1e-5 of the sum.
-    assert np.abs(got - truth).max() < 1e-4 * _scale(d), np.abs(got - truth).max() / _scale(d)
+    # What bounds this entry is the rows themselves (_tol): a few 1e-5 of the sum typically, 4e-4 at worst.
+    assert np.abs(got - truth).max() < _tol(s, d) * _scale(d), (np.abs(got - truth).max() / _scale(d), _tol(s, d))
+
+
+def test_more_channels_than_one_group_of_beam_planes():
+    """70 channels: the per-channel beam planes are built 64 channels at a time (PLANE_GROUP), the kernel is launched per group"""
+    nant = 9
+    d = _decomposable(_problem(4, 300, 70, 5, nant), nant)
+    s = _single(d)
+    got = _call_s(s)
+    assert got.dtype == np.complex64 and got.shape == (300, 70, 2, 2)
+    assert np.abs(got - _chain64(s)).max() < _tol(s, d) * _scale(d)
 
 
 def test_row_layouts_dies_and_the_plan_guard():
@@ -116,7 +141,7 @@ def test_row_layouts_dies_and_the_plan_guard():
     s = _single(d)
     got = _call_s(s)
     truth = _chain64(s)
-    assert np.abs(got - truth).max() < 1e-4 * _scale(d)
+    assert np.abs(got - truth).max() < _tol(s, d) * _scale(d)
     # DIEs and base visibilities on top: predict_vis's complex64 kernel
     rng = np.random.default_rng(5)
     shp = (d["ntime"], nant, 4, 2, 2)

@@ -98,7 +98,8 @@ def fused_gemm_c64_sweep(seed):
         out = FC._call_s(s)
         assert out.dtype == np.complex64, out.dtype
         ref = FC._chain64(s)
-        assert out.shape == ref.shape and (out.size == 0 or np.abs(out - ref).max() < 1e-4 * FU._scale(d)), (nant, nrow, nchan, nsrc)
+        assert out.shape == ref.shape and (out.size == 0 or np.abs(out - ref).max() < FC._tol(s, d) * FU._scale(d)), (
+            nant, nrow, nchan, nsrc, np.abs(out - ref).max() / FU._scale(d), FC._tol(s, d))
     finally:
         os.environ.pop("AFHIP_GEMM_MIN_FILL", None)
 
