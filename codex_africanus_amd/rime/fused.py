@@ -414,7 +414,7 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
         if single_route:
             vis = _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
                             beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,
-                            convention, nsrc, nrow, nchan)
+                            convention, nsrc, nrow, nchan, allow_chunks=die1_jones is None and base_vis is None)
             if die1_jones is None and base_vis is None:
                 return vis
             return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
@@ -504,7 +504,8 @@ def _all_single(*arrays):
 
 
 def _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents,
-              beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation, convention, nsrc, nrow, nchan):
+              beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation, convention, nsrc, nrow, nchan,
+              allow_chunks=True):
     """The single-precision GEMM form (af_fused_predict_antennas_c64) inside an open Call: complex64 result."""
     bshape = tuple(int(s) for s in brightness.shape)
     if bshape == (nsrc, 2, 2):
@@ -526,8 +527,22 @@ def _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, f
     p_out, h = c.out((nrow, nchan, 2, 2), c64)
     ws_bytes = int(_lib.load().af_fused_predict_c64_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
     p_ws = c.scratch(ws_bytes)
+    conv = _lib.CONVENTION[convention]
+    if not c.device_mode and plan.time_sorted and not explicit_plan and allow_chunks:
+        # numpy caller, rows in time order: timestep-aligned row chunks whose downloads overlap the next chunk's kernels
+        # (Call.result_rows), as on the double-precision GEMM route
+        nap = int(plan.rowmap.shape[1])
+
+        def launch(r0, r1, p_rows):
+            t0, t1 = int(plan.step[r0]), int(plan.step[r1 - 1]) + 1
+            off = lambda ptr, nbytes: None if ptr is None else ctypes.c_void_p(ptr.value + nbytes)
+            _lib.call("af_fused_predict_antennas_c64", off(p_au, t0 * nant * 24), off(p_rm, t0 * nap * nap * 4), t1 - t0, nrow,
+                      p_lm, p_fr, p_b, nsrc, nchan, p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, off(p_pa, t0 * nant * 4),
+                      ntime - t0, nant, off(p_pe, t0 * nant * nchan * 8), p_as, off(p_rot, t0 * nant * 32), conv, p_out, p_ws,
+                      max(ws_bytes, 256), c.stream)
+        return c.result_rows(h, launch, edges=plan.step_first)
     _lib.call("af_fused_predict_antennas_c64", p_au, p_rm, plan.nsteps, nrow, p_lm, p_fr, p_b, nsrc, nchan, p_beam, beam_lw,
-              beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_rot, _lib.CONVENTION[convention], p_out, p_ws,
+              beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_rot, conv, p_out, p_ws,
               max(ws_bytes, 256), c.stream)
     if explicit_plan and nrow:
         # (the guard fills float64 words with NaN: a complex64 result is nrow * nchan * 4 of them)

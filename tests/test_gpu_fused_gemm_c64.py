@@ -135,6 +135,25 @@ def test_more_channels_than_one_group_of_beam_planes():
     assert np.abs(got - _chain64(s)).max() < _tol(s, d) * _scale(d)
 
 
+def test_numpy_call_downloads_in_timestep_aligned_chunks(monkeypatch):
+    """as on the double-precision GEMM route: the numpy-in / numpy-out call produces its complex64 result in timestep-aligned
+    row chunks whose downloads overlap the next chunk's kernels -- same bits as the one-piece call, also with a step that has
+    no rows"""
+    nant = 24
+    d = _decomposable(_problem(41, 6 * 276 + 100, 5, 13, nant), nant, seed=15)
+    keep = (d["time_index"] != 2)
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        d[k] = d[k][keep]
+    s = _single(d)
+    monkeypatch.setenv("AFHIP_D2H_PIPELINE", "0")
+    whole = _call_s(s)
+    monkeypatch.delenv("AFHIP_D2H_PIPELINE")
+    monkeypatch.setenv("AFHIP_D2H_CHUNK_MB", "0.05")     # 160 B per row: ~330 rows per chunk, cut at step boundaries (276 rows)
+    piped = _call_s(s)
+    assert piped.dtype == np.complex64 and np.array_equal(piped, whole)
+    assert np.abs(whole - _chain64(s)).max() < _tol(s, d) * _scale(d)
+
+
 def test_row_layouts_dies_and_the_plan_guard():
     nant = 19
     d = _decomposable(_problem(5, 1500, 4, 17, nant), nant, seed=2, keep=0.8, swap=0.3, shuffle=True, autos=True)
