@@ -29,7 +29,9 @@
 //             wave i % 4, real and imaginary accumulators; per source and tile two v_mfma_f64_16x16x4:
 //                 Cr += [Gr0 Gr1 Gi0 Gi1] . [Hr0 Hr1 Hi0 Hi1]^T      Ci += [Gi0 Gi1 -Gr0 -Gr1] . [Hr0 Hr1 Hi0 Hi1]^T
 //             (Re and Im of sum_k G_k conj(H_k)); epilogue: tile element (p,i,q,j) -> row(t,p,q) of the output through
-//             the plan's row map; an off-diagonal tile also serves row(t,q,p) with the conjugate transpose.
+//             the plan's row map; an off-diagonal tile also serves row(t,q,p) with the conjugate transpose -- right for
+//             HERMITIAN brightness matrices X_s only ((A_p X A_q^H)^H = A_q X^H A_p^H): callers send anything else to
+//             af_fused_predict_c128 (include/afhip.h; rime/fused.py::_hermitian).
 // fp64 MFMA and fp64 VALU share one pipe on gfx950, so the matrix cores buy no rate; what the
 // formulation buys is the flop count (36 of the 64 tiles of M at 64 antennas: 73 flop per (row, chan, source) instead of
 // ~126) and a pure-FMA instruction stream.

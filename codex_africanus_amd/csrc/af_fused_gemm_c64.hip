@@ -110,6 +110,14 @@ __device__ __forceinline__ void for_each_const_s(F &&fn, std::integer_sequence<i
     (fn(std::integral_constant<int, Js>{}), ...);
 }
 
+// Operand element of antenna slot `ant` inside its panel of 4 q4 antennas, and back.  In sampling round QL the sixteen
+// quads of a wave store the terms of slots QL, 4 + QL, 8 + QL, ...: with the antennas in their own order those stores
+// would land 4-way on the same banks (element stride 8 floats; profiles/r06_fused_dde_ant_c64_pmc_summary.json of the first
+// version: 42 % of the LDS cycles were conflicts).  Slot 4 i + QL -> element QL q4 + i: the quads of one store are
+// consecutive elements.  Tiles are blocks of 8 consecutive ELEMENTS; the epilogue maps them back.
+__device__ __forceinline__ int slot_antenna_s(int slot, int q4) { return (slot % q4) * 4 + slot / q4; }
+__device__ __forceinline__ int antenna_slot_s(int ant, int q4) { return (ant & 3) * q4 + (ant >> 2); }
+
 template <int QL> __device__ __forceinline__ float quad_bcastf(float x)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), QL * 0x55, 0xf, 0xf, true));
@@ -293,12 +301,12 @@ if constexpr (FORM == FORM_3M) {
         constexpr int pb = tile_row_s<RECT, NBR, NBC>(T0 + j), qb = tile_col_s<RECT, NBR, NBC>(T0 + j);
         if (RECT && qb >= tile.nc_act) return;
         const int jj = c16 & 1;
-        const int q = tile.col_ant0 + qb * 8 + (c16 >> 1);
+        const int q = tile.col_ant0 + slot_antenna_s(qb * 8 + (c16 >> 1), RECT ? 2 * tile.nc_act : G::NAC / 4);
         int r1[4], r2[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int i = 4 * kq + reg;                        // D row of accumulator register `reg`
-            const int p = tile.row_ant0 + pb * 8 + (i >> 1);
+            const int p = tile.row_ant0 + slot_antenna_s(pb * 8 + (i >> 1), G::NAR / 4);
             r1[reg] = rm[p * nap + q];
             r2[reg] = (RECT || pb != qb) ? rm[q * nap + p] : -1;   // the same antennas the other way round: V_qp = V_pq^H
         }
@@ -352,11 +360,11 @@ __device__ __forceinline__ void matrix_wave_row(const float *__restrict__ lds, i
         constexpr int qb = decltype(jc)::value;
         if (qb >= tile.nc_act) return;
         const int jj = c16 & 1;
-        const int q = tile.col_ant0 + qb * 8 + (c16 >> 1);
+        const int q = tile.col_ant0 + slot_antenna_s(qb * 8 + (c16 >> 1), 2 * tile.nc_act);
         int r1[4], r2[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int p = tile.row_ant0 + W * 8 + ((4 * kq + reg) >> 1);
+            const int p = tile.row_ant0 + slot_antenna_s(W * 8 + ((4 * kq + reg) >> 1), G::NAR / 4);
             r1[reg] = rm[p * nap + q];
             r2[reg] = rm[q * nap + p];
         }
@@ -526,10 +534,14 @@ __global__ __launch_bounds__(S_THREADS) void fused_gemm_c64_kernel(
         asm volatile("" : "+v"(e_slot));
         const bool have = T.src < nsrc && slot_ok(e_slot);
         const bool col_term = !RECT || e_slot < NAC;
-        // operand rows / columns are the antennas in their own order (element 2 antenna + Jones row): eight consecutive
-        // terms' stores cover 16 consecutive banks per Jones column, the other column 16 banks further (plane_stride)
-        const int h_off = T.buf * BUF + e_sl * SRC + 2 * (col_term ? e_slot : 0);
-        const int g_off = T.buf * BUF + e_sl * SRC + G::HP * CSH + 2 * (RECT ? (col_term ? 0 : e_slot - NAC) : e_slot);
+        // operand element of the term's antenna (antenna_slot_s: the quads of one store are consecutive elements -- 16
+        // consecutive banks per Jones column, the other column 16 banks further, plane_stride); the slots of an absent last
+        // column block (RECT, nc_act < NBC) keep their own places behind the real ones
+        const int h_slot = !RECT ? antenna_slot_s(e_slot, NAC / 4)
+                                 : (!col_term ? 0 : (e_slot < 8 * tile.nc_act ? antenna_slot_s(e_slot, 2 * tile.nc_act) : e_slot));
+        const int h_off = T.buf * BUF + e_sl * SRC + 2 * h_slot;
+        const int g_off = T.buf * BUF + e_sl * SRC + G::HP * CSH +
+                          2 * antenna_slot_s(RECT ? (col_term ? 0 : e_slot - NAC) : e_slot, G::NAR / 4);
         S.info = (RECT ? (col_term ? h_off : g_off) : h_off) | (int)((unsigned)col_term << 30) | (int)((unsigned)have << 31);
         S.slot = e_slot;
         const int bsrc = T.src < nsrc ? T.src : 0;

@@ -377,6 +377,7 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
         raise ValueError("gauss_shape must have shape (source, 3)")
     with Call(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, feed_rotation, gauss_shape, stokes, spi,
               ref_freq, *beam_args) as c:
+        brightness_given = brightness           # (the caller's object: what _hermitian remembers verdicts by)
         if flat_spectrum:
             if _is_torch(brightness):
                 brightness = brightness[:, None].expand(nsrc, nchan, 2, 2)
@@ -408,6 +409,8 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
             gemm = plan.decomposable and gauss_shape is None and nrow > 0 and \
                 plan.fill >= float(os.environ.get("AFHIP_GEMM_MIN_FILL", GEMM_MIN_FILL)) and \
                 os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
+            # ... and Hermitian brightness matrices (_hermitian: the sky model's always are)
+            gemm = gemm and (model or _hermitian(brightness_given))
             # every input single precision: the reference computes this chain in float32 / complex64
             # (africanus/util/type_inference.py:24-26); the GEMM form has a single-precision kernel of its own
             single_route = gemm and all_single and os.environ.get("AFHIP_FUSED_C64", "1") != "0"
@@ -495,6 +498,43 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
         return vis
     # base_vis is added, then the DIEs applied, in the reference's order (africanus/rime/predict.py:605-612)
     return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+
+
+_herm_ident = collections.OrderedDict()      # identity of a device brightness tensor -> verdict (see _hermitian)
+
+
+def _hermitian(brightness):
+    """Are the (..., 2, 2) brightness matrices Hermitian -- X[1,0] == conj(X[0,1]), real diagonal -- exactly?  Coherency
+    matrices made from real Stokes parameters (africanus.model.coherency.convert) always are; the reference's chain accepts
+    any complex matrices (``einsum("srf,sfij->srfij", phase, brightness)``).  The GEMM form needs it: it evaluates the upper
+    block triangle of ``M = G H^H`` and serves the baseline stored the other way round with the conjugate transpose of the
+    computed element, ``V_qp = (A_p X A_q^H)^H = A_q X^H A_p^H`` -- which is ``A_q X A_p^H`` only for Hermitian ``X``.  Anything
+    else takes the lane-per-row kernel.  numpy: checked directly; a device tensor: one small device reduction and ONE host
+    read per tensor object and in-place version (the verdict is remembered by identity, as plans are)."""
+    if brightness is None:
+        return True
+    if _is_torch(brightness):
+        import weakref
+        key = (brightness.data_ptr(), tuple(brightness.shape), str(brightness.dtype), brightness._version)
+        with _plan_lock:
+            hit = _herm_ident.get(key)
+            if hit is not None and hit[0]() is brightness:
+                _herm_ident.move_to_end(key)
+                return hit[1]
+        x = brightness
+        ok = bool(((x[..., 1, 0] == x[..., 0, 1].conj()) & (x[..., 0, 0].imag == 0) & (x[..., 1, 1].imag == 0)).all().item()) \
+            if x.is_complex() else bool((x[..., 1, 0] == x[..., 0, 1]).all().item())
+        with _plan_lock:
+            for k in [k for k, (r, _) in _herm_ident.items() if r() is None]:
+                del _herm_ident[k]
+            _herm_ident[key] = (weakref.ref(brightness), ok)
+            while len(_herm_ident) > 64:
+                _herm_ident.popitem(last=False)
+        return ok
+    x = np.asarray(brightness)
+    if not np.iscomplexobj(x):
+        return bool(np.array_equal(x[..., 1, 0], x[..., 0, 1]))
+    return bool(np.array_equal(x[..., 1, 0], np.conj(x[..., 0, 1])) and not x[..., 0, 0].imag.any() and not x[..., 1, 1].imag.any())
 
 
 def _all_single(*arrays):

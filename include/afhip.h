@@ -336,6 +336,11 @@ int af_fused_predict_c128(const int32_t *items, int64_t nitems, const int32_t *a
  *   depends on the baseline: use af_fused_predict_c128).  nant <= 64: one workgroup per (timestep, channel) holds the
  *   whole upper block triangle; 65 .. 512 antennas: the blocks of 8 antennas are cut into super-blocks of 8 blocks,
  *   one workgroup per (timestep, channel, super-block or half of a pair of super-blocks).
+ *   BRIGHTNESS MUST BE HERMITIAN (X[1][0] == conj X[0][1], real diagonal: what africanus.model.coherency.convert makes of
+ *   real Stokes parameters): the entry evaluates the upper block triangle of M and serves a baseline stored the other way
+ *   round with the conjugate transpose of the computed element, A_q X^H A_p^H.  The reference's chain accepts any complex
+ *   matrices; a binding must send others to af_fused_predict_c128 (codex_africanus_amd.rime.fused._hermitian does).  The
+ *   same holds for af_fused_predict_antennas_c64.
  * af_fused_gemm_slots(nant): baseline slots (8 x 8-antenna tiles x 64) the GEMM form evaluates per (timestep, channel),
  *   what its cost is proportional to (rows per step / slots = the fill factor callers dispatch by); 0 beyond 512. */
 int af_fused_plan_antennas(const int64_t *time_index_host, const int32_t *antenna1_host, const int32_t *antenna2_host,

@@ -288,6 +288,32 @@ def test_plan_cache_by_identity_does_not_outlive_the_plan_cache(monkeypatch):
     fused._plan_ident.clear()
 
 
+def test_only_hermitian_brightness_takes_the_gemm_form():
+    """Round 6: the GEMM form serves a baseline stored the other way round with the conjugate transpose of the computed
+    element, which is right only for Hermitian brightness matrices; the dispatcher's test (host side)"""
+    import torch
+    from codex_africanus_amd.rime import fused
+    rng = np.random.default_rng(3)
+    I, Q, U, V = rng.random(7) + 1, 0.1 * rng.standard_normal(7), 0.1 * rng.standard_normal(7), 0.1 * rng.standard_normal(7)
+    X = np.stack([I + Q, U + 1j * V, U - 1j * V, I - Q], -1).reshape(7, 2, 2)            # linear feeds, real Stokes
+    Xc = np.broadcast_to(X[:, None], (7, 5, 2, 2)) * np.linspace(1, 2, 5)[None, :, None, None]
+    for x in (X, Xc, X.astype(np.complex64), X.real.copy(), torch.from_numpy(np.ascontiguousarray(Xc))):
+        assert fused._hermitian(x)
+    bad = np.array(Xc)
+    bad[3, 2, 1, 0] += 1e-12                                    # exactly, not approximately
+    bad2 = np.array(X)
+    bad2[0, 0, 0] += 1e-9j                                      # a diagonal entry with an imaginary part
+    bad3 = rng.standard_normal((7, 2, 2)) + 1j * rng.standard_normal((7, 2, 2))
+    for x in (bad, bad2, bad3, torch.from_numpy(bad), bad3.real.copy()):
+        assert not fused._hermitian(x)
+    assert fused._hermitian(None)
+    # a device tensor's verdict is remembered by identity and in-place version
+    t = torch.from_numpy(np.ascontiguousarray(Xc))
+    assert fused._hermitian(t) and fused._hermitian(t)
+    t[0, 0, 0, 1] += 1.0
+    assert not fused._hermitian(t)
+
+
 def test_wgridder_plane_count_folds_the_w_range():
     """af_wgrid_planes (host arithmetic only): the planes cover [min |w|, max |w|] -- visibilities with w < 0 are evaluated
     at their mirror points (real image) -- with plane 0 W/2 - 1 spacings below the smallest |w| and no spare plane behind

@@ -240,6 +240,40 @@ def test_gemm_form_against_the_reference_itself(case):
     assert np.abs(gen - ref).max() <= 1e-9 * scale
 
 
+@pytest.mark.parametrize("single", [False, True])
+def test_brightness_matrices_that_are_not_hermitian(single, monkeypatch):
+    """The reference's chain takes ANY complex (source, chan, 2, 2) brightness (einsum("srf,sfij->srfij")); coherency matrices
+    of real Stokes parameters are Hermitian, and the GEMM form relies on it (a baseline stored with its antennas in the other
+    block order gets the conjugate transpose of the computed element: A_q X^H A_p^H, not A_q X A_p^H).  Round 6: such a call
+    takes the lane-per-row kernel -- and gives the reference's answer; until then a quarter of these rows were wrong
+    (tools/r6_check_hermitian.py: 280 of 1200, by up to 0.25 of the summed brightness)."""
+    nant = 19
+    d = _decomposable(_problem(31, 1200, 4, 11, nant), nant, seed=3, swap=0.3)
+    rng = np.random.default_rng(7)
+    d["X"] = d["X"] + 0.3 * (rng.standard_normal(d["X"].shape) + 1j * rng.standard_normal(d["X"].shape))     # no symmetry left
+    assert not fused._hermitian(d["X"])
+    if single:
+        import test_gpu_fused_gemm_c64 as FC
+        s = FC._single(d)
+        out = FC._call_s(s)
+        assert out.dtype == np.complex64
+        ref = FC._chain64(s)
+        assert np.abs(out - ref).max() <= 6.1e-8 * np.abs(ref).max() + 1e-9 * _scale(d)         # computed in double, rounded once
+        return
+    out = _call(d)
+    ref = _oracle_chain(d, True)
+    assert np.abs(out - ref).max() < 1e-9 * _scale(d)
+    monkeypatch.setenv("AFHIP_FUSED_GEMM", "0")
+    assert np.array_equal(out, _call(d))                  # it WAS the lane-per-row kernel
+    monkeypatch.delenv("AFHIP_FUSED_GEMM")
+    # device tensors: the same route (one small reduction + one host read per brightness tensor)
+    import torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dev = rime.fused_predict_vis(t(d["time_index"]), t(d["ant1"]), t(d["ant2"]), t(d["lm"]), t(d["uvw"]), t(d["frequency"]), t(d["X"]),
+                                 t(d["beam"]), t(d["extents"]), t(d["beam_freq_map"]), t(d["pa"]), t(d["pe"]), t(d["as"]))
+    assert np.array_equal(dev.cpu().numpy(), out)
+
+
 def test_fill_factor_dispatch(monkeypatch):
     """the GEMM form pays for every baseline slot of the block triangle, the row kernel for every row: a
     20-antenna sub-array on a 64-antenna axis (190 rows per step against 2304 slots) must take the row kernel"""

@@ -102,7 +102,9 @@ def _tol(s, d):
     lm = s["lm"].astype(np.float64)
     n = np.sqrt(1.0 - (lm ** 2).sum(1)) - 1.0
     reach = float((np.abs(lm).sum(1) + np.abs(n)).max())
-    return 2.0 * np.pi * float(s["frequency"].max()) / 299792458.0 * reach * plan.residual + 2e-5
+    # |V_ij| <= (sum_a |E_ia|) (sum_b |E_jb|) max |X_ab|: the beam's gain on top of the brightness _scale() measures
+    gain = float(np.abs(s["beam"]).sum(axis=-1).max()) ** 2
+    return 2.0 * np.pi * float(s["frequency"].max()) / 299792458.0 * reach * plan.residual * max(gain, 1.0) + 2e-5
 
 
 def _call_s(s, **kw):
