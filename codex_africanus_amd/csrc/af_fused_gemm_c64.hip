@@ -131,7 +131,6 @@ struct C2f {
     float re, im;
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
-#if 1
 // complex arithmetic on (re, im) pairs: v_pk_mul_f32 / v_pk_fma_f32, two float32 operations per instruction (54.6 -> 53.5 ms)
 __device__ __forceinline__ C2f cmulf(C2f a, C2f b)
 {
@@ -151,22 +150,7 @@ __device__ __forceinline__ void cmacf(C2f &acc, C2f a, C2f b)
     z = __builtin_elementwise_fma(ai, bs, z);
     acc.re = z.x; acc.im = z.y;
 }
-#else
-__device__ __forceinline__ C2f cmulf(C2f a, C2f b)
-{
-    C2f z;
-    z.re = fmaf(a.re, b.re, -__fmul_rn(a.im, b.im));
-    z.im = fmaf(a.re, b.im, __fmul_rn(a.im, b.re));
-    return z;
-}
-__device__ __forceinline__ void cmacf(C2f &acc, C2f a, C2f b)
-{
-    acc.re = fmaf(a.re, b.re, acc.re);
-    acc.re = fmaf(-a.im, b.im, acc.re);
-    acc.im = fmaf(a.re, b.im, acc.im);
-    acc.im = fmaf(a.im, b.re, acc.im);
-}
-#endif
+
 struct alignas(4) F3 {
     float x, y, z;
 };
@@ -221,7 +205,6 @@ __global__ void beam_plane_kernel_f32(const float2 *__restrict__ beam, int64_t n
 __device__ __forceinline__ C2f beam_reduce1f(const F3 (&v)[4], const float (&wt)[4])
 {
     float cre = 0.0f, cim = 0.0f, absc = 0.0f;
-#if 1
     v2f c2 = {0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -230,14 +213,7 @@ __device__ __forceinline__ C2f beam_reduce1f(const F3 (&v)[4], const float (&wt)
         absc = fmaf(wt[k], v[k].z, absc);
     }
     cre = c2.x; cim = c2.y;
-#else
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        cre = fmaf(wt[k], v[k].x, cre);
-        cim = fmaf(wt[k], v[k].y, cim);
-        absc = fmaf(wt[k], v[k].z, absc);
-    }
-#endif
+
     const float n2 = fmaf(cre, cre, __fmul_rn(cim, cim));
     const float sc = (n2 == 0.0f) ? absc : __fmul_rn(absc, __builtin_amdgcn_rsqf(n2));
     C2f r;
