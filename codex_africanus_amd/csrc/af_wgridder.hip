@@ -1923,7 +1923,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         int *sums = reinterpret_cast<int *>(ws + L.sums);
         // two levels, atomics in LDS: a few hundred coarse bins of F = 2^S fine keys each (F counters must fit LDS)
         int S = 0;
-        while (af_cdiv(nbins, 1 << S) > 512 && S < 13) ++S;          // F <= 8192 counters = 32 KB of LDS
+        static const int cmax_env = getenv("AFHIP_WGRID_SORT_BINS") ? atoi(getenv("AFHIP_WGRID_SORT_BINS")) : 512;   // A/B hook
+        const int cmax = cmax_env < 64 ? 64 : (cmax_env > 2048 ? 2048 : cmax_env);
+        while (af_cdiv(nbins, 1 << S) > cmax && S < 13) ++S;         // F <= 8192 counters = 32 KB of LDS
         const int C = (int)af_cdiv(nbins, 1 << S), NB = (int)af_cdiv(nvis, WG_VPB);
         if (sort_env >= 2 && C <= 2048) {
             int *keys = reinterpret_cast<int *>(ws + L.vidx);          // the keys live where the final indices go
