@@ -1923,7 +1923,9 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         int *sums = reinterpret_cast<int *>(ws + L.sums);
         // two levels, atomics in LDS: a few hundred coarse bins of F = 2^S fine keys each (F counters must fit LDS)
         int S = 0;
-        static const int cmax_env = getenv("AFHIP_WGRID_SORT_BINS") ? atoi(getenv("AFHIP_WGRID_SORT_BINS")) : 512;   // A/B hook
+        // (round 6: at most 1024 coarse bins instead of 512 -- configs[4]'s 655 360 keys then make 640 workgroups of the
+        //  fine pass instead of 320 on 256 CUs: whole step 17.44 -> 17.15 ms, same box; 2048: 17.18.  A/B hook:)
+        static const int cmax_env = getenv("AFHIP_WGRID_SORT_BINS") ? atoi(getenv("AFHIP_WGRID_SORT_BINS")) : 1024;
         const int cmax = cmax_env < 64 ? 64 : (cmax_env > 2048 ? 2048 : cmax_env);
         while (af_cdiv(nbins, 1 << S) > cmax && S < 13) ++S;         // F <= 8192 counters = 32 KB of LDS
         const int C = (int)af_cdiv(nbins, 1 << S), NB = (int)af_cdiv(nvis, WG_VPB);
