@@ -1,5 +1,5 @@
-// wgridder-style degridding (image -> visibilities) and its exact transpose (visibilities -> image, further down) with
-// a requested accuracy against the direct transform.
+// wgridder-style degridding (image -> visibilities) with a requested accuracy against the direct transform, and the host
+// section of its exact transpose (visibilities -> image; that direction's kernels: af_wgridder_adjoint.hip).
 //
 // Counterpart of africanus.gridding.wgridder.model (africanus/gridding/wgridder/im2vis.py:14-61), whose arithmetic is
 // ducc0.wgridder.dirty2ms -- a third-party module (ducc0 >= 0.35, pyproject.toml:14) that is neither vendored in the
@@ -38,6 +38,7 @@
 #include <mutex>
 
 #include "af_common.h"
+#include "af_wgrid_device.h"
 #include "af_wgrid_taps.h"
 
 namespace {
@@ -141,79 +142,7 @@ void wg_side_release(bool all, hipStream_t st)
     }
 }
 
-__device__ __forceinline__ double es_kernel(double t, double inv_half_w, double beta)
-{
-    const double x = t * inv_half_w;           // [-1, 1] inside the support
-    const double s = 1.0 - x * x;
-    return s > 0.0 ? exp(beta * (sqrt(s) - 1.0)) : 0.0;
-}
-
-// The W taps of a visibility along one axis: psi at offsets f, f + 1, ..., f + W - 1 from the visibility, f = (first cell)
-// - (position) in [-W/2, -W/2 + 1).  An exp and a sqrt in fp64 per tap cost ~150 instructions; for W <= 10 the taps come
-// from per-tap polynomials in u = 2 (f + W/2) - 1 instead (degree W + 2, Horner, coefficients in the kernel arguments =
-// scalar operands), as ducc0 does.  psi has a square-root singularity at the ends of its support, where it is ~10^-W:
-// the fit stalls at an absolute error of ~5 10^-(W+1) = epsilon / 200, which is what the accuracy contract can ignore;
-// the deconvolution keeps the exact psihat.  Every kernel of both directions takes its weights from this one function
-// (the transpose relation between `model` and `dirty` holds to rounding only if they do).
-constexpr int WG_POLYW = 10, WG_POLYD = WG_POLYW + 2;
-struct WgPoly { double c[WG_POLYW][WG_POLYD + 1]; };
-template <int W>
-__device__ __forceinline__ void wg_taps(const WgPoly &P, double f, double beta, double (&out)[W])
-{
-    if constexpr (W <= WG_POLYW) {
-        const double u = 2.0 * (f + 0.5 * (double)W) - 1.0;
-#pragma unroll
-        for (int a = 0; a < W; ++a) {
-            double acc = P.c[a][W + 2];
-#pragma unroll
-            for (int d = W + 1; d >= 0; --d) acc = fma(acc, u, P.c[a][d]);
-            out[a] = acc;
-        }
-    } else {
-        constexpr double inv_half_w = 2.0 / (double)W;
-#pragma unroll
-        for (int a = 0; a < W; ++a) out[a] = es_kernel(f + (double)a, inv_half_w, beta);
-    }
-}
-// The three axes' taps of one visibility in ONE walk over the coefficients (same Horner steps per polynomial as wg_taps:
-// the same bits).  The coefficients are kernel arguments -- W (W + 3) doubles in scalar registers, 140 registers at W = 7,
-// more than a wave has: three separate walks made the compiler keep them all and park them in vector-register lanes
-// (v_writelane / v_readlane: ~400 instructions per chunk of the tile kernel); walked once, each is loaded, used three times
-// and forgotten.
-template <int W>
-__device__ __forceinline__ void wg_taps3(const WgPoly &P, double fu, double fv, double fw, double beta, double (&ku)[W],
-                                         double (&kv)[W], double (&kw)[W])
-{
-    if constexpr (W <= WG_POLYW) {
-        const double uu = 2.0 * (fu + 0.5 * (double)W) - 1.0, uv = 2.0 * (fv + 0.5 * (double)W) - 1.0,
-                     uw = 2.0 * (fw + 0.5 * (double)W) - 1.0;
-#pragma unroll
-        for (int a = 0; a < W; ++a) {
-            double au = P.c[a][W + 2], av = au, aw = au;
-#pragma unroll
-            for (int d = W + 1; d >= 0; --d) {
-                const double c = P.c[a][d];
-                au = fma(au, uu, c);
-                av = fma(av, uv, c);
-                aw = fma(aw, uw, c);
-            }
-            ku[a] = au; kv[a] = av; kw[a] = aw;
-        }
-    } else {
-        wg_taps<W>(P, fu, beta, ku);
-        wg_taps<W>(P, fv, beta, kv);
-        wg_taps<W>(P, fw, beta, kw);
-    }
-}
-// the weight of plane k0 + a, a = k - k0 in 0 .. W - 1 (lane-dependent): a chain of selects, no indexed registers
-template <int W>
-__device__ __forceinline__ double wg_pick(const double (&kw)[W], int a)
-{
-    double r = 0.0;
-#pragma unroll
-    for (int t = 0; t < W; ++t) r = a == t ? kw[t] : r;
-    return r;
-}
+// (the kernel psi, its per-tap polynomials WgPoly and the tap functions wg_taps / wg_taps3 / wg_pick: af_wgrid_device.h)
 
 // A[x, y] = cu[x] cv[y] / (n psihat_w(dw (n - 1))) and nm1[x, y] = n - 1 (0 and A = cu cv without w-stacking);
 // psihat_w(xi) = (W/2) sum_q wq psi(tq) cos(pi W xi tq) over the Gauss-Legendre nodes tq in (0, 1) (even integrand)
@@ -655,28 +584,7 @@ struct WgSort {
     int W, do_w, nplanes, kb, nty, tile;
     int exact, kfirst;      // exact: one bucket per first plane kfirst .. kfirst + kb - 1, other visibilities left out
 };
-// (in everything below "u" is the SLOW axis of the stored planes and "v" the fast one: the planes are v-major, so the
-// host hands uvw's v as this code's u -- component 1 -- and u as its v)
-constexpr int WG_CU = 1, WG_CV = 0;
-// The w fold.  The image is real, so V(-u, -v, -w) = conj V(u, v, w): with w-stacking every visibility with w < 0 is
-// evaluated (or, in the adjoint, gridded) at the mirrored point and conjugated.  The planes then cover [min |w|, max |w|]
-// instead of [min w, max w] -- about half as many for an array whose baselines point either way (ducc0's wgridder
-// treats w < 0 the same way).  Every kernel takes a row's sign from here, so they agree on it to the last bit; the
-// products with +-1.0 are exact.
-__device__ __forceinline__ double wg_fold_sign(const double *__restrict__ uvw_row, int do_w)
-{
-    return do_w && uvw_row[2] < 0.0 ? -1.0 : 1.0;
-}
-// first cell of a visibility's support along one axis, wrapped onto the grid: the sort key and the tile kernel must
-// agree on it to the last bit, so both call this
-__device__ __forceinline__ int wg_first_cell(double g, int W, int n)
-{
-    const double t = ceil(g - 0.5 * W);                     // |t| < 1e15: exact in double
-    const double m = t - (double)n * floor(t / (double)n);
-    int p = (int)m;
-    p = p < 0 ? p + n : p;                                  // (rounding of t / n at multiples of n)
-    return p >= n ? p - n : p;
-}
+// (WG_CU / WG_CV, the w fold wg_fold_sign and wg_first_cell: af_wgrid_device.h, shared with the adjoint)
 __device__ __forceinline__ int wg_vis_key(const WgSort &q, int64_t i)
 {
     const unsigned r = (unsigned)i / (unsigned)q.nchan_b, c = (unsigned)i - r * (unsigned)q.nchan_b;   // nvis < 2^31
@@ -1263,328 +1171,9 @@ __global__ void wg_finish(double2 *__restrict__ vis, const double *__restrict__ 
     vis[o] = v;
 }
 
-// ================= the adjoint: visibilities -> image (africanus/gridding/wgridder/vis2im.py:15-72, ducc0's ms2dirty) =====
-//     dirty[x, y] = (1 / n) sum_{r, c} Re( wgt vis exp(+2 pi i nu/c (u x + v y - w (n - 1))) )
-// (test_wgridder.py:18-46).  Exactly the transpose of the operator above, plane by plane: the visibilities are spread
-// with the same taps onto the w-plane grids, every grid is transformed back (rows along u, the nx image rows gathered
-// into the staging array, rows along v), multiplied by exp(-2 pi i w_k (n - 1)) and by the same taper A, and its real
-// part added to the image.
+// ================= the adjoint: visibilities -> image: its device passes live in af_wgridder_adjoint.hip (not on the
+// SURVEY 8 hot path); the host section below drives both directions =================
 
-// ======================================================================================================================
-// NOT ON THE SURVEY 8 HOT PATH from here to the host section: the ADJOINT side (visibilities -> image: wg_grid_planes,
-// wg_grid_tiles, wg_gather_rows, wg_add_plane; entry af_wgrid_vis2im_f64).  Built in round 2 beside the forward operator
-// because the reference's only pin for its wgridder wrappers is the pair's adjointness and DFT accuracy
-// (gridding/wgridder/tests/test_wgridder.py:116-); kept as the forward path's cross-check, not tuned since, not a
-// roofline row.  The forward path (BASELINE configs[4] as named) uses nothing below this line except the host dispatch.
-// ======================================================================================================================
-// (small calls) one lane per visibility, hardware fp64 atomics into the planes
-template <int W>
-__global__ __launch_bounds__(256) void wg_grid_planes(const double *__restrict__ uvw, const double *__restrict__ freq,
-                                                      int64_t nrow, int64_t nchan_b, int64_t chan0, int64_t nchan_total,
-                                                      double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
-                                                      double celly, double beta, double w0, double dw, int pk0, int pk1,
-                                                      int do_w, const unsigned char *__restrict__ mask,
-                                                      const double *__restrict__ wgt, const double2 *__restrict__ vis,
-                                                      const WgPoly poly)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrow * nchan_b) return;
-    const int64_t r = i / nchan_b, c = i - r * nchan_b;
-    const int64_t o = r * nchan_total + chan0 + c;
-    if (mask && !mask[o]) return;
-    double2 val = vis[o];
-    if (wgt) { val.x *= wgt[o]; val.y *= wgt[o]; }
-    const double sg = wg_fold_sign(uvw + 3 * r, do_w);
-    val.y *= sg;                                            // w < 0: conj(vis) at the mirrored point
-    const double fl = sg * (freq[c] / AF_LIGHTSPEED);
-    double gw = 0.0;
-    int k0 = 0, k1 = 1, k0u = 0;
-    if (do_w) {
-        gw = (uvw[3 * r + 2] * fl - w0) / dw;
-        if (!isfinite(gw)) return;
-        k0 = (int)ceil(gw - 0.5 * W);
-        k1 = k0 + W;
-        k0u = k0;
-        k0 = k0 < pk0 ? pk0 : k0;
-        k1 = k1 > pk1 ? pk1 : k1;
-        if (k0 >= k1) return;
-    }
-    const double gu = uvw[3 * r + WG_CU] * fl * cellx * (double)nu, gv = uvw[3 * r + WG_CV] * fl * celly * (double)nv;
-    if (!(isfinite(gu) && isfinite(gv) && fabs(gu) < 1e15 && fabs(gv) < 1e15)) return;
-    const double fu = ceil(gu - 0.5 * W) - gu, fv = ceil(gv - 0.5 * W) - gv;
-    const int pu0 = wg_first_cell(gu, W, (int)nu), pv0 = wg_first_cell(gv, W, (int)nv);
-    double ku[W], kv[W], kwv[W];
-#pragma unroll
-    for (int t = 0; t < W; ++t) kwv[t] = t == 0 ? 1.0 : 0.0;
-    wg_taps<W>(poly, fu, beta, ku);
-    wg_taps<W>(poly, fv, beta, kv);
-    if (do_w) wg_taps<W>(poly, (double)k0u - gw, beta, kwv);
-    for (int k = k0; k < k1; ++k) {
-        const double kw = wg_pick<W>(kwv, k - k0u);
-        double *__restrict__ grid = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * nu * nv);
-#pragma unroll
-        for (int a = 0; a < W; ++a) {
-            int pa = pu0 + a;
-            pa = pa >= nu ? pa - (int)nu : pa;
-            const double wa = kw * ku[a];
-#pragma unroll
-            for (int b = 0; b < W; ++b) {
-                int pb = pv0 + b;
-                pb = pb >= nv ? pb - (int)nv : pb;
-                const double wt = wa * kv[b];
-                double *cell = grid + 2 * ((int64_t)pa * nv + pb);
-                unsafeAtomicAdd(cell, wt * val.x);
-                unsafeAtomicAdd(cell + 1, wt * val.y);
-            }
-        }
-    }
-}
-
-// (large calls) The visibilities sorted by (tile, first w-plane) -- exactly: one sort bucket per plane -- are taken
-// through LDS: a workgroup owns a chunk of <= 4096 visibilities of one tile and keeps the tile's cells of W consecutive
-// planes in a ring of LDS images (plane k in slot k mod W).  A visibility adds its W x W taps to its W planes with plain
-// LDS read-add-writes (one lane per tap: distinct cells; every image belongs to one wave, so no atomics); when the sorted
-// list moves on to a higher first plane, the planes that can receive nothing more are added to the grids in memory
-// (hardware fp64 atomics: neighbouring tiles share the halo cells) and their slots cleared.  Every (chunk, plane) is
-// flushed once: W^3 atomics per visibility become (T + W - 1)^2 per (chunk, plane).
-constexpr int WG_GCHUNK = 4096;
-constexpr int WG_GKB = 256;          // buckets (first planes) of one exact sort: calls with more planes sort per batch of planes
-__host__ __device__ constexpr int wg_gtile(int W) { return W <= 8 ? 12 : (W <= 12 ? 8 : 4); }   // ring + table <= 160 KB
-template <int W>
-__global__ __launch_bounds__(256) void wg_grid_tiles(const double *__restrict__ uvw, const double *__restrict__ freq,
-                                                     int64_t nchan_b, int64_t chan0, int64_t nchan_total,
-                                                     double2 *__restrict__ grids, int64_t nu, int64_t nv, double cellx,
-                                                     double celly, double beta, double w0, double dw, int pk0, int pk1,
-                                                     int do_w, const unsigned *__restrict__ idx, const int *__restrict__ start,
-                                                     int kb, const int2 *__restrict__ chunks, const int *__restrict__ nchunks,
-                                                     const double *__restrict__ wgt, const double2 *__restrict__ vis,
-                                                     const WgPoly poly)
-{
-    constexpr int T = wg_gtile(W), R = T + W - 1, RR = R * R;
-    constexpr int NT = 4 * W;                   // table doubles per visibility: val.re ku[], val.im ku[], kv[], kw[]
-    constexpr int NE = (2 * RR + 63) / 64;      // doubles of the region per lane (flush)
-    constexpr int NP = (W * W + 63) / 64;       // tap passes (one for W <= 8)
-    __shared__ double2 ring[W * RR];
-    __shared__ double tab[64 * NT];
-    if ((int)blockIdx.x >= *nchunks) return;
-    const int2 ch = chunks[blockIdx.x];
-    // four waves share the chunk: every wave walks ALL its visibilities, but adds only to the ring slots it owns
-    // (slot % 4 == wave) -- no two waves ever touch the same LDS image, so no atomics and no barriers in the walk
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nty = (int)((nv + T - 1) / T);
-    const int tu = ch.x / nty, tv = ch.x - tu * nty;
-    int n = start[(ch.x + 1) * kb] - ch.y;
-    n = n > WG_GCHUNK ? WG_GCHUNK : n;
-    const int64_t plane = nu * nv;
-
-    for (int e = tid; e < W * RR; e += 256) ring[e] = make_double2(0.0, 0.0);
-    // The flush works on DOUBLES, not cells: lane l of pass q takes double l + 64 q of the region's 2 R R (re, im
-    // interleaved), so that one atomic instruction covers whole contiguous runs of a grid row -- 64 consecutive doubles =
-    // four full 128-byte lines -- instead of every other double of twice as many lines (the flush atomics are what bounds
-    // this kernel: 4.8e9 of them per call at the ~1.6e11 / s the memory side sustains)
-    int gofs[NE];                               // grid offset (in doubles) of this lane's doubles of the region, wrapped
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        const int d = lane + 64 * q, e = d >> 1, a = e / R, b = e - a * R;
-        int gu_ = tu * T + a, gv_ = tv * T + b;          // wrapped by subtraction: no 64-bit %
-        while (gu_ >= (int)nu) gu_ -= (int)nu;
-        while (gv_ >= (int)nv) gv_ -= (int)nv;
-        gofs[q] = d < 2 * RR ? (int)(2 * ((int64_t)gu_ * nv + gv_) + (d & 1)) : -1;
-    }
-    // this lane's tap(s): row a, column b, offset a R + b -- dealt to the lanes so that the lane groups of the 16-byte
-    // LDS accesses repeat as few cells mod 16 (reads) / mod 8 (writes) as possible (af_wgrid_taps.h; in row-major lane
-    // order W = 7 paid 11 conflict cycles on top of the 12 of one read + write, and the LDS is what bounds this kernel)
-    static_assert(WgTaps<W>::NP == NP, "tap table and kernel disagree on the number of passes");
-    int ta[NP], tb[NP], tcell[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int t = WgTaps<W>::tap(p, lane);
-        ta[p] = t >= 0 ? t / W : -1;
-        tb[p] = t >= 0 ? t % W : 0;
-        tcell[p] = t >= 0 ? (t / W) * R + t % W : 0;
-    }
-    // plane k -> memory, slot cleared (by the wave that owns the slot)
-    auto retire = [&](int k) {
-        const int slot = ((k % W) + W) % W;
-        if ((slot & 3) != wave) return;
-        const bool live = k >= pk0 && k < pk1;
-        double *__restrict__ g = reinterpret_cast<double *>(grids + (int64_t)(k - pk0) * plane);
-        double *__restrict__ rs = reinterpret_cast<double *>(ring + slot * RR);
-        double v[NE];                           // all the reads first: one LDS round trip per plane, not NE
-#pragma unroll
-        for (int q = 0; q < NE; ++q) v[q] = gofs[q] >= 0 ? rs[lane + 64 * q] : 0.0;
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            if (v[q] != 0.0) {
-                if (live) unsafeAtomicAdd(g + gofs[q], v[q]);
-                rs[lane + 64 * q] = 0.0;
-            }
-        }
-    };
-    int kcur = 0;
-    bool started = false;
-    __syncthreads();
-    // inputs of visibilities base .. base + 63 (lane v of every wave: visibility base + v): loaded one batch ahead, so
-    // that the two dependent memory round trips (sorted index -> row) hide behind the walk of the batch before
-    struct Inputs { double2 val; double u, v, w, fl; bool valid; };
-    auto load_inputs = [&](int base) {
-        Inputs in;
-        in.valid = base + lane < n;
-        in.val = make_double2(0.0, 0.0);
-        in.u = in.v = in.w = in.fl = 0.0;
-        if (in.valid) {
-            const unsigned i = idx[ch.y + base + lane];
-            const unsigned r = i / (unsigned)nchan_b, c = i - r * (unsigned)nchan_b;
-            const int64_t o = (int64_t)r * nchan_total + chan0 + c;
-            const double sg = wg_fold_sign(uvw + 3 * (int64_t)r, do_w);
-            in.fl = sg * (freq[c] / AF_LIGHTSPEED);
-            in.u = uvw[3 * (int64_t)r + WG_CU];
-            in.v = uvw[3 * (int64_t)r + WG_CV];
-            in.w = uvw[3 * (int64_t)r + 2];
-            if (wave == 0) {
-                in.val = vis[o];
-                if (wgt) { const double g = wgt[o]; in.val.x *= g; in.val.y *= g; }
-                in.val.y *= sg;                             // w < 0: conj(vis) at the mirrored point
-            }
-        }
-        return in;
-    };
-    Inputs nxt = load_inputs(0);
-    for (int base = 0; base < n; base += 64) {
-        // the table of visibilities base .. base + 63: wave 0 writes val ku[], wave 1 kv[], wave 2 the plane weights;
-        // every wave keeps the visibility's first plane and offset
-        const Inputs in = nxt;
-        int k0 = 0x7fffffff, lofs = 0;
-        if (in.valid) {
-            const double fl = in.fl;
-            double gw = 0.0;
-            k0 = 0;
-            if (do_w) {
-                gw = (in.w * fl - w0) / dw;
-                k0 = (int)ceil(gw - 0.5 * W);
-            }
-            const double gu = in.u * fl * cellx * (double)nu;
-            const double gv = in.v * fl * celly * (double)nv;
-            double *__restrict__ t = tab + lane * NT;
-            double kk[W];
-            if (wave == 0) {
-                const double2 val = in.val;
-                wg_taps<W>(poly, ceil(gu - 0.5 * W) - gu, beta, kk);
-#pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    t[a] = val.x * kk[a];
-                    t[W + a] = val.y * kk[a];
-                }
-            } else if (wave == 1) {
-                wg_taps<W>(poly, ceil(gv - 0.5 * W) - gv, beta, kk);
-#pragma unroll
-                for (int a = 0; a < W; ++a) t[2 * W + a] = kk[a];
-            } else if (wave == 2) {
-                // the plane weights in SLOT order (plane k0 + a lives in slot (k0 + a) mod W): the walk then reads
-                // them at compile-time offsets and needs no per-visibility scalar arithmetic
-                int sl = ((k0 % W) + W) % W;
-#pragma unroll
-                for (int a = 0; a < W; ++a) kk[a] = a == 0 ? 1.0 : 0.0;
-                if (do_w) wg_taps<W>(poly, (double)k0 - gw, beta, kk);
-#pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    t[3 * W + sl] = kk[a];
-                    sl = sl + 1 == W ? 0 : sl + 1;
-                }
-            }
-            lofs = (wg_first_cell(gu, W, (int)nu) - tu * T) * R + wg_first_cell(gv, W, (int)nv) - tv * T;
-        }
-        if (base + 64 < n) nxt = load_inputs(base + 64);
-        __syncthreads();
-        const int nb = n - base < 64 ? n - base : 64;
-        // the walk, compiled once per wave number so that the slots a wave owns are compile-time constants (a dynamic
-        // ownership test per slot cost ~40 scalar branches per visibility)
-        auto walk = [&](auto wvc) {
-            constexpr int WV = decltype(wvc)::value;
-            constexpr int NS = (W - WV + 3) / 4;      // slots WV, WV + 4, ...
-            for (int j = 0; j < nb; ++j) {
-                const int k0j = __builtin_amdgcn_readlane(k0, j), lofsj = __builtin_amdgcn_readlane(lofs, j);
-                if (!started) { kcur = k0j; started = true; }
-                if (k0j > kcur) {                // planes below k0j are complete for this chunk
-                    const int upto = k0j - kcur < W ? k0j : kcur + W;
-                    for (int k = kcur; k < upto; ++k) retire(k);
-                    kcur = k0j;
-                }
-                if (NS == 0) continue;
-                const double *__restrict__ t = tab + j * NT;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    if (ta[p] < 0) continue;
-                    const double kvb = t[2 * W + tb[p]];
-                    const double pre = t[ta[p]] * kvb, pim = t[W + ta[p]] * kvb;
-                    const int cell = lofsj + tcell[p];
-                    double2 v[NS > 0 ? NS : 1];
-                    double kw[NS > 0 ? NS : 1];
-#pragma unroll
-                    for (int m = 0; m < NS; ++m) {
-                        kw[m] = t[3 * W + WV + 4 * m];
-                        v[m] = ring[(WV + 4 * m) * RR + cell];
-                    }
-#pragma unroll
-                    for (int m = 0; m < NS; ++m) {
-                        v[m].x = fma(kw[m], pre, v[m].x);
-                        v[m].y = fma(kw[m], pim, v[m].y);
-                    }
-#pragma unroll
-                    for (int m = 0; m < NS; ++m) ring[(WV + 4 * m) * RR + cell] = v[m];
-                }
-            }
-        };
-        switch (wave) {
-        case 0: walk(std::integral_constant<int, 0>{}); break;
-        case 1: walk(std::integral_constant<int, 1>{}); break;
-        case 2: walk(std::integral_constant<int, 2>{}); break;
-        default: walk(std::integral_constant<int, 3>{}); break;
-        }
-        __syncthreads();
-    }
-    if (started)
-        for (int k = kcur; k < kcur + W; ++k) retire(k);
-}
-
-// S[ix * nv + pv] = G[pv * nu + pu(ix)]: the nx image rows of a plane (transformed along u), v contiguous again
-__global__ __launch_bounds__(256) void wg_gather_rows(const double2 *__restrict__ G, int64_t nx, int64_t nu, int64_t nv,
-                                                      double2 *__restrict__ S)
-{
-    __shared__ double2 tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int64_t ix0 = (int64_t)blockIdx.x * 32, pv0 = (int64_t)blockIdx.y * 32;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t pv = pv0 + ty + 8 * j, ix = ix0 + tx;
-        int64_t pu = ix - nx / 2;
-        pu = pu < 0 ? pu + nu : pu;
-        tile[ty + 8 * j][tx] = (pv < nv && ix < nx) ? G[pv * nu + pu] : make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t ix = ix0 + ty + 8 * j, pv = pv0 + tx;
-        if (ix < nx && pv < nv) S[ix * nv + pv] = tile[tx][ty + 8 * j];
-    }
-}
-
-// image[ix, iy] (+)= A Re( S[ix, pv(iy)] exp(-2 pi i w_k (n - 1)) )
-__global__ __launch_bounds__(256) void wg_add_plane(const double2 *__restrict__ S, const double *__restrict__ A,
-                                                    const double *__restrict__ nm1, int64_t nx, int64_t ny, int64_t nv,
-                                                    double wk, int first, double *__restrict__ image)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx * ny) return;
-    const int64_t ix = i / ny, iy = i - ix * ny;
-    int64_t pv = iy - ny / 2;
-    pv = pv < 0 ? pv + nv : pv;
-    const double2 g = S[ix * nv + pv];
-    double sn, cs;
-    sincospi(2.0 * wk * nm1[i], &sn, &cs);
-    const double v = A[i] * (g.x * cs + g.y * sn);
-    image[i] = first ? v : image[i] + v;
-}
 
 struct WgWs { size_t hist, perm, key, sums, shist, soffs, vcount, vstart, vcursor, vidx, vkr, chunks, stage, stage_in, col_in, tw, tw2, poly, grid, A, nm1, total; int nbins, ntiles, gtiles; };
 int wg_kb(int64_t planes_total) { return planes_total < 1 ? 1 : (planes_total > WG_KB ? WG_KB : (int)planes_total); }
@@ -1838,7 +1427,7 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
         AF_LAUNCH_CHECK();
     }
 
-    const unsigned nb_img = (unsigned)af_cdiv(nx * ny, 256), nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
+    const unsigned nb_vis = (unsigned)af_cdiv(nrow * nchan_band, 256);
     // large image -> vis calls: the sort and the zero fill on the side stream (wg_side_stream), beside the transforms
     static const int sort_env = getenv("AFHIP_WGRID_SORT") ? atoi(getenv("AFHIP_WGRID_SORT")) : 1;
     const bool tiled = sort_env && nvis >= 65536 && nvis < (1LL << 31) && nu * nv < (1LL << 32);   // (32-bit cell offsets in the tile kernels)
@@ -1991,45 +1580,30 @@ int wg_run(bool adjoint, const double *uvw, const double *freq, int64_t nrow, in
             const int rc = sort_visibilities(1, pk0 - kernel_width + 1);
             if (rc != AF_OK) return rc;
         }
-#define AF_WG_LAUNCH(WC)                                                                                               \
-    if (tiled)                                                                                                         \
-        hipLaunchKernelGGL((wg_grid_tiles<WC>), dim3(max_chunks), dim3(256), 0, st, uvw, freq, nchan_band, chan0,        \
-                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, vidx, vstart,  \
-                           kb, chunks, nchunks, wgt, reinterpret_cast<const double2 *>(vis), poly);                      \
-    else                                                                                                               \
-        hipLaunchKernelGGL((wg_grid_planes<WC>), dim3(nb_vis), dim3(256), 0, st, uvw, freq, nrow, nchan_band, chan0,     \
-                           nchan_total, grid, nv, nu, celly, cellx, beta, w0, dw, pk0, pk1, do_wstacking, mask, wgt,     \
-                           reinterpret_cast<const double2 *>(vis), poly)
-        af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
-        switch (kernel_width) {
-        case 4: AF_WG_LAUNCH(4); break;
-        case 5: AF_WG_LAUNCH(5); break;
-        case 6: AF_WG_LAUNCH(6); break;
-        case 7: AF_WG_LAUNCH(7); break;
-        case 8: AF_WG_LAUNCH(8); break;
-        case 9: AF_WG_LAUNCH(9); break;
-        case 10: AF_WG_LAUNCH(10); break;
-        case 11: AF_WG_LAUNCH(11); break;
-        case 12: AF_WG_LAUNCH(12); break;
-        case 13: AF_WG_LAUNCH(13); break;
-        case 14: AF_WG_LAUNCH(14); break;
-        case 15: AF_WG_LAUNCH(15); break;
-        default: AF_WG_LAUNCH(16); break;
+        {   // (the stored planes are v-major: this code's "u" is the host's v, af_wgrid_device.h)
+            WgSpreadArgs sa{};
+            sa.uvw = uvw; sa.freq = freq;
+            sa.nrow = nrow; sa.nchan_b = nchan_band; sa.chan0 = chan0; sa.nchan_total = nchan_total;
+            sa.grids = grid;
+            sa.nu = nv; sa.nv = nu;
+            sa.cellx = celly; sa.celly = cellx; sa.beta = beta; sa.w0 = w0; sa.dw = dw;
+            sa.pk0 = pk0; sa.pk1 = pk1; sa.do_w = do_wstacking;
+            sa.mask = mask; sa.wgt = wgt; sa.vis = reinterpret_cast<const double2 *>(vis);
+            sa.idx = vidx; sa.start = vstart; sa.kb = kb; sa.chunks = chunks; sa.nchunks = nchunks;
+            af_prof_begin(st);      // measurement hook: the visibility pass of this plane batch
+            wg_adjoint_spread(kernel_width, tiled, tiled ? (unsigned)max_chunks : nb_vis, st, sa, poly);
+            af_prof_end(st);
         }
-        af_prof_end(st);
-#undef AF_WG_LAUNCH
         AF_LAUNCH_CHECK();
         for (int k = pk0; k < pk1; ++k) {
             double2 *gk = grid + (int64_t)(k - pk0) * nu * nv;
             int rc = wg_fft_rows((int)nu, (int)nv, gk, st, true);                // back along u, every column
             if (rc != AF_OK) return rc;
-            hipLaunchKernelGGL(wg_gather_rows, dim3((unsigned)af_cdiv(nx, 32), (unsigned)af_cdiv(nv, 32)), dim3(256), 0, st,
-                               gk, nx, nu, nv, S);
+            wg_adjoint_gather_rows(gk, nx, nu, nv, S, st);
             AF_LAUNCH_CHECK();
             rc = wg_fft_rows((int)nv, (int)nx, S, st, true);                     // back along v, the image's rows only
             if (rc != AF_OK) return rc;
-            hipLaunchKernelGGL(wg_add_plane, dim3(nb_img), dim3(256), 0, st, S, A, nm1, nx, ny, nv, w0 + k * dw,
-                               (int)(k == 0), image_out);
+            wg_adjoint_add_plane(S, A, nm1, nx, ny, nv, w0 + k * dw, (int)(k == 0), image_out, st);
             AF_LAUNCH_CHECK();
         }
     }

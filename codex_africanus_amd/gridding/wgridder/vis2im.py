@@ -18,7 +18,7 @@ def dirty(uvw, freq, vis, freq_bin_idx, freq_bin_counts, nx, ny, cell, weights=N
     ducc0.wgridder.ms2dirty, not vendored: parity unpinned).  What the reference's tests pin, and what holds here
     (africanus/gridding/wgridder/tests/test_wgridder.py:18-108): relative l2 error <= ``epsilon`` against
     ``(1/n) sum_rc Re(w V exp(+2 pi i nu/c (u x + v y - w (n - 1))))``, and ``dirty`` is the adjoint of ``model``
-    (test_wgridder.py:111-188): here the exact transpose, same w-planes and taps (csrc/af_wgridder.hip).
+    (test_wgridder.py:111-188): here the exact transpose, same w-planes and taps (csrc/af_wgridder_adjoint.hip; host section in csrc/af_wgridder.hip).
     """
     dt = np_dtype_of(vis)
     if dt == np.complex64:
