@@ -19,6 +19,7 @@ Workloads (--workload), one per BASELINE config a single GPU can run:
                  GEMM per (timestep, channel) on the fp64 matrix cores (= fused_dde --uvw antennas)
     fused_dde_ant128  the same on a 128-antenna array: the GEMM form in super-tiles (65 .. 256 antennas)
     fused_dde_ant_c64  fused_dde_ant with every input single precision (complex64 out): the GEMM form on the fp32 matrix cores
+    fused_dde_c64      fused_dde (uvw drawn per row) with every input single precision: the lane-per-row kernel in packed float32
     degrid       convolutional degridding of a 4096^2 grid, 1e6 rows x 64 chan, 7x7 taps: BASELINE configs[4]
     wgrid        wgridder-style degridding of a 4096^2 image at epsilon 1e-5: BASELINE configs[4] as named
 The default run (N = 1, headline shape) also times every other workload for a few steps and reports them under
@@ -81,7 +82,7 @@ def parse(argv=None):
     p.add_argument("--sources", type=int, default=DEFAULT_SHAPE["sources"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default="auto", choices=["auto", "exact", "recurrence"])
-    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "degrid", "wgrid",
+    p.add_argument("--workload", default="dft", choices=["dft", "dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "fused_dde_c64", "degrid", "wgrid",
                                                          "wgrid_f32planes"])
     p.add_argument("--uvw", default="random", choices=["random", "antennas"],
                    help="fused_dde: uvw drawn per row (BASELINE's recipe: not antenna-decomposable, lane-per-row kernel) or "

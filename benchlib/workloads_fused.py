@@ -423,3 +423,58 @@ class FusedDdeAntC64(FusedDde):
                  note="single precision: 64 flop per (row, chan, src) (8 complex MACs) against the fp32 matrix peak (157.3 TFLOP/s); "
                       "v_mfma_f32_16x16x4_f32, 3M form on diagonal super-blocks")
         return r
+
+
+class FusedDdeC64(FusedDdeAntC64):
+    """BASELINE configs[2] as it draws its uvw (per row: nothing decomposes) in SINGLE PRECISION: every input float32 /
+    complex64, complex64 out (af_fused_predict_c64: the lane-per-row kernel with packed float32 Jones algebra, float32 beam
+    planes and sampler, phases in double).  No chi^2 in its step.  Errors are against the float64 chain on the same float32
+    values."""
+
+    def __init__(self, args, rank, dev, lib, _lib, t):
+        import torch
+        FusedDde.__init__(self, args, rank, dev, lib, _lib, t)
+        h = self.h
+        f, c = np.float32, np.complex64
+        for k, dt in (("lm", f), ("freq", f), ("extents", f), ("beam_freq_map", f), ("pa", f), ("pe", f), ("asc", f), ("uvw", f),
+                      ("X", c), ("beam", c)):
+            h[k] = h[k].astype(dt)
+        keep = {k: self.dv[k] for k in ("items", "groups", "a1", "a2")}
+        self.dv = dict(keep, X=t(h["X"]), beam=t(h["beam"]), ext=t(h["extents"]), fmap=t(h["beam_freq_map"]), pa=t(h["pa"]),
+                       pe=t(h["pe"]), asc=t(h["asc"]), lm=t(h["lm"]), uvw=t(h["uvw"]), freq=t(h["freq"]))
+        self.ws_bytes = int(lib.af_fused_predict_c64_workspace_bytes(args.sources, args.chans, self.LW, self.MH, self.NUD))
+        self.d_ws = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=dev)
+        self.label = ("fused predict with per-antenna beam-cube DDEs, %d antennas, uvw drawn per row (BASELINE configs[2]), SINGLE "
+                      "precision (float32 / complex64 in, complex64 out): lane-per-row kernel, packed float32" % self.NANT)
+
+    def predict(self, d_vis, stream, P):
+        a, v = self.args, self.dv
+        self._lib.call("af_fused_predict_c64", P(v["items"]), self.n_items, P(v["a1"]), P(v["a2"]),
+                       None if v["groups"] is None else P(v["groups"]), a.rows, P(v["lm"]), P(v["uvw"]), P(v["freq"]), P(v["X"]),
+                       a.sources, a.chans, P(v["beam"]), self.LW, self.MH, self.NUD, P(v["ext"]), P(v["fmap"]), P(v["pa"]),
+                       self.ntime, self.NANT, P(v["pe"]), P(v["asc"]), None, None, self._lib.CONVENTION["fourier"], P(d_vis),
+                       P(self.d_ws), self.ws_bytes, stream)
+
+    def front_end_check(self, d_vis, rank, world, dev):
+        """rime.fused_predict_vis on the same single-precision tensors must take the same route: same bits"""
+        import torch
+        from codex_africanus_amd import rime
+        v = self.dv
+        ti = torch.from_numpy(self.h["time_index"]).to(dev)
+        vis = rime.fused_predict_vis(ti, v["a1"], v["a2"], v["lm"], v["uvw"], v["freq"], v["X"], v["beam"], v["ext"], v["fmap"], v["pa"],
+                                     v["pe"], v["asc"])
+        if vis.dtype != torch.complex64 or not bool(torch.equal(vis.reshape(d_vis.shape), d_vis)):
+            raise SystemExit("rank %d: rime.fused_predict_vis on single-precision tensors differs from af_fused_predict_c64" % rank)
+        return "rime.fused_predict_vis(float32 / complex64 tensors) == af_fused_predict_c64: bit-equal, complex64"
+
+    def roofline(self, kernel_s):
+        r = FusedDde.roofline(self, kernel_s)
+        a = self.args
+        units = float(a.rows) * a.chans * a.sources
+        r.update(kernel="fused_rows_c64_kernel", peak_tflops=FP32_PEAK_TFLOPS,
+                 executed={"packed_f32_instructions_per_unit": 24.0, "fp64_instructions_per_unit": 6.0,
+                           "note": "accumulating waves, per (row, chan, src): 24 packed float32 instructions (M = G E^H, acc += y M) + "
+                                   "9 float32 + 6 fp64 for the phasor"},
+                 note="single precision: 150 flop per (row, chan, src) (SURVEY 8(d)'s count, as the fp64 row kernel's line) against "
+                      "the fp32 vector peak (157.3 TFLOP/s, packed)")
+        return r

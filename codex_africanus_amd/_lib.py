@@ -134,6 +134,8 @@ _SIGNATURES = {
     "af_fused_predict_c64_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "af_fused_predict_antennas_c64": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                                              _vp, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
+    "af_fused_predict_c64": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                                    _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "af_fused_predict_antennas_model_c128": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp,
                                                     _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp,
                                                     _vp, _vp, _int, _vp, _vp, _sz, _vp]),

@@ -248,9 +248,9 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
                       corr_schema=(("XX", "XY"), ("YX", "YY")), spectral_base=0, plan=None):
     """See :func:`_fused_predict_vis` (below) for the arguments.  Result type: the reference's rule for the chain this
     call replaces -- the promoted type of the inputs (africanus/util/type_inference.py:24-26): complex64 when EVERY
-    floating-point input is single precision, complex128 otherwise.  Single-precision calls on antenna-decomposable rows
-    with a beam are COMPUTED in single precision (``af_fused_predict_antennas_c64``); every other route computes in double and
-    rounds once at the end (closer to the float64 chain than the reference's float32 arithmetic)."""
+    floating-point input is single precision, complex128 otherwise.  Single-precision calls with a beam are COMPUTED in
+    single precision (``af_fused_predict_antennas_c64`` on antenna-decomposable rows, ``af_fused_predict_c64`` on any others;
+    phases in double); the routes without a beam and the sky-model routes compute in double and round once at the end."""
     vis = _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
                              parallactic_angles, point_errors, antenna_scaling, die1_jones, base_vis, die2_jones, convention,
                              feed_rotation, gauss_shape, stokes, spi, ref_freq, corr_schema, spectral_base, plan)
@@ -398,7 +398,7 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
                 raise ValueError("antenna_scaling must have shape (ant, chan, 2)")
             if feed_rotation is not None and tuple(feed_rotation.shape) != (ntime, nant, 2, 2):
                 raise ValueError("feed_rotation must have shape (time, ant, 2, 2)")
-            all_single = not model and _all_single(lm, uvw, frequency, brightness, feed_rotation, *beam_args)
+            all_single = not model and _all_single(lm, uvw, frequency, brightness, feed_rotation, gauss_shape, *beam_args)
             if plan is None:
                 plan = fused_plan(time_index, antenna1, antenna2, nant, grouped=True,
                                   uvw=None if gauss_shape is not None else uvw, single=all_single)
@@ -413,7 +413,15 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
             gemm = gemm and (model or _hermitian(brightness_given))
             # every input single precision: the reference computes this chain in float32 / complex64
             # (africanus/util/type_inference.py:24-26); the GEMM form has a single-precision kernel of its own
-            single_route = gemm and all_single and os.environ.get("AFHIP_FUSED_C64", "1") != "0"
+            # (and the lane-per-row kernel too: rows that do not decompose, Gaussian shapes, non-Hermitian brightness)
+            single_route = all_single and os.environ.get("AFHIP_FUSED_C64", "1") != "0"
+        if single_route and not gemm:
+            vis = _rows_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
+                            beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,
+                            gauss_shape, convention, nsrc, nrow, nchan)
+            if die1_jones is None and base_vis is None:
+                return vis
+            return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
         if single_route:
             vis = _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
                             beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,
@@ -587,6 +595,33 @@ def _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, f
     if explicit_plan and nrow:
         # (the guard fills float64 words with NaN: a complex64 result is nrow * nchan * 4 of them)
         _check_plan(c, plan, True, time_index, antenna1, antenna2, c.inp(uvw, np.float64), nrow, p_out, nrow * nchan * 4)
+    return c.result(h)
+
+
+def _rows_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents,
+              beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation, gauss_shape, convention, nsrc, nrow,
+              nchan):
+    """The single-precision lane-per-row form (af_fused_predict_c64) inside an open Call: complex64 result."""
+    beam_lw, beam_mh, beam_nud = (int(s) for s in beam.shape[:3])
+    ntime, nant = (int(s) for s in parallactic_angles.shape)
+    f32, c64 = np.float32, np.complex64
+    p_items = c.inp(plan.device(plan.items, c), np.int32)
+    p_groups = None if plan.groups is None else c.inp(plan.device(plan.groups, c), np.int32)
+    p_a1 = c.inp(plan.device(plan.antenna1, c), np.int32)
+    p_a2 = c.inp(plan.device(plan.antenna2, c), np.int32)
+    p_lm, p_uvw, p_fr, p_b = c.inp(lm, f32), c.inp(uvw, f32), c.inp(frequency, f32), c.inp(brightness, c64)
+    p_beam, p_ext, p_map = c.inp(beam, c64), c.inp(beam_lm_extents, f32), c.inp(beam_freq_map, f32)
+    p_pa, p_pe, p_as = c.inp(parallactic_angles, f32), c.inp(point_errors, f32), c.inp(antenna_scaling, f32)
+    p_rot, p_gs = c.inp(feed_rotation, c64), c.inp(gauss_shape, f32)
+    p_out, h = c.out((nrow, nchan, 2, 2), c64)
+    ws_bytes = int(_lib.load().af_fused_predict_c64_workspace_bytes(nsrc, nchan, beam_lw, beam_mh, beam_nud))
+    p_ws = c.scratch(ws_bytes)
+    _lib.call("af_fused_predict_c64", p_items, plan.n_items, p_a1, p_a2, p_groups, nrow, p_lm, p_uvw, p_fr, p_b, nsrc, nchan,
+              p_beam, beam_lw, beam_mh, beam_nud, p_ext, p_map, p_pa, ntime, nant, p_pe, p_as, p_rot, p_gs,
+              _lib.CONVENTION[convention], p_out, p_ws, max(ws_bytes, 256), c.stream)
+    if explicit_plan and nrow:
+        # (the guard fills float64 words with NaN: a complex64 result is nrow * nchan * 4 of them)
+        _check_plan(c, plan, False, time_index, antenna1, antenna2, c.inp(uvw, np.float64), nrow, p_out, nrow * nchan * 4)
     return c.result(h)
 
 

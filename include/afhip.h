@@ -372,6 +372,21 @@ int af_fused_predict_antennas_c64(const double *ant_uvw, const int32_t *rowmap, 
                                   const float *point_errors, const float *antenna_scaling, const float *feed_rotation,
                                   int convention, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The SINGLE-PRECISION form of af_fused_predict_c128 (round 6): ANY uvw (rows that do not decompose by antenna -- BASELINE
+ * configs[2] as it draws its uvw --, Gaussian shapes, non-Hermitian brightness), every floating-point array float32 /
+ * complex64, complex64 out; items / groups / antenna1 / antenna2 as planned by af_fused_plan_rows / af_fused_plan_groups.
+ * Replaces the same reference chain as af_fused_predict_c128 for single-precision callers (the precision rule and file:line
+ * as for af_fused_predict_antennas_c64 above).  Packed float32 Jones algebra, float32 beam planes and sampler; the phase
+ * argument l u + m v + n w and its reduction in double (csrc/af_fused_predict_c64.hip).  Workspace:
+ * af_fused_predict_c64_workspace_bytes.  nant <= 664. */
+int af_fused_predict_c64(const int32_t *items, int64_t nitems, const int32_t *antenna1, const int32_t *antenna2,
+                         const int32_t *groups, int64_t nrow, const float *lm, const float *uvw, const float *frequency,
+                         const float *brightness, int64_t nsrc, int64_t nchan, const float *beam, int64_t beam_lw,
+                         int64_t beam_mh, int64_t beam_nud, const float *beam_lm_extents, const float *beam_freq_map,
+                         const float *parallactic_angles, int64_t ntime, int64_t nant, const float *point_errors,
+                         const float *antenna_scaling, const float *feed_rotation, const float *gauss_shape, int convention,
+                         float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Plan guard (DEVICE pointers except none; O(row) on the device, no host round trip).  The predict entries above read
  * the PLAN's arrays (items / groups / antenna1 / antenna2, ant_uvw / rowmap), not the call's own index arrays and uvw: a
  * plan re-used with other rows or other uvw would silently compute with the old ones (the reference has no plan:

@@ -42,7 +42,7 @@ def test_extras_ride_only_in_the_default_single_gpu_line(bench):
     assert bench.extras_requested(bench.parse(["--workload", "degrid"]), 1) == ()
     assert bench.extras_requested(bench.parse(["--extras", "none"]), 1) == ()
     assert bench.extras_requested(bench.parse(["--rows", "5000", "--extras", "degrid,wgrid"]), 1) == ("degrid", "wgrid")
-    assert bench.extras_requested(bench.parse(["--workload", "degrid", "--extras", "all"]), 1) == ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "wgrid", "wgrid_f32planes")
+    assert bench.extras_requested(bench.parse(["--workload", "degrid", "--extras", "all"]), 1) == ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "fused_dde_c64", "wgrid", "wgrid_f32planes")
     with pytest.raises(SystemExit):
         bench.extras_requested(bench.parse(["--extras", "nonsense"]), 1)
 

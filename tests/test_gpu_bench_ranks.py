@@ -147,7 +147,7 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert r["n_gpus"] == 1 and "cpu_baseline" in r and r["cpu_baseline"]["probe_rows"] >= 16
     assert r["cpu_baseline"]["numba_calibration"]["value"] == 0.026
     w = r["workloads"]
-    assert set(w) == {"dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "degrid", "wgrid", "wgrid_f32planes"}
+    assert set(w) == {"dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "fused_dde_c64", "degrid", "wgrid", "wgrid_f32planes"}
     for name, e in w.items():
         assert "error" not in e, (name, e)
         assert e["ms_per_step"] > 0 and e["kernel_ms"] > 0 and e["roofline"]["frac"] > 0
@@ -157,6 +157,7 @@ def test_default_line_carries_the_other_single_gpu_configs():
     assert w["dft_f32"]["fp64_max_abs_err"] < 1e-3      # single precision: absolute error of sums of ~100 unit terms
     # (single precision rows: float32 differences of antenna coordinates carry ~1e-4 m of rounding = 1e-4 rad per term)
     assert w["fused_dde_ant_c64"]["fp64_max_abs_err"] < 1e-2 and w["fused_dde_ant_c64"]["roofline"]["kernel"] == "fused_gemm_c64_kernel"
+    assert w["fused_dde_c64"]["fp64_max_abs_err"] < 1e-2 and w["fused_dde_c64"]["roofline"]["kernel"] == "fused_rows_c64_kernel"
     assert w["degrid"]["fp64_max_abs_err"] < 1e-9
     assert w["gauss"]["fp64_max_abs_err"] < 1e-8 and w["gauss"]["roofline"]["kernel"].startswith("dft_mfma_kernel")
 
@@ -172,7 +173,7 @@ def test_the_driver_visible_keys_of_the_default_line():
     line = lines[0]
     r = json.loads(line)
     roof = r["roofline"]
-    names = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "degrid", "wgrid", "wgrid_f32planes")
+    names = ("dft_complex", "dft_f32", "gauss", "fused_dde", "fused_dde_ant", "fused_dde_ant128", "fused_dde_ant_c64", "fused_dde_c64", "degrid", "wgrid", "wgrid_f32planes")
     assert set(roof["others"]) == set(names)
     for n in names:
         ms, kernel_ms, frac, err_, value = roof["others"][n]

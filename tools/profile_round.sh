@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 gauss fused_dde fused_dde_ant fused_dde_ant128 fused_dde_ant_c64 degrid wgrid wgrid_f32planes}"
+WORKLOADS="${WORKLOADS:-dft dft_complex dft_f32 gauss fused_dde fused_dde_ant fused_dde_ant128 fused_dde_ant_c64 fused_dde_c64 degrid wgrid wgrid_f32planes}"
 T="timeout 900"    # a profiler pass that hangs must not take the box with it
 # the line the driver gets: headline + every other single-GPU workload under "workloads"
 # (SKIP_DEFAULT=1 / SKIP_AUX=1: re-profile a subset of WORKLOADS only)

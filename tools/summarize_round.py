@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
 DOMINANT = {"dft": "dft_mfma_kernel", "dft_complex": "dft_mfma_kernel", "dft_f32": "dft_f32_kernel", "gauss": "dft_mfma_kernel", "fused_dde": "fused_predict_kernel",
-            "fused_dde_ant": "fused_gemm3_kernel", "fused_dde_ant128": "fused_gemm3_kernel", "fused_dde_ant_c64": "fused_gemm_c64_kernel",
+            "fused_dde_ant": "fused_gemm3_kernel", "fused_dde_ant128": "fused_gemm3_kernel", "fused_dde_ant_c64": "fused_gemm_c64_kernel", "fused_dde_c64": "fused_rows_c64_kernel",
             "degrid": "degrid_coop_kernel", "wgrid": "wg_degrid_tiles", "wgrid_f32planes": "wg_degrid_tiles"}
 
 
