@@ -81,9 +81,11 @@ __device__ __forceinline__ v2f phasor_f32(const float2 *__restrict__ tab, double
     const float2 t = tab[k & (PH_TABLE - 1)];
     const float sn = __fmul_rn(th, 6.1359231515425649e-03f);                        // 2 pi / 1024
     const float cs = fmaf(__fmul_rn(th, th), -1.8824776459647568e-05f, 1.0f);       // (2 pi / 1024)^2 / 2
-    v2f r;
-    r.x = fmaf(t.x, cs, -__fmul_rn(t.y, sn));
-    r.y = fmaf(t.x, sn, __fmul_rn(t.y, cs));
+    // table entry times (cs + i sn): (tx cs, tx sn) then (- ty sn, + ty cs)
+    const v2f tt = {t.x, t.y}, rs = {cs, sn};
+    v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=&v"(p) : "v"(tt), "v"(rs));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=&v"(r) : "v"(tt), "v"(rs), "v"(p));
     return r;
 }
 
@@ -487,7 +489,8 @@ AF_EXPORT int af_fused_predict_c64(const int32_t *items, int64_t nitems, const i
     }
     if (st > nsrc) st = (int)nsrc;
     if (st < 1) st = 1;
-    // the unrolled form: 64-antenna stride, 8 sources per batch (no Gaussian shapes)
+    // the unrolled form: 64-antenna stride, 8 sources per batch (no Gaussian shapes).  Measured on one box at BASELINE
+    // configs[2]: 109.3 ms; the rolled loop on batches of 16 sources (half the barriers) 113.8 ms
     const bool unroll = NPv == 64 && !gauss && nsrc >= 8;
     if (unroll) st = 8;
     const size_t lds_bytes = (size_t)fixed + (size_t)2 * 2 * st * 2 * npp * 16;

@@ -106,6 +106,43 @@ def fused_gemm_c64_sweep(seed):
         os.environ.pop("AFHIP_GEMM_MIN_FILL", None)
 
 
+def fused_rows_c64_sweep(seed):
+    """the single-precision lane-per-row form (round 6: af_fused_predict_c64) at random array sizes and batch shapes -- uvw drawn
+    per row, rows or groups, optional feed rotation / Gaussian shapes -- against the oracle's float64 chain on the promoted values
+    (Gaussian shapes: against the double-precision kernel on the promoted values)"""
+    import test_gpu_fused_gemm_c64 as FC
+    import test_gpu_fused_rows_c64 as FR
+    from codex_africanus_amd.rime import fused
+    rng = np.random.default_rng(seed)
+    nant = int(rng.choice([2, 3, 5, 7, 8, 16, 17, 31, 33, 40, 63, 64, 65, 70, 100, 128, 129, 150, 200]))
+    nbl = nant * (nant - 1) // 2
+    nrow = int(rng.integers(1, min(2 * nbl, nbl + 3000) + 2))
+    nchan, nsrc = int(rng.integers(1, 5)), int(rng.integers(1, 40))
+    d = FU._problem(seed, nrow, nchan, nsrc, nant)
+    s = FR._rows_single(d)
+    kw = {}
+    if rng.integers(0, 2):
+        kw["feed_rotation"] = rime.feed_rotation(s["pa"], "linear")
+    gauss = bool(rng.integers(0, 3) == 0)
+    if gauss:
+        gs = np.zeros((nsrc, 3), np.float32)
+        k = (nsrc + 1) // 2
+        gs[::2] = np.stack([rng.uniform(1e-4, 4e-4, k), rng.uniform(5e-5, 1e-4, k), rng.uniform(0, np.pi, k)], axis=1).astype(np.float32)
+        kw["gauss_shape"] = gs
+    plan = fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, grouped=bool(rng.integers(0, 2)), uvw=s["uvw"], single=True)
+    out = FC._call_s(s, plan=plan, **kw)
+    assert out.dtype == np.complex64, out.dtype
+    if kw:
+        p = lambda a: a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+        ref = rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], p(s["lm"]), p(s["uvw"]), p(s["frequency"]), p(s["X"]),
+                                     p(s["beam"]), p(s["extents"]), p(s["beam_freq_map"]), p(s["pa"]), p(s["pe"]), p(s["as"]),
+                                     **{k_: p(v) for k_, v in kw.items()})
+    else:
+        ref = FC._chain64(s)
+    assert out.shape == ref.shape and (out.size == 0 or np.abs(out - ref).max() < FR._tol(s) * FU._scale(d)), (
+        nant, nrow, nchan, nsrc, sorted(kw), np.abs(out - ref).max() / FU._scale(d), FR._tol(s))
+
+
 def beam_and_phase_sweep(seed):
     """beam_cube_dde (arbitrary correlation dims, out-of-band channels, off-cube sources) and phase_delay"""
     rng = np.random.default_rng(seed)
@@ -183,7 +220,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 only = os.environ.get("AFHIP_STRESS_ONLY")          # e.g. "fused_gemm_sweep,fused_gemm_c64_sweep": only the sweeps named
 sweeps = [F.test_im_to_vis_random_shapes, F.test_vis_to_im_random_shapes, F.test_wsclean_predict_random_shapes,
           F.test_predict_vis_random_shapes_bit_exact, F.test_degridder_gridder_random_shapes, calibration_sweep,
-          fused_sweep, fused_gemm_sweep, fused_gemm_c64_sweep, beam_and_phase_sweep, convert_and_chi2_sweep, wgridder_sweep]
+          fused_sweep, fused_gemm_sweep, fused_gemm_c64_sweep, fused_rows_c64_sweep, beam_and_phase_sweep, convert_and_chi2_sweep, wgridder_sweep]
 if only:
     sweeps = [fn for fn in sweeps if fn.__name__ in only.split(",")]
 t0 = time.time()
