@@ -102,6 +102,8 @@ def measure(args, workload, steps, warmup, rank, world, dev, dist, cpu_seconds, 
         return None
     max_err = check_rows(wl, d_vis, nrow, args.check_rows, dev) if args.check_rows > 0 else None
     res = {
+        # the arithmetic type the path computes in: single-precision workloads (complex64 out) say so
+        "dtype": "f32" if getattr(wl, "vis_dtype", "complex128") == "complex64" else "f64",
         "label": wl.label + ("; chi^2 summed in the transform's epilogue (the entry's _chi2 form)" if fused_chi2 else ""),
         "has_chi2": have_chi2, "ranks_reported": reported, "elapsed": elapsed, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "value": reported * nrow * nchan / (elapsed / steps) / 1e6,
@@ -127,7 +129,7 @@ def headline_json(args, res, world_desc, backend_desc):
     out = {
         "metric": METRIC, "value": res["value"], "unit": "Mvis/s",
         "n_gpus": n, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res.get("dtype", "f64"), "data": "synthetic",
         "config": {
             "workload": res["label"] + (" + per-channel chi^2" if res.get("has_chi2", True) else " (no chi^2 in the step)")
                         + ("" if n == 1 else " + " + backend_desc),
