@@ -480,7 +480,7 @@ AF_EXPORT int af_fused_predict_c64(const int32_t *items, int64_t nitems, const i
     const int64_t fixed = 48 * npa + PH_TABLE * 8 + 32 * npa;   // coefficient planes, phasor table, feed rotations
     // sources per batch: two buffers of E and G (64 bytes per (source, antenna)); whole super-rounds of the 256 sampling lanes
     int st = (int)((160 * 1024 - fixed) / (2 * 64 * npp));
-    if (st > 2047 / 1) st = 2047;
+    if (st > 2047) st = 2047;                                // (a term's source slot is 11 bits of its `info` word)
     if ((int64_t)st * np > 4096) st = (int)(4096 / np);     // (at most 16 super-rounds per batch)
     {
         int64_t m = 1;

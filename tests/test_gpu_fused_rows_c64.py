@@ -141,6 +141,20 @@ def test_more_channels_than_one_group_of_beam_planes_and_dies():
     assert np.array_equal(full, oracle.predict_vis(s["time_index"], s["ant1"], s["ant2"], None, got[None], None, die, bvis, die))
 
 
+def test_empty_calls():
+    """no rows -> (0, chan, 2, 2); no sources -> zeros: both complex64"""
+    nant = 12
+    s = _rows_single(_problem(7, 600, 4, 9, nant))
+    e = dict(s)
+    for k in ("time_index", "ant1", "ant2", "uvw"):
+        e[k] = s[k][:0]
+    out = _call_s(e)
+    assert out.dtype == np.complex64 and out.shape == (0, 4, 2, 2)
+    z = dict(s, lm=s["lm"][:0], X=s["X"][:0])
+    out = _call_s(z)
+    assert out.dtype == np.complex64 and out.shape == (600, 4, 2, 2) and not out.any()
+
+
 def test_stale_plan_is_refused():
     nant = 12
     s = _rows_single(_problem(7, 600, 4, 9, nant))
