@@ -49,6 +49,35 @@ __device__ __forceinline__ v2f cmulc2(v2f a, v2f b)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=&v"(r) : "v"(a), "v"(b), "v"(t));
     return r;
 }
+// (the same in single steps, for callers that interleave several products)
+__device__ __forceinline__ v2f cmulc2_a(v2f a, v2f b)
+{
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=&v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ v2f cmulc2_b(v2f a, v2f b, v2f t)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=&v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ void cmacc2_a(v2f &acc, v2f a, v2f b)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void cmacc2_b(v2f &acc, v2f a, v2f b)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void cmac2_a(v2f &acc, v2f a, v2f b)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void cmac2_b(v2f &acc, v2f a, v2f b)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void cmacc2(v2f &acc, v2f a, v2f b)
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
@@ -362,11 +391,14 @@ __global__ __launch_bounds__(R_THREADS) void fused_rows_c64_kernel(
         v2f y = phasor_f32(ldsT, fma(n, ws[k], fma(m, vs[k], __dmul_rn(l, us[k]))));                              \
         if constexpr (GAUSS) { if (extended) y = y * v2f{shape[k], shape[k]}; }                                  \
         LOADS;                                                                                                   \
-        v2f M0 = cmulc2(Gp0, Eq0); cmacc2(M0, Gp1, Eq1);                                                         \
-        v2f M1 = cmulc2(Gp0, Eq2); cmacc2(M1, Gp1, Eq3);                                                         \
-        v2f M2 = cmulc2(Gp2, Eq0); cmacc2(M2, Gp3, Eq1);                                                         \
-        v2f M3 = cmulc2(Gp2, Eq2); cmacc2(M3, Gp3, Eq3);                                                         \
-        cmac2(acc[k][0], y, M0); cmac2(acc[k][1], y, M1); cmac2(acc[k][2], y, M2); cmac2(acc[k][3], y, M3);      \
+        /* the four elements of M side by side, step by step: no instruction reads the result of the one before it */ \
+        v2f M0, M1, M2, M3;                                                                                      \
+        { v2f t0 = cmulc2_a(Gp0, Eq0), t1 = cmulc2_a(Gp0, Eq2), t2 = cmulc2_a(Gp2, Eq0), t3 = cmulc2_a(Gp2, Eq2); \
+          M0 = cmulc2_b(Gp0, Eq0, t0); M1 = cmulc2_b(Gp0, Eq2, t1); M2 = cmulc2_b(Gp2, Eq0, t2); M3 = cmulc2_b(Gp2, Eq2, t3); } \
+        cmacc2_a(M0, Gp1, Eq1); cmacc2_a(M1, Gp1, Eq3); cmacc2_a(M2, Gp3, Eq1); cmacc2_a(M3, Gp3, Eq3);          \
+        cmacc2_b(M0, Gp1, Eq1); cmacc2_b(M1, Gp1, Eq3); cmacc2_b(M2, Gp3, Eq1); cmacc2_b(M3, Gp3, Eq3);          \
+        cmac2_a(acc[k][0], y, M0); cmac2_a(acc[k][1], y, M1); cmac2_a(acc[k][2], y, M2); cmac2_a(acc[k][3], y, M3); \
+        cmac2_b(acc[k][0], y, M0); cmac2_b(acc[k][1], y, M1); cmac2_b(acc[k][2], y, M2); cmac2_b(acc[k][3], y, M3); \
     } while (0)
             if constexpr (GR) {
                 // slots k = 2 i + j: (p0,q0) (p0,q1) (p1,q1) (p1,q0); every operand change is one two-read load
