@@ -220,8 +220,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     """
     from .rime.fused import fused_predict_vis as _fused, cached_plan, _all_single
     # every input single precision: plans of float32 rows decompose at their own precision (the single-precision GEMM form)
-    single = stokes is None and _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents, beam_freq_map,
-                                            parallactic_angles, point_errors, antenna_scaling)
+    single = _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents, beam_freq_map,
+                         parallactic_angles, point_errors, antenna_scaling, stokes, spi, ref_freq)
     chunks = chunks or {}
     if (die1_jones is None) != (die2_jones is None):
         raise ValueError("Both die1_jones and die2_jones must be present or absent")

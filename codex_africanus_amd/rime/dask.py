@@ -206,8 +206,8 @@ def _fused_block(time_index, antenna1, antenna2, lm, uvw, frequency, brightness,
     pa_ = u(pa)
     with placement.block(block_id):
         uvw_ = u(uvw)
-        single = stokes is None and _all_single(u(lm), uvw_, frequency, u(brightness), u(feed_rot), u(beam), u(extents), u(freq_map),
-                                                pa_, u(pe), u(ascale))
+        single = _all_single(u(lm), uvw_, frequency, u(brightness), u(feed_rot), u(beam), u(extents), u(freq_map),
+                             pa_, u(pe), u(ascale), u(stokes), u(spi), u(ref_freq))
         plan = None if beam is None else cached_plan(time_index, antenna1, antenna2, pa_.shape[1],
                                                       uvw=None if gauss_shape is not None else uvw_, single=single)
         vis = _np_fused(time_index, antenna1, antenna2, u(lm), uvw_, frequency, u(brightness), u(beam), u(extents),

@@ -46,6 +46,7 @@ class FusedPlan(object):
         # are not (known to be) antenna-decomposable and the call runs on the lane-per-row kernel
         self.ant_uvw = self.rowmap = self.residual = None
         self.tol = DECOMPOSE_TOL
+        self.single_tol = False     # the tolerance is single precision's (fused_plan(..., single=True) on float32 rows)
         # rows over the baseline slots the GEMM form evaluates (nsteps x upper block triangle of 8-antenna blocks): the
         # GEMM form pays for every slot, the lane-per-row kernel for every row (fused_predict_vis picks by this)
         self.fill = 1.0
@@ -142,6 +143,7 @@ def fused_plan(time_index, antenna1, antenna2, nant, grouped=True, uvw=None, dec
                   uvw_h.ctypes.data_as(ctypes.c_void_p), nrow, nant, tol, nsteps, ant_uvw.ctypes.data_as(ctypes.c_void_p),
                   rowmap.ctypes.data_as(ctypes.c_void_p), ctypes.byref(resid), ctypes.byref(ok))
         plan.residual, plan.tol = resid.value, tol
+        plan.single_tol = decompose_tol is None and tol != DECOMPOSE_TOL
         plan.fill = nrow / float(nsteps * int(_lib.load().af_fused_gemm_slots(nant)))
         if ok.value:
             plan.ant_uvw, plan.rowmap = ant_uvw, rowmap
@@ -250,7 +252,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     call replaces -- the promoted type of the inputs (africanus/util/type_inference.py:24-26): complex64 when EVERY
     floating-point input is single precision, complex128 otherwise.  Single-precision calls with a beam are COMPUTED in
     single precision (``af_fused_predict_antennas_c64`` on antenna-decomposable rows, ``af_fused_predict_c64`` on any others;
-    phases in double); the routes without a beam and the sky-model routes compute in double and round once at the end."""
+    phases in double; a sky model given as ``stokes`` / ``spi`` / ``ref_freq`` is first turned into the complex64 brightness
+    array); the routes without a beam compute in double and round once at the end."""
     vis = _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
                              parallactic_angles, point_errors, antenna_scaling, die1_jones, base_vis, die2_jones, convention,
                              feed_rotation, gauss_shape, stokes, spi, ref_freq, corr_schema, spectral_base, plan)
@@ -362,6 +365,18 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
         if die1_jones is None and base_vis is None:
             return vis
         return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+    model_made = False
+    if model and have_beam and os.environ.get("AFHIP_FUSED_C64", "1") != "0" and \
+            _all_single(lm, uvw, frequency, stokes, spi, ref_freq, feed_rotation, gauss_shape, *beam_args):
+        # a sky model with EVERY input single precision: the single-precision kernels take a brightness array, so it is made
+        # first -- the reference's own order of work (africanus/rime/examples/predict.py:494-498), 32 bytes per (source, channel),
+        # complex64 -- and the call goes on as one with `brightness` (Hermitian by construction: real Stokes parameters)
+        from ..model.spectral import spectral_model
+        from ..model.coherency import convert
+        brightness = convert(spectral_model(stokes, spi, ref_freq, frequency, base=spectral_base),
+                             ["I", "Q", "U", "V"], [list(r) for r in corr_schema])
+        stokes = spi = ref_freq = None
+        model, model_made = False, True
     bshape = tuple(int(s) for s in brightness.shape) if brightness is not None else (nsrc, nchan, 2, 2)
     if bshape == (nsrc, 2, 2):
         flat_spectrum = True
@@ -410,11 +425,15 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
                 plan.fill >= float(os.environ.get("AFHIP_GEMM_MIN_FILL", GEMM_MIN_FILL)) and \
                 os.environ.get("AFHIP_FUSED_GEMM", "1") != "0"
             # ... and Hermitian brightness matrices (_hermitian: the sky model's always are)
-            gemm = gemm and (model or _hermitian(brightness_given))
+            gemm = gemm and (model or model_made or _hermitian(brightness_given))
             # every input single precision: the reference computes this chain in float32 / complex64
             # (africanus/util/type_inference.py:24-26); the GEMM form has a single-precision kernel of its own
             # (and the lane-per-row kernel too: rows that do not decompose, Gaussian shapes, non-Hermitian brightness)
             single_route = all_single and os.environ.get("AFHIP_FUSED_C64", "1") != "0"
+            # a plan whose rows decompose only at single precision's tolerance (fused_plan(..., single=True)) serves the
+            # single-precision GEMM form alone: in double its residual (~1e-4 m) would be the error of the result
+            if gemm and plan.single_tol and not single_route:
+                gemm = False
         if single_route and not gemm:
             vis = _rows_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
                             beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,

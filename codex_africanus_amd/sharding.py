@@ -169,8 +169,8 @@ def fused_predict_shard(rank, world_size, time_index, antenna1, antenna2, lm, uv
     plan = None
     if beam is not None and stop > start:
         from .rime.fused import _all_single
-        single = kwargs.get("stokes") is None and _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents,
-                                                              beam_freq_map, parallactic_angles, point_errors, antenna_scaling)
+        single = _all_single(lm, uvw, frequency, brightness, feed_rotation, beam, beam_lm_extents, beam_freq_map, parallactic_angles,
+                             point_errors, antenna_scaling, kwargs.get("stokes"), kwargs.get("spi"), kwargs.get("ref_freq"))
         plan = cached_plan(ti, a1, a2, int(parallactic_angles.shape[1]),
                            uvw=None if kwargs.get("gauss_shape") is not None else uvw[rows], single=single)
     vis = fused_predict_vis(ti, a1, a2, lm, uvw[rows], frequency, brightness, beam, beam_lm_extents, beam_freq_map,

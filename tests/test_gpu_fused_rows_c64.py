@@ -222,3 +222,46 @@ def test_the_entry_through_the_c_abi():
     assert lib.af_fused_predict_c64(*args()) == 0
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_sky_model_in_single_precision_takes_the_single_precision_kernels(spy, monkeypatch):
+    """stokes / spi / ref_freq with every input single precision: the brightness array is made first (complex64, the
+    reference's own order of work, rime/examples/predict.py:494-498) and the call runs on the single-precision kernels --
+    the GEMM form on Measurement-Set rows, this kernel on any others"""
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+    nant, nsrc = 24, 13
+    rng = np.random.default_rng(12)
+    stokes = np.stack([rng.lognormal(0, 1, nsrc)] + [0.1 * rng.standard_normal(nsrc) for _ in range(3)], axis=1).astype(np.float32)
+    spi = rng.uniform(-1.0, 0.2, (nsrc, 2, 4)).astype(np.float32)
+    rf = rng.uniform(0.9e9, 1.5e9, nsrc).astype(np.float32)
+    p = lambda a: a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+    for decomposable, entry in ((True, "af_fused_predict_antennas_c64"), (False, "af_fused_predict_c64")):
+        d = _problem(5, 2000, 4, nsrc, nant)
+        s = _single(_decomposable(d, nant)) if decomposable else _rows_single(d)
+        del spy[:]
+        got = rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], s["lm"], s["uvw"], s["frequency"], None, s["beam"],
+                                     s["extents"], s["beam_freq_map"], s["pa"], s["pe"], s["as"], stokes=stokes, spi=spi, ref_freq=rf)
+        assert got.dtype == np.complex64 and entry in spy, spy
+        st = oracle.spectral_model(p(stokes), p(spi), p(rf), p(s["frequency"]), base=0)
+        I, Q, U, V = (st[..., k] for k in range(4))           # noqa: E741
+        X = np.stack([I + Q, U + 1j * V, U - 1j * V, I - Q], axis=-1).reshape(nsrc, 4, 2, 2)
+        s2 = dict(s, X=X.astype(np.complex64))
+        d2 = dict(d, X=X)
+        tol = _tol(s2) if not decomposable else max(_tol(s2), __import__("test_gpu_fused_gemm_c64")._tol(s2, d2))
+        assert np.abs(got - _chain64(s2)).max() < tol * _scale(d2) + 1e-6 * _scale(d2)
+
+
+def test_a_plan_at_single_precision_tolerance_is_not_used_in_double(spy, monkeypatch):
+    """float32 rows of a Measurement Set decompose only at their own precision (fused_plan(..., single=True)); a call that
+    computes in double -- here: the single-precision kernels switched off -- must not take the GEMM form with such a plan"""
+    monkeypatch.setenv("AFHIP_GEMM_MIN_FILL", "0")
+    monkeypatch.setenv("AFHIP_FUSED_C64", "0")
+    nant = 12
+    d = _decomposable(_problem(7, 600, 4, 9, nant), nant)
+    s = _single(d)
+    plan = fused.fused_plan(s["time_index"], s["ant1"], s["ant2"], nant, uvw=s["uvw"], single=True)
+    assert plan.decomposable and plan.single_tol
+    out = _call_s(s, plan=plan)
+    assert out.dtype == np.complex64 and "af_fused_predict_c128" in spy and "af_fused_predict_antennas_c128" not in spy
+    truth = _chain64(s)
+    assert np.abs(out - truth).max() <= 6.1e-8 * np.abs(truth).max() + 1e-9 * _scale(d)      # double, rounded once
