@@ -23,23 +23,26 @@ struct C2f {
     float re, im;
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
-// complex arithmetic on (re, im) pairs: v_pk_mul_f32 / v_pk_fma_f32, two float32 operations per instruction (54.6 -> 53.5 ms)
+// complex arithmetic on (re, im) pairs: v_pk_mul_f32 / v_pk_fma_f32, two float32 operations per instruction (54.6 -> 53.5 ms),
+// the swaps and signs of the products as operand modifiers (op_sel picks the half of a source that feeds the LOW result,
+// op_sel_hi the HIGH one) -- written as asm: from vector expressions the compiler builds the swapped / negated pairs with
+// v_mov / v_xor.  Early-clobber outputs: a result whose HIGH half reads the LOW half of a source must not share its registers.
 __device__ __forceinline__ C2f cmulf(C2f a, C2f b)
 {
-    const v2f bb = {b.re, b.im}, bs = {-b.im, b.re};
-    const v2f ar = {a.re, a.re}, ai = {a.im, a.im};
-    const v2f z = __builtin_elementwise_fma(ar, bb, ai * bs);
+    const v2f av = {a.re, a.im}, bv = {b.re, b.im};
+    v2f t, z;       // (ar br, ar bi) then (- ai bi, + ai br)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=&v"(t) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=&v"(z) : "v"(av), "v"(bv), "v"(t));
     C2f r;
     r.re = z.x; r.im = z.y;
     return r;
 }
 __device__ __forceinline__ void cmacf(C2f &acc, C2f a, C2f b)
 {
-    const v2f bb = {b.re, b.im}, bs = {-b.im, b.re};
-    const v2f ar = {a.re, a.re}, ai = {a.im, a.im};
+    const v2f av = {a.re, a.im}, bv = {b.re, b.im};
     v2f z = {acc.re, acc.im};
-    z = __builtin_elementwise_fma(ar, bb, z);
-    z = __builtin_elementwise_fma(ai, bs, z);
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(z) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(z) : "v"(av), "v"(bv));
     acc.re = z.x; acc.im = z.y;
 }
 
