@@ -204,13 +204,15 @@ __device__ __forceinline__ void chain_phasor(const float2 *tab, double x, float 
 }
 
 // n = sqrt(1 - l^2 - m^2) - 1 (kernels.py:54, unclamped) in float64 from the float32 coordinates
+// (clamp: phase_delay's n = sqrt(max(0, 1 - l^2 - m^2)) - 1, africanus/rime/phase.py:42-43 -- AF_DFT_CLAMP_N)
 __global__ void f32_prep_src(const float *__restrict__ lm, int64_t nsrc, double *__restrict__ lmn, int *__restrict__ srcbad,
-                             int *__restrict__ flags)
+                             int *__restrict__ flags, int clamp)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsrc) return;
     const double l = (double)lm[2 * s], m = (double)lm[2 * s + 1];
     double n = 1.0 - l * l - m * m;
+    if (clamp && n < 0.0) n = 0.0;
     n = sqrt(n) - 1.0;
     const bool bad = !(isfinite(l) && isfinite(m) && isfinite(n));
     srcbad[s] = bad ? 1 : 0;
@@ -910,6 +912,8 @@ AF_EXPORT int af_im_to_vis_f32(const float *image, int image_is_complex, const f
 {
     AF_REQUIRE(convention == AF_CONVENTION_FOURIER || convention == AF_CONVENTION_CASA,
                "convention not in ('fourier', 'casa')");
+    const int clamp_n = (mode & AF_DFT_CLAMP_N) ? 1 : 0;
+    mode &= ~AF_DFT_CLAMP_N;
     AF_REQUIRE(mode == AF_DFT_AUTO || mode == AF_DFT_EXACT || mode == AF_DFT_RECURRENCE, "af_im_to_vis_f32: unknown mode %d", mode);
     AF_REQUIRE(nsrc >= 0 && nrow >= 0 && nchan >= 0 && ncorr >= 0, "af_im_to_vis_f32: negative extent");
     AF_REQUIRE(nsrc < (1LL << 31), "af_im_to_vis_f32: nsrc too large");
@@ -937,7 +941,7 @@ AF_EXPORT int af_im_to_vis_f32(const float *image, int image_is_complex, const f
     AF_HIP(hipMemsetAsync(ws + L.tilestate, 0, (size_t)L.ntile * sizeof(int), st));
     hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc,
                        reinterpret_cast<double *>(ws + L.lmn), reinterpret_cast<int *>(ws + L.srcbad),
-                       reinterpret_cast<int *>(ws + L.flags));
+                       reinterpret_cast<int *>(ws + L.flags), clamp_n);
     AF_LAUNCH_CHECK();
     {
         int64_t blocks = af_cdiv(nrow, 256 * 16);
@@ -1009,7 +1013,7 @@ AF_EXPORT int af_vis_to_im_f32(const float *vis, const float *uvw, const float *
     float *rec = reinterpret_cast<float *>(ws + L.records), *partial = reinterpret_cast<float *>(ws + L.partial);
     AF_HIP(hipMemsetAsync(wflags, 0, 16 * sizeof(int), st));
     AF_HIP(hipMemsetAsync(chan_any, 0, (size_t)L.ntile * L.ct * sizeof(int), st));
-    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, lmn, srcbad, wflags);
+    hipLaunchKernelGGL(f32_prep_src, dim3((unsigned)af_cdiv(nsrc, 256)), dim3(256), 0, st, lm, nsrc, lmn, srcbad, wflags, 0);
     AF_LAUNCH_CHECK();
     // vis_to_im's 'fourier' is exp(+2 pi i ...): the opposite sign of im_to_vis (kernels.py:113-118)
     hipLaunchKernelGGL(f32_prep_freq, dim3((unsigned)af_cdiv(L.ntile, 64)), dim3(64), 0, st, frequency, nchan, L.ntile, L.ct,

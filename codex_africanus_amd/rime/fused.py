@@ -253,7 +253,8 @@ def fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, bright
     floating-point input is single precision, complex128 otherwise.  Single-precision calls with a beam are COMPUTED in
     single precision (``af_fused_predict_antennas_c64`` on antenna-decomposable rows, ``af_fused_predict_c64`` on any others;
     phases in double; a sky model given as ``stokes`` / ``spi`` / ``ref_freq`` is first turned into the complex64 brightness
-    array); the routes without a beam compute in double and round once at the end."""
+    array); without a beam and without Gaussian shapes: the single-precision direct transform (``af_im_to_vis_f32``, phases
+    in double); Gaussian sources without a beam and the sky model without a beam compute in double and round once."""
     vis = _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam, beam_lm_extents, beam_freq_map,
                              parallactic_angles, point_errors, antenna_scaling, die1_jones, base_vis, die2_jones, convention,
                              feed_rotation, gauss_shape, stokes, spi, ref_freq, corr_schema, spectral_base, plan)
@@ -445,6 +446,20 @@ def _fused_predict_vis(time_index, antenna1, antenna2, lm, uvw, frequency, brigh
             vis = _gemm_c64(c, plan, explicit_plan, time_index, antenna1, antenna2, lm, uvw, frequency, brightness, beam,
                             beam_lm_extents, beam_freq_map, parallactic_angles, point_errors, antenna_scaling, feed_rotation,
                             convention, nsrc, nrow, nchan, allow_chunks=die1_jones is None and base_vis is None)
+            if die1_jones is None and base_vis is None:
+                return vis
+            return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)
+        if not have_beam and _all_single(lm, uvw, frequency, brightness) and os.environ.get("AFHIP_FUSED_C64", "1") != "0":
+            # no DDEs, every input single precision: sum_s K X_s by the single-precision direct transform (complex image,
+            # phase_delay's clamped n, phases in double: csrc/af_im_to_vis_f32.hip)
+            f32 = np.float32
+            p_lm, p_uvw, p_fr, p_b = c.inp(lm, f32), c.inp(uvw, f32), c.inp(frequency, f32), c.inp(brightness, np.complex64)
+            p_out, h = c.out((nrow, nchan, 2, 2), np.complex64)
+            ws_bytes = int(_lib.load().af_im_to_vis_f32_workspace_bytes(nsrc, nchan, 4, 1))
+            p_ws = c.scratch(ws_bytes)
+            _lib.call("af_im_to_vis_f32", p_b, 1, p_uvw, p_lm, p_fr, nsrc, nrow, nchan, 4, _lib.CONVENTION[convention],
+                      _lib.AF_DFT_AUTO | _lib.AF_DFT_CLAMP_N, p_out, p_ws, max(ws_bytes, 256), c.stream)
+            vis = c.result(h)
             if die1_jones is None and base_vis is None:
                 return vis
             return predict_vis(time_index, antenna1, antenna2, None, vis[None], None, die1_jones, base_vis, die2_jones)

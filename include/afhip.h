@@ -162,7 +162,8 @@ int af_im_to_vis_chi2_f64(const double *image, int image_is_complex, const doubl
  * close to the float64 transform of the same inputs as the reference's float32 loop.  ncorr in {1, 2, 4}
  * (AF_ENOTSUP otherwise: promote and call af_im_to_vis_f64).  Same zero-pixel / NaN-source semantics, same `mode`
  * values (AF_DFT_RECURRENCE additionally asserts that the float32 frequency axis is meant to be uniform: its
- * rounding is then not followed channel by channel).
+ * rounding is then not followed channel by channel); `mode | AF_DFT_CLAMP_N`: n = sqrt(max(0, 1 - l^2 - m^2)) - 1, phase_delay's
+ * form (africanus/rime/phase.py:42-43) -- what the fused predict without DDEs asks for on single-precision inputs.
  * The _f32 transforms are a CONVENIENCE for single-precision callers (the dtype contract, half the bytes), not a fast
  * path: at BASELINE configs[1]'s counts af_im_to_vis_f32 runs 1.08 x the rate of af_im_to_vis_f64 (0.46 of the fp32
  * vector peak: the 8-cycle v_mfma_f32_4x4x1 blocks leave no issue slots for the float32 phasor recurrence beside them,

@@ -265,3 +265,23 @@ def test_a_plan_at_single_precision_tolerance_is_not_used_in_double(spy, monkeyp
     assert out.dtype == np.complex64 and "af_fused_predict_c128" in spy and "af_fused_predict_antennas_c128" not in spy
     truth = _chain64(s)
     assert np.abs(out - truth).max() <= 6.1e-8 * np.abs(truth).max() + 1e-9 * _scale(d)      # double, rounded once
+
+
+def test_without_a_beam_the_single_precision_direct_transform(spy):
+    """no DDEs, every input single precision: sum_s K X_s by af_im_to_vis_f32 (complex image, phase_delay's clamped n -- one
+    source here sits outside the unit disc --, phases in double); one double array among the inputs: the double transform"""
+    nant = 12
+    d = _problem(7, 600, 4, 9, nant)
+    s = _rows_single(d)
+    s["lm"] = s["lm"].copy()
+    s["lm"][3] = (0.8, 0.7)                                   # l^2 + m^2 > 1: n = -1 (clamped), not NaN
+    out = rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], s["lm"], s["uvw"], s["frequency"], s["X"])
+    assert out.dtype == np.complex64 and "af_im_to_vis_f32" in spy and "af_im_to_vis_f64" not in spy
+    p = lambda a: a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+    phase = oracle.phase_delay(p(s["lm"]), p(s["uvw"]), p(s["frequency"]))
+    truth = np.einsum("srf,sfij->rfij", phase, p(s["X"]))
+    assert np.isfinite(truth).all() and np.abs(out - truth).max() < 1e-5 * _scale(d), np.abs(out - truth).max() / _scale(d)
+    del spy[:]
+    out64 = rime.fused_predict_vis(s["time_index"], s["ant1"], s["ant2"], p(s["lm"]), s["uvw"], s["frequency"], s["X"])
+    assert out64.dtype == np.complex128 and "af_im_to_vis_f64" in spy
+    assert np.abs(out64 - truth).max() < 1e-9 * _scale(d)
