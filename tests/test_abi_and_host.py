@@ -238,6 +238,38 @@ def test_gemm_plan_host_side_up_to_512_antennas():
     assert fused.fused_plan(ti[:10], a1[:10] % 3, a2[:10] % 3 + 3, 520, uvw=uvw[:10]).decomposable is False   # > 512 antennas
 
 
+def test_plans_of_single_precision_rows_say_at_which_tolerance_they_decompose():
+    """Round 6 (host side only).  float32 rows of a Measurement Set are differences of antenna coordinates only to their own
+    rounding: they decompose at 2^-22 max |uvw| when the call is all single precision (``single=True``) -- and such a plan is
+    marked (``single_tol``), because the double-precision GEMM route must not take it (rime.fused._fused_predict_vis) --
+    and not at the double tolerance.  An explicit ``decompose_tol`` is the caller's decision and is not marked."""
+    from codex_africanus_amd.rime import fused
+    rng = np.random.default_rng(11)
+    nant, ntime = 20, 3
+    a1, a2 = np.triu_indices(nant, 1)
+    nbl = a1.shape[0]
+    ti = np.repeat(np.arange(ntime), nbl)
+    a1, a2 = np.tile(a1, ntime).astype(np.int32), np.tile(a2, ntime).astype(np.int32)
+    x = (rng.uniform(-1, 1, (ntime, nant, 3)) * [3000.0, 3000.0, 300.0]).astype(np.float32)
+    uvw32 = x[ti, a1] - x[ti, a2]
+    assert uvw32.dtype == np.float32
+    loose = fused.fused_plan(ti, a1, a2, nant, uvw=uvw32, single=True)
+    assert loose.decomposable and loose.single_tol and 1e-10 < loose.residual <= loose.tol < 2e-3
+    strict = fused.fused_plan(ti, a1, a2, nant, uvw=uvw32)
+    assert not strict.decomposable and not strict.single_tol and strict.tol == fused.DECOMPOSE_TOL
+    assert strict.items is not None and strict.groups is not None          # the lane-per-row kernels' plan is always there
+    chosen = fused.fused_plan(ti, a1, a2, nant, uvw=uvw32, decompose_tol=1e-3)
+    assert chosen.decomposable and not chosen.single_tol
+    # double rows: `single` changes nothing
+    uvw64 = x.astype(np.float64)[ti, a1] - x.astype(np.float64)[ti, a2]
+    exact = fused.fused_plan(ti, a1, a2, nant, uvw=uvw64, single=True)
+    assert exact.decomposable and not exact.single_tol and exact.residual <= 1e-10
+    # the cache keeps the two kinds apart
+    assert fused.cached_plan(ti, a1, a2, nant, uvw=uvw32, single=True).decomposable
+    assert not fused.cached_plan(ti, a1, a2, nant, uvw=uvw32, single=False).decomposable
+    assert fused._all_single(uvw32, None, x) and not fused._all_single(uvw32, uvw64)
+
+
 def test_plan_cache_by_identity_does_not_outlive_the_plan_cache(monkeypatch):
     """the identity index of cached_plan (tensor objects -> plan) held strong references to plans keyed by
     tensors that no longer exist -- the row-chunk front-ends pass fresh slices every call -- so plans (host arrays + device
